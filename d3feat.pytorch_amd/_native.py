@@ -1,0 +1,102 @@
+"""ctypes binding of ``libd3feat_hip.so`` (the C ABI declared in ``include/d3feat_hip.h``).
+
+There is deliberately NO fallback: if the HIP library is missing or a tensor is not a CUDA/HIP tensor, every
+operator raises ``RuntimeError`` (the reference's only error type, cpp_neighbors/wrapper.cpp:77).
+"""
+import ctypes as C
+import os
+import subprocess
+
+_PKG_DIR = os.path.dirname(os.path.abspath(__file__))
+_REPO = os.path.dirname(_PKG_DIR)
+LIB_PATH = os.path.join(_PKG_DIR, "libd3feat_hip.so")
+CSRC = os.path.join(_PKG_DIR, "csrc")
+SOURCES = ["radius_neighbors.hip", "grid_subsample.hip", "kpconv.hip", "pool.hip", "detection.hip", "loss.hip",
+           "matching.hip", "misc.hip"]
+
+_vp, _i, _f, _sz = C.c_void_p, C.c_int, C.c_float, C.c_size_t
+
+# name -> (restype, argtypes); mirrors include/d3feat_hip.h one to one
+SIGNATURES = {
+    "d3f_version": (C.c_char_p, []),
+    "d3f_device_arch_ok": (_i, []),
+    "d3f_radius_grid_ws_bytes": (_sz, [_i]),
+    "d3f_radius_grid_build": (_i, [_vp, _i, _vp, _i, _f, _vp, _sz, _vp, _vp]),
+    "d3f_radius_query": (_i, [_vp, _vp, _i, _vp, _vp, _i, _vp, _i, _f, _i, _vp, _vp, _vp, _vp, _vp]),
+    "d3f_grid_subsample_ws_bytes": (_sz, [_i, _i]),
+    "d3f_grid_subsample": (_i, [_vp, _i, _vp, _i, _f, _i, _i, _vp, _vp, _vp, _vp, _sz, _vp, _vp]),
+    "d3f_kpconv_ws_bytes": (_sz, [_i, _i, _i, _i, _i, _i]),
+    "d3f_kpconv_forward": (_i, [_vp, _i, _vp, _i, _vp, _i, _vp, _i, _vp, _i, _vp, _i, _f, _vp, _vp, _vp, _sz, _vp]),
+    "d3f_kpconv_backward": (_i, [_vp, _i, _vp, _i, _vp, _i, _vp, _i, _vp, _i, _vp, _i, _f, _vp, _vp, _vp, _vp, _vp,
+                                 _sz, _vp]),
+    "d3f_max_pool_forward": (_i, [_vp, _i, _i, _vp, _i, _i, _vp, _vp, _vp]),
+    "d3f_max_pool_backward": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp]),
+    "d3f_closest_pool_forward": (_i, [_vp, _i, _i, _vp, _i, _i, _vp, _vp]),
+    "d3f_closest_pool_backward": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp]),
+    "d3f_global_max": (_i, [_vp, _sz, _vp, _vp, _sz, _vp]),
+    "d3f_detection_scores_forward": (_i, [_vp, _i, _i, _vp, _i, _vp, _i, _vp, _vp]),
+    "d3f_detection_scores_ws_bytes": (_sz, [_i, _i]),
+    "d3f_detection_scores_backward": (_i, [_vp, _i, _i, _vp, _i, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "d3f_circle_det_loss_stats_floats": (_sz, [_i]),
+    "d3f_circle_det_loss_ws_bytes": (_sz, [_i]),
+    "d3f_circle_det_loss_forward": (_i, [_vp, _vp, _i, _i, _vp, _vp, _vp, _f, _f, _f, _f, _vp, _vp, _vp, _vp, _vp,
+                                         _vp]),
+    "d3f_circle_det_loss_backward": (_i, [_vp, _vp, _i, _i, _vp, _vp, _vp, _f, _f, _f, _f, _vp, _vp, _vp, _vp, _vp,
+                                          _vp, _vp, _vp, _vp, _sz, _vp]),
+    "d3f_mutual_nn": (_i, [_vp, _i, _vp, _i, _i, _vp, _vp, _vp, _vp]),
+}
+
+ERRORS = {-1: "invalid argument", -2: "workspace too small", -3: "HIP launch failure"}
+STATUS_BITS = {1: "a query has more in-radius candidates than the kernel can rank (512)",
+               2: "a point lies outside the addressable cell grid",
+               4: "voxel hash table full"}
+
+
+def build(verbose=False):
+    """Compile every HIP source for gfx950 into the in-tree shared library (cross-compiles without a GPU)."""
+    cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
+           "-I" + os.path.join(_REPO, "include"), "-o", LIB_PATH] + [os.path.join(CSRC, s) for s in SOURCES]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return LIB_PATH
+
+
+def _needs_build():
+    if not os.path.exists(LIB_PATH):
+        return True
+    t = os.path.getmtime(LIB_PATH)
+    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(_REPO, "include", "d3feat_hip.h")]
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+_lib = None
+
+
+def lib():
+    """The loaded library; raises RuntimeError if it has not been built (no silent fallback)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                "libd3feat_hip.so is not built: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(hipcc --offload-arch=gfx950).  d3feat_pytorch_amd has no CPU or PyTorch fallback.")
+        try:
+            handle = C.CDLL(LIB_PATH)
+        except OSError as e:  # pragma: no cover
+            raise RuntimeError("cannot load %s: %s" % (LIB_PATH, e))
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(handle, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = handle
+    return _lib
+
+
+def check(rc, what):
+    if rc != 0:
+        raise RuntimeError("%s failed: %s" % (what, ERRORS.get(rc, "error %d" % rc)))
+
+
+def status_message(word):
+    return "; ".join(msg for bit, msg in STATUS_BITS.items() if word & bit)

@@ -1,0 +1,81 @@
+// Shared device helpers for libd3feat_hip.so (gfx950 only; wave = 64).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "d3feat_hip.h"
+
+#define D3F_WAVE 64
+#define D3F_MAX_BATCH 64  // clouds per stacked batch the kernels index by linear scan
+
+#define D3F_LAUNCH_CHECK()                          \
+  do {                                              \
+    if (hipGetLastError() != hipSuccess) return D3F_ELAUNCH; \
+  } while (0)
+
+namespace d3f {
+
+static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+static inline int cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
+
+// Carves aligned sub-buffers out of one caller-provided workspace.
+struct Carver {
+  char* base;
+  size_t off;
+  explicit Carver(void* p) : base((char*)p), off(0) {}
+  template <typename T>
+  T* take(size_t n) {
+    off = align_up(off, 256);
+    T* r = (T*)(base + off);
+    off += n * sizeof(T);
+    return r;
+  }
+};
+
+// (batch element, first row of that element) of stacked row `i`, given per-element lengths.
+__device__ __forceinline__ void locate_batch(const int32_t* __restrict__ len, int B, int i, int& b, int& start) {
+  int s = 0, k = 0;
+  for (; k < B - 1; ++k) {
+    const int l = len[k];
+    if (i < s + l) break;
+    s += l;
+  }
+  b = k;
+  start = s;
+}
+
+__device__ __forceinline__ int batch_offset(const int32_t* __restrict__ len, int b) {
+  int s = 0;
+  for (int k = 0; k < b; ++k) s += len[k];
+  return s;
+}
+
+// squared distance with the reference's float32 evaluation order and NO fused multiply-add:
+// d2 = dx*dx; d2 += dy*dy; d2 += dz*dz   (nanoflann.hpp:433-441)
+__device__ __forceinline__ float sqdist_exact(float ax, float ay, float az, float bx, float by, float bz) {
+  const float dx = __fsub_rn(ax, bx), dy = __fsub_rn(ay, by), dz = __fsub_rn(az, bz);
+  float d2 = __fmul_rn(dx, dx);
+  d2 = __fadd_rn(d2, __fmul_rn(dy, dy));
+  d2 = __fadd_rn(d2, __fmul_rn(dz, dz));
+  return d2;
+}
+
+__device__ __forceinline__ int lane_id() { return threadIdx.x & (D3F_WAVE - 1); }
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+__device__ __forceinline__ int wave_sum_i(int v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+}  // namespace d3f

@@ -1,0 +1,245 @@
+// Fused descriptor-matching loss: all-pairs L2 distance + circle loss + detector loss, forward and backward.
+//
+// Replaces reference utils/loss.py: cdist 'euclidean' (:8-44), CircleLoss.forward (:111-141) and
+// DetLoss.forward (:149-158) -- ~40 small PyTorch launches and two host syncs per step in the reference.
+// M (sampled correspondences) is 128 in training / 64 in validation (config.py:78), so the whole problem
+// (M*M = 16k distances) lives in ONE workgroup: distances go to the caller's `dists` buffer (an output of the
+// reference API as well), row/column statistics to LDS, and a single launch produces both losses + metrics.
+//
+// Semantics reproduced literally (including the reference's quirk that masked entries contribute exp(-0) = 1 to
+// the log-sum-exp because their detached weight is clamped to 0):
+//   D      = sqrt(sum_c (a_i - p_j)^2 + 1e-12)
+//   pos    = D - 1e5*neg_mask,  pw = max(0, pos - pos_margin)       T+ = s*(pos - pos_margin)*pw
+//   neg    = D + 1e5*(1-neg_mask), nw = max(0, neg_margin - neg)    T- = s*(neg_margin - neg)*nw
+//   desc   = mean_i softplus(lse_j T+ + lse_j T-)/s + mean_j softplus(lse_i T+ + lse_i T-)/s
+//   det    = mean_i (D_ii - min_j (D + 1e5*I)_ij) * (sa_i + sp_i)
+#include "common.hpp"
+
+namespace {
+
+constexpr int kThreads = 1024;
+constexpr int kMaxM = 1024;
+
+struct LossParams {
+  float s, safe_radius, pos_margin, neg_margin;
+};
+
+__device__ __forceinline__ float softplus_t(float x) { return x > 20.0f ? x : log1pf(expf(x)); }
+__device__ __forceinline__ float sigmoid_sp(float x) { return x > 20.0f ? 1.0f : 1.0f / (1.0f + expf(-x)); }
+
+__device__ __forceinline__ void terms(float d, bool negm, const LossParams& P, float& tpos, float& pw, float& tneg,
+                                      float& nw) {
+  const float pos = d - 1e5f * (negm ? 1.0f : 0.0f);
+  pw = fmaxf(0.0f, pos - P.pos_margin);
+  tpos = P.s * (pos - P.pos_margin) * pw;
+  const float neg = d + 1e5f * (negm ? 0.0f : 1.0f);
+  nw = fmaxf(0.0f, P.neg_margin - neg);
+  tneg = P.s * (P.neg_margin - neg) * nw;
+}
+
+// wave-cooperative statistics of one row (stride 1) or one column (stride M) of D
+__device__ void line_stats(const float* __restrict__ D, const uint8_t* __restrict__ negm, int M, long base, long stride,
+                           int self, const LossParams& P, float& lse_p, float& lse_n, float& sumd, float& cmin,
+                           int& carg) {
+  const int lane = threadIdx.x & 63;
+  float mp = -INFINITY, mn = -INFINITY, sd = 0.0f, cm = INFINITY;
+  int ca = 0x7fffffff;
+  for (int t = lane; t < M; t += 64) {
+    const float d = D[base + t * stride];
+    float tp, pw, tn, nw;
+    terms(d, negm[base + t * stride] != 0, P, tp, pw, tn, nw);
+    mp = fmaxf(mp, tp);
+    mn = fmaxf(mn, tn);
+    sd += d;
+    const float dm = d + (t == self ? 1e5f : 0.0f);
+    if (dm < cm) { cm = dm; ca = t; }
+  }
+  mp = d3f::wave_max(mp);
+  mn = d3f::wave_max(mn);
+  sd = d3f::wave_sum(sd);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {  // (value, index) lexicographic min -> first minimal index like torch.min
+    const float ov = __shfl_xor(cm, o, 64);
+    const int oa = __shfl_xor(ca, o, 64);
+    if (ov < cm || (ov == cm && oa < ca)) { cm = ov; ca = oa; }
+  }
+  float ep = 0.0f, en = 0.0f;
+  for (int t = lane; t < M; t += 64) {
+    const float d = D[base + t * stride];
+    float tp, pw, tn, nw;
+    terms(d, negm[base + t * stride] != 0, P, tp, pw, tn, nw);
+    ep += expf(tp - mp);
+    en += expf(tn - mn);
+  }
+  ep = d3f::wave_sum(ep);
+  en = d3f::wave_sum(en);
+  lse_p = mp + logf(ep);
+  lse_n = mn + logf(en);
+  sumd = sd;
+  cmin = cm;
+  carg = ca;
+}
+
+__device__ float block_sum(float v, float* sh) {
+  v = d3f::wave_sum(v);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+  __syncthreads();
+  float t = 0.0f;
+  for (int w = 0; w < (int)(blockDim.x >> 6); ++w) t += sh[w];
+  return t;
+}
+
+// stats layout (floats): [0,M) lse_pr  [M,2M) lse_nr  [2M,3M) lse_pc  [3M,4M) lse_nc  [4M,5M) cn  [5M,6M) cnarg(int)
+__global__ __launch_bounds__(kThreads) void loss_fwd_kernel(
+    const float* __restrict__ a, const float* __restrict__ p, int M, int C, const uint8_t* __restrict__ negm,
+    const float* __restrict__ sa, const float* __restrict__ sp, LossParams P, float* __restrict__ D,
+    float* __restrict__ fp_out, float* __restrict__ avgneg_out, float* __restrict__ scalars,
+    float* __restrict__ stats) {
+  __shared__ float sh[16];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, nw = blockDim.x >> 6;
+  for (int t = tid; t < M * M; t += blockDim.x) {
+    const int i = t / M, j = t % M;
+    float acc = 0.0f;
+    for (int c = 0; c < C; ++c) {
+      const float df = a[(size_t)i * C + c] - p[(size_t)j * C + c];
+      acc += df * df;
+    }
+    D[t] = sqrtf(acc + 1e-12f);
+  }
+  __threadfence_block();
+  __syncthreads();
+  for (int i = wave; i < M; i += nw) {
+    float lp, ln, sd, cm; int ca;
+    line_stats(D, negm, M, (long)i * M, 1, i, P, lp, ln, sd, cm, ca);
+    if (lane == 0) {
+      stats[i] = lp;
+      stats[M + i] = ln;
+      stats[4 * M + i] = cm;
+      ((int*)stats)[5 * M + i] = ca;
+      const float fp = D[(size_t)i * M + i];  // max_j D*I = D_ii (D > 0)
+      fp_out[i] = fp;
+      avgneg_out[i] = (sd - fp) / (float)(M - 1);
+    }
+  }
+  for (int j = wave; j < M; j += nw) {
+    float lp, ln, sd, cm; int ca;
+    line_stats(D, negm, M, (long)j, M, j, P, lp, ln, sd, cm, ca);
+    if (lane == 0) {
+      stats[2 * M + j] = lp;
+      stats[3 * M + j] = ln;
+    }
+  }
+  __threadfence_block();
+  __syncthreads();
+  float l = 0.0f, dt = 0.0f, ac = 0.0f, fps = 0.0f, ans = 0.0f;
+  for (int i = tid; i < M; i += blockDim.x) {
+    l += softplus_t(stats[i] + stats[M + i]) / P.s + softplus_t(stats[2 * M + i] + stats[3 * M + i]) / P.s;
+    const float diff = fp_out[i] - stats[4 * M + i];
+    dt += diff * (sa[i] + sp[i]);
+    ac += diff < 0.0f ? 1.0f : 0.0f;
+    fps += fp_out[i];
+    ans += avgneg_out[i];
+  }
+  l = block_sum(l, sh);
+  dt = block_sum(dt, sh);
+  ac = block_sum(ac, sh);
+  fps = block_sum(fps, sh);
+  ans = block_sum(ans, sh);
+  if (tid == 0) {
+    scalars[0] = l / (float)M;
+    scalars[1] = dt / (float)M;
+    scalars[2] = ac * 100.0f / (float)M;
+    scalars[3] = fps / (float)M;
+    scalars[4] = ans / (float)M;
+    scalars[5] = 0.0f;
+  }
+}
+
+__global__ __launch_bounds__(kThreads) void loss_bwd_kernel(
+    const float* __restrict__ a, const float* __restrict__ p, int M, int C, const uint8_t* __restrict__ negm,
+    const float* __restrict__ sa, const float* __restrict__ sp, LossParams P, const float* __restrict__ D,
+    const float* __restrict__ stats, const float* __restrict__ g_desc, const float* __restrict__ g_det,
+    float* __restrict__ G, float* __restrict__ ga, float* __restrict__ gp, float* __restrict__ gsa,
+    float* __restrict__ gsp) {
+  const int tid = threadIdx.x;
+  const float gd = g_desc ? *g_desc : 0.0f, gt = g_det ? *g_det : 0.0f;
+  const float invM = 1.0f / (float)M;
+  for (int t = tid; t < M * M; t += blockDim.x) {
+    const int i = t / M, j = t % M;
+    const float d = D[t];
+    float tp, pw, tn, nw;
+    terms(d, negm[t] != 0, P, tp, pw, tn, nw);
+    const float sr = sigmoid_sp(stats[i] + stats[M + i]);
+    const float sc = sigmoid_sp(stats[2 * M + j] + stats[3 * M + j]);
+    float g = gd * invM * (sr * (expf(tp - stats[i]) * pw - expf(tn - stats[M + i]) * nw) +
+                           sc * (expf(tp - stats[2 * M + j]) * pw - expf(tn - stats[3 * M + j]) * nw));
+    const float w = gt * invM * (sa[i] + sp[i]);
+    if (j == i) g += w;
+    if (j == ((const int*)stats)[5 * M + i]) g -= w;
+    G[t] = g / d;
+  }
+  __threadfence_block();
+  __syncthreads();
+  for (int t = tid; t < M * C; t += blockDim.x) {
+    const int i = t / C, c = t % C;
+    const float ai = a[t];
+    float acc = 0.0f;
+    for (int j = 0; j < M; ++j) acc += G[(size_t)i * M + j] * (ai - p[(size_t)j * C + c]);
+    ga[t] = acc;
+  }
+  for (int t = tid; t < M * C; t += blockDim.x) {
+    const int j = t / C, c = t % C;
+    const float pj = p[t];
+    float acc = 0.0f;
+    for (int i = 0; i < M; ++i) acc += G[(size_t)i * M + j] * (pj - a[(size_t)i * C + c]);
+    gp[t] = acc;
+  }
+  for (int i = tid; i < M; i += blockDim.x) {
+    const float v = gt * invM * (D[(size_t)i * M + i] - stats[4 * M + i]);
+    if (gsa) gsa[i] = v;
+    if (gsp) gsp[i] = v;
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t d3f_circle_det_loss_stats_floats(int M) { return 6 * (size_t)(M > 0 ? M : 1); }
+size_t d3f_circle_det_loss_ws_bytes(int M) { return sizeof(float) * (size_t)(M > 0 ? M : 1) * (size_t)(M > 0 ? M : 1); }
+
+int d3f_circle_det_loss_forward(const float* anchor, const float* positive, int M, int C, const uint8_t* neg_mask,
+                                const float* anc_score, const float* pos_score, float log_scale, float safe_radius,
+                                float pos_margin, float neg_margin, float* dists, float* furthest_positive,
+                                float* average_negative, float* out_scalars, float* stats, void* stream) {
+  if (!anchor || !positive || !neg_mask || !anc_score || !pos_score || !dists || !furthest_positive ||
+      !average_negative || !out_scalars || !stats || M < 2 || M > kMaxM || C < 1)
+    return D3F_EINVAL;
+  LossParams P = {log_scale, safe_radius, pos_margin, neg_margin};
+  loss_fwd_kernel<<<1, kThreads, 0, (hipStream_t)stream>>>(anchor, positive, M, C, neg_mask, anc_score, pos_score, P,
+                                                            dists, furthest_positive, average_negative, out_scalars,
+                                                            stats);
+  D3F_LAUNCH_CHECK();
+  return D3F_OK;
+}
+
+int d3f_circle_det_loss_backward(const float* anchor, const float* positive, int M, int C, const uint8_t* neg_mask,
+                                 const float* anc_score, const float* pos_score, float log_scale, float safe_radius,
+                                 float pos_margin, float neg_margin, const float* dists, const float* stats,
+                                 const float* grad_desc, const float* grad_det, float* grad_anchor,
+                                 float* grad_positive, float* grad_anc_score, float* grad_pos_score, void* ws,
+                                 size_t ws_bytes, void* stream) {
+  if (!anchor || !positive || !neg_mask || !anc_score || !pos_score || !dists || !stats || !grad_anchor ||
+      !grad_positive || !ws || M < 2 || M > kMaxM || C < 1)
+    return D3F_EINVAL;
+  if (ws_bytes < d3f_circle_det_loss_ws_bytes(M)) return D3F_EWORKSPACE;
+  LossParams P = {log_scale, safe_radius, pos_margin, neg_margin};
+  loss_bwd_kernel<<<1, kThreads, 0, (hipStream_t)stream>>>(anchor, positive, M, C, neg_mask, anc_score, pos_score, P,
+                                                            dists, stats, grad_desc, grad_det, (float*)ws, grad_anchor,
+                                                            grad_positive, grad_anc_score, grad_pos_score);
+  D3F_LAUNCH_CHECK();
+  return D3F_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,105 @@
+// Neighbor max-pool and nearest ("closest") pool, forward + backward.
+//
+// Replaces reference models/blocks.py:94-110 (max_pool: cat zero shadow row, gather [n2,H,d], torch.max over H)
+// and :79-91 (closest_pool: gather column 0).  The reference materialises the gathered [n2,H,d] tensor; here a
+// thread owns one (query, channel) pair; consecutive lanes own consecutive channels, so every neighbor row is read
+// as coalesced 256-B segments and the neighbor index is (nearly) wave-uniform.
+#include "common.hpp"
+
+namespace {
+
+// argmax convention: first maximal neighbor in row order, like torch.max(dim=1) on CPU/ROCm.
+__global__ void max_pool_fwd_kernel(const float* __restrict__ x, int Ns, int C, const int32_t* __restrict__ idx,
+                                    int Nq, int H, float* __restrict__ out, int32_t* __restrict__ argmax) {
+  const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= (size_t)Nq * C) return;
+  const int n = (int)(t / C), c = (int)(t % C);
+  const int32_t* row = idx + (size_t)n * H;
+  float best = -INFINITY;
+  int arg = Ns;
+  for (int h = 0; h < H; ++h) {
+    const int m = row[h];
+    const bool real = m >= 0 && m < Ns;
+    const float v = real ? x[(size_t)m * C + c] : 0.0f;  // shadow row is zeros (blocks.py:103)
+    if (v > best || h == 0) {
+      best = v;
+      arg = real ? m : Ns;
+    }
+  }
+  out[(size_t)n * C + c] = best;
+  if (argmax) argmax[(size_t)n * C + c] = arg;
+}
+
+__global__ void max_pool_bwd_kernel(const float* __restrict__ go, const int32_t* __restrict__ argmax, int Nq, int C,
+                                    int Ns, float* __restrict__ gx) {
+  const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= (size_t)Nq * C) return;
+  const int m = argmax[t];
+  if (m >= 0 && m < Ns) atomicAdd(&gx[(size_t)m * C + (t % C)], go[t]);
+}
+
+__global__ void closest_pool_fwd_kernel(const float* __restrict__ x, int Ns, int C, const int32_t* __restrict__ idx,
+                                        int Nq, int H, float* __restrict__ out) {
+  const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= (size_t)Nq * C) return;
+  const int n = (int)(t / C), c = (int)(t % C);
+  const int m = idx[(size_t)n * H];
+  out[t] = (m >= 0 && m < Ns) ? x[(size_t)m * C + c] : 0.0f;
+}
+
+__global__ void closest_pool_bwd_kernel(const float* __restrict__ go, const int32_t* __restrict__ idx, int Nq, int H,
+                                        int C, int Ns, float* __restrict__ gx) {
+  const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= (size_t)Nq * C) return;
+  const int n = (int)(t / C), c = (int)(t % C);
+  const int m = idx[(size_t)n * H];
+  if (m >= 0 && m < Ns) atomicAdd(&gx[(size_t)m * C + c], go[t]);
+}
+
+}  // namespace
+
+extern "C" {
+
+int d3f_max_pool_forward(const float* x, int Ns, int C, const int32_t* idx, int Nq, int H, float* out,
+                         int32_t* argmax_out, void* stream) {
+  if (!x || !idx || !out || Ns < 0 || C < 1 || Nq < 0 || H < 1) return D3F_EINVAL;
+  if (Nq == 0) return D3F_OK;
+  max_pool_fwd_kernel<<<d3f::cdiv((long long)Nq * C, 256), 256, 0, (hipStream_t)stream>>>(x, Ns, C, idx, Nq, H, out,
+                                                                                          argmax_out);
+  D3F_LAUNCH_CHECK();
+  return D3F_OK;
+}
+
+int d3f_max_pool_backward(const float* grad_out, const int32_t* argmax, int Nq, int C, int Ns, float* grad_x,
+                          void* stream) {
+  if (!grad_out || !argmax || !grad_x || Nq < 0 || C < 1 || Ns < 0) return D3F_EINVAL;
+  if (hipMemsetAsync(grad_x, 0, sizeof(float) * (size_t)Ns * C, (hipStream_t)stream) != hipSuccess) return D3F_ELAUNCH;
+  if (Nq == 0) return D3F_OK;
+  max_pool_bwd_kernel<<<d3f::cdiv((long long)Nq * C, 256), 256, 0, (hipStream_t)stream>>>(grad_out, argmax, Nq, C, Ns,
+                                                                                          grad_x);
+  D3F_LAUNCH_CHECK();
+  return D3F_OK;
+}
+
+int d3f_closest_pool_forward(const float* x, int Ns, int C, const int32_t* idx, int Nq, int H, float* out,
+                             void* stream) {
+  if (!x || !idx || !out || Ns < 0 || C < 1 || Nq < 0 || H < 1) return D3F_EINVAL;
+  if (Nq == 0) return D3F_OK;
+  closest_pool_fwd_kernel<<<d3f::cdiv((long long)Nq * C, 256), 256, 0, (hipStream_t)stream>>>(x, Ns, C, idx, Nq, H,
+                                                                                              out);
+  D3F_LAUNCH_CHECK();
+  return D3F_OK;
+}
+
+int d3f_closest_pool_backward(const float* grad_out, const int32_t* idx, int Nq, int H, int C, int Ns, float* grad_x,
+                              void* stream) {
+  if (!grad_out || !idx || !grad_x || Nq < 0 || C < 1 || Ns < 0 || H < 1) return D3F_EINVAL;
+  if (hipMemsetAsync(grad_x, 0, sizeof(float) * (size_t)Ns * C, (hipStream_t)stream) != hipSuccess) return D3F_ELAUNCH;
+  if (Nq == 0) return D3F_OK;
+  closest_pool_bwd_kernel<<<d3f::cdiv((long long)Nq * C, 256), 256, 0, (hipStream_t)stream>>>(grad_out, idx, Nq, H, C,
+                                                                                              Ns, grad_x);
+  D3F_LAUNCH_CHECK();
+  return D3F_OK;
+}
+
+}  // extern "C"

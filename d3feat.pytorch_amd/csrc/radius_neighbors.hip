@@ -1,0 +1,277 @@
+// Fixed-radius neighbor search on a hashed uniform cell list.
+//
+// Replaces reference cpp_wrappers/cpp_neighbors (neighbors.cpp:211-333, nanoflann kd-tree on one CPU thread).
+// Same result contract: per query the supports of the SAME batch element with d2 < r2 (strict, float32,
+// ((dx*dx)+(dy*dy))+(dz*dz) without FMA -- nanoflann.hpp:433-441,249-251), ascending in d2; ties in d2 are
+// ordered by support index (the reference leaves them unspecified); row padded with Ns (neighbors.cpp:324).
+//
+// Design (CDNA4): supports are bucketed by a 64-bit cell key (batch, cx, cy, cz) hashed into a power-of-two
+// table; the cell edge is radius*(1+1e-4) and cell coordinates are computed in f64 so a 27-cell scan provably
+// covers every accepted support.  A point is accepted only while scanning ITS OWN cell key, so hash collisions
+// neither lose nor duplicate candidates.  One 64-lane wave serves one query: lanes 0..26 look up the 27
+// buckets, a wave prefix sum flattens their ranges so all 64 lanes test candidates, survivors are compacted
+// with ballot/popcount into LDS as (d2 bits << 32 | index) and ranked by a wave-wide bitonic network
+// (register shuffles for <= 64 candidates, LDS otherwise).
+#include "common.hpp"
+
+namespace {
+
+constexpr double kCellSlack = 1.0 + 1e-4;
+constexpr int kCand = 512;       // ranked candidates per query (overflow -> D3F_ST_CAND_OVERFLOW)
+constexpr int kQueryWaves = 4;   // queries per workgroup
+
+__host__ __device__ inline uint32_t table_size_for(int Ns) {
+  uint32_t m = 64;
+  while (m < 2u * (uint32_t)(Ns > 0 ? Ns : 1)) m <<= 1;
+  return m;
+}
+
+struct GridLayout {
+  uint32_t M;
+  int32_t* cnt;      // [M + 64]  per-bucket population; cnt[M] is the global range allocator
+  int32_t* start;    // [M]
+  int32_t* end;      // [M]       fill cursor during the scatter == range end afterwards
+  uint64_t* key_tmp; // [Ns]      cell key of support i (input order)
+  float4* pts;       // [Ns]      supports in bucket order: x, y, z, bit-cast global index
+  uint64_t* key;     // [Ns]      cell key per sorted support
+  size_t bytes;
+};
+
+GridLayout grid_layout(void* ws, int Ns) {
+  GridLayout g;
+  g.M = table_size_for(Ns);
+  d3f::Carver c(ws);
+  const size_t n = (size_t)(Ns > 0 ? Ns : 1);
+  g.cnt = c.take<int32_t>(g.M + 64);
+  g.start = c.take<int32_t>(g.M);
+  g.end = c.take<int32_t>(g.M);
+  g.key_tmp = c.take<uint64_t>(n);
+  g.pts = c.take<float4>(n);
+  g.key = c.take<uint64_t>(n);
+  g.bytes = d3f::align_up(c.off, 256);
+  return g;
+}
+
+__device__ __forceinline__ int cell_coord(float v, double inv_cell) { return (int)floor((double)v * inv_cell); }
+
+__device__ __forceinline__ uint64_t pack_key(int b, int cx, int cy, int cz) {
+  return ((uint64_t)(uint32_t)b << 48) | ((uint64_t)(uint32_t)(cx + 32768) << 32) |
+         ((uint64_t)(uint32_t)(cy + 32768) << 16) | (uint64_t)(uint32_t)(cz + 32768);
+}
+
+__device__ __forceinline__ uint32_t bucket_of(uint64_t key, uint32_t mask) {
+  return (uint32_t)((key * 0x9E3779B97F4A7C15ull) >> 32) & mask;
+}
+
+__global__ void grid_count_kernel(const float* __restrict__ s, int Ns, const int32_t* __restrict__ s_len, int B,
+                                  double inv_cell, uint32_t mask, int32_t* __restrict__ cnt,
+                                  uint64_t* __restrict__ key_tmp, int32_t* __restrict__ status) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= Ns) return;
+  int b, st;
+  d3f::locate_batch(s_len, B, i, b, st);
+  const int cx = cell_coord(s[3 * i + 0], inv_cell), cy = cell_coord(s[3 * i + 1], inv_cell),
+            cz = cell_coord(s[3 * i + 2], inv_cell);
+  if (cx < -32767 || cx > 32766 || cy < -32767 || cy > 32766 || cz < -32767 || cz > 32766)
+    atomicOr(status, D3F_ST_CELL_RANGE);
+  const uint64_t key = pack_key(b, cx, cy, cz);
+  key_tmp[i] = key;
+  atomicAdd(&cnt[bucket_of(key, mask)], 1);
+}
+
+__global__ void grid_alloc_kernel(uint32_t M, int32_t* __restrict__ cnt, int32_t* __restrict__ start,
+                                  int32_t* __restrict__ end) {
+  const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= M) return;
+  const int c = cnt[b];
+  const int s = c ? atomicAdd(&cnt[M], c) : 0;  // ranges need to be disjoint, not ordered
+  start[b] = s;
+  end[b] = s;
+}
+
+__global__ void grid_scatter_kernel(const float* __restrict__ s, int Ns, uint32_t mask,
+                                    const uint64_t* __restrict__ key_tmp, int32_t* __restrict__ end,
+                                    float4* __restrict__ pts, uint64_t* __restrict__ key) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= Ns) return;
+  const uint64_t k = key_tmp[i];
+  const int pos = atomicAdd(&end[bucket_of(k, mask)], 1);
+  pts[pos] = make_float4(s[3 * i + 0], s[3 * i + 1], s[3 * i + 2], __int_as_float(i));
+  key[pos] = k;
+}
+
+struct WaveScratch {
+  uint64_t cand[kCand];
+  uint64_t nkey[32];
+  int pre[32];
+  int st[32];
+};
+
+__device__ __forceinline__ uint64_t shfl_xor_u64(uint64_t v, int m) {
+  const uint32_t lo = __shfl_xor((uint32_t)v, m, 64), hi = __shfl_xor((uint32_t)(v >> 32), m, 64);
+  return ((uint64_t)hi << 32) | lo;
+}
+
+__global__ __launch_bounds__(kQueryWaves * 64) void radius_query_kernel(
+    const float* __restrict__ q, int Nq, const int32_t* __restrict__ q_len, const int32_t* __restrict__ s_len, int B,
+    int Ns, double inv_cell, float r2, uint32_t mask, const int32_t* __restrict__ start,
+    const int32_t* __restrict__ end, const float4* __restrict__ pts, const uint64_t* __restrict__ key, int width,
+    int32_t* __restrict__ out_idx, int32_t* __restrict__ out_counts, int32_t* __restrict__ max_count,
+    int32_t* __restrict__ status) {
+  __shared__ WaveScratch scratch[kQueryWaves];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int qi = blockIdx.x * kQueryWaves + wave;
+  if (qi >= Nq) return;  // no workgroup barrier below: waves are independent
+  WaveScratch& ws = scratch[wave];
+  volatile uint64_t* cand = ws.cand;
+
+  int b, qstart;
+  d3f::locate_batch(q_len, B, qi, b, qstart);
+  const float qx = q[3 * qi + 0], qy = q[3 * qi + 1], qz = q[3 * qi + 2];
+  const int cx = cell_coord(qx, inv_cell), cy = cell_coord(qy, inv_cell), cz = cell_coord(qz, inv_cell);
+
+  // lanes 0..26: one neighbor cell each
+  int len = 0;
+  if (lane < 27) {
+    const int dx = lane % 3 - 1, dy = (lane / 3) % 3 - 1, dz = lane / 9 - 1;
+    const uint64_t nk = pack_key(b, cx + dx, cy + dy, cz + dz);
+    const uint32_t bk = bucket_of(nk, mask);
+    const int st = start[bk];
+    len = end[bk] - st;
+    ws.nkey[lane] = nk;
+    ws.st[lane] = st;
+  }
+  int incl = len;
+#pragma unroll
+  for (int o = 1; o < 32; o <<= 1) {
+    const int t = __shfl_up(incl, o, 64);
+    if (lane >= o) incl += t;
+  }
+  if (lane < 32) ws.pre[lane] = incl - len;  // exclusive prefix; entries 27..31 == total
+  const int P = __shfl(incl, 31, 64);
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+
+  int T = 0;
+  for (int p0 = 0; p0 < P; p0 += 64) {
+    const int p = p0 + lane;
+    bool ok = false;
+    uint64_t packed = 0;
+    if (p < P) {
+      int lo = 0;  // largest j with pre[j] <= p
+#pragma unroll
+      for (int step = 16; step > 0; step >>= 1) {
+        const int j = lo + step;
+        if (j < 27 && ws.pre[j] <= p) lo = j;
+      }
+      const int pos = ws.st[lo] + (p - ws.pre[lo]);
+      const float4 sp = pts[pos];
+      if (key[pos] == ws.nkey[lo]) {
+        const float d2 = d3f::sqdist_exact(qx, qy, qz, sp.x, sp.y, sp.z);
+        ok = d2 < r2;
+        packed = ((uint64_t)__float_as_uint(d2) << 32) | (uint32_t)__float_as_int(sp.w);
+      }
+    }
+    const uint64_t m = __ballot(ok);
+    if (ok) {
+      const int slot = T + __popcll(m & ((1ull << lane) - 1ull));
+      if (slot < kCand) cand[slot] = packed;
+    }
+    T += __popcll(m);
+  }
+  if (lane == 0) {
+    if (out_counts) out_counts[qi] = T;
+    if (max_count && T > *max_count) atomicMax(max_count, T);
+    if (T > kCand) atomicOr(status, D3F_ST_CAND_OVERFLOW);
+  }
+  const int Tc = T < kCand ? T : kCand;
+  int32_t* row = out_idx + (size_t)qi * width;
+
+  if (Tc <= 64) {
+    // rank in registers: 64-key bitonic network over the wave
+    uint64_t v = lane < Tc ? cand[lane] : ~0ull;
+#pragma unroll
+    for (int k = 2; k <= 64; k <<= 1) {
+#pragma unroll
+      for (int j = k >> 1; j > 0; j >>= 1) {
+        const uint64_t o = shfl_xor_u64(v, j);
+        const bool up = (lane & k) == 0, lower = (lane & j) == 0;
+        const uint64_t mn = v < o ? v : o, mx = v < o ? o : v;
+        v = (lower == up) ? mn : mx;
+      }
+    }
+    if (lane < width) row[lane] = lane < Tc ? (int32_t)(uint32_t)v : Ns;
+    for (int c = 64 + lane; c < width; c += 64) row[c] = Ns;
+    return;
+  }
+
+  int n = 128;
+  while (n < Tc) n <<= 1;
+  for (int i = Tc + lane; i < n; i += 64) cand[i] = ~0ull;
+  for (int k = 2; k <= n; k <<= 1) {
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      for (int t = lane; t < (n >> 1); t += 64) {
+        const int a = ((t & ~(j - 1)) << 1) | (t & (j - 1));
+        const int c = a | j;
+        const bool up = (a & k) == 0;
+        const uint64_t va = cand[a], vc = cand[c];
+        if ((va > vc) == up) {
+          cand[a] = vc;
+          cand[c] = va;
+        }
+      }
+    }
+  }
+  for (int c = lane; c < width; c += 64) row[c] = c < Tc ? (int32_t)(uint32_t)cand[c] : Ns;
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t d3f_radius_grid_ws_bytes(int Ns) { return grid_layout(nullptr, Ns).bytes; }
+
+int d3f_radius_grid_build(const float* supports, int Ns, const int32_t* s_len, int B, float radius, void* grid_ws,
+                          size_t grid_ws_bytes, int32_t* status, void* stream_) {
+  if (!supports || !s_len || !grid_ws || !status || Ns < 0 || B < 1 || B > D3F_MAX_BATCH || !(radius > 0.0f))
+    return D3F_EINVAL;
+  hipStream_t stream = (hipStream_t)stream_;
+  GridLayout g = grid_layout(grid_ws, Ns);
+  if (grid_ws_bytes < g.bytes) return D3F_EWORKSPACE;
+  const double inv_cell = 1.0 / ((double)radius * kCellSlack);
+  if (hipMemsetAsync(g.cnt, 0, sizeof(int32_t) * (g.M + 64), stream) != hipSuccess) return D3F_ELAUNCH;
+  if (Ns > 0) {
+    grid_count_kernel<<<d3f::cdiv(Ns, 256), 256, 0, stream>>>(supports, Ns, s_len, B, inv_cell, g.M - 1, g.cnt,
+                                                             g.key_tmp, status);
+    D3F_LAUNCH_CHECK();
+  }
+  grid_alloc_kernel<<<d3f::cdiv(g.M, 256), 256, 0, stream>>>(g.M, g.cnt, g.start, g.end);
+  D3F_LAUNCH_CHECK();
+  if (Ns > 0) {
+    grid_scatter_kernel<<<d3f::cdiv(Ns, 256), 256, 0, stream>>>(supports, Ns, g.M - 1, g.key_tmp, g.end, g.pts, g.key);
+    D3F_LAUNCH_CHECK();
+  }
+  return D3F_OK;
+}
+
+int d3f_radius_query(const void* grid_ws, const float* queries, int Nq, const int32_t* q_len, const float* supports,
+                     int Ns, const int32_t* s_len, int B, float radius, int width, int32_t* out_idx,
+                     int32_t* out_counts, int32_t* max_count, int32_t* status, void* stream_) {
+  (void)supports;
+  if (!grid_ws || !queries || !q_len || !s_len || !out_idx || !status || Nq < 0 || Ns < 0 || B < 1 ||
+      B > D3F_MAX_BATCH || width < 1 || width > kCand || !(radius > 0.0f))
+    return D3F_EINVAL;
+  if (Nq == 0) return D3F_OK;
+  hipStream_t stream = (hipStream_t)stream_;
+  GridLayout g = grid_layout(const_cast<void*>(grid_ws), Ns);
+  const double inv_cell = 1.0 / ((double)radius * kCellSlack);
+  const float r2 = radius * radius;  // float32 product, like neighbors.cpp:226
+  radius_query_kernel<<<d3f::cdiv(Nq, kQueryWaves), kQueryWaves * 64, 0, stream>>>(
+      queries, Nq, q_len, s_len, B, Ns, inv_cell, r2, g.M - 1, g.start, g.end, g.pts, g.key, width, out_idx,
+      out_counts, max_count, status);
+  D3F_LAUNCH_CHECK();
+  return D3F_OK;
+}
+
+}  // extern "C"

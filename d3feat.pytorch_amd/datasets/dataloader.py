@@ -1,0 +1,260 @@
+"""Device-resident batch construction: mirror of the reference's ``datasets/dataloader.py``.
+
+Reference functions and what replaces them:
+  batch_grid_subsampling_kpconv (dataloader.py:12-50)   -> HIP voxel-hash subsampling (csrc/grid_subsample.hip)
+  batch_neighbors_kpconv        (dataloader.py:52-67)   -> HIP cell-list radius search (csrc/radius_neighbors.hip)
+  collate_fn_descriptor         (dataloader.py:69-189)  -> the same block walk, executed on the GPU: the voxel levels
+                                                           are chained on the device (one host read-back of the level
+                                                           sizes per pair instead of 17 CPU calls), one cell list per
+                                                           level serves its conv / pool / upsample searches
+  calibrate_neighbors           (dataloader.py:191-223) -> count-only queries + device histogram
+In the reference these run on CPU inside DataLoader worker processes and gate the GPU; here they are stream-ordered
+kernels in the training process.  Inputs may be NumPy arrays / CPU tensors (as the reference's datasets yield) or
+device tensors; outputs are device tensors (the reference's ``.to(device)`` loop becomes a no-op).
+
+Index tensors are int32 by default (the reference casts to int64, dataloader.py:161-163, which doubles the bytes the
+KPConv gather has to read); pass ``index_dtype=torch.int64`` for bit-for-bit dtype parity.
+"""
+import numpy as np
+import torch
+
+from .. import ops
+
+
+def _device(device=None):
+    if device is not None:
+        return torch.device(device)
+    if not torch.cuda.is_available():
+        raise RuntimeError("d3feat_pytorch_amd needs a HIP device: the batch builder runs on the GPU (no CPU path)")
+    return torch.device("cuda", torch.cuda.current_device())
+
+
+def _to_dev(a, dtype, device):
+    if isinstance(a, torch.Tensor):
+        return a.to(device=device, dtype=dtype).contiguous()
+    return torch.as_tensor(np.ascontiguousarray(a), dtype=dtype).to(device)
+
+
+def batch_grid_subsampling_kpconv(points, batches_len, features=None, labels=None, sampleDl=0.1, max_p=0, verbose=0,
+                                  random_grid_orient=True, order=ops.ORDER_REFERENCE):
+    """(s_points float32 [N',3], s_len int32 [B]) -- reference dataloader.py:12-22 (points-only branch).
+
+    Rows come in the reference's order (``order=ops.ORDER_REFERENCE``).  Feature / label averaging (the branches
+    D3Feat's collate never takes, dataloader.py:24-50) is not implemented on the device."""
+    if features is not None or labels is not None:
+        raise NotImplementedError("grid subsampling of features/labels is outside the D3Feat hot path")
+    dev = points.device if isinstance(points, torch.Tensor) and points.is_cuda else _device()
+    p = _to_dev(points, torch.float32, dev)
+    out, out_len, total, status = ops.grid_subsample_raw(p, batches_len, sampleDl, max_p=max_p, order=order)
+    n = int(total.item())  # the one read-back this standalone form needs
+    status.raise_if_set()
+    if n < 1:
+        raise RuntimeError("Error")  # cpp_subsampling/wrapper.cpp:266
+    return out[:n], out_len
+
+
+def batch_neighbors_kpconv(queries, supports, q_batches, s_batches, radius, max_neighbors):
+    """int32 [Nq, min(max_neighbors, max_count)] neighbor table -- reference dataloader.py:52-67.
+
+    Rows: supports of the same cloud with d2 < radius^2, ascending d2 (ties by index), padded with len(supports)."""
+    dev = queries.device if isinstance(queries, torch.Tensor) and queries.is_cuda else _device()
+    q = _to_dev(queries, torch.float32, dev)
+    s = _to_dev(supports, torch.float32, dev)
+    grid = ops.RadiusGrid(s, s_batches, radius)
+    if max_neighbors > 0:
+        idx, mx = grid.query(q, q_batches, int(max_neighbors), want_max=True)
+        width = min(int(mx.item()), int(max_neighbors))
+    else:
+        _, mx = grid.query(q, q_batches, 1, want_max=True)
+        width = int(mx.item())
+        idx = grid.query(q, q_batches, max(width, 1)) if width > 0 else None
+    grid.status.raise_if_set()
+    if width < 1:
+        raise RuntimeError("Error")  # cpp_neighbors/wrapper.cpp:201-205: an all-empty result is an error
+    return idx if idx.shape[1] == width else idx[:, :width].contiguous()
+
+
+# north-star spellings
+batch_neighbors = batch_neighbors_kpconv
+batch_grid_subsampling = batch_grid_subsampling_kpconv
+
+
+class _Walk:
+    """The reference's block walk (dataloader.py:98-178): which layers convolve, which pool, with what radius."""
+
+    def __init__(self, config):
+        self.layers = []  # dicts: conv_r (or None), pool (bool), pool_r, dl, up_r
+        r_normal = config.first_subsampling_dl * config.conv_radius
+        layer_blocks = []
+        arch = config.architecture
+        for block_i, block in enumerate(arch):
+            if 'global' in block or 'upsample' in block:
+                break
+            if not ('pool' in block or 'strided' in block):
+                layer_blocks += [block]
+                if block_i < len(arch) - 1 and not ('upsample' in arch[block_i + 1]):
+                    continue
+            entry = {'conv_r': None, 'pool': False}
+            if layer_blocks:
+                if np.any(['deformable' in blck for blck in layer_blocks[:-1]]):
+                    entry['conv_r'] = r_normal * config.deform_radius / config.conv_radius
+                else:
+                    entry['conv_r'] = r_normal
+            if 'pool' in block or 'strided' in block:
+                entry['pool'] = True
+                entry['dl'] = 2 * r_normal / config.conv_radius
+                entry['pool_r'] = (r_normal * config.deform_radius / config.conv_radius) if 'deformable' in block \
+                    else r_normal
+                entry['up_r'] = 2 * entry['pool_r']
+            self.layers.append(entry)
+            r_normal *= 2
+            layer_blocks = []
+
+
+def build_pyramid(points, lengths, config, neighborhood_limits, index_dtype=torch.int32, exact_width=False,
+                  order=ops.ORDER_REFERENCE):
+    """points [N0,3] + stack lengths [B] -> dict(points, neighbors, pools, upsamples, stack_lengths) on the device.
+
+    One host synchronisation (level sizes) per call; with ``exact_width`` a second one trims every neighbor table
+    to the reference's width min(limit, max_count)."""
+    dev = points.device
+    walk = _Walk(config)
+    L = len(walk.layers)
+    status = ops.DeviceStatus(dev)
+    # 1. chain the voxel levels on the device
+    cap_pts, lens, totals = [points], [ops._lens(lengths, dev, "lengths")], []
+    for li, e in enumerate(walk.layers):
+        if not e['pool']:
+            continue
+        out, out_len, total, _ = ops.grid_subsample_raw(cap_pts[-1], lens[-1], e['dl'], order=order, status=status)
+        cap_pts.append(out)
+        lens.append(out_len)
+        totals.append(total)
+    if totals:
+        sizes = torch.cat(totals + [status.word]).tolist()  # the single read-back
+        if sizes[-1]:
+            status.raise_if_set()
+        pts = [points] + [cap_pts[i + 1][:sizes[i]] for i in range(len(totals))]
+    else:
+        pts = [points]
+    # 2. neighbor tables; one cell list per (level, radius)
+    grids = {}
+
+    def grid_for(level, radius):
+        key = (level, float(radius))
+        if key not in grids:
+            grids[key] = ops.RadiusGrid(pts[level], lens[level], radius, status=status)
+        return grids[key]
+
+    empty_idx = torch.zeros((0, 1), dtype=index_dtype, device=dev)
+    neighbors, pools, upsamples, maxima = [], [], [], []
+    level = 0
+    for li, e in enumerate(walk.layers):
+        lim = int(neighborhood_limits[li])
+
+        def run(qlevel, slevel, radius):
+            res = grid_for(slevel, radius).query(pts[qlevel], lens[qlevel], lim, want_max=exact_width)
+            if exact_width:
+                maxima.append(res[1])
+                return res[0]
+            return res
+
+        neighbors.append(run(level, level, e['conv_r']) if e['conv_r'] is not None else empty_idx)
+        if e['pool']:
+            pools.append(run(level + 1, level, e['pool_r']))
+            upsamples.append(run(level, level + 1, e['up_r']))
+            level += 1
+        else:
+            pools.append(empty_idx)
+            upsamples.append(empty_idx)
+    if exact_width and maxima:
+        mx = torch.cat(maxima).tolist()  # second read-back; walk in the order the maxima were appended
+        k = 0
+        for li, e in enumerate(walk.layers):
+            for name, lst, present in (("n", neighbors, e['conv_r'] is not None), ("p", pools, e['pool']),
+                                       ("u", upsamples, e['pool'])):
+                if not present:
+                    continue
+                w = mx[k]
+                k += 1
+                if w < 1:
+                    raise RuntimeError("Error")
+                if w < lst[li].shape[1]:
+                    lst[li] = lst[li][:, :w].contiguous()
+    if index_dtype != torch.int32:
+        neighbors = [t.to(index_dtype) for t in neighbors]
+        pools = [t.to(index_dtype) for t in pools]
+        upsamples = [t.to(index_dtype) for t in upsamples]
+    n_levels = len(neighbors)
+    out_pts = [pts[min(i, len(pts) - 1)] for i in range(n_levels)]
+    out_lens = [lens[min(i, len(lens) - 1)] for i in range(n_levels)]
+    return {'points': out_pts, 'neighbors': neighbors, 'pools': pools, 'upsamples': upsamples,
+            'stack_lengths': out_lens, '_status': status}
+
+
+def collate_fn_descriptor(list_data, config, neighborhood_limits, device=None, index_dtype=torch.int32,
+                          exact_width=True):
+    """One fragment pair -> the multi-scale batch dict of the reference (dataloader.py:69-189), built on the GPU."""
+    assert len(list_data) == 1
+    dev = _device(device)
+    pts0, pts1, feat0, feat1, sel_corr, dist_keypts = list_data[0]
+    p0, p1 = _to_dev(pts0, torch.float32, dev), _to_dev(pts1, torch.float32, dev)
+    points = torch.cat([p0, p1], dim=0)
+    feats = torch.cat([_to_dev(feat0, torch.float32, dev), _to_dev(feat1, torch.float32, dev)], dim=0)
+    lengths = torch.tensor([p0.shape[0], p1.shape[0]], dtype=torch.int32, device=dev)
+    d = build_pyramid(points, lengths, config, neighborhood_limits, index_dtype=index_dtype, exact_width=exact_width)
+    d.pop('_status')
+    d['features'] = feats
+    d['corr'] = sel_corr.to(dev) if isinstance(sel_corr, torch.Tensor) else torch.from_numpy(np.asarray(sel_corr)).to(dev)
+    d['dist_keypts'] = dist_keypts.to(dev) if isinstance(dist_keypts, torch.Tensor) \
+        else torch.from_numpy(np.asarray(dist_keypts)).to(dev)
+    return d
+
+
+def calibrate_neighbors(dataset, config, collate_fn=None, keep_ratio=0.8, samples_threshold=2000, device=None):
+    """Per-layer neighbor cap = the keep_ratio quantile of the neighborhood-size histogram (dataloader.py:191-223).
+
+    The reference materialises uncapped neighbor matrices on CPU; here only per-query counts leave the kernel."""
+    dev = _device(device)
+    hist_n = int(np.ceil(4 / 3 * np.pi * (config.deform_radius + 1) ** 3))
+    walk = _Walk(config)
+    n_layers = config.num_layers
+    hists = torch.zeros((n_layers, hist_n), dtype=torch.int64, device=dev)
+    for i in range(len(dataset)):
+        pts0, pts1 = dataset[i][0], dataset[i][1]
+        p = torch.cat([_to_dev(pts0, torch.float32, dev), _to_dev(pts1, torch.float32, dev)], dim=0)
+        lens = torch.tensor([len(pts0), len(pts1)], dtype=torch.int32, device=dev)
+        for li, e in enumerate(walk.layers[:n_layers]):
+            if e['conv_r'] is not None:
+                _, counts = ops.RadiusGrid(p, lens, e['conv_r']).query(p, lens, 1, want_counts=True)
+                c = counts.long()
+                hists[li] += torch.bincount(c[c < hist_n], minlength=hist_n)[:hist_n]
+            if e['pool']:
+                p, lens = batch_grid_subsampling_kpconv(p, lens, sampleDl=e['dl'])
+        if int(hists.sum(dim=1).min().item()) > samples_threshold:
+            break
+    h = hists.cpu().numpy()
+    cumsum = np.cumsum(h.T, axis=0)
+    return np.sum(cumsum < (keep_ratio * cumsum[hist_n - 1, :]), axis=0)
+
+
+class _PairLoader:
+    """Minimal stand-in for the reference's DataLoader (dataloader.py:225-238): batch_size 1, collate on device."""
+
+    def __init__(self, dataset, config, neighborhood_limits, shuffle):
+        self.dataset, self.config, self.limits, self.shuffle = dataset, config, neighborhood_limits, shuffle
+        self.batch_size = 1
+
+    def __len__(self):
+        return len(self.dataset)
+
+    def __iter__(self):
+        order = np.random.permutation(len(self.dataset)) if self.shuffle else np.arange(len(self.dataset))
+        for i in order:
+            yield collate_fn_descriptor([self.dataset[int(i)]], self.config, self.limits)
+
+
+def get_dataloader(dataset, batch_size=1, num_workers=0, shuffle=True, neighborhood_limits=None):
+    if neighborhood_limits is None:
+        neighborhood_limits = calibrate_neighbors(dataset, dataset.config, collate_fn=collate_fn_descriptor)
+    return _PairLoader(dataset, dataset.config, neighborhood_limits, shuffle), neighborhood_limits

@@ -1,0 +1,87 @@
+"""KPFCNN encoder/decoder + detector head: host-side mirror of the reference's ``models/architectures.py``.
+
+The reference file itself runs unchanged on top of ``d3feat_pytorch_amd.models.blocks`` (that is the drop-in
+boundary); this module is the copy-free equivalent that travels with the repo, because
+the reference tree is not present on the GPU box.  Same constructor (``KPFCNN(config)``), same sub-module names
+(``encoder_blocks`` / ``decoder_blocks`` -> identical ``state_dict`` keys), same forward contract
+(architectures.py:299-320: ``(F.normalize(x), scores)``), and ``detection_scores`` (architectures.py:322-368) is the
+fused HIP kernel instead of ~25 PyTorch ops over a gathered [N,H,C] tensor.
+"""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .. import ops
+from .blocks import KPConv, block_decider  # noqa: F401
+
+
+def _moves_level(block):
+    return any(tag in block for tag in ('pool', 'strided', 'upsample', 'global'))
+
+
+class KPFCNN(nn.Module):
+    def __init__(self, config, verbose=False):
+        super(KPFCNN, self).__init__()
+        arch = list(config.architecture)
+        layer = 0
+        r = config.first_subsampling_dl * config.conv_radius
+        in_dim = config.in_features_dim
+        out_dim = config.first_features_dim
+        self.K = config.num_kernel_points
+
+        # ---- encoder: every block up to the first upsampling one (architectures.py:209-254)
+        self.encoder_blocks = nn.ModuleList()
+        self.encoder_skip_dims = []
+        self.encoder_skips = []
+        first_up = len(arch)
+        for i, block in enumerate(arch):
+            if 'equivariant' in block and out_dim % 3 != 0:
+                raise ValueError('Equivariant block but features dimension is not a factor of 3')
+            if _moves_level(block):
+                self.encoder_skips.append(i)
+                self.encoder_skip_dims.append(in_dim)
+            if 'upsample' in block:
+                first_up = i
+                break
+            self.encoder_blocks.append(block_decider(block, r, in_dim, out_dim, layer, config))
+            in_dim = out_dim // 2 if 'simple' in block else out_dim
+            if 'pool' in block or 'strided' in block:
+                layer += 1
+                r *= 2
+                out_dim *= 2
+
+        # ---- decoder: skip features are concatenated in front of the block that follows an upsampling
+        self.decoder_blocks = nn.ModuleList()
+        self.decoder_concats = []
+        for j, block in enumerate(arch[first_up:]):
+            if j > 0 and 'upsample' in arch[first_up + j - 1]:
+                in_dim += self.encoder_skip_dims[layer]
+                self.decoder_concats.append(j)
+            self.decoder_blocks.append(block_decider(block, r, in_dim, out_dim, layer, config))
+            in_dim = out_dim
+            if 'upsample' in block:
+                layer -= 1
+                r *= 0.5
+                out_dim = out_dim // 2
+        if verbose:
+            print(self)
+
+    def forward(self, batch):
+        x = batch['features'].clone().detach()
+        skips = []
+        for i, op in enumerate(self.encoder_blocks):
+            if i in self.encoder_skips:
+                skips.append(x)
+            x = op(x, batch)
+        for j, op in enumerate(self.decoder_blocks):
+            if j in self.decoder_concats:
+                x = torch.cat([x, skips.pop()], dim=1)
+            x = op(x, batch)
+        scores = self.detection_scores(batch, x)
+        features = F.normalize(x, p=2, dim=-1)
+        return features, scores
+
+    def detection_scores(self, inputs, features):
+        """Saliency score of every point [N,1] (reference architectures.py:322-368); eval mode adds the
+        local-maximum gate."""
+        return ops.detection_scores(features, inputs['neighbors'][0], training=self.training)

@@ -1,0 +1,294 @@
+"""Drop-in mirror of the reference's ``models/blocks.py`` operator API on the HIP kernels.
+
+Same names, constructor arguments, parameter names (``weights`` [K,Cin,Cout], ``kernel_points`` [K,3] -- fixed by
+checkpoints) and call signatures as the reference (models/blocks.py: gather:35, closest_pool:79, max_pool:94,
+global_average:113, KPConv:143, block_decider:395, BatchNormBlock:441, UnaryBlock:481, LastUnaryBlock:518,
+SimpleBlock:544, ResnetBottleneckBlock:601, GlobalAverageBlock:689, NearestUpsampleBlock:702, MaxPoolBlock:720), so
+``models/architectures.py`` (``from models.blocks import *``; ``block_decider(...)``; ``isinstance(m, KPConv)``)
+runs on top of it unchanged.  The operators themselves are the hand-written HIP kernels of
+``libd3feat_hip.so`` -- there is no PyTorch implementation of the hot path in this file.
+
+Out of scope here (never enabled by D3Feat's config, config.py:39-46): deformable / modulated KPConv, the
+'constant' / 'gaussian' influences and 'closest' aggregation; they raise NotImplementedError.
+"""
+import math
+
+import torch
+import torch.nn as nn
+from torch.nn.init import kaiming_uniform_
+from torch.nn.parameter import Parameter
+
+from .. import ops
+from ..kernels.kernel_points import load_kernels
+# north-star spellings of the two preprocessing operators live next to KPConv as well
+from ..datasets.dataloader import (batch_grid_subsampling_kpconv, batch_neighbors_kpconv,  # noqa: F401
+                                   batch_grid_subsampling, batch_neighbors)
+
+__all__ = ['gather', 'radius_gaussian', 'closest_pool', 'max_pool', 'global_average', 'KPConv', 'block_decider',
+           'BatchNormBlock', 'UnaryBlock', 'LastUnaryBlock', 'SimpleBlock', 'ResnetBottleneckBlock',
+           'GlobalAverageBlock', 'NearestUpsampleBlock', 'MaxPoolBlock', 'batch_neighbors_kpconv',
+           'batch_grid_subsampling_kpconv', 'batch_neighbors', 'batch_grid_subsampling',
+           'nn', 'torch', 'math', 'Parameter']
+
+
+def gather(x, idx, method=2):
+    """x[idx] with shape idx.shape + x.shape[1:] (reference blocks.py:35-66; all three methods are equal in value)."""
+    if method not in (0, 1, 2):
+        raise ValueError('Unkown method')
+    return x[idx.long()]
+
+
+def radius_gaussian(sq_r, sig, eps=1e-9):
+    return torch.exp(-sq_r / (2 * sig ** 2 + eps))
+
+
+def closest_pool(x, inds):
+    """Features of the closest neighbor: x'[inds[:, 0]] with a zero shadow row (reference blocks.py:79-91)."""
+    return ops.closest_pool(x, inds)
+
+
+def max_pool(x, inds):
+    """Channel-wise max over each neighborhood, zero shadow row (reference blocks.py:94-110)."""
+    return ops.max_pool(x, inds)
+
+
+def global_average(x, batch_lengths):
+    """Per-cloud mean of the stacked features (reference blocks.py:113-134)."""
+    out, i0 = [], 0
+    for length in batch_lengths:
+        length = int(length)
+        out.append(torch.mean(x[i0:i0 + length], dim=0))
+        i0 += length
+    return torch.stack(out)
+
+
+class KPConv(nn.Module):
+    """Kernel point convolution (reference blocks.py:143-387), rigid kernel."""
+
+    def __init__(self, kernel_size, p_dim, in_channels, out_channels, KP_extent, radius,
+                 fixed_kernel_points='center', KP_influence='linear', aggregation_mode='sum',
+                 deformable=False, modulated=False):
+        super(KPConv, self).__init__()
+        self.K = kernel_size
+        self.p_dim = p_dim
+        self.in_channels = in_channels
+        self.out_channels = out_channels
+        self.radius = radius
+        self.KP_extent = KP_extent
+        self.fixed_kernel_points = fixed_kernel_points
+        self.KP_influence = KP_influence
+        self.aggregation_mode = aggregation_mode
+        self.deformable = deformable
+        self.modulated = modulated
+        self.min_d2 = None
+        self.deformed_KP = None
+        self.offset_features = None
+        self.offset_dim = None
+        self.offset_conv = None
+        self.offset_bias = None
+        if deformable or modulated and deformable:
+            raise NotImplementedError('deformable KPConv is outside the D3Feat hot path (config.py:45-46)')
+        if KP_influence != 'linear' or aggregation_mode != 'sum':
+            raise NotImplementedError("only KP_influence='linear', aggregation_mode='sum' (config.py:39,41)")
+        if p_dim != 3 or kernel_size > 16:
+            raise NotImplementedError('HIP KPConv supports 3-D points and at most 16 kernel points')
+        self.weights = Parameter(torch.zeros((self.K, in_channels, out_channels), dtype=torch.float32),
+                                 requires_grad=True)
+        self.reset_parameters()
+        self.kernel_points = self.init_KP()
+
+    def reset_parameters(self):
+        kaiming_uniform_(self.weights, a=math.sqrt(5))
+
+    def init_KP(self):
+        kp = load_kernels(self.radius, self.K, dimension=self.p_dim, fixed=self.fixed_kernel_points)
+        return Parameter(torch.tensor(kp, dtype=torch.float32), requires_grad=False)
+
+    def forward(self, q_pts, s_pts, neighb_inds, x):
+        return ops.kpconv(q_pts, s_pts, neighb_inds, x, self.kernel_points, self.weights, self.KP_extent)
+
+    def __repr__(self):
+        return 'KPConv(radius: {:.2f}, extent: {:.2f}, in_feat: {:d}, out_feat: {:d})'.format(
+            self.radius, self.KP_extent, self.in_channels, self.out_channels)
+
+
+def block_decider(block_name, radius, in_dim, out_dim, layer_ind, config):
+    """Block factory with the reference's block vocabulary (blocks.py:395-438)."""
+    if block_name == 'unary':
+        return UnaryBlock(in_dim, out_dim, config.use_batch_norm, config.batch_norm_momentum)
+    if block_name == 'last_unary':
+        return LastUnaryBlock(in_dim, 32, config.use_batch_norm, config.batch_norm_momentum)
+    if block_name.startswith('simple'):
+        return SimpleBlock(block_name, in_dim, out_dim, radius, layer_ind, config)
+    if block_name.startswith('resnetb'):
+        return ResnetBottleneckBlock(block_name, in_dim, out_dim, radius, layer_ind, config)
+    if block_name in ('max_pool', 'max_pool_wide'):
+        return MaxPoolBlock(layer_ind)
+    if block_name == 'global_average':
+        return GlobalAverageBlock()
+    if block_name == 'nearest_upsample':
+        return NearestUpsampleBlock(layer_ind)
+    raise ValueError('Unknown block name in the architecture definition : ' + block_name)
+
+
+class BatchNormBlock(nn.Module):
+    """BatchNorm1d over the stacked points, or a learned bias when use_bn is False (reference blocks.py:441-478)."""
+
+    def __init__(self, in_dim, use_bn, bn_momentum):
+        super(BatchNormBlock, self).__init__()
+        self.bn_momentum = bn_momentum
+        self.use_bn = use_bn
+        self.in_dim = in_dim
+        if self.use_bn:
+            self.batch_norm = nn.BatchNorm1d(in_dim, momentum=bn_momentum)
+        else:
+            self.bias = Parameter(torch.zeros(in_dim, dtype=torch.float32), requires_grad=True)
+
+    def reset_parameters(self):
+        nn.init.zeros_(self.bias)
+
+    def forward(self, x):
+        if self.use_bn:
+            return self.batch_norm(x.unsqueeze(2).transpose(0, 2)).transpose(0, 2).squeeze()
+        return x + self.bias
+
+    def __repr__(self):
+        return 'BatchNormBlock(in_feat: {:d}, momentum: {:.3f}, only_bias: {:s})'.format(
+            self.in_dim, self.bn_momentum, str(not self.use_bn))
+
+
+class UnaryBlock(nn.Module):
+    """Linear + (BN | bias) + LeakyReLU(0.1) (reference blocks.py:481-515)."""
+
+    def __init__(self, in_dim, out_dim, use_bn, bn_momentum, no_relu=False):
+        super(UnaryBlock, self).__init__()
+        self.bn_momentum = bn_momentum
+        self.use_bn = use_bn
+        self.no_relu = no_relu
+        self.in_dim = in_dim
+        self.out_dim = out_dim
+        self.mlp = nn.Linear(in_dim, out_dim, bias=True)
+        self.batch_norm = BatchNormBlock(out_dim, self.use_bn, self.bn_momentum)
+        if not no_relu:
+            self.leaky_relu = nn.LeakyReLU(0.1)
+
+    def forward(self, x, batch=None):
+        x = self.batch_norm(self.mlp(x))
+        return x if self.no_relu else self.leaky_relu(x)
+
+    def __repr__(self):
+        return 'UnaryBlock(in_feat: {:d}, out_feat: {:d}, BN: {:s}, ReLU: {:s})'.format(
+            self.in_dim, self.out_dim, str(self.use_bn), str(not self.no_relu))
+
+
+class LastUnaryBlock(nn.Module):
+    """Plain Linear head (reference blocks.py:518-541)."""
+
+    def __init__(self, in_dim, out_dim, use_bn, bn_momentum, no_relu=False):
+        super(LastUnaryBlock, self).__init__()
+        self.in_dim = in_dim
+        self.out_dim = out_dim
+        self.mlp = nn.Linear(in_dim, out_dim, bias=True)
+
+    def forward(self, x, batch=None):
+        return self.mlp(x)
+
+    def __repr__(self):
+        return 'LastUnaryBlock(in_feat: {:d}, out_feat: {:d})'.format(self.in_dim, self.out_dim)
+
+
+def _layer_inputs(block_name, layer_ind, batch):
+    """(queries, supports, neighbor table) of a block: strided blocks pool onto the next level (blocks.py:588-595)."""
+    if 'strided' in block_name:
+        return batch['points'][layer_ind + 1], batch['points'][layer_ind], batch['pools'][layer_ind]
+    return batch['points'][layer_ind], batch['points'][layer_ind], batch['neighbors'][layer_ind]
+
+
+def _make_kpconv(block_name, in_dim, out_dim, radius, config):
+    extent = radius * config.KP_extent / config.conv_radius
+    return KPConv(config.num_kernel_points, config.in_points_dim, in_dim, out_dim, extent, radius,
+                  fixed_kernel_points=config.fixed_kernel_points, KP_influence=config.KP_influence,
+                  aggregation_mode=config.aggregation_mode, deformable='deform' in block_name,
+                  modulated=config.modulated)
+
+
+class SimpleBlock(nn.Module):
+    """KPConv(in -> out/2) + bias/BN + LeakyReLU (reference blocks.py:544-598)."""
+
+    def __init__(self, block_name, in_dim, out_dim, radius, layer_ind, config):
+        super(SimpleBlock, self).__init__()
+        self.bn_momentum = config.batch_norm_momentum
+        self.use_bn = config.use_batch_norm
+        self.layer_ind = layer_ind
+        self.block_name = block_name
+        self.in_dim = in_dim
+        self.out_dim = out_dim
+        self.KPConv = _make_kpconv(block_name, in_dim, out_dim // 2, radius, config)
+        self.batch_norm = BatchNormBlock(out_dim // 2, self.use_bn, self.bn_momentum)
+        self.leaky_relu = nn.LeakyReLU(0.1)
+
+    def forward(self, x, batch):
+        q_pts, s_pts, inds = _layer_inputs(self.block_name, self.layer_ind, batch)
+        return self.leaky_relu(self.batch_norm(self.KPConv(q_pts, s_pts, inds, x)))
+
+
+class ResnetBottleneckBlock(nn.Module):
+    """unary(in -> out/4) -> KPConv -> unary(out/4 -> out) + shortcut (reference blocks.py:601-686)."""
+
+    def __init__(self, block_name, in_dim, out_dim, radius, layer_ind, config):
+        super(ResnetBottleneckBlock, self).__init__()
+        self.bn_momentum = config.batch_norm_momentum
+        self.use_bn = config.use_batch_norm
+        self.block_name = block_name
+        self.layer_ind = layer_ind
+        self.in_dim = in_dim
+        self.out_dim = out_dim
+        mid = out_dim // 4
+        self.unary1 = UnaryBlock(in_dim, mid, self.use_bn, self.bn_momentum) if in_dim != mid else nn.Identity()
+        self.KPConv = _make_kpconv(block_name, mid, mid, radius, config)
+        self.batch_norm_conv = BatchNormBlock(mid, self.use_bn, self.bn_momentum)
+        self.unary2 = UnaryBlock(mid, out_dim, self.use_bn, self.bn_momentum, no_relu=True)
+        if in_dim != out_dim:
+            self.unary_shortcut = UnaryBlock(in_dim, out_dim, self.use_bn, self.bn_momentum, no_relu=True)
+        else:
+            self.unary_shortcut = nn.Identity()
+        self.leaky_relu = nn.LeakyReLU(0.1)
+
+    def forward(self, features, batch):
+        q_pts, s_pts, inds = _layer_inputs(self.block_name, self.layer_ind, batch)
+        x = self.unary1(features)
+        x = self.leaky_relu(self.batch_norm_conv(self.KPConv(q_pts, s_pts, inds, x)))
+        x = self.unary2(x)
+        shortcut = max_pool(features, inds) if 'strided' in self.block_name else features
+        return self.leaky_relu(x + self.unary_shortcut(shortcut))
+
+
+class GlobalAverageBlock(nn.Module):
+    def __init__(self):
+        super(GlobalAverageBlock, self).__init__()
+
+    def forward(self, x, batch):
+        return global_average(x, batch['stack_lengths'][-1])
+
+
+class NearestUpsampleBlock(nn.Module):
+    """Nearest-neighbor upsampling onto the finer level (reference blocks.py:702-717)."""
+
+    def __init__(self, layer_ind):
+        super(NearestUpsampleBlock, self).__init__()
+        self.layer_ind = layer_ind
+
+    def forward(self, x, batch):
+        return closest_pool(x, batch['upsamples'][self.layer_ind - 1])
+
+    def __repr__(self):
+        return 'NearestUpsampleBlock(layer: {:d} -> {:d})'.format(self.layer_ind, self.layer_ind - 1)
+
+
+class MaxPoolBlock(nn.Module):
+    def __init__(self, layer_ind):
+        super(MaxPoolBlock, self).__init__()
+        self.layer_ind = layer_ind
+
+    def forward(self, x, batch):
+        return max_pool(x, batch['pools'][self.layer_ind + 1])

@@ -1,0 +1,356 @@
+"""Tensor-level operators over the C ABI (device tensors in, device tensors out, autograd where the reference
+has it).  Every function here launches hand-written HIP kernels from ``libd3feat_hip.so``; none has a PyTorch or
+CPU fallback.  Reference locations are cited per operator.
+"""
+import torch
+
+from . import _native
+
+ORDER_REFERENCE = 0   # row order of the reference's std::unordered_map iteration (grid_subsampling.cpp:85)
+ORDER_FIRST_SEEN = 1  # cells in order of their first input point
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _f32(t, name):
+    if not isinstance(t, torch.Tensor) or not t.is_cuda:
+        raise RuntimeError("%s must be a CUDA/HIP tensor (d3feat_pytorch_amd has no CPU path)" % name)
+    if t.dtype != torch.float32:
+        t = t.float()
+    return t.contiguous()
+
+
+def _i32(t, name):
+    if not isinstance(t, torch.Tensor) or not t.is_cuda:
+        raise RuntimeError("%s must be a CUDA/HIP tensor (d3feat_pytorch_amd has no CPU path)" % name)
+    if t.dtype != torch.int32:
+        t = t.to(torch.int32)  # the reference hands LongTensors (dataloader.py:161-163)
+    return t.contiguous()
+
+
+def _lens(t, device, name):
+    """Stack lengths as an int32 device tensor (accepts lists / CPU tensors like the reference's q_batches)."""
+    if not isinstance(t, torch.Tensor):
+        t = torch.as_tensor(t, dtype=torch.int32)
+    return t.to(device=device, dtype=torch.int32).contiguous().view(-1)
+
+
+def _ws(nbytes, device):
+    return torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
+
+
+def _p(t):
+    return t.data_ptr() if t is not None else None
+
+
+class DeviceStatus:
+    """int32 device word the kernels OR error bits into; checked at the caller's next natural sync."""
+
+    def __init__(self, device):
+        self.word = torch.zeros(1, dtype=torch.int32, device=device)
+
+    def raise_if_set(self):
+        v = int(self.word.item())
+        if v:
+            raise RuntimeError(_native.status_message(v) or ("device status %d" % v))
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# radius neighbors (cpp_wrappers/cpp_neighbors; datasets/dataloader.py:52-67)
+# ---------------------------------------------------------------------------------------------------------------
+class RadiusGrid:
+    """Cell list of one support cloud for one radius; serves any number of query sets."""
+
+    def __init__(self, supports, s_len, radius, status=None):
+        self.supports = _f32(supports, "supports")
+        if self.supports.dim() != 2 or self.supports.shape[1] != 3:
+            raise RuntimeError("Wrong dimensions : support.shape is not (N, 3)")
+        dev = self.supports.device
+        self.s_len = _lens(s_len, dev, "s_batches")
+        self.radius = float(radius)
+        self.status = status if status is not None else DeviceStatus(dev)
+        L = _native.lib()
+        self.Ns = int(self.supports.shape[0])
+        nbytes = L.d3f_radius_grid_ws_bytes(self.Ns)
+        self.ws = _ws(nbytes, dev)
+        _native.check(L.d3f_radius_grid_build(_p(self.supports), self.Ns, _p(self.s_len), int(self.s_len.numel()),
+                                              self.radius, _p(self.ws), nbytes, _p(self.status.word), _stream()),
+                      "d3f_radius_grid_build")
+
+    def query(self, queries, q_len, width, want_counts=False, want_max=False):
+        """int32 [Nq, width] neighbor table (+ per-query uncapped counts, + device max count)."""
+        q = _f32(queries, "queries")
+        if q.dim() != 2 or q.shape[1] != 3:
+            raise RuntimeError("Wrong dimensions : query.shape is not (N, 3)")
+        q_len = _lens(q_len, q.device, "q_batches")
+        if q_len.numel() != self.s_len.numel():
+            raise RuntimeError("Wrong number of batch elements: different for queries and supports ")
+        Nq = int(q.shape[0])
+        out = torch.empty((Nq, int(width)), dtype=torch.int32, device=q.device)
+        counts = torch.empty(Nq, dtype=torch.int32, device=q.device) if want_counts else None
+        mx = torch.zeros(1, dtype=torch.int32, device=q.device) if want_max else None
+        _native.check(_native.lib().d3f_radius_query(_p(self.ws), _p(q), Nq, _p(q_len), _p(self.supports), self.Ns,
+                                                     _p(self.s_len), int(q_len.numel()), self.radius, int(width),
+                                                     _p(out), _p(counts), _p(mx), _p(self.status.word), _stream()),
+                      "d3f_radius_query")
+        res = (out,)
+        if want_counts:
+            res += (counts,)
+        if want_max:
+            res += (mx,)
+        return res if len(res) > 1 else out
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# grid subsampling (cpp_wrappers/cpp_subsampling; datasets/dataloader.py:12-22)
+# ---------------------------------------------------------------------------------------------------------------
+def grid_subsample_raw(points, lens, sampleDl, max_p=0, order=ORDER_REFERENCE, status=None):
+    """Sync-free form: returns (out_points [capacity,3], out_len [B] int32, out_total [1] int32).
+
+    ``points`` may itself be a capacity buffer: only the first sum(lens) rows are read, so pyramid levels chain
+    on the device without reading lengths back."""
+    p = _f32(points, "points")
+    if p.dim() != 2 or p.shape[1] != 3:
+        raise RuntimeError("Wrong dimensions : points.shape is not (N, 3)")
+    dev = p.device
+    lens = _lens(lens, dev, "batches")
+    status = status if status is not None else DeviceStatus(dev)
+    N, B = int(p.shape[0]), int(lens.numel())
+    L = _native.lib()
+    nbytes = L.d3f_grid_subsample_ws_bytes(N, B)
+    ws = _ws(nbytes, dev)
+    out = torch.empty((N, 3), dtype=torch.float32, device=dev)
+    out_len = torch.empty(B, dtype=torch.int32, device=dev)
+    total = torch.empty(1, dtype=torch.int32, device=dev)
+    _native.check(L.d3f_grid_subsample(_p(p), N, _p(lens), B, float(sampleDl), int(max_p), int(order), _p(out),
+                                       _p(out_len), _p(total), _p(ws), nbytes, _p(status.word), _stream()),
+                  "d3f_grid_subsample")
+    return out, out_len, total, status
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# KPConv (models/blocks.py:237-382)
+# ---------------------------------------------------------------------------------------------------------------
+class _KPConvFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, q_pts, s_pts, idx, x, kernel_points, weights, extent):
+        L = _native.lib()
+        Nq, Ns, H = int(q_pts.shape[0]), int(s_pts.shape[0]), int(idx.shape[1])
+        K, Cin, Cout = int(weights.shape[0]), int(weights.shape[1]), int(weights.shape[2])
+        out = torch.empty((Nq, Cout), dtype=torch.float32, device=x.device)
+        nn = torch.empty(Nq, dtype=torch.float32, device=x.device)
+        nbytes = L.d3f_kpconv_ws_bytes(Nq, Ns, H, K, Cin, Cout)
+        ws = _ws(nbytes, x.device)
+        _native.check(L.d3f_kpconv_forward(_p(q_pts), Nq, _p(s_pts), Ns, _p(idx), H, _p(x), Cin, _p(kernel_points), K,
+                                           _p(weights), Cout, float(extent), _p(out), _p(nn), _p(ws), nbytes,
+                                           _stream()), "d3f_kpconv_forward")
+        ctx.save_for_backward(q_pts, s_pts, idx, x, kernel_points, weights, nn)
+        ctx.extent = float(extent)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        q_pts, s_pts, idx, x, kernel_points, weights, nn = ctx.saved_tensors
+        L = _native.lib()
+        Nq, Ns, H = int(q_pts.shape[0]), int(s_pts.shape[0]), int(idx.shape[1])
+        K, Cin, Cout = int(weights.shape[0]), int(weights.shape[1]), int(weights.shape[2])
+        need_x, need_w = ctx.needs_input_grad[3], ctx.needs_input_grad[5]
+        gx = torch.empty_like(x) if need_x else None
+        gw = torch.empty_like(weights) if need_w else None
+        if need_x or need_w:
+            go = grad_out.contiguous().float()
+            nbytes = L.d3f_kpconv_ws_bytes(Nq, Ns, H, K, Cin, Cout)
+            ws = _ws(nbytes, x.device)
+            _native.check(L.d3f_kpconv_backward(_p(q_pts), Nq, _p(s_pts), Ns, _p(idx), H, _p(x), Cin,
+                                                _p(kernel_points), K, _p(weights), Cout, ctx.extent, _p(nn), _p(go),
+                                                _p(gx), _p(gw), _p(ws), nbytes, _stream()), "d3f_kpconv_backward")
+        return None, None, None, gx, None, gw, None
+
+
+def kpconv(q_pts, s_pts, neighb_inds, x, kernel_points, weights, extent):
+    """Rigid KPConv, 'linear' influence, 'sum' aggregation.  Shapes as KPConv.forward (blocks.py:237)."""
+    q_pts, s_pts, x = _f32(q_pts, "q_pts"), _f32(s_pts, "s_pts"), _f32(x, "x")
+    idx = _i32(neighb_inds, "neighb_inds")
+    kp, w = _f32(kernel_points, "kernel_points"), _f32(weights, "weights")
+    if x.shape[0] != s_pts.shape[0] or x.shape[1] != w.shape[1] or idx.shape[0] != q_pts.shape[0]:
+        raise RuntimeError("KPConv: inconsistent shapes q%s s%s idx%s x%s W%s" % (
+            tuple(q_pts.shape), tuple(s_pts.shape), tuple(idx.shape), tuple(x.shape), tuple(w.shape)))
+    return _KPConvFn.apply(q_pts, s_pts, idx, x, kp, w, float(extent))
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# pools (models/blocks.py:79-110)
+# ---------------------------------------------------------------------------------------------------------------
+class _MaxPoolFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, idx):
+        Ns, C = int(x.shape[0]), int(x.shape[1])
+        Nq, H = int(idx.shape[0]), int(idx.shape[1])
+        out = torch.empty((Nq, C), dtype=torch.float32, device=x.device)
+        arg = torch.empty((Nq, C), dtype=torch.int32, device=x.device)
+        _native.check(_native.lib().d3f_max_pool_forward(_p(x), Ns, C, _p(idx), Nq, H, _p(out), _p(arg), _stream()),
+                      "d3f_max_pool_forward")
+        ctx.save_for_backward(arg)
+        ctx.shape = (Ns, C)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        (arg,) = ctx.saved_tensors
+        Ns, C = ctx.shape
+        go = grad_out.contiguous().float()
+        gx = torch.empty((Ns, C), dtype=torch.float32, device=go.device)
+        _native.check(_native.lib().d3f_max_pool_backward(_p(go), _p(arg), int(arg.shape[0]), C, Ns, _p(gx), _stream()),
+                      "d3f_max_pool_backward")
+        return gx, None
+
+
+def max_pool(x, inds):
+    return _MaxPoolFn.apply(_f32(x, "x"), _i32(inds, "inds"))
+
+
+class _ClosestPoolFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, idx):
+        Ns, C = int(x.shape[0]), int(x.shape[1])
+        Nq, H = int(idx.shape[0]), int(idx.shape[1])
+        out = torch.empty((Nq, C), dtype=torch.float32, device=x.device)
+        _native.check(_native.lib().d3f_closest_pool_forward(_p(x), Ns, C, _p(idx), Nq, H, _p(out), _stream()),
+                      "d3f_closest_pool_forward")
+        ctx.save_for_backward(idx)
+        ctx.shape = (Ns, C)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        (idx,) = ctx.saved_tensors
+        Ns, C = ctx.shape
+        go = grad_out.contiguous().float()
+        gx = torch.empty((Ns, C), dtype=torch.float32, device=go.device)
+        _native.check(_native.lib().d3f_closest_pool_backward(_p(go), _p(idx), int(idx.shape[0]), int(idx.shape[1]),
+                                                              C, Ns, _p(gx), _stream()), "d3f_closest_pool_backward")
+        return gx, None
+
+
+def closest_pool(x, inds):
+    idx = _i32(inds, "inds")
+    if idx.dim() == 1:
+        idx = idx.view(-1, 1)
+    return _ClosestPoolFn.apply(_f32(x, "x"), idx)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# detector score (models/architectures.py:322-368)
+# ---------------------------------------------------------------------------------------------------------------
+def global_max(x):
+    x = _f32(x, "x")
+    out = torch.empty(1, dtype=torch.float32, device=x.device)
+    ws = _ws(256, x.device)
+    _native.check(_native.lib().d3f_global_max(_p(x), x.numel(), _p(out), _p(ws), 256, _stream()), "d3f_global_max")
+    return out
+
+
+class _DetScoreFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, feat, idx, training):
+        N, C, H = int(feat.shape[0]), int(feat.shape[1]), int(idx.shape[1])
+        fmax = global_max(feat)
+        scores = torch.empty((N, 1), dtype=torch.float32, device=feat.device)
+        _native.check(_native.lib().d3f_detection_scores_forward(_p(feat), N, C, _p(idx), H, _p(fmax),
+                                                                 1 if training else 0, _p(scores), _stream()),
+                      "d3f_detection_scores_forward")
+        ctx.save_for_backward(feat, idx, fmax)
+        ctx.training = bool(training)
+        return scores
+
+    @staticmethod
+    def backward(ctx, grad_scores):
+        feat, idx, fmax = ctx.saved_tensors
+        if not ctx.training:
+            raise RuntimeError("detection_scores: backward is defined for training mode only")
+        N, C, H = int(feat.shape[0]), int(feat.shape[1]), int(idx.shape[1])
+        gs = grad_scores.contiguous().float()
+        gf = torch.empty_like(feat)
+        ws = _ws(256, feat.device)
+        _native.check(_native.lib().d3f_detection_scores_backward(_p(feat), N, C, _p(idx), H, _p(fmax), _p(gs), _p(gf),
+                                                                  _p(ws), 256, _stream()),
+                      "d3f_detection_scores_backward")
+        return gf, None, None
+
+
+def detection_scores(features, neighbors, training=True):
+    """scores [N,1] from un-normalised descriptors [N,C] and the layer-0 neighbor table."""
+    return _DetScoreFn.apply(_f32(features, "features"), _i32(neighbors, "neighbors"), bool(training))
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# circle + detector loss (utils/loss.py:8-44,111-141,149-158)
+# ---------------------------------------------------------------------------------------------------------------
+class _CircleDetFn(torch.autograd.Function):
+    """Returns (scalars[6], dists[M,M], furthest_positive[M], average_negative[M]); scalars[0] = desc loss,
+    scalars[1] = det loss are differentiable wrt anchor / positive / scores."""
+
+    @staticmethod
+    def forward(ctx, anchor, positive, neg_mask, anc_score, pos_score, log_scale, safe_radius, pos_margin,
+                neg_margin):
+        L = _native.lib()
+        M, C = int(anchor.shape[0]), int(anchor.shape[1])
+        dev = anchor.device
+        dists = torch.empty((M, M), dtype=torch.float32, device=dev)
+        fp = torch.empty(M, dtype=torch.float32, device=dev)
+        an = torch.empty(M, dtype=torch.float32, device=dev)
+        scalars = torch.empty(6, dtype=torch.float32, device=dev)
+        stats = torch.empty(L.d3f_circle_det_loss_stats_floats(M), dtype=torch.float32, device=dev)
+        _native.check(L.d3f_circle_det_loss_forward(_p(anchor), _p(positive), M, C, _p(neg_mask), _p(anc_score),
+                                                    _p(pos_score), float(log_scale), float(safe_radius),
+                                                    float(pos_margin), float(neg_margin), _p(dists), _p(fp), _p(an),
+                                                    _p(scalars), _p(stats), _stream()), "d3f_circle_det_loss_forward")
+        ctx.save_for_backward(anchor, positive, neg_mask, anc_score, pos_score, dists, stats)
+        ctx.params = (float(log_scale), float(safe_radius), float(pos_margin), float(neg_margin))
+        ctx.mark_non_differentiable(dists, fp, an)
+        return scalars, dists, fp, an
+
+    @staticmethod
+    def backward(ctx, g_scalars, g_dists, g_fp, g_an):
+        anchor, positive, neg_mask, anc_score, pos_score, dists, stats = ctx.saved_tensors
+        L = _native.lib()
+        M, C = int(anchor.shape[0]), int(anchor.shape[1])
+        g = g_scalars.contiguous().float()
+        ga, gp = torch.empty_like(anchor), torch.empty_like(positive)
+        gsa, gsp = torch.empty_like(anc_score), torch.empty_like(pos_score)
+        nbytes = L.d3f_circle_det_loss_ws_bytes(M)
+        ws = _ws(nbytes, anchor.device)
+        s, sr, pm, nm = ctx.params
+        _native.check(L.d3f_circle_det_loss_backward(_p(anchor), _p(positive), M, C, _p(neg_mask), _p(anc_score),
+                                                     _p(pos_score), s, sr, pm, nm, _p(dists), _p(stats),
+                                                     g.data_ptr(), g.data_ptr() + 4, _p(ga), _p(gp), _p(gsa), _p(gsp),
+                                                     _p(ws), nbytes, _stream()), "d3f_circle_det_loss_backward")
+        return ga, gp, None, gsa, gsp, None, None, None, None
+
+
+def circle_det_loss(anchor, positive, dist_keypts, anc_score, pos_score, log_scale=10.0, safe_radius=0.1,
+                    pos_margin=0.1, neg_margin=1.4):
+    anchor, positive = _f32(anchor, "anchor"), _f32(positive, "positive")
+    if not dist_keypts.is_cuda:
+        raise RuntimeError("dist_keypts must be a CUDA/HIP tensor")
+    neg_mask = (dist_keypts > safe_radius).to(torch.uint8).contiguous()  # evaluated in the caller's dtype (f64)
+    sa = _f32(anc_score, "anc_score").reshape(-1)
+    sp = _f32(pos_score, "pos_score").reshape(-1)
+    return _CircleDetFn.apply(anchor, positive, neg_mask, sa, sp, log_scale, safe_radius, pos_margin, neg_margin)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# dense mutual-NN matching (geometric_registration/common.py:5-21)
+# ---------------------------------------------------------------------------------------------------------------
+def mutual_nn(source_desc, target_desc):
+    """(row_argmin [Ns], col_argmin [Nt], mutual [Ns]) int32 device tensors."""
+    s, t = _f32(source_desc, "source_desc"), _f32(target_desc, "target_desc")
+    Ns, Nt, C = int(s.shape[0]), int(t.shape[0]), int(s.shape[1])
+    ra = torch.empty(Ns, dtype=torch.int32, device=s.device)
+    ca = torch.empty(Nt, dtype=torch.int32, device=s.device)
+    mu = torch.empty(Ns, dtype=torch.int32, device=s.device)
+    _native.check(_native.lib().d3f_mutual_nn(_p(s), Ns, _p(t), Nt, C, _p(ra), _p(ca), _p(mu), _stream()),
+                  "d3f_mutual_nn")
+    return ra, ca, mu

@@ -1,0 +1,162 @@
+/* d3feat_hip.h -- C ABI of libd3feat_hip.so, the MI355X (gfx950) implementation of the D3Feat hot path.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer unless the name ends in _host;
+ *   - all tensors are dense row-major; point clouds are [N,3] float32, features [N,C] float32,
+ *     neighbor tables [Nq,H] int32 with the reference's shadow convention: entry == Ns (number of
+ *     support rows) means "no neighbor" (reference neighbors.cpp:324, blocks.py:277,356);
+ *   - batch (stack) lengths are int32 device arrays of B entries, like the reference's q_batches /
+ *     s_batches (cpp_neighbors/wrapper.cpp:85-86);
+ *   - `stream` is a hipStream_t passed as void*; calls are asynchronous and stream-ordered, never
+ *     synchronise, never allocate; scratch comes from the caller (`ws`, size from *_ws_bytes);
+ *   - return value: 0 on success, negative D3F_E* on a host-detectable argument error.  Device-detected
+ *     conditions (candidate overflow, cell-range overflow) are OR-ed into the int32 status word the
+ *     caller supplies; the Python layer maps both to RuntimeError, the reference's only error type
+ *     (cpp_neighbors/wrapper.cpp:77,95,...).
+ *
+ * Each entry point names the reference interface it replaces.
+ */
+#ifndef D3FEAT_HIP_H_
+#define D3FEAT_HIP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define D3F_OK 0
+#define D3F_EINVAL (-1)     /* bad argument (shape / null / unsupported size) */
+#define D3F_EWORKSPACE (-2) /* workspace too small */
+#define D3F_ELAUNCH (-3)    /* HIP launch failure */
+
+/* bits of the device status word */
+#define D3F_ST_CAND_OVERFLOW 1  /* a query had more in-radius candidates than the kernel can rank */
+#define D3F_ST_CELL_RANGE 2     /* a point fell outside the +-32767-cell addressable grid */
+#define D3F_ST_TABLE_FULL 4     /* voxel hash table full (workspace sized for fewer points) */
+
+const char* d3f_version(void);
+int d3f_device_arch_ok(void); /* 1 if the current HIP device is gfx950 */
+
+/* ------------------------------------------------------------------------------------------------
+ * Radius neighbors -- replaces radius_neighbors.batch_query
+ *   (cpp_wrappers/cpp_neighbors/wrapper.cpp:58-238 -> neighbors/neighbors.cpp:211-333) and the column
+ *   truncation of datasets/dataloader.py:52-67 (batch_neighbors_kpconv).
+ * One uniform cell list ("grid") is built per support cloud + radius and can serve several query sets
+ * (conv, pool and upsample searches of one pyramid level share it).
+ * ---------------------------------------------------------------------------------------------- */
+size_t d3f_radius_grid_ws_bytes(int Ns);
+/* Build the cell list of `supports` for `radius` into grid_ws. */
+int d3f_radius_grid_build(const float* supports, int Ns, const int32_t* s_len, int B, float radius,
+                          void* grid_ws, size_t grid_ws_bytes, int32_t* status, void* stream);
+/* Query: out_idx [Nq,width] gets, per query, the in-radius supports of the same batch element, ordered by
+ * (d2, index) ascending, first `width` kept, padded with Ns.  out_counts [Nq] (optional) = uncapped count;
+ * max_count (optional, 1 int32, caller-zeroed) = max over queries.  d2 arithmetic and the strict d2 < r2 test
+ * follow nanoflann.hpp:433-441,249-251 bit for bit. */
+int d3f_radius_query(const void* grid_ws, const float* queries, int Nq, const int32_t* q_len,
+                     const float* supports, int Ns, const int32_t* s_len, int B, float radius, int width,
+                     int32_t* out_idx, int32_t* out_counts, int32_t* max_count, int32_t* status, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Grid subsampling -- replaces grid_subsampling.subsample_batch, points-only branch
+ *   (cpp_wrappers/cpp_subsampling/wrapper.cpp:62-333 -> grid_subsampling/grid_subsampling.cpp:5-211),
+ *   i.e. batch_grid_subsampling_kpconv (datasets/dataloader.py:12-22).
+ * order: D3F_ORDER_REFERENCE reproduces the reference's row order (iteration order of the libstdc++
+ *   std::unordered_map<size_t,...> it accumulates into, grid_subsampling.cpp:48,85);
+ *   D3F_ORDER_FIRST_SEEN emits cells in order of their first input point (cheaper).
+ * N is a row CAPACITY: only the first sum(len) rows are read, so levels can be chained without reading
+ * lengths back to the host.  Outputs: out_points [<=N,3] (caller provides N rows), out_len [B], out_total [1].
+ * ---------------------------------------------------------------------------------------------- */
+#define D3F_ORDER_REFERENCE 0
+#define D3F_ORDER_FIRST_SEEN 1
+size_t d3f_grid_subsample_ws_bytes(int N, int B);
+int d3f_grid_subsample(const float* points, int N, const int32_t* len, int B, float sampleDl, int max_p, int order,
+                       float* out_points, int32_t* out_len, int32_t* out_total, void* ws, size_t ws_bytes,
+                       int32_t* status, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * KPConv -- replaces models/blocks.py:237-382 (KPConv.forward, rigid / 'linear' / 'sum' path) and its
+ *   autograd backward.
+ *   out[n,:] = ( sum_k ( sum_h w[n,h,k] * x[idx[n,h],:] ) @ W[k] ) / nn[n]
+ *   w = max(0, 1 - |(s[idx[n,h]] - q[n]) - kp[k]| / extent),  nn[n] = max(1, #{h : sum_c x[idx[n,h],c] > 0})
+ * nn_out [Nq] float32 is saved for the backward pass.
+ * ---------------------------------------------------------------------------------------------- */
+int d3f_kpconv_forward(const float* q_pts, int Nq, const float* s_pts, int Ns, const int32_t* idx, int H,
+                       const float* x, int Cin, const float* kernel_points, int K, const float* weights, int Cout,
+                       float extent, float* out, float* nn_out, void* ws, size_t ws_bytes, void* stream);
+size_t d3f_kpconv_ws_bytes(int Nq, int Ns, int H, int K, int Cin, int Cout);
+/* grad_x [Ns,Cin] and grad_w [K,Cin,Cout] are OVERWRITTEN (zeroed inside). */
+int d3f_kpconv_backward(const float* q_pts, int Nq, const float* s_pts, int Ns, const int32_t* idx, int H,
+                        const float* x, int Cin, const float* kernel_points, int K, const float* weights, int Cout,
+                        float extent, const float* nn, const float* grad_out, float* grad_x, float* grad_w,
+                        void* ws, size_t ws_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Pools -- replace models/blocks.py:94-110 (max_pool) and :79-91 (closest_pool).
+ * ---------------------------------------------------------------------------------------------- */
+/* out[n,c] = max_h x'[idx[n,h],c], x' = x plus a zero shadow row; argmax_out [Nq,C] int32 = winning support row
+ * (Ns if the shadow won), saved for backward. */
+int d3f_max_pool_forward(const float* x, int Ns, int C, const int32_t* idx, int Nq, int H, float* out,
+                         int32_t* argmax_out, void* stream);
+int d3f_max_pool_backward(const float* grad_out, const int32_t* argmax, int Nq, int C, int Ns, float* grad_x,
+                          void* stream);
+/* out[n,:] = x'[idx[n,0],:]  (idx has row stride H) */
+int d3f_closest_pool_forward(const float* x, int Ns, int C, const int32_t* idx, int Nq, int H, float* out,
+                             void* stream);
+int d3f_closest_pool_backward(const float* grad_out, const int32_t* idx, int Nq, int H, int C, int Ns, float* grad_x,
+                              void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Detector score -- replaces KPFCNN.detection_scores (models/architectures.py:322-368).
+ * feat [N,C] un-normalised descriptors, idx = neighbors[0] [N,H].  feat_max [1] is a device scalar holding
+ * max(feat) (d3f_global_max computes it).  training != 0: soft score; training == 0 additionally applies the
+ * local-maximum gate (:361-366).
+ * ---------------------------------------------------------------------------------------------- */
+int d3f_global_max(const float* x, size_t n, float* out_max, void* ws /* >= 4 bytes */, size_t ws_bytes, void* stream);
+int d3f_detection_scores_forward(const float* feat, int N, int C, const int32_t* idx, int H, const float* feat_max,
+                                 int training, float* scores, void* stream);
+/* grad_feat [N,C] is OVERWRITTEN.  Includes the gradient through the global max normaliser. */
+int d3f_detection_scores_backward(const float* feat, int N, int C, const int32_t* idx, int H, const float* feat_max,
+                                  const float* grad_scores, float* grad_feat, void* ws, size_t ws_bytes,
+                                  void* stream);
+size_t d3f_detection_scores_ws_bytes(int N, int C);
+
+/* ------------------------------------------------------------------------------------------------
+ * Descriptor loss -- replaces utils/loss.py: cdist(:8-44, 'euclidean'), CircleLoss.forward(:111-141),
+ * DetLoss.forward(:149-158), fused into one single-workgroup launch (M <= 1024 sampled correspondences).
+ * anchor/positive [M,C]; neg_mask [M,M] uint8 = (dist_keypts > safe_radius), evaluated by the caller in the
+ * dtype the dataset supplies (float64 in the reference, loss.py:116); anc_score/pos_score [M].
+ * Outputs: dists [M,M], furthest_positive [M], average_negative [M],
+ *   out_scalars[0..5] = desc_loss, det_loss, accuracy(%), mean furthest_positive, mean average_negative, 0;
+ *   stats [d3f_circle_det_loss_stats_floats(M)] = row/column log-sum-exps + closest negatives, kept for backward.
+ * backward: gradients of  grad_desc*desc_loss + grad_det*det_loss  (device scalars; either may be NULL = 0)
+ *   wrt anchor, positive [M,C] and the two score vectors [M] (optional).
+ * ---------------------------------------------------------------------------------------------- */
+size_t d3f_circle_det_loss_stats_floats(int M);
+size_t d3f_circle_det_loss_ws_bytes(int M);
+int d3f_circle_det_loss_forward(const float* anchor, const float* positive, int M, int C, const uint8_t* neg_mask,
+                                const float* anc_score, const float* pos_score, float log_scale, float safe_radius,
+                                float pos_margin, float neg_margin, float* dists, float* furthest_positive,
+                                float* average_negative, float* out_scalars, float* stats, void* stream);
+int d3f_circle_det_loss_backward(const float* anchor, const float* positive, int M, int C, const uint8_t* neg_mask,
+                                 const float* anc_score, const float* pos_score, float log_scale, float safe_radius,
+                                 float pos_margin, float neg_margin, const float* dists, const float* stats,
+                                 const float* grad_desc, const float* grad_det, float* grad_anchor,
+                                 float* grad_positive, float* grad_anc_score, float* grad_pos_score, void* ws,
+                                 size_t ws_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Dense matching -- replaces build_correspondence (geometric_registration/common.py:5-21): the
+ * [Ns,Nt] distance matrix sqrt(2 - 2 S.T^T) is never materialised; an f32 MFMA tile kernel keeps a running
+ * row arg-min (and, with the operands swapped, the column arg-min).  row_argmin [Ns], col_argmin [Nt] int32
+ * (lowest index on ties, like np.argmin), mutual [Ns] int32 (optional) = 1 where col_argmin[row_argmin[i]] == i.
+ * C in {16, 32, 64, 128}.
+ * ---------------------------------------------------------------------------------------------- */
+int d3f_mutual_nn(const float* src_desc, int Ns, const float* tgt_desc, int Nt, int C, int32_t* row_argmin,
+                  int32_t* col_argmin, int32_t* mutual, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* D3FEAT_HIP_H_ */

@@ -1,0 +1,61 @@
+"""Shared helpers for the parity tests."""
+import hashlib
+
+import numpy as np
+
+
+def sha(a):
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+def d2_exact(q, s):
+    """float32 ((dx*dx)+(dy*dy))+(dz*dz), the reference's evaluation order (nanoflann.hpp:433-441)."""
+    q = q.astype(np.float32)
+    s = s.astype(np.float32)
+    d = (q - s).astype(np.float32)
+    sq = (d * d).astype(np.float32)
+    return ((sq[..., 0] + sq[..., 1]).astype(np.float32) + sq[..., 2]).astype(np.float32)
+
+
+def neighbor_d2(queries, supports, table):
+    """d2 of every table entry (inf for the shadow index)."""
+    ns = supports.shape[0]
+    pad = np.concatenate([supports, np.full((1, 3), np.nan, np.float32)], 0)
+    d2 = d2_exact(queries[:, None, :], pad[table])
+    d2[table >= ns] = np.inf
+    return d2
+
+
+def assert_neighbors_equal_tie_aware(queries, supports, ours, ref, what=""):
+    """Neighbor tables must agree exactly except for the ORDER inside groups of equal d2, which the reference leaves
+    unspecified (std::sort on distance only, nanoflann.hpp:208-214).  Returns (#tie rows, #rows)."""
+    ours = np.asarray(ours).astype(np.int64)
+    ref = np.asarray(ref).astype(np.int64)
+    assert ours.shape == ref.shape, "%s shape %s vs %s" % (what, ours.shape, ref.shape)
+    da = neighbor_d2(queries, supports, ours)
+    db = neighbor_d2(queries, supports, ref)
+    assert np.array_equal(da, db), "%s: per-slot squared distances differ (bit-exact check)" % what
+    bad = np.nonzero((ours != ref).any(axis=1))[0]
+    width = ours.shape[1]
+    for r in bad:
+        a, b, d = ours[r], ref[r], da[r]
+        start = 0
+        while start < width:
+            end = start
+            while end + 1 < width and d[end + 1] == d[start]:
+                end += 1
+            last_group_cut = end == width - 1  # a tie group cut by the column limit may keep different members
+            if not last_group_cut:
+                assert sorted(a[start:end + 1]) == sorted(b[start:end + 1]), "%s row %d: tie group differs" % (what, r)
+            start = end + 1
+    return len(bad), ours.shape[0]
+
+
+def rel_err(a, b):
+    a = np.asarray(a, np.float64)
+    b = np.asarray(b, np.float64)
+    return float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-30))
+
+
+class Cfg:
+    pass
