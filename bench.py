@@ -1,0 +1,199 @@
+#!/usr/bin/env python
+"""Headline benchmark: fragment-pairs/sec (fwd+bwd) on 3DMatch-shaped synthetic pairs -- BASELINE.json configs[2]:
+full D3Feat U-Net forward+backward on one fragment pair (~19k + 19k points, 32-d descriptors), circle + detector loss,
+radius search + grid subsampling ON THE DEVICE, SGD step included.
+
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+One "step" = one pass of the whole hot path over one pair: pyramid build (13 radius searches + 4 voxel levels) ->
+KPFCNN forward -> fused loss -> backward -> (all-reduce) -> guarded SGD.  Inputs (the two raw fragments, the sampled
+correspondences and their distance matrix) are resident in HBM before the timed region.  Each rank processes its own
+pairs (weak scaling); the only data-path collective is the RCCL gradient all-reduce.  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+if REPO not in sys.path:
+    sys.path.insert(0, REPO)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s spec, ~6.3 TB/s achievable)
+
+
+def kpconv_fwd_bytes(Nq, Ns, H, K, Cin, Cout):
+    """Algorithmic bytes of one KPConv forward (gather-expanded logical bytes, int32 indices)."""
+    return 12 * Nq + 4 * Nq * H + Nq * H * (12 + 4 * Cin) + 4 * K * Cin * Cout + 180 + 4 * Nq * Cout
+
+
+def kpconv_bwd_bytes(Nq, Ns, H, K, Cin, Cout):
+    return kpconv_fwd_bytes(Nq, Ns, H, K, Cin, Cout) + 4 * Nq * Cout + 4 * Ns * Cin + 4 * K * Cin * Cout
+
+
+def cpu_baseline(item, cfg, limits, budget_s=20.0):
+    """The CPU oracle (C++ radius search / voxel subsampling restatement + PyTorch-CPU restatement of the network,
+    losses, backward, SGD) timed on this host -- a reported baseline, not the thing shipped."""
+    from oracle import native as onat, ops_ref
+    from d3feat_pytorch_amd.models.architectures import KPFCNN
+    np.random.seed(0)
+    torch.manual_seed(0)
+    model = KPFCNN(cfg)
+    sd = {k: v.detach().clone().requires_grad_(v.requires_grad and not k.endswith('kernel_points'))
+          for k, v in model.state_dict().items()}
+    for k, p in model.named_parameters():
+        sd[k].requires_grad_(p.requires_grad)
+    params = [v for v in sd.values() if v.requires_grad]
+    opt = torch.optim.SGD(params, lr=cfg.lr, momentum=cfg.momentum, weight_decay=cfg.weight_decay)
+    pts0, pts1, _, _, corr, dk = item
+    corr_t, dk_t = torch.from_numpy(corr).long(), torch.from_numpy(dk)
+    times = []
+    t_start = time.time()
+    while True:
+        t0 = time.time()
+        batch = ops_ref.collate(pts0, pts1, cfg, limits, onat)
+        batch['features'] = torch.ones((pts0.shape[0] + pts1.shape[0], 1))
+        opt.zero_grad()
+        feats, scores = ops_ref.kpfcnn_forward(sd, batch, cfg, training=True)
+        n0 = pts0.shape[0]
+        loss, _, _, _, dists = ops_ref.circle_loss(feats[corr_t[:, 0]], feats[corr_t[:, 1] + n0], dk_t)
+        det = ops_ref.det_loss(dists, scores[corr_t[:, 0]], scores[corr_t[:, 1] + n0])
+        (loss + det).backward()
+        opt.step()
+        times.append(time.time() - t0)
+        if len(times) >= 2 and (time.time() - t_start) > budget_s:
+            break
+        if len(times) >= 8:
+            break
+    steady = times[1:] if len(times) > 1 else times
+    return {"value": round(1.0 / float(np.median(steady)), 4), "unit": "fragment-pairs/s",
+            "cores": int(torch.get_num_threads()), "kind": "port",
+            "sample": "%d timed steps (after 1 warm-up) of the same S1-class pair: CPU oracle collate (C++ cell-list "
+                      "search + unordered_map voxel subsampling, 1 thread) + PyTorch-CPU fwd/loss/bwd/SGD on %d "
+                      "intra-op threads; median %.2f s/pair" % (len(steady), torch.get_num_threads(),
+                                                                float(np.median(steady)))}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--pairs", type=int, default=4, help="distinct synthetic pairs per rank (cycled)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-budget", type=float, default=20.0)
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", rank=rank, world_size=world,
+                                device_id=torch.device("cuda", local_rank))
+    assert world == args.gpus or world == 1, "launch with torch.distributed.run for --gpus > 1"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    from d3feat_pytorch_amd import _native, config as cfgmod, ops, synthetic
+    from d3feat_pytorch_amd.datasets import dataloader as dl
+    from d3feat_pytorch_amd.train import TrainStep
+    _native.lib()  # fail loudly if the HIP library is missing
+
+    cfg = cfgmod.default_config()
+
+    def gpu_subsample(points, lengths, dlen):
+        p, b = dl.batch_grid_subsampling_kpconv(torch.as_tensor(points).to(dev), torch.as_tensor(lengths).to(dev),
+                                                sampleDl=dlen)
+        return p.cpu().numpy(), b.cpu().numpy()
+
+    host_items, items = [], []
+    for i in range(args.pairs):
+        sa, sb = 100 * rank + 2 * i + 1, 100 * rank + 2 * i + 2   # rank r uses seeds (100r+2i+1, 100r+2i+2)
+        it = synthetic.make_pair(sa, sb, gpu_subsample)
+        host_items.append(it)
+        items.append(tuple(torch.from_numpy(np.ascontiguousarray(a)).to(dev) for a in it))
+
+    class _DS:
+        config = cfg
+
+        def __len__(self):
+            return 1
+
+        def __getitem__(self, i):
+            return host_items[0]
+    limits = [int(x) for x in dl.calibrate_neighbors(_DS(), cfg, samples_threshold=10 ** 9)]
+
+    ts = TrainStep(cfg, limits, dev, world_size=world, seed=0)
+    prof = ops.EventProfiler()
+
+    for w in range(args.warmup):
+        ts.step(items[w % len(items)])
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    ops.set_profiler(prof)
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        out = ts.step(items[k % len(items)])
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    ops.set_profiler(None)
+    elapsed = torch.tensor([t1 - t0], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(elapsed, op=dist.ReduceOp.MAX)
+    elapsed = float(elapsed.item())
+    loss_val = float(out[0].item())
+
+    if rank == 0:
+        n_pts = [int(it[0].shape[0] + it[1].shape[0]) for it in items]
+        summary = prof.summary()
+        dom = max(summary.items(), key=lambda kv: kv[1]["total_ms"]) if summary else None
+        roofline = None
+        if dom is not None:
+            label, st = dom
+            achieved = st["bytes_per_call"] / (st["avg_ms"] * 1e-3) / 1e9
+            roofline = {"bound": "hbm", "kernel": label, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
+                        "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                        "avg_us": round(st["avg_ms"] * 1e3, 2), "calls": st["calls"],
+                        "algorithmic_bytes_per_launch": int(st["bytes_per_call"]),
+                        "share_of_step": round(st["total_ms"] / (elapsed * 1e3), 4)}
+        res = {
+            "metric": "fragment-pairs/sec (fwd+bwd) on 3DMatch-shaped pairs",
+            "value": round(args.steps * world / elapsed, 3),
+            "unit": "fragment-pairs/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "configs[2]: full D3Feat KPFCNN fwd+bwd on one fragment pair per step "
+                                   "(%d stacked points avg, 128 correspondences, 32-d descriptors, circle+detector loss, "
+                                   "on-device radius search + grid subsample, SGD step)" % int(np.mean(n_pts)),
+                       "points_per_pair": n_pts, "neighbor_limits": limits, "pairs_per_rank": len(items),
+                       "parallelism": "dp%d" % world, "final_loss": round(loss_val, 5)},
+            "roofline": roofline,
+            "kernels": {k: {"avg_us": round(v["avg_ms"] * 1e3, 2), "calls": v["calls"],
+                            "total_ms": round(v["total_ms"], 3)} for k, v in
+                        sorted(summary.items(), key=lambda kv: -kv[1]["total_ms"])[:12]},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            res["cpu_baseline"] = cpu_baseline(host_items[0], cfg, limits, budget_s=args.cpu_budget)
+        print(json.dumps(res))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -20,6 +20,7 @@ _vp, _i, _f, _sz = C.c_void_p, C.c_int, C.c_float, C.c_size_t
 SIGNATURES = {
     "d3f_version": (C.c_char_p, []),
     "d3f_device_arch_ok": (_i, []),
+    "d3f_device_arch_name": (_i, [C.c_char_p, _i]),
     "d3f_radius_grid_ws_bytes": (_sz, [_i]),
     "d3f_radius_grid_build": (_i, [_vp, _i, _vp, _i, _f, _vp, _sz, _vp, _vp]),
     "d3f_radius_query": (_i, [_vp, _vp, _i, _vp, _vp, _i, _vp, _i, _f, _i, _vp, _vp, _vp, _vp, _vp]),
@@ -54,7 +55,11 @@ STATUS_BITS = {1: "a query has more in-radius candidates than the kernel can ran
 
 def build(verbose=False):
     """Compile every HIP source for gfx950 into the in-tree shared library (cross-compiles without a GPU)."""
-    cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
+    # -ffp-contract=off: HIP's __fmul_rn/__fadd_rn are plain operators on AMD, so with the default contract=fast
+    # the compiler fuses the "exact" d2 = (dx*dx + dy*dy) + dz*dz into FMAs and the strict d2 < r2 test / the
+    # distance order stop matching the reference's x86 arithmetic bit for bit.  Fusion is requested explicitly
+    # (fmaf / MFMA) where it is wanted.
+    cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared",
            "-I" + os.path.join(_REPO, "include"), "-o", LIB_PATH] + [os.path.join(CSRC, s) for s in SOURCES]
     if verbose:
         print(" ".join(cmd))
@@ -77,6 +82,12 @@ def lib():
     """The loaded library; raises RuntimeError if it has not been built (no silent fallback)."""
     global _lib
     if _lib is None:
+        try:  # bring up torch's HIP context first: the library shares torch's bundled HIP runtime
+            import torch
+            if torch.cuda.is_available():
+                torch.cuda.init()
+        except ImportError:  # pragma: no cover
+            pass
         if not os.path.exists(LIB_PATH):
             raise RuntimeError(
                 "libd3feat_hip.so is not built: run `python -c 'import __graft_entry__ as g; g.build()'` "

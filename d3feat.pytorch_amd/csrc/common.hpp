@@ -51,7 +51,8 @@ __device__ __forceinline__ int batch_offset(const int32_t* __restrict__ len, int
 }
 
 // squared distance with the reference's float32 evaluation order and NO fused multiply-add:
-// d2 = dx*dx; d2 += dy*dy; d2 += dz*dz   (nanoflann.hpp:433-441)
+// d2 = dx*dx; d2 += dy*dy; d2 += dz*dz   (nanoflann.hpp:433-441).  NOTE: on AMD the __f*_rn intrinsics are plain
+// operators, so this is only exact because the library is compiled with -ffp-contract=off (see _native.build).
 __device__ __forceinline__ float sqdist_exact(float ax, float ay, float az, float bx, float by, float bz) {
   const float dx = __fsub_rn(ax, bx), dy = __fsub_rn(ay, by), dz = __fsub_rn(az, bz);
   float d2 = __fmul_rn(dx, dx);

@@ -14,6 +14,67 @@ def _stream():
     return torch.cuda.current_stream().cuda_stream
 
 
+# ---------------------------------------------------------------------------------------------------------------
+# optional per-operator HIP-event timing (bench.py): events are recorded on the stream the kernels are launched on
+# ---------------------------------------------------------------------------------------------------------------
+_PROFILER = None
+
+
+def set_profiler(p):
+    global _PROFILER
+    _PROFILER = p
+
+
+class _Region:
+    def __init__(self, prof, label, nbytes):
+        self.prof, self.label, self.nbytes = prof, label, nbytes
+
+    def __enter__(self):
+        if self.prof is not None:
+            self.e0 = torch.cuda.Event(enable_timing=True)
+            self.e1 = torch.cuda.Event(enable_timing=True)
+            self.e0.record(torch.cuda.current_stream())
+        return self
+
+    def __exit__(self, *exc):
+        if self.prof is not None:
+            self.e1.record(torch.cuda.current_stream())
+            self.prof.records.append((self.label, self.nbytes, self.e0, self.e1))
+        return False
+
+
+def _region(label, nbytes=0):
+    return _Region(_PROFILER, label, nbytes)
+
+
+class EventProfiler:
+    """Collects (label, algorithmic bytes, start event, end event) per C-ABI call; summary() after a sync."""
+
+    def __init__(self):
+        self.records = []
+
+    def summary(self):
+        torch.cuda.synchronize()
+        out = {}
+        for label, nbytes, e0, e1 in self.records:
+            ms = e0.elapsed_time(e1)
+            d = out.setdefault(label, {"calls": 0, "total_ms": 0.0, "bytes_per_call": nbytes})
+            d["calls"] += 1
+            d["total_ms"] += ms
+        for d in out.values():
+            d["avg_ms"] = d["total_ms"] / d["calls"]
+        return out
+
+
+def kpconv_fwd_bytes(Nq, Ns, H, K, Cin, Cout):
+    """Algorithmic (gather-expanded, int32-index) bytes of one KPConv forward -- SURVEY.md section 8d."""
+    return 12 * Nq + 4 * Nq * H + Nq * H * (12 + 4 * Cin) + 4 * K * Cin * Cout + 180 + 4 * Nq * Cout
+
+
+def kpconv_bwd_bytes(Nq, Ns, H, K, Cin, Cout):
+    return kpconv_fwd_bytes(Nq, Ns, H, K, Cin, Cout) + 4 * Nq * Cout + 4 * Ns * Cin + 4 * K * Cin * Cout
+
+
 def _f32(t, name):
     if not isinstance(t, torch.Tensor) or not t.is_cuda:
         raise RuntimeError("%s must be a CUDA/HIP tensor (d3feat_pytorch_amd has no CPU path)" % name)
@@ -75,9 +136,10 @@ class RadiusGrid:
         self.Ns = int(self.supports.shape[0])
         nbytes = L.d3f_radius_grid_ws_bytes(self.Ns)
         self.ws = _ws(nbytes, dev)
-        _native.check(L.d3f_radius_grid_build(_p(self.supports), self.Ns, _p(self.s_len), int(self.s_len.numel()),
-                                              self.radius, _p(self.ws), nbytes, _p(self.status.word), _stream()),
-                      "d3f_radius_grid_build")
+        with _region("radius_grid_build[Ns=%d]" % self.Ns, 12 * self.Ns + 24 * self.Ns):
+            _native.check(L.d3f_radius_grid_build(_p(self.supports), self.Ns, _p(self.s_len),
+                                                  int(self.s_len.numel()), self.radius, _p(self.ws), nbytes,
+                                                  _p(self.status.word), _stream()), "d3f_radius_grid_build")
 
     def query(self, queries, q_len, width, want_counts=False, want_max=False):
         """int32 [Nq, width] neighbor table (+ per-query uncapped counts, + device max count)."""
@@ -91,10 +153,11 @@ class RadiusGrid:
         out = torch.empty((Nq, int(width)), dtype=torch.int32, device=q.device)
         counts = torch.empty(Nq, dtype=torch.int32, device=q.device) if want_counts else None
         mx = torch.zeros(1, dtype=torch.int32, device=q.device) if want_max else None
-        _native.check(_native.lib().d3f_radius_query(_p(self.ws), _p(q), Nq, _p(q_len), _p(self.supports), self.Ns,
-                                                     _p(self.s_len), int(q_len.numel()), self.radius, int(width),
-                                                     _p(out), _p(counts), _p(mx), _p(self.status.word), _stream()),
-                      "d3f_radius_query")
+        with _region("radius_query[Nq=%d,Ns=%d]" % (Nq, self.Ns), 12 * Nq + 12 * self.Ns + 4 * Nq * int(width)):
+            _native.check(_native.lib().d3f_radius_query(_p(self.ws), _p(q), Nq, _p(q_len), _p(self.supports), self.Ns,
+                                                         _p(self.s_len), int(q_len.numel()), self.radius, int(width),
+                                                         _p(out), _p(counts), _p(mx), _p(self.status.word),
+                                                         _stream()), "d3f_radius_query")
         res = (out,)
         if want_counts:
             res += (counts,)
@@ -124,9 +187,10 @@ def grid_subsample_raw(points, lens, sampleDl, max_p=0, order=ORDER_REFERENCE, s
     out = torch.empty((N, 3), dtype=torch.float32, device=dev)
     out_len = torch.empty(B, dtype=torch.int32, device=dev)
     total = torch.empty(1, dtype=torch.int32, device=dev)
-    _native.check(L.d3f_grid_subsample(_p(p), N, _p(lens), B, float(sampleDl), int(max_p), int(order), _p(out),
-                                       _p(out_len), _p(total), _p(ws), nbytes, _p(status.word), _stream()),
-                  "d3f_grid_subsample")
+    with _region("grid_subsample[cap=%d]" % N, 24 * N):
+        _native.check(L.d3f_grid_subsample(_p(p), N, _p(lens), B, float(sampleDl), int(max_p), int(order), _p(out),
+                                           _p(out_len), _p(total), _p(ws), nbytes, _p(status.word), _stream()),
+                      "d3f_grid_subsample")
     return out, out_len, total, status
 
 
@@ -143,9 +207,11 @@ class _KPConvFn(torch.autograd.Function):
         nn = torch.empty(Nq, dtype=torch.float32, device=x.device)
         nbytes = L.d3f_kpconv_ws_bytes(Nq, Ns, H, K, Cin, Cout)
         ws = _ws(nbytes, x.device)
-        _native.check(L.d3f_kpconv_forward(_p(q_pts), Nq, _p(s_pts), Ns, _p(idx), H, _p(x), Cin, _p(kernel_points), K,
-                                           _p(weights), Cout, float(extent), _p(out), _p(nn), _p(ws), nbytes,
-                                           _stream()), "d3f_kpconv_forward")
+        with _region("kpconv_fwd[Nq=%d,Cin=%d,Cout=%d,H=%d]" % (Nq, Cin, Cout, H),
+                     kpconv_fwd_bytes(Nq, Ns, H, K, Cin, Cout)):
+            _native.check(L.d3f_kpconv_forward(_p(q_pts), Nq, _p(s_pts), Ns, _p(idx), H, _p(x), Cin,
+                                               _p(kernel_points), K, _p(weights), Cout, float(extent), _p(out),
+                                               _p(nn), _p(ws), nbytes, _stream()), "d3f_kpconv_forward")
         ctx.save_for_backward(q_pts, s_pts, idx, x, kernel_points, weights, nn)
         ctx.extent = float(extent)
         return out
@@ -163,9 +229,12 @@ class _KPConvFn(torch.autograd.Function):
             go = grad_out.contiguous().float()
             nbytes = L.d3f_kpconv_ws_bytes(Nq, Ns, H, K, Cin, Cout)
             ws = _ws(nbytes, x.device)
-            _native.check(L.d3f_kpconv_backward(_p(q_pts), Nq, _p(s_pts), Ns, _p(idx), H, _p(x), Cin,
-                                                _p(kernel_points), K, _p(weights), Cout, ctx.extent, _p(nn), _p(go),
-                                                _p(gx), _p(gw), _p(ws), nbytes, _stream()), "d3f_kpconv_backward")
+            with _region("kpconv_bwd[Nq=%d,Cin=%d,Cout=%d,H=%d]" % (Nq, Cin, Cout, H),
+                         kpconv_bwd_bytes(Nq, Ns, H, K, Cin, Cout)):
+                _native.check(L.d3f_kpconv_backward(_p(q_pts), Nq, _p(s_pts), Ns, _p(idx), H, _p(x), Cin,
+                                                    _p(kernel_points), K, _p(weights), Cout, ctx.extent, _p(nn),
+                                                    _p(go), _p(gx), _p(gw), _p(ws), nbytes, _stream()),
+                              "d3f_kpconv_backward")
         return None, None, None, gx, None, gw, None
 
 
@@ -190,8 +259,9 @@ class _MaxPoolFn(torch.autograd.Function):
         Nq, H = int(idx.shape[0]), int(idx.shape[1])
         out = torch.empty((Nq, C), dtype=torch.float32, device=x.device)
         arg = torch.empty((Nq, C), dtype=torch.int32, device=x.device)
-        _native.check(_native.lib().d3f_max_pool_forward(_p(x), Ns, C, _p(idx), Nq, H, _p(out), _p(arg), _stream()),
-                      "d3f_max_pool_forward")
+        with _region("max_pool_fwd[Nq=%d,C=%d]" % (Nq, C), 4 * Nq * H + 4 * Nq * H * C + 4 * Nq * C):
+            _native.check(_native.lib().d3f_max_pool_forward(_p(x), Ns, C, _p(idx), Nq, H, _p(out), _p(arg),
+                                                             _stream()), "d3f_max_pool_forward")
         ctx.save_for_backward(arg)
         ctx.shape = (Ns, C)
         return out
@@ -258,9 +328,10 @@ class _DetScoreFn(torch.autograd.Function):
         N, C, H = int(feat.shape[0]), int(feat.shape[1]), int(idx.shape[1])
         fmax = global_max(feat)
         scores = torch.empty((N, 1), dtype=torch.float32, device=feat.device)
-        _native.check(_native.lib().d3f_detection_scores_forward(_p(feat), N, C, _p(idx), H, _p(fmax),
-                                                                 1 if training else 0, _p(scores), _stream()),
-                      "d3f_detection_scores_forward")
+        with _region("detection_fwd[N=%d]" % N, 4 * N * H + 4 * N * H * C + 4 * N * C + 4 * N):
+            _native.check(_native.lib().d3f_detection_scores_forward(_p(feat), N, C, _p(idx), H, _p(fmax),
+                                                                     1 if training else 0, _p(scores), _stream()),
+                          "d3f_detection_scores_forward")
         ctx.save_for_backward(feat, idx, fmax)
         ctx.training = bool(training)
         return scores
@@ -274,9 +345,10 @@ class _DetScoreFn(torch.autograd.Function):
         gs = grad_scores.contiguous().float()
         gf = torch.empty_like(feat)
         ws = _ws(256, feat.device)
-        _native.check(_native.lib().d3f_detection_scores_backward(_p(feat), N, C, _p(idx), H, _p(fmax), _p(gs), _p(gf),
-                                                                  _p(ws), 256, _stream()),
-                      "d3f_detection_scores_backward")
+        with _region("detection_bwd[N=%d]" % N, 4 * N * H + 4 * N * H * C + 12 * N * C + 4 * N):
+            _native.check(_native.lib().d3f_detection_scores_backward(_p(feat), N, C, _p(idx), H, _p(fmax), _p(gs),
+                                                                      _p(gf), _p(ws), 256, _stream()),
+                          "d3f_detection_scores_backward")
         return gf, None, None
 
 

@@ -42,9 +42,9 @@ class LazyList(list):
         self._load()
         return super().__repr__()
 
-    def mean(self):
+    def device_mean(self):
         """Device-side mean (what trainer.py:99-100 computes with np.mean) without the read-back."""
-        return self._t.mean() if self._t is not None else torch.tensor(super().__iter__()).mean()
+        return self._t.mean() if self._t is not None else torch.tensor(list(super().__iter__())).mean()
 
 
 def cdist(a, b, metric='euclidean'):

@@ -37,7 +37,8 @@ extern "C" {
 #define D3F_ST_TABLE_FULL 4     /* voxel hash table full (workspace sized for fewer points) */
 
 const char* d3f_version(void);
-int d3f_device_arch_ok(void); /* 1 if the current HIP device is gfx950 */
+int d3f_device_arch_ok(void); /* 1 if the current HIP device is gfx950, 0 otherwise, <0 = -(hipError_t) */
+int d3f_device_arch_name(char* out, int n); /* gcnArchName of the current device */
 
 /* ------------------------------------------------------------------------------------------------
  * Radius neighbors -- replaces radius_neighbors.batch_query

@@ -1,0 +1,149 @@
+"""CPU: host-side logic of the package -- no kernel launches."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+import d3feat_pytorch_amd as pkg
+from d3feat_pytorch_amd import config as cfgmod
+from d3feat_pytorch_amd import ops, synthetic
+from d3feat_pytorch_amd.datasets import dataloader as dl
+from d3feat_pytorch_amd.kernels.kernel_points import base_disposition, load_kernels
+from d3feat_pytorch_amd.models import blocks
+from d3feat_pytorch_amd.models.architectures import KPFCNN
+from d3feat_pytorch_amd.utils.loss import CircleLoss, DetLoss, LazyList
+
+REF = "/root/reference"
+
+
+def test_ops_refuse_cpu_tensors_loudly():
+    x = torch.zeros(4, 3)
+    with pytest.raises(RuntimeError):
+        ops.kpconv(x, x, torch.zeros(4, 2, dtype=torch.long), torch.zeros(4, 1), torch.zeros(15, 3),
+                   torch.zeros(15, 1, 8), 0.06)
+    with pytest.raises(RuntimeError):
+        ops.max_pool(torch.zeros(4, 8), torch.zeros(2, 3, dtype=torch.long))
+    with pytest.raises(RuntimeError):
+        ops.detection_scores(torch.zeros(4, 32), torch.zeros(4, 3, dtype=torch.long))
+    with pytest.raises(RuntimeError):
+        ops.RadiusGrid(x, [4], 0.1)
+    if not torch.cuda.is_available():
+        with pytest.raises(RuntimeError):
+            dl.batch_neighbors_kpconv(np.zeros((4, 3), np.float32), np.zeros((4, 3), np.float32), [4], [4], 0.1, 10)
+
+
+def test_block_walk_matches_reference_radii():
+    cfg = cfgmod.default_config()
+    w = dl._Walk(cfg)
+    assert len(w.layers) == 5
+    for l, e in enumerate(w.layers):
+        assert e['conv_r'] == pytest.approx(0.075 * 2 ** l)
+        assert e['pool'] == (l < 4)
+        if l < 4:
+            assert e['dl'] == pytest.approx(0.06 * 2 ** l) and e['up_r'] == pytest.approx(0.15 * 2 ** l)
+    assert cfg.architecture[:5] == ['simple', 'resnetb', 'resnetb_strided', 'resnetb', 'resnetb']
+    assert cfg.architecture[-2:] == ['nearest_upsample', 'last_unary'] and len(cfg.architecture) == 22
+
+
+def test_kernel_points_contract():
+    base = base_disposition(15, 3, 'center')
+    assert base.shape == (15, 3) and np.allclose(base[0], 0)
+    assert abs(np.linalg.norm(base[1:], axis=1).mean() - 0.66) < 1e-6
+    d = np.linalg.norm(base[:, None] - base[None], axis=-1) + np.eye(15)
+    assert d.min() > 0.3  # well spread
+    np.random.seed(3)
+    kp = load_kernels(0.075, 15, 3, 'center')
+    assert kp.dtype == np.float32 and kp.shape == (15, 3) and np.abs(kp).max() < 0.075
+
+
+def test_model_state_dict_layout_matches_golden(golden_s0, golden_s1):
+    np.random.seed(0)
+    torch.manual_seed(0)
+    model = KPFCNN(cfgmod.default_config(first_features_dim=16))
+    sd = model.state_dict()
+    gold = {k[3:]: golden_s0[k].shape for k in golden_s0.files if k.startswith('sd.')}
+    assert set(sd) == set(gold)
+    for k, v in sd.items():
+        assert tuple(v.shape) == tuple(gold[k]), k
+    # identical construction order + same torch CPU RNG => identical initial weights as the reference model
+    for k, v in sd.items():
+        if not k.endswith('kernel_points'):
+            assert np.array_equal(v.numpy(), golden_s0['sd.' + k]), k
+    np.random.seed(0)
+    torch.manual_seed(0)
+    full = KPFCNN(cfgmod.default_config())
+    n_params = sum(p.numel() for p in full.parameters() if p.requires_grad)
+    assert n_params == 24316320
+    for k, v in full.state_dict().items():
+        if not k.endswith('kernel_points'):
+            s = golden_s1['sdsum.' + k]
+            assert abs(float(v.double().sum()) - s[0]) <= 1e-9 * max(1.0, s[1]), k
+
+
+def test_lazy_list_and_loss_signatures():
+    t = torch.tensor([1.0, 2.0, 3.0])
+    ll = LazyList(t)
+    assert len(ll) == 3 and float(ll.device_mean()) == 2.0 and list(ll) == [1.0, 2.0, 3.0] and ll[1] == 2.0
+    assert float(np.mean(ll)) == 2.0
+    c = CircleLoss(dist_type='euclidean', log_scale=10, safe_radius=0.1, pos_margin=0.1, neg_margin=1.4)
+    assert c.pos_optimal == 0.1 and c.neg_optimal == 1.4
+    with pytest.raises(NotImplementedError):
+        CircleLoss(dist_type='cosine')
+    with pytest.raises(RuntimeError):
+        DetLoss()(torch.zeros(4, 4), torch.zeros(4, 1), torch.zeros(4, 1))
+
+
+def test_synthetic_is_deterministic_and_shaped(native):
+    sub = lambda p, l, d: native.subsample_batch(p, l, sampleDl=d)  # noqa: E731
+    a = synthetic.make_pair(11, 12, sub, n_raw=40000, scale=0.2, num_node=64)
+    b = synthetic.make_pair(11, 12, sub, n_raw=40000, scale=0.2, num_node=64)
+    for x, y in zip(a, b):
+        assert np.array_equal(x, y)
+    assert a[0].dtype == np.float32 and a[4].shape == (64, 2) and a[5].shape == (64, 64) and a[5].dtype == np.float64
+    assert a[2].shape == (a[0].shape[0], 1)
+
+
+def test_unsupported_modes_raise():
+    with pytest.raises(NotImplementedError):
+        blocks.KPConv(15, 3, 8, 8, 0.06, 0.075, deformable=True)
+    with pytest.raises(NotImplementedError):
+        blocks.KPConv(15, 3, 8, 8, 0.06, 0.075, KP_influence='gaussian')
+    with pytest.raises(ValueError):
+        blocks.block_decider('nonsense', 0.1, 8, 8, 0, cfgmod.default_config())
+
+
+@pytest.mark.skipif(not os.path.isdir(REF), reason="reference tree not mounted")
+def test_reference_architectures_runs_on_our_blocks_unchanged():
+    """Drop-in boundary: the reference's models/architectures.py imported as-is, with `models.blocks` resolved to
+    this package, builds the same network (same parameter names and shapes)."""
+    saved = {k: sys.modules.get(k) for k in list(sys.modules) if k == 'models' or k.startswith('models.')}
+    for k in saved:
+        sys.modules.pop(k, None)
+    try:
+        pkg.install_reference_aliases(['models', 'models.blocks'], overwrite=True)
+        import importlib.util
+        spec = importlib.util.spec_from_file_location('ref_architectures', os.path.join(REF, 'models', 'architectures.py'))
+        mod = importlib.util.module_from_spec(spec)
+        import contextlib
+        import io
+        with contextlib.redirect_stdout(io.StringIO()):
+            spec.loader.exec_module(mod)
+            np.random.seed(0)
+            torch.manual_seed(0)
+            ref_model = mod.KPFCNN(cfgmod.default_config(first_features_dim=16))
+        assert isinstance(ref_model.encoder_blocks[0].KPConv, blocks.KPConv)
+        np.random.seed(0)
+        torch.manual_seed(0)
+        ours = KPFCNN(cfgmod.default_config(first_features_dim=16))
+        a, b = ref_model.state_dict(), ours.state_dict()
+        assert list(a) == list(b)
+        for k in a:
+            assert torch.equal(a[k], b[k]), k
+    finally:
+        for k in [k for k in sys.modules if k == 'models' or k.startswith('models.')]:
+            sys.modules.pop(k, None)
+        for k, v in saved.items():
+            if v is not None:
+                sys.modules[k] = v
