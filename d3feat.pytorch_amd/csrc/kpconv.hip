@@ -227,6 +227,16 @@ int launch_wf(const float* q_pts, const float* s_pts, const int32_t* idx, const 
   return D3F_OK;
 }
 
+// kpconv_fused.hip
+bool kpconv_fused_supported(int Cin, int Cout, int K);
+size_t kpconv_fused_ws_bytes(int Ns);
+int kpconv_forward_fused(const float* q_pts, int Nq, const float* s_pts, int Ns, const int32_t* idx, int H,
+                         const float* x, int Cin, const float* kp, int K, const float* W, int Cout, float extent,
+                         float* out, float* nn_out, void* ws, hipStream_t stream);
+int kpconv_backward_fused(const float* q_pts, int Nq, const float* s_pts, int Ns, const int32_t* idx, int H,
+                          const float* x, int Cin, const float* kp, int K, const float* W, int Cout, float extent,
+                          const float* nn, const float* gout, float* gx, float* gw, void* ws, hipStream_t stream);
+
 }  // namespace d3f
 
 using namespace d3f;
@@ -238,7 +248,9 @@ size_t d3f_kpconv_ws_bytes(int Nq, int Ns, int H, int K, int Cin, int Cout) {
   const size_t n = (size_t)(Nq > 0 ? Nq : 1), kc = (size_t)K * Cin;
   const size_t wf = align_up(sizeof(float) * n * kc, 256);                                  // wf
   const size_t gw = align_up(sizeof(float) * n * (kc > (size_t)Cout ? kc : (size_t)Cout), 256);  // gW / scaled grad
-  return wf + gw + 256;
+  const size_t generic = wf + gw + 256;
+  const size_t fused = kpconv_fused_ws_bytes(Ns) + 256;
+  return generic > fused ? generic : fused;
 }
 
 static int kp_args_ok(const void* q_pts, int Nq, const void* s_pts, int Ns, const void* idx, int H, const void* x,
@@ -256,6 +268,9 @@ int d3f_kpconv_forward(const float* q_pts, int Nq, const float* s_pts, int Ns, c
   if (ws_bytes < d3f_kpconv_ws_bytes(Nq, Ns, H, K, Cin, Cout)) return D3F_EWORKSPACE;
   if (Nq == 0) return D3F_OK;
   hipStream_t stream = (hipStream_t)stream_;
+  if (kpconv_fused_supported(Cin, Cout, K))
+    return kpconv_forward_fused(q_pts, Nq, s_pts, Ns, idx, H, x, Cin, kernel_points, K, weights, Cout, extent, out,
+                                nn_out, ws, stream);
   float* wf = (float*)ws;
   int rc = launch_wf<true>(q_pts, s_pts, idx, x, kernel_points, Nq, Ns, H, Cin, K, extent, wf, nn_out, stream);
   if (rc) return rc;
@@ -281,6 +296,12 @@ int d3f_kpconv_backward(const float* q_pts, int Nq, const float* s_pts, int Ns, 
     if (grad_w && hipMemsetAsync(grad_w, 0, sizeof(float) * (size_t)KC * Cout, stream) != hipSuccess)
       return D3F_ELAUNCH;
     return D3F_OK;
+  }
+  if (kpconv_fused_supported(Cin, Cout, K)) {
+    if (grad_w && hipMemsetAsync(grad_w, 0, sizeof(float) * (size_t)KC * Cout, stream) != hipSuccess)
+      return D3F_ELAUNCH;
+    return kpconv_backward_fused(q_pts, Nq, s_pts, Ns, idx, H, x, Cin, kernel_points, K, weights, Cout, extent, nn,
+                                 grad_out, grad_x, grad_w, ws, stream);
   }
   int rc;
   if (grad_w) {

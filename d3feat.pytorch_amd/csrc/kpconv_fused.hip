@@ -1,52 +1,44 @@
 // Fused KPConv kernels for gfx950: neighbor gather + influence weights + K-way aggregation + (K*Cin)->Cout
-// contraction + neighbor-count normalisation in ONE launch, both matrix products on v_mfma_f32_16x16x4_f32.
+// contraction + neighbor-count normalisation in ONE launch (forward), and the matching grad-input / grad-weight
+// kernels; every matrix product runs on v_mfma_f32_16x16x4_f32 (exact f32 FMA chains).
 //
 // Reference semantics: models/blocks.py:277-380 (see kpconv.hip).  Mapping to the hardware:
 //
-//   workgroup = 4 waves = one tile of 16 queries.  Input channels are walked in super-chunks of CC = 16*CV (<= 64).
+//   workgroup = 4 waves = one tile of 16 queries.  Input channels are walked in chunks of CC = 16*CV (<= 64).
 //
-//   phase A (aggregation, per wave: 4 of the 16 queries, one after the other)
+//   FORWARD
+//   phase A (aggregation, per wave: 4 of the 16 queries, one after the other; kpconv_tile.hpp)
 //     MFMA  D[k, c] += A[k, h] * B[h, c]   with  A = influence weights w[q, h, k]  (16 kernel-point rows x 4 neighbors)
 //                                                  B = gathered features x[idx[q,h], c] (4 neighbors x 16 channels)
 //     lane l = (k = l & 15, hh = l >> 4) computes ITS OWN A element (one sqrt per lane, the kernel point lives in
-//     3 VGPRs) and loads ITS OWN B elements as one CV-wide vector, so the weights never touch LDS.  Channel c of
-//     MFMA r in column j is  cbase + j*CV + r : a column permutation that makes the x gather a 16*CV-float
-//     contiguous row segment per 16 lanes (64..256 B).
-//     Supports are read from a packed float4 {x, y, z, [sum_c x > 0]} array (one 16-B load instead of four).
+//     3 VGPRs) and loads ITS OWN B elements as one CV-wide vector, so the weights never touch LDS.
+//     Supports come from a packed float4 {x, y, z, [sum_c x > 0]} array (one 16-B gather instead of four loads).
 //   the 16 x (K*CC) tile of weighted features goes to LDS (row stride K*CC + 4 floats)
 //   phase B (contraction): out[16 x Cout] += wf[16 x K*CC] @ W[k*Cin + c, :]; A fragments are 16-B LDS reads
 //     (4 MFMA k-steps each), B fragments stream from L2; waves split the Cout blocks (and the reduction range when
 //     Cout < 64, combined through LDS float atomics).  Accumulators stay in registers across channel chunks.
 //   epilogue: divide by nn (count of neighbors with positive feature sum) and store.
-#include "common.hpp"
+//   Few-point / wide layers (the bottom of the U-Net: 150..600 points, 256..512 channels) would leave the chip
+//   empty with one workgroup per tile, so the launch additionally splits Cout into slabs (grid.y) and the channel
+//   chunks (grid.z, partial sums combined with global float atomics into a zeroed output).
+//
+//   GRAD INPUT   gx[idx[q,h], c] += sum_k w[q,h,k] * gW[q,k,c],   gW = (g/nn) @ W^T
+//   phase 1: gW tile [16 x K*CC] by MFMA (A = g tile from LDS, B = 16 rows x 64 B of W per lane group) -> LDS
+//   phase 2: per query, E[16 neighbors x 16 channels] = w^T[16 x K] @ gW[q][K x 16] by MFMA, rows scattered with
+//            global float atomics (64-B contiguous per row).
+//
+//   GRAD WEIGHTS dW[k*Cin + c, o] = sum_q wf[q,k,c] * g[q,o]/nn[q]
+//   persistent workgroups own a (32-channel, 32-output) block of dW in registers, walk their share of query tiles
+//   (phase A again + a 16 x 32 gradient tile in LDS, MFMA with the QUERY as reduction index) and flush once with
+//   atomics.
+#include "kpconv_tile.hpp"
 
 namespace d3f {
 
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-
-template <int CV>
-struct VecT;
-template <>
-struct VecT<1> { typedef float type; };
-template <>
-struct VecT<2> { typedef float2 type; };
-template <>
-struct VecT<4> { typedef float4 type; };
-
-template <int CV>
-__device__ __forceinline__ float vget(const typename VecT<CV>::type& v, int r);
-template <>
-__device__ __forceinline__ float vget<1>(const float& v, int) { return v; }
-template <>
-__device__ __forceinline__ float vget<2>(const float2& v, int r) { return r == 0 ? v.x : v.y; }
-template <>
-__device__ __forceinline__ float vget<4>(const float4& v, int r) { return r == 0 ? v.x : (r == 1 ? v.y : (r == 2 ? v.z : v.w)); }
-
-// spack[n] = {s.x, s.y, s.z, (sum_c x[n,c] > 0) ? 1 : 0}; one wave per 64/CPW supports
+// spack[n] = {s.x, s.y, s.z, (sum_c x[n,c] > 0) ? 1 : 0}; 16 lanes cooperate on one support row
 __global__ __launch_bounds__(256) void pack_supports_kernel(const float* __restrict__ s_pts,
                                                             const float* __restrict__ x, int Ns, int Cin,
                                                             float4* __restrict__ spack) {
-  // 16 lanes cooperate on one support row
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
   const int n = t >> 4, l = t & 15;
   float s = 0.0f;
@@ -59,19 +51,19 @@ __global__ __launch_bounds__(256) void pack_supports_kernel(const float* __restr
                            s > 0.0f ? 1.0f : 0.0f);
 }
 
+// ================================================================================================ forward
 template <int CV, int NBW, int WK>
 __global__ __launch_bounds__(256) void kpconv_fwd_fused_kernel(
     const float* __restrict__ q_pts, const float4* __restrict__ spack, const int32_t* __restrict__ idx,
     const float* __restrict__ x, const float* __restrict__ kp, const float* __restrict__ W, int Nq, int Ns, int H,
     int Cin, int Cout, int K, float extent, float* __restrict__ out, float* __restrict__ nn_out) {
-  typedef typename VecT<CV>::type xvec;
   constexpr int CC = 16 * CV;
   constexpr int WN = 4 / WK;
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int RS = K * CC + 4;
-  float* wf = lds;             // [16][RS]
-  float* nn_l = lds + 16 * RS; // [16]
-  float* red = nn_l + 16;      // [16][Cout] when WK > 1
+  float* wf = lds;              // [16][RS]
+  float* nn_l = lds + 16 * RS;  // [16]
+  float* red = nn_l + 16;       // [16][16*NBW*WN] when WK > 1
 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int li = lane & 15, lg = lane >> 4;
@@ -81,15 +73,19 @@ __global__ __launch_bounds__(256) void kpconv_fwd_fused_kernel(
               kz = klive ? kp[3 * li + 2] : 0.0f;
   const int wn = (WK == 1) ? wave : (WK == 2 ? (wave & 1) : 0);
   const int wk = (WK == 1) ? 0 : (WK == 2 ? (wave >> 1) : wave);
+  constexpr int SLAB = 16 * NBW * WN;
+  const int n_base = blockIdx.y * SLAB;  // Cout slab of this workgroup
+  const bool split = gridDim.z > 1;      // channel chunks shared between workgroups -> atomic epilogue
 
   f32x4 acc2[NBW];
 #pragma unroll
   for (int nb = 0; nb < NBW; ++nb) acc2[nb] = (f32x4){0.f, 0.f, 0.f, 0.f};
   if (WK > 1)
-    for (int t = threadIdx.x; t < 16 * Cout; t += 256) red[t] = 0.0f;
+    for (int t = threadIdx.x; t < 16 * SLAB; t += 256) red[t] = 0.0f;
 
   const int nchunks = Cin / CC;
-  for (int ch = 0; ch < nchunks; ++ch) {
+  bool first = true;
+  for (int ch = blockIdx.z; ch < nchunks; ch += gridDim.z) {
     const int cbase = ch * CC;
     // ------------------------------------------------------------------ phase A
 #pragma unroll 1
@@ -100,56 +96,26 @@ __global__ __launch_bounds__(256) void kpconv_fwd_fused_kernel(
 #pragma unroll
       for (int r = 0; r < CV; ++r) acc[r] = (f32x4){0.f, 0.f, 0.f, 0.f};
       float cnt = 0.0f;
-      if (q < Nq) {
-        const float qx = q_pts[3 * (size_t)q + 0], qy = q_pts[3 * (size_t)q + 1], qz = q_pts[3 * (size_t)q + 2];
-        const int32_t* row = idx + (size_t)q * H;
-#pragma unroll 4
-        for (int h0 = 0; h0 < H; h0 += 4) {
-          const int h = h0 + lg;
-          const int n = h < H ? row[h] : Ns;
-          const bool valid = (unsigned)n < (unsigned)Ns;
-          float w = 0.0f;
-          xvec xv;
-          if (valid) {
-            const float4 sp = spack[n];
-            const float dx = (sp.x - qx) - kx, dy = (sp.y - qy) - ky, dz = (sp.z - qz) - kz;
-            const float d2 = dx * dx + dy * dy + dz * dz;
-            w = klive ? fmaxf(0.0f, 1.0f - sqrtf(d2) / extent) : 0.0f;
-            xv = *(const xvec*)(x + (size_t)n * Cin + cbase + li * CV);
-            cnt += (li == 0) ? sp.w : 0.0f;
-          } else {
-            xv = xvec();
-          }
-#pragma unroll
-          for (int r = 0; r < CV; ++r) acc[r] = __builtin_amdgcn_mfma_f32_16x16x4f32(w, vget<CV>(xv, r), acc[r], 0, 0, 0);
-        }
-      }
-      // D layout: row k = 4*lg + r2, column j = li  ->  channel cbase + li*CV + r
-#pragma unroll
-      for (int r2 = 0; r2 < 4; ++r2) {
-        const int k = 4 * lg + r2;
-        if (k < K) {
-          float* dst = wf + ql * RS + k * CC + li * CV;
-          if (CV == 1) dst[0] = acc[0][r2];
-          if (CV == 2) *(float2*)dst = make_float2(acc[0][r2], acc[CV > 1 ? 1 : 0][r2]);
-          if (CV == 4)
-            *(float4*)dst = make_float4(acc[0][r2], acc[CV > 1 ? 1 : 0][r2], acc[CV > 2 ? 2 : 0][r2],
-                                        acc[CV > 3 ? 3 : 0][r2]);
-        }
-      }
-      if (ch == 0) {
+      if (q < Nq)
+        aggregate_query<CV>(idx + (size_t)q * H, H, Ns, spack, x, Cin, cbase, q_pts[3 * (size_t)q + 0],
+                            q_pts[3 * (size_t)q + 1], q_pts[3 * (size_t)q + 2], kx, ky, kz, klive, extent, li, lg, acc,
+                            cnt);
+      store_wf_tile<CV>(wf + ql * RS, K, li, lg, acc);
+      if (first) {
         cnt += __shfl_xor(cnt, 16, 64);
         cnt += __shfl_xor(cnt, 32, 64);
         if (lane == 0) {
           const float v = fmaxf(cnt, 1.0f);
           nn_l[ql] = v;
-          if (q < Nq) nn_out[q] = v;
+          if (q < Nq && blockIdx.y == 0 && blockIdx.z == 0) nn_out[q] = v;
         }
       }
     }
+    first = false;
     __syncthreads();
     // ------------------------------------------------------------------ phase B
     const int steps = (K * CC) >> 4;
+#pragma unroll 2
     for (int s = wk; s < steps; s += WK) {
       const int kc0 = s << 4;
       const float4 a = *(const float4*)(wf + li * RS + kc0 + 4 * lg);
@@ -157,7 +123,7 @@ __global__ __launch_bounds__(256) void kpconv_fwd_fused_kernel(
       const float* wrow = W + (size_t)(k * Cin + cbase + c0 + 4 * lg) * Cout;
 #pragma unroll
       for (int nb = 0; nb < NBW; ++nb) {
-        const int col = (wn + nb * WN) * 16 + li;
+        const int col = n_base + (wn + nb * WN) * 16 + li;
         const float b0 = wrow[col], b1 = wrow[Cout + col], b2 = wrow[2 * Cout + col], b3 = wrow[3 * Cout + col];
         acc2[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b0, acc2[nb], 0, 0, 0);
         acc2[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b1, acc2[nb], 0, 0, 0);
@@ -171,11 +137,15 @@ __global__ __launch_bounds__(256) void kpconv_fwd_fused_kernel(
   if (WK == 1) {
 #pragma unroll
     for (int nb = 0; nb < NBW; ++nb) {
-      const int col = (wn + nb * WN) * 16 + li;
+      const int col = n_base + (wn + nb * WN) * 16 + li;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int rowl = 4 * lg + r;
-        if (q0 + rowl < Nq) out[(size_t)(q0 + rowl) * Cout + col] = acc2[nb][r] / nn_l[rowl];
+        if (q0 + rowl < Nq) {
+          const float v = acc2[nb][r] / nn_l[rowl];
+          if (split) atomicAdd(&out[(size_t)(q0 + rowl) * Cout + col], v);
+          else out[(size_t)(q0 + rowl) * Cout + col] = v;
+        }
       }
     }
   } else {
@@ -183,16 +153,198 @@ __global__ __launch_bounds__(256) void kpconv_fwd_fused_kernel(
     for (int nb = 0; nb < NBW; ++nb) {
       const int col = (wn + nb * WN) * 16 + li;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) atomicAdd(&red[(4 * lg + r) * Cout + col], acc2[nb][r]);
+      for (int r = 0; r < 4; ++r) atomicAdd(&red[(4 * lg + r) * SLAB + col], acc2[nb][r]);
     }
     __syncthreads();
-    for (int t = threadIdx.x; t < 16 * Cout; t += 256) {
-      const int rowl = t / Cout;
-      if (q0 + rowl < Nq) out[(size_t)q0 * Cout + t] = red[t] / nn_l[rowl];
+    for (int t = threadIdx.x; t < 16 * SLAB; t += 256) {
+      const int rowl = t / SLAB, col = n_base + t % SLAB;
+      if (q0 + rowl < Nq) {
+        const float v = red[t] / nn_l[rowl];
+        if (split) atomicAdd(&out[(size_t)(q0 + rowl) * Cout + col], v);
+        else out[(size_t)(q0 + rowl) * Cout + col] = v;
+      }
     }
   }
 }
 
+// ================================================================================================ grad input
+template <int CV>
+__global__ __launch_bounds__(256) void kpconv_bwd_dx_kernel(
+    const float* __restrict__ q_pts, const float4* __restrict__ spack, const int32_t* __restrict__ idx,
+    const float* __restrict__ kp, const float* __restrict__ W, const float* __restrict__ nn,
+    const float* __restrict__ gout, int Nq, int Ns, int H, int Cin, int Cout, int K, float extent,
+    float* __restrict__ gx) {
+  constexpr int CC = 16 * CV;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int RS = K * CC + 4, GS = Cout + 4;
+  float* gw = lds;            // [16][RS]   gW tile of this channel chunk
+  float* gl = lds + 16 * RS;  // [16][GS]   (grad_out / nn) tile
+
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int li = lane & 15, lg = lane >> 4;
+  const int q0 = blockIdx.x * 16;
+  const int cbase = blockIdx.y * CC;
+
+  for (int t = threadIdx.x; t < 16 * Cout; t += 256) {
+    const int r = t / Cout, o = t % Cout;
+    const int q = q0 + r;
+    gl[r * GS + o] = q < Nq ? gout[(size_t)q * Cout + o] / nn[q] : 0.0f;
+  }
+  __syncthreads();
+  // ---- phase 1: gW[q, kc] = sum_o g[q, o] * W[kc, o]
+  const int nkb = (K * CC) >> 4;
+  for (int kb = wave; kb < nkb; kb += 4) {
+    const int kc0 = kb << 4;
+    const int k = kc0 / CC, c0 = kc0 % CC;
+    const float* wr = W + (size_t)(k * Cin + cbase + c0 + li) * Cout + 4 * lg;
+    const float* ar = gl + li * GS + 4 * lg;
+    f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
+    for (int o0 = 0; o0 < Cout; o0 += 16) {
+      const float4 a = *(const float4*)(ar + o0);
+      const float4 b = *(const float4*)(wr + o0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b.x, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b.y, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, b.z, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, b.w, acc, 0, 0, 0);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) gw[(4 * lg + r) * RS + kc0 + li] = acc[r];
+  }
+  __syncthreads();
+  // ---- phase 2: per query, E[h, c] = sum_k w[q,h,k] * gW[q,k,c]; scatter rows to gx
+  float kpx[4], kpy[4], kpz[4];
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    const int k = 4 * s + lg;
+    const bool live = k < K;
+    kpx[s] = live ? kp[3 * k + 0] : 0.0f;
+    kpy[s] = live ? kp[3 * k + 1] : 0.0f;
+    kpz[s] = live ? kp[3 * k + 2] : 0.0f;
+  }
+#pragma unroll 1
+  for (int i = 0; i < 4; ++i) {
+    const int ql = wave * 4 + i;
+    const int q = q0 + ql;
+    if (q >= Nq) continue;
+    const float qx = q_pts[3 * (size_t)q + 0], qy = q_pts[3 * (size_t)q + 1], qz = q_pts[3 * (size_t)q + 2];
+    const int32_t* row = idx + (size_t)q * H;
+    const float* gq = gw + ql * RS;
+    for (int h0 = 0; h0 < H; h0 += 16) {
+      const int h = h0 + li;
+      const int n = h < H ? row[h] : Ns;
+      const bool valid = (unsigned)n < (unsigned)Ns;
+      const float4 sp = spack[valid ? n : 0];
+      float wk[4];
+#pragma unroll
+      for (int s = 0; s < 4; ++s)
+        wk[s] = (valid && 4 * s + lg < K) ? kp_influence(sp, qx, qy, qz, kpx[s], kpy[s], kpz[s], extent) : 0.0f;
+      int nrow[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) nrow[r] = __shfl(n, 4 * lg + r, 64);
+#pragma unroll
+      for (int cb = 0; cb < CV; ++cb) {
+        f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+          const int k = 4 * s + lg;
+          const float b = k < K ? gq[k * CC + cb * 16 + li] : 0.0f;
+          acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wk[s], b, acc, 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if ((unsigned)nrow[r] < (unsigned)Ns) atomicAdd(&gx[(size_t)nrow[r] * Cin + cbase + cb * 16 + li], acc[r]);
+      }
+    }
+  }
+}
+
+// ================================================================================================ grad weights
+// One workgroup owns the dW block [K x CC channels(cbase..) x 16*SB outputs(obase..)] and walks query tiles
+// blockIdx.x, blockIdx.x + gridDim.x, ...   (kc-block, o-block) pairs are dealt round-robin to the 4 waves.
+template <int CV, int SB>
+__global__ __launch_bounds__(256) void kpconv_bwd_dw_kernel(
+    const float* __restrict__ q_pts, const float4* __restrict__ spack, const int32_t* __restrict__ idx,
+    const float* __restrict__ x, const float* __restrict__ kp, const float* __restrict__ nn,
+    const float* __restrict__ gout, int Nq, int Ns, int H, int Cin, int Cout, int K, float extent,
+    float* __restrict__ gW) {
+  constexpr int CC = 16 * CV;
+  constexpr int SLAB = 16 * SB;
+  constexpr int GS = SLAB + 4;
+  constexpr int MAXP = (16 * CV * SB + 3) / 4;  // pairs per wave (K <= 16 -> at most 16*CV kc-blocks)
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int RS = K * CC + 4;
+  float* wf = lds;            // [16][RS]
+  float* gl = lds + 16 * RS;  // [16][GS]
+
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int li = lane & 15, lg = lane >> 4;
+  const int cbase = blockIdx.y * CC, obase = blockIdx.z * SLAB;
+  const bool klive = li < K;
+  const float kx = klive ? kp[3 * li + 0] : 0.0f, ky = klive ? kp[3 * li + 1] : 0.0f,
+              kz = klive ? kp[3 * li + 2] : 0.0f;
+  const int nkb = (K * CC) >> 4;
+  const int npairs = nkb * SB;
+
+  f32x4 acc2[MAXP];
+#pragma unroll
+  for (int j = 0; j < MAXP; ++j) acc2[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const int tiles = (Nq + 15) >> 4;
+  for (int tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
+    const int q0 = tile * 16;
+    for (int t = threadIdx.x; t < 16 * SLAB; t += 256) {
+      const int r = t / SLAB, o = t % SLAB;
+      const int q = q0 + r;
+      gl[r * GS + o] = q < Nq ? gout[(size_t)q * Cout + obase + o] / nn[q] : 0.0f;
+    }
+#pragma unroll 1
+    for (int i = 0; i < 4; ++i) {
+      const int ql = wave * 4 + i;
+      const int q = q0 + ql;
+      f32x4 acc[CV];
+#pragma unroll
+      for (int r = 0; r < CV; ++r) acc[r] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      float cnt = 0.0f;
+      if (q < Nq)
+        aggregate_query<CV>(idx + (size_t)q * H, H, Ns, spack, x, Cin, cbase, q_pts[3 * (size_t)q + 0],
+                            q_pts[3 * (size_t)q + 1], q_pts[3 * (size_t)q + 2], kx, ky, kz, klive, extent, li, lg, acc,
+                            cnt);
+      store_wf_tile<CV>(wf + ql * RS, K, li, lg, acc);
+    }
+    __syncthreads();
+    // dW[kc, o] += sum_q wf[q, kc] * g[q, o]    (A[i = kc][kk = q], B[kk = q][j = o])
+#pragma unroll
+    for (int j = 0; j < MAXP; ++j) {
+      const int p = wave + 4 * j;
+      if (p < npairs) {
+        const int kb = p / SB, ob = p % SB;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+          const float a = wf[(4 * s + lg) * RS + kb * 16 + li];
+          const float b = gl[(4 * s + lg) * GS + ob * 16 + li];
+          acc2[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc2[j], 0, 0, 0);
+        }
+      }
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int j = 0; j < MAXP; ++j) {
+    const int p = wave + 4 * j;
+    if (p < npairs) {
+      const int kb = p / SB, ob = p % SB;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int kc = kb * 16 + 4 * lg + r;  // D row
+        const int k = kc / CC, c = kc % CC;
+        atomicAdd(&gW[(size_t)(k * Cin + cbase + c) * Cout + obase + ob * 16 + li], acc2[j][r]);
+      }
+    }
+  }
+}
+
+// ================================================================================================ host side
 bool kpconv_fused_supported(int Cin, int Cout, int K) {
   const bool cin_ok = (Cin == 16 || Cin == 32 || (Cin % 64 == 0 && Cin <= 512));
   const bool cout_ok = (Cout == 16 || Cout == 32 || Cout == 64 || Cout == 128 || Cout == 256 || Cout == 512);
@@ -201,20 +353,39 @@ bool kpconv_fused_supported(int Cin, int Cout, int K) {
 
 size_t kpconv_fused_ws_bytes(int Ns) { return align_up(sizeof(float4) * (size_t)(Ns > 0 ? Ns : 1), 256); }
 
+static int pack_supports(const float* s_pts, const float* x, int Ns, int Cin, float4* spack, hipStream_t stream) {
+  if (Ns > 0) {
+    pack_supports_kernel<<<cdiv((long long)Ns * 16, 256), 256, 0, stream>>>(s_pts, x, Ns, Cin, spack);
+    D3F_LAUNCH_CHECK();
+  }
+  return D3F_OK;
+}
+
 template <int CV>
 static int launch_fused_cv(const float* q_pts, const float4* spack, const int32_t* idx, const float* x,
                            const float* kp, const float* W, int Nq, int Ns, int H, int Cin, int Cout, int K,
                            float extent, float* out, float* nn_out, hipStream_t stream) {
-  const int grid = cdiv(Nq, 16);
+  const int tiles = cdiv(Nq, 16);
   const int CC = 16 * CV;
+  const int nchunks = Cin / CC;
   const size_t lds_base = sizeof(float) * (size_t)(16 * (K * CC + 4) + 16);
+  // Work decomposition: the whole Cout in one workgroup when there are plenty of query tiles (phase A is then
+  // computed once per tile); for the deep, few-point layers split Cout into slabs (grid.y), then the channel chunks
+  // (grid.z, atomic combine into a zeroed output) until the launch covers the 256 CUs a few times over.
+  int slab = Cout;
+  while (slab > 64 && (long long)tiles * (Cout / slab) < 512) slab >>= 1;
+  int zsplit = 1;
+  while (zsplit < nchunks && (long long)tiles * (Cout / slab) * zsplit < 512) zsplit <<= 1;
+  if (zsplit > nchunks) zsplit = nchunks;
+  if (zsplit > 1 && hipMemsetAsync(out, 0, sizeof(float) * (size_t)Nq * Cout, stream) != hipSuccess) return D3F_ELAUNCH;
 #define D3F_LAUNCH(NBW, WK)                                                                                     \
   {                                                                                                             \
-    const size_t lds = lds_base + ((WK) > 1 ? sizeof(float) * 16 * (size_t)Cout : 0);                           \
+    const size_t lds = lds_base + ((WK) > 1 ? sizeof(float) * 16 * (size_t)slab : 0);                           \
+    dim3 grid(tiles, Cout / slab, zsplit);                                                                      \
     kpconv_fwd_fused_kernel<CV, NBW, WK><<<grid, 256, lds, stream>>>(q_pts, spack, idx, x, kp, W, Nq, Ns, H, Cin, \
                                                                       Cout, K, extent, out, nn_out);            \
   }
-  switch (Cout) {
+  switch (slab) {
     case 16: D3F_LAUNCH(1, 4) break;
     case 32: D3F_LAUNCH(1, 2) break;
     case 64: D3F_LAUNCH(1, 1) break;
@@ -232,13 +403,51 @@ int kpconv_forward_fused(const float* q_pts, int Nq, const float* s_pts, int Ns,
                          const float* x, int Cin, const float* kp, int K, const float* W, int Cout, float extent,
                          float* out, float* nn_out, void* ws, hipStream_t stream) {
   float4* spack = (float4*)ws;
-  if (Ns > 0) {
-    pack_supports_kernel<<<cdiv((long long)Ns * 16, 256), 256, 0, stream>>>(s_pts, x, Ns, Cin, spack);
-    D3F_LAUNCH_CHECK();
-  }
+  int rc = pack_supports(s_pts, x, Ns, Cin, spack, stream);
+  if (rc) return rc;
   if (Cin == 16) return launch_fused_cv<1>(q_pts, spack, idx, x, kp, W, Nq, Ns, H, Cin, Cout, K, extent, out, nn_out, stream);
   if (Cin == 32) return launch_fused_cv<2>(q_pts, spack, idx, x, kp, W, Nq, Ns, H, Cin, Cout, K, extent, out, nn_out, stream);
   return launch_fused_cv<4>(q_pts, spack, idx, x, kp, W, Nq, Ns, H, Cin, Cout, K, extent, out, nn_out, stream);
+}
+
+int kpconv_backward_fused(const float* q_pts, int Nq, const float* s_pts, int Ns, const int32_t* idx, int H,
+                          const float* x, int Cin, const float* kp, int K, const float* W, int Cout, float extent,
+                          const float* nn, const float* gout, float* gx, float* gw, void* ws, hipStream_t stream) {
+  float4* spack = (float4*)ws;
+  int rc = pack_supports(s_pts, x, Ns, Cin, spack, stream);
+  if (rc) return rc;
+  const int tiles = cdiv(Nq, 16);
+  if (gx) {
+    const int CV = Cin == 16 ? 1 : (Cin == 32 ? 2 : 4);
+    const int CC = 16 * CV;
+    const size_t lds = sizeof(float) * (size_t)(16 * (K * CC + 4) + 16 * (Cout + 4));
+    dim3 grid(tiles, Cin / CC);
+    if (CV == 1) kpconv_bwd_dx_kernel<1><<<grid, 256, lds, stream>>>(q_pts, spack, idx, kp, W, nn, gout, Nq, Ns, H, Cin, Cout, K, extent, gx);
+    else if (CV == 2) kpconv_bwd_dx_kernel<2><<<grid, 256, lds, stream>>>(q_pts, spack, idx, kp, W, nn, gout, Nq, Ns, H, Cin, Cout, K, extent, gx);
+    else kpconv_bwd_dx_kernel<4><<<grid, 256, lds, stream>>>(q_pts, spack, idx, kp, W, nn, gout, Nq, Ns, H, Cin, Cout, K, extent, gx);
+    D3F_LAUNCH_CHECK();
+  }
+  if (gw) {
+    const int CV = Cin == 16 ? 1 : 2;
+    const int SB = Cout == 16 ? 1 : 2;
+    const int CC = 16 * CV, SLAB = 16 * SB;
+    const int ny = Cin / CC, nz = Cout / SLAB;
+    int G = cdiv(768, ny * nz);
+    if (G > tiles) G = tiles;
+    if (G < 1) G = 1;
+    const size_t lds = sizeof(float) * (size_t)(16 * (K * CC + 4) + 16 * (SLAB + 4));
+    dim3 grid(G, ny, nz);
+#define D3F_DW(CVV, SBB)                                                                                          \
+  kpconv_bwd_dw_kernel<CVV, SBB><<<grid, 256, lds, stream>>>(q_pts, spack, idx, x, kp, nn, gout, Nq, Ns, H, Cin, Cout, \
+                                                             K, extent, gw)
+    if (CV == 1 && SB == 1) D3F_DW(1, 1);
+    else if (CV == 1) D3F_DW(1, 2);
+    else if (SB == 1) D3F_DW(2, 1);
+    else D3F_DW(2, 2);
+#undef D3F_DW
+    D3F_LAUNCH_CHECK();
+  }
+  return D3F_OK;
 }
 
 }  // namespace d3f
