@@ -228,7 +228,7 @@ int launch_wf(const float* q_pts, const float* s_pts, const int32_t* idx, const 
 }
 
 // kpconv_fused.hip
-bool kpconv_fused_supported(int Cin, int Cout, int K);
+bool kpconv_fused_supported(int Cin, int Cout, int K, int H, int Ns);
 size_t kpconv_fused_ws_bytes(int Ns);
 int kpconv_forward_fused(const float* q_pts, int Nq, const float* s_pts, int Ns, const int32_t* idx, int H,
                          const float* x, int Cin, const float* kp, int K, const float* W, int Cout, float extent,
@@ -241,7 +241,12 @@ int kpconv_backward_fused(const float* q_pts, int Nq, const float* s_pts, int Ns
 
 using namespace d3f;
 
+namespace d3f { void kpconv_set_debug_flags(int f); }
+
 extern "C" {
+
+// profiling aid (not part of the operator contract): run-time ablation switches of the fused forward kernel
+void d3f_debug_set_flags(int flags) { d3f::kpconv_set_debug_flags(flags); }
 
 size_t d3f_kpconv_ws_bytes(int Nq, int Ns, int H, int K, int Cin, int Cout) {
   (void)Ns; (void)H;
@@ -268,7 +273,7 @@ int d3f_kpconv_forward(const float* q_pts, int Nq, const float* s_pts, int Ns, c
   if (ws_bytes < d3f_kpconv_ws_bytes(Nq, Ns, H, K, Cin, Cout)) return D3F_EWORKSPACE;
   if (Nq == 0) return D3F_OK;
   hipStream_t stream = (hipStream_t)stream_;
-  if (kpconv_fused_supported(Cin, Cout, K))
+  if (kpconv_fused_supported(Cin, Cout, K, H, Ns))
     return kpconv_forward_fused(q_pts, Nq, s_pts, Ns, idx, H, x, Cin, kernel_points, K, weights, Cout, extent, out,
                                 nn_out, ws, stream);
   float* wf = (float*)ws;
@@ -297,7 +302,7 @@ int d3f_kpconv_backward(const float* q_pts, int Nq, const float* s_pts, int Ns, 
       return D3F_ELAUNCH;
     return D3F_OK;
   }
-  if (kpconv_fused_supported(Cin, Cout, K)) {
+  if (kpconv_fused_supported(Cin, Cout, K, H, Ns)) {
     if (grad_w && hipMemsetAsync(grad_w, 0, sizeof(float) * (size_t)KC * Cout, stream) != hipSuccess)
       return D3F_ELAUNCH;
     return kpconv_backward_fused(q_pts, Nq, s_pts, Ns, idx, H, x, Cin, kernel_points, K, weights, Cout, extent, nn,

@@ -35,6 +35,10 @@
 
 namespace d3f {
 
+// ablation switches for profiling (profiles/ablate_kpconv.py): bit0 skip phase A, bit1 skip phase B, bit2 skip stores
+static int g_debug_flags = 0;
+void kpconv_set_debug_flags(int f) { g_debug_flags = f; }
+
 // spack[n] = {s.x, s.y, s.z, (sum_c x[n,c] > 0) ? 1 : 0}; 16 lanes cooperate on one support row
 __global__ __launch_bounds__(256) void pack_supports_kernel(const float* __restrict__ s_pts,
                                                             const float* __restrict__ x, int Ns, int Cin,
@@ -56,11 +60,11 @@ template <int CV, int NBW, int WK>
 __global__ __launch_bounds__(256) void kpconv_fwd_fused_kernel(
     const float* __restrict__ q_pts, const float4* __restrict__ spack, const int32_t* __restrict__ idx,
     const float* __restrict__ x, const float* __restrict__ kp, const float* __restrict__ W, int Nq, int Ns, int H,
-    int Cin, int Cout, int K, float extent, float* __restrict__ out, float* __restrict__ nn_out) {
+    int Cin, int Cout, int K, float extent, float* __restrict__ out, float* __restrict__ nn_out, int dbg) {
   constexpr int CC = 16 * CV;
   constexpr int WN = 4 / WK;
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  const int RS = K * CC + 4;
+  constexpr int RS = 16 * CC + 4;  // 16 kernel-point rows per query (row 15 is zero padding when K = 15)
   float* wf = lds;              // [16][RS]
   float* nn_l = lds + 16 * RS;  // [16]
   float* red = nn_l + 16;       // [16][16*NBW*WN] when WK > 1
@@ -69,17 +73,25 @@ __global__ __launch_bounds__(256) void kpconv_fwd_fused_kernel(
   const int li = lane & 15, lg = lane >> 4;
   const int q0 = blockIdx.x * 16;
   const bool klive = li < K;
-  const float kx = klive ? kp[3 * li + 0] : 0.0f, ky = klive ? kp[3 * li + 1] : 0.0f,
-              kz = klive ? kp[3 * li + 2] : 0.0f;
+  const float kx = klive ? kp[3 * li + 0] : kFarKernelPoint, ky = klive ? kp[3 * li + 1] : kFarKernelPoint,
+              kz = klive ? kp[3 * li + 2] : kFarKernelPoint;
+  const __amdgpu_buffer_rsrc_t rs_sp = make_rsrc(spack, (unsigned)Ns * 16u);
+  const __amdgpu_buffer_rsrc_t rs_x = make_rsrc(x, (unsigned)Ns * (unsigned)Cin * 4u);
+  const float inv_extent = 1.0f / extent;
   const int wn = (WK == 1) ? wave : (WK == 2 ? (wave & 1) : 0);
   const int wk = (WK == 1) ? 0 : (WK == 2 ? (wave >> 1) : wave);
   constexpr int SLAB = 16 * NBW * WN;
   const int n_base = blockIdx.y * SLAB;  // Cout slab of this workgroup
   const bool split = gridDim.z > 1;      // channel chunks shared between workgroups -> atomic epilogue
 
-  f32x4 acc2[NBW];
+  // two accumulators per output block when a wave owns a single block: v_mfma_f32_16x16x4_f32 has a 40-cycle
+  // dependent-accumulator latency against a 32-cycle issue interval, so back-to-back MFMAs must alternate targets
+  constexpr int NACC = NBW == 1 ? 2 : 1;
+  f32x4 acc2[NBW][NACC];
 #pragma unroll
-  for (int nb = 0; nb < NBW; ++nb) acc2[nb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  for (int nb = 0; nb < NBW; ++nb)
+#pragma unroll
+    for (int a = 0; a < NACC; ++a) acc2[nb][a] = (f32x4){0.f, 0.f, 0.f, 0.f};
   if (WK > 1)
     for (int t = threadIdx.x; t < 16 * SLAB; t += 256) red[t] = 0.0f;
 
@@ -88,52 +100,62 @@ __global__ __launch_bounds__(256) void kpconv_fwd_fused_kernel(
   for (int ch = blockIdx.z; ch < nchunks; ch += gridDim.z) {
     const int cbase = ch * CC;
     // ------------------------------------------------------------------ phase A
-#pragma unroll 1
-    for (int i = 0; i < 4; ++i) {
-      const int ql = wave * 4 + i;
-      const int q = q0 + ql;
-      f32x4 acc[CV];
-#pragma unroll
-      for (int r = 0; r < CV; ++r) acc[r] = (f32x4){0.f, 0.f, 0.f, 0.f};
-      float cnt = 0.0f;
-      if (q < Nq)
-        aggregate_query<CV>(idx + (size_t)q * H, H, Ns, spack, x, Cin, cbase, q_pts[3 * (size_t)q + 0],
-                            q_pts[3 * (size_t)q + 1], q_pts[3 * (size_t)q + 2], kx, ky, kz, klive, extent, li, lg, acc,
-                            cnt);
-      store_wf_tile<CV>(wf + ql * RS, K, li, lg, acc);
-      if (first) {
-        cnt += __shfl_xor(cnt, 16, 64);
-        cnt += __shfl_xor(cnt, 32, 64);
-        if (lane == 0) {
-          const float v = fmaxf(cnt, 1.0f);
-          nn_l[ql] = v;
-          if (q < Nq && blockIdx.y == 0 && blockIdx.z == 0) nn_out[q] = v;
-        }
-      }
-    }
-    first = false;
+    if (!(dbg & 1))
+    aggregate_wave<CV>(q_pts, idx, q0 + wave * 4, Nq, H, Ns, rs_sp, rs_x, Cin, cbase, kx, ky, kz, inv_extent, lane,
+                       first ? nn_l + wave * 4 : nullptr,
+                       [&](int i, const f32x4(&acc)[CV]) { store_wf_tile<CV>(wf + (wave * 4 + i) * RS, li, lg, acc); });
     __syncthreads();
+    if (first && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x < 16 && q0 + (int)threadIdx.x < Nq)
+      nn_out[q0 + threadIdx.x] = nn_l[threadIdx.x];
+    first = false;
     // ------------------------------------------------------------------ phase B
     const int steps = (K * CC) >> 4;
-#pragma unroll 2
-    for (int s = wk; s < steps; s += WK) {
-      const int kc0 = s << 4;
-      const float4 a = *(const float4*)(wf + li * RS + kc0 + 4 * lg);
-      const int k = kc0 / CC, c0 = kc0 % CC;
-      const float* wrow = W + (size_t)(k * Cin + cbase + c0 + 4 * lg) * Cout;
+    // The W fragments stream from L2 and each 16-row step is only 4*NBW MFMAs, so a step-at-a-time loop pays one
+    // L2 round trip per step.  Instead BS steps are fetched back to back (4*NBW*BS loads in flight per lane) and
+    // then consumed; BS is sized for ~32 registers of fragments.
+    constexpr int BS = NBW >= 8 ? 1 : (NBW == 4 ? 2 : (NBW == 2 ? 4 : 8));
+    for (int s0 = wk; s0 < ((dbg & 2) ? 0 : steps); s0 += WK * BS) {
+      float b[BS][NBW][4];
 #pragma unroll
-      for (int nb = 0; nb < NBW; ++nb) {
-        const int col = n_base + (wn + nb * WN) * 16 + li;
-        const float b0 = wrow[col], b1 = wrow[Cout + col], b2 = wrow[2 * Cout + col], b3 = wrow[3 * Cout + col];
-        acc2[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b0, acc2[nb], 0, 0, 0);
-        acc2[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b1, acc2[nb], 0, 0, 0);
-        acc2[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, b2, acc2[nb], 0, 0, 0);
-        acc2[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, b3, acc2[nb], 0, 0, 0);
+      for (int j = 0; j < BS; ++j) {
+        const int sj = min(s0 + j * WK, steps - 1);  // clamped: the surplus loads of the last batch are discarded
+        const int kc0 = sj << 4;
+        const int k = kc0 / CC, c0 = kc0 % CC;
+        const float* wrow = W + (size_t)(k * Cin + cbase + c0 + 4 * lg) * Cout;
+#pragma unroll
+        for (int nb = 0; nb < NBW; ++nb) {
+          const int col = n_base + (wn + nb * WN) * 16 + li;
+          b[j][nb][0] = wrow[col];
+          b[j][nb][1] = wrow[Cout + col];
+          b[j][nb][2] = wrow[2 * Cout + col];
+          b[j][nb][3] = wrow[3 * Cout + col];
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < BS; ++j) {
+        const int sj = s0 + j * WK;
+        if (sj < steps) {
+          const float4 a = *(const float4*)(wf + li * RS + (sj << 4) + 4 * lg);
+          const float av[4] = {a.x, a.y, a.z, a.w};
+#pragma unroll
+          for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int nb = 0; nb < NBW; ++nb)
+              acc2[nb][t % NACC] =
+                  __builtin_amdgcn_mfma_f32_16x16x4f32(av[t], b[j][nb][t], acc2[nb][t % NACC], 0, 0, 0);
+        }
       }
     }
     __syncthreads();
   }
   // ------------------------------------------------------------------ epilogue
+  if (dbg & 4) return;
+  f32x4 accf[NBW];
+#pragma unroll
+  for (int nb = 0; nb < NBW; ++nb) {
+    accf[nb] = acc2[nb][0];
+    if (NACC == 2) accf[nb] += acc2[nb][NACC - 1];
+  }
   if (WK == 1) {
 #pragma unroll
     for (int nb = 0; nb < NBW; ++nb) {
@@ -142,7 +164,7 @@ __global__ __launch_bounds__(256) void kpconv_fwd_fused_kernel(
       for (int r = 0; r < 4; ++r) {
         const int rowl = 4 * lg + r;
         if (q0 + rowl < Nq) {
-          const float v = acc2[nb][r] / nn_l[rowl];
+          const float v = accf[nb][r] / nn_l[rowl];
           if (split) atomicAdd(&out[(size_t)(q0 + rowl) * Cout + col], v);
           else out[(size_t)(q0 + rowl) * Cout + col] = v;
         }
@@ -153,7 +175,7 @@ __global__ __launch_bounds__(256) void kpconv_fwd_fused_kernel(
     for (int nb = 0; nb < NBW; ++nb) {
       const int col = (wn + nb * WN) * 16 + li;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) atomicAdd(&red[(4 * lg + r) * SLAB + col], acc2[nb][r]);
+      for (int r = 0; r < 4; ++r) atomicAdd(&red[(4 * lg + r) * SLAB + col], accf[nb][r]);
     }
     __syncthreads();
     for (int t = threadIdx.x; t < 16 * SLAB; t += 256) {
@@ -176,7 +198,8 @@ __global__ __launch_bounds__(256) void kpconv_bwd_dx_kernel(
     float* __restrict__ gx) {
   constexpr int CC = 16 * CV;
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  const int RS = K * CC + 4, GS = Cout + 4;
+  constexpr int RS = 16 * CC + 4;
+  const int GS = Cout + 4;
   float* gw = lds;            // [16][RS]   gW tile of this channel chunk
   float* gl = lds + 16 * RS;  // [16][GS]   (grad_out / nn) tile
 
@@ -184,6 +207,7 @@ __global__ __launch_bounds__(256) void kpconv_bwd_dx_kernel(
   const int li = lane & 15, lg = lane >> 4;
   const int q0 = blockIdx.x * 16;
   const int cbase = blockIdx.y * CC;
+  const __amdgpu_buffer_rsrc_t rs_sp = make_rsrc(spack, (unsigned)Ns * 16u);
 
   for (int t = threadIdx.x; t < 16 * Cout; t += 256) {
     const int r = t / Cout, o = t % Cout;
@@ -213,14 +237,15 @@ __global__ __launch_bounds__(256) void kpconv_bwd_dx_kernel(
   }
   __syncthreads();
   // ---- phase 2: per query, E[h, c] = sum_k w[q,h,k] * gW[q,k,c]; scatter rows to gx
+  const float inv_extent = 1.0f / extent;
   float kpx[4], kpy[4], kpz[4];
 #pragma unroll
   for (int s = 0; s < 4; ++s) {
     const int k = 4 * s + lg;
     const bool live = k < K;
-    kpx[s] = live ? kp[3 * k + 0] : 0.0f;
-    kpy[s] = live ? kp[3 * k + 1] : 0.0f;
-    kpz[s] = live ? kp[3 * k + 2] : 0.0f;
+    kpx[s] = live ? kp[3 * k + 0] : kFarKernelPoint;
+    kpy[s] = live ? kp[3 * k + 1] : kFarKernelPoint;
+    kpz[s] = live ? kp[3 * k + 2] : kFarKernelPoint;
   }
 #pragma unroll 1
   for (int i = 0; i < 4; ++i) {
@@ -228,17 +253,18 @@ __global__ __launch_bounds__(256) void kpconv_bwd_dx_kernel(
     const int q = q0 + ql;
     if (q >= Nq) continue;
     const float qx = q_pts[3 * (size_t)q + 0], qy = q_pts[3 * (size_t)q + 1], qz = q_pts[3 * (size_t)q + 2];
+    float cx[4], cy[4], cz[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) { cx[s] = qx + kpx[s]; cy[s] = qy + kpy[s]; cz[s] = qz + kpz[s]; }
     const int32_t* row = idx + (size_t)q * H;
     const float* gq = gw + ql * RS;
     for (int h0 = 0; h0 < H; h0 += 16) {
       const int h = h0 + li;
-      const int n = h < H ? row[h] : Ns;
-      const bool valid = (unsigned)n < (unsigned)Ns;
-      const float4 sp = spack[valid ? n : 0];
+      const int n = (int)min((unsigned)(h < H ? row[h] : Ns), (unsigned)Ns);
+      const float4 sp = buf_load_f4(rs_sp, (unsigned)n * 16u);
       float wk[4];
 #pragma unroll
-      for (int s = 0; s < 4; ++s)
-        wk[s] = (valid && 4 * s + lg < K) ? kp_influence(sp, qx, qy, qz, kpx[s], kpy[s], kpz[s], extent) : 0.0f;
+      for (int s = 0; s < 4; ++s) wk[s] = n < Ns ? kp_influence(sp, cx[s], cy[s], cz[s], inv_extent) : 0.0f;
       int nrow[4];
 #pragma unroll
       for (int r = 0; r < 4; ++r) nrow[r] = __shfl(n, 4 * lg + r, 64);
@@ -273,7 +299,7 @@ __global__ __launch_bounds__(256) void kpconv_bwd_dw_kernel(
   constexpr int GS = SLAB + 4;
   constexpr int MAXP = (16 * CV * SB + 3) / 4;  // pairs per wave (K <= 16 -> at most 16*CV kc-blocks)
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  const int RS = K * CC + 4;
+  constexpr int RS = 16 * CC + 4;
   float* wf = lds;            // [16][RS]
   float* gl = lds + 16 * RS;  // [16][GS]
 
@@ -281,8 +307,11 @@ __global__ __launch_bounds__(256) void kpconv_bwd_dw_kernel(
   const int li = lane & 15, lg = lane >> 4;
   const int cbase = blockIdx.y * CC, obase = blockIdx.z * SLAB;
   const bool klive = li < K;
-  const float kx = klive ? kp[3 * li + 0] : 0.0f, ky = klive ? kp[3 * li + 1] : 0.0f,
-              kz = klive ? kp[3 * li + 2] : 0.0f;
+  const float kx = klive ? kp[3 * li + 0] : kFarKernelPoint, ky = klive ? kp[3 * li + 1] : kFarKernelPoint,
+              kz = klive ? kp[3 * li + 2] : kFarKernelPoint;
+  const __amdgpu_buffer_rsrc_t rs_sp = make_rsrc(spack, (unsigned)Ns * 16u);
+  const __amdgpu_buffer_rsrc_t rs_x = make_rsrc(x, (unsigned)Ns * (unsigned)Cin * 4u);
+  const float inv_extent = 1.0f / extent;
   const int nkb = (K * CC) >> 4;
   const int npairs = nkb * SB;
 
@@ -298,20 +327,9 @@ __global__ __launch_bounds__(256) void kpconv_bwd_dw_kernel(
       const int q = q0 + r;
       gl[r * GS + o] = q < Nq ? gout[(size_t)q * Cout + obase + o] / nn[q] : 0.0f;
     }
-#pragma unroll 1
-    for (int i = 0; i < 4; ++i) {
-      const int ql = wave * 4 + i;
-      const int q = q0 + ql;
-      f32x4 acc[CV];
-#pragma unroll
-      for (int r = 0; r < CV; ++r) acc[r] = (f32x4){0.f, 0.f, 0.f, 0.f};
-      float cnt = 0.0f;
-      if (q < Nq)
-        aggregate_query<CV>(idx + (size_t)q * H, H, Ns, spack, x, Cin, cbase, q_pts[3 * (size_t)q + 0],
-                            q_pts[3 * (size_t)q + 1], q_pts[3 * (size_t)q + 2], kx, ky, kz, klive, extent, li, lg, acc,
-                            cnt);
-      store_wf_tile<CV>(wf + ql * RS, K, li, lg, acc);
-    }
+    aggregate_wave<CV>(q_pts, idx, q0 + wave * 4, Nq, H, Ns, rs_sp, rs_x, Cin, cbase, kx, ky, kz, inv_extent, lane,
+                       (float*)nullptr,
+                       [&](int i, const f32x4(&acc)[CV]) { store_wf_tile<CV>(wf + (wave * 4 + i) * RS, li, lg, acc); });
     __syncthreads();
     // dW[kc, o] += sum_q wf[q, kc] * g[q, o]    (A[i = kc][kk = q], B[kk = q][j = o])
 #pragma unroll
@@ -345,10 +363,11 @@ __global__ __launch_bounds__(256) void kpconv_bwd_dw_kernel(
 }
 
 // ================================================================================================ host side
-bool kpconv_fused_supported(int Cin, int Cout, int K) {
+bool kpconv_fused_supported(int Cin, int Cout, int K, int H, int Ns) {
   const bool cin_ok = (Cin == 16 || Cin == 32 || (Cin % 64 == 0 && Cin <= 512));
   const bool cout_ok = (Cout == 16 || Cout == 32 || Cout == 64 || Cout == 128 || Cout == 256 || Cout == 512);
-  return cin_ok && cout_ok && K >= 1 && K <= 16;
+  const bool addr_ok = (double)Ns * Cin * 4.0 < 4294967295.0;  // 32-bit buffer offsets
+  return cin_ok && cout_ok && addr_ok && K >= 1 && K <= 16 && H >= 1 && H <= 64;  // one index row per wave load
 }
 
 size_t kpconv_fused_ws_bytes(int Ns) { return align_up(sizeof(float4) * (size_t)(Ns > 0 ? Ns : 1), 256); }
@@ -368,7 +387,7 @@ static int launch_fused_cv(const float* q_pts, const float4* spack, const int32_
   const int tiles = cdiv(Nq, 16);
   const int CC = 16 * CV;
   const int nchunks = Cin / CC;
-  const size_t lds_base = sizeof(float) * (size_t)(16 * (K * CC + 4) + 16);
+  const size_t lds_base = sizeof(float) * (size_t)(16 * (16 * CC + 4) + 16);
   // Work decomposition: the whole Cout in one workgroup when there are plenty of query tiles (phase A is then
   // computed once per tile); for the deep, few-point layers split Cout into slabs (grid.y), then the channel chunks
   // (grid.z, atomic combine into a zeroed output) until the launch covers the 256 CUs a few times over.
@@ -383,7 +402,7 @@ static int launch_fused_cv(const float* q_pts, const float4* spack, const int32_
     const size_t lds = lds_base + ((WK) > 1 ? sizeof(float) * 16 * (size_t)slab : 0);                           \
     dim3 grid(tiles, Cout / slab, zsplit);                                                                      \
     kpconv_fwd_fused_kernel<CV, NBW, WK><<<grid, 256, lds, stream>>>(q_pts, spack, idx, x, kp, W, Nq, Ns, H, Cin, \
-                                                                      Cout, K, extent, out, nn_out);            \
+                                                                      Cout, K, extent, out, nn_out, g_debug_flags); \
   }
   switch (slab) {
     case 16: D3F_LAUNCH(1, 4) break;
@@ -420,7 +439,7 @@ int kpconv_backward_fused(const float* q_pts, int Nq, const float* s_pts, int Ns
   if (gx) {
     const int CV = Cin == 16 ? 1 : (Cin == 32 ? 2 : 4);
     const int CC = 16 * CV;
-    const size_t lds = sizeof(float) * (size_t)(16 * (K * CC + 4) + 16 * (Cout + 4));
+    const size_t lds = sizeof(float) * (size_t)(16 * (16 * CC + 4) + 16 * (Cout + 4));
     dim3 grid(tiles, Cin / CC);
     if (CV == 1) kpconv_bwd_dx_kernel<1><<<grid, 256, lds, stream>>>(q_pts, spack, idx, kp, W, nn, gout, Nq, Ns, H, Cin, Cout, K, extent, gx);
     else if (CV == 2) kpconv_bwd_dx_kernel<2><<<grid, 256, lds, stream>>>(q_pts, spack, idx, kp, W, nn, gout, Nq, Ns, H, Cin, Cout, K, extent, gx);
@@ -435,7 +454,7 @@ int kpconv_backward_fused(const float* q_pts, int Nq, const float* s_pts, int Ns
     int G = cdiv(768, ny * nz);
     if (G > tiles) G = tiles;
     if (G < 1) G = 1;
-    const size_t lds = sizeof(float) * (size_t)(16 * (K * CC + 4) + 16 * (SLAB + 4));
+    const size_t lds = sizeof(float) * (size_t)(16 * (16 * CC + 4) + 16 * (SLAB + 4));
     dim3 grid(G, ny, nz);
 #define D3F_DW(CVV, SBB)                                                                                          \
   kpconv_bwd_dw_kernel<CVV, SBB><<<grid, 256, lds, stream>>>(q_pts, spack, idx, x, kp, nn, gout, Nq, Ns, H, Cin, Cout, \

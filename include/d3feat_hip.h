@@ -39,6 +39,7 @@ extern "C" {
 const char* d3f_version(void);
 int d3f_device_arch_ok(void); /* 1 if the current HIP device is gfx950, 0 otherwise, <0 = -(hipError_t) */
 int d3f_device_arch_name(char* out, int n); /* gcnArchName of the current device */
+void d3f_debug_set_flags(int flags);      /* profiling aid: ablation switches of the fused KPConv forward (0 = off) */
 
 /* ------------------------------------------------------------------------------------------------
  * Radius neighbors -- replaces radius_neighbors.batch_query
