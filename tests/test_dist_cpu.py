@@ -1,0 +1,86 @@
+"""CPU, 2 processes over gloo: the data-parallel exchange of the training step (flat gradient buffer, bucketed
+all-reduce mean, NaN/Inf guard decided on the REDUCED gradient so every rank takes the same decision)."""
+import os
+import socket
+import sys
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, ret):
+    sys.path.insert(0, REPO)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from d3feat_pytorch_amd.train import FlatParams, GuardedSGD, allreduce_mean_
+    torch.manual_seed(0)  # identical initial model on every rank
+    model = torch.nn.Sequential(torch.nn.Linear(7, 13), torch.nn.LeakyReLU(0.1), torch.nn.Linear(13, 5))
+    flat = FlatParams(model)
+    opt = GuardedSGD(flat, lr=0.1, momentum=0.9, weight_decay=1e-3)
+    ref = torch.nn.Sequential(torch.nn.Linear(7, 13), torch.nn.LeakyReLU(0.1), torch.nn.Linear(13, 5))
+    ref.load_state_dict(model.state_dict())
+    ref_opt = torch.optim.SGD(ref.parameters(), lr=0.1, momentum=0.9, weight_decay=1e-3)
+    ok = True
+    for step in range(4):
+        # every rank sees its own data; the reference model sees the concatenation of both ranks' data
+        g = torch.Generator().manual_seed(100 * step)
+        xs = [torch.randn(6, 7, generator=g) for _ in range(world)]
+        ys = [torch.randn(6, 5, generator=g) for _ in range(world)]
+        flat.zero_grad()
+        loss = ((model(xs[rank]) - ys[rank]) ** 2).mean()
+        loss.backward()
+        poison = step == 2 and rank == 1  # a non-finite gradient on ONE rank must stop the step on ALL ranks
+        if poison:
+            flat.grad[3] = float("nan")
+        allreduce_mean_(flat.grad, world, n_buckets=3)
+        stepped = bool(opt.step().item())
+        ref_opt.zero_grad()
+        rl = sum(((ref(xs[r]) - ys[r]) ** 2).mean() for r in range(world)) / world
+        rl.backward()
+        if step != 2:
+            ref_opt.step()
+        ok &= stepped == (step != 2)
+        for p, q in zip(model.parameters(), ref.parameters()):
+            ok &= torch.allclose(p, q, atol=1e-6)
+    # all ranks hold identical parameters
+    mine = flat.data.clone()
+    other = [torch.zeros_like(mine) for _ in range(world)]
+    dist.all_gather(other, mine)
+    ok &= all(torch.equal(o, other[0]) for o in other)
+    ok &= int(opt.skipped.item()) == 1
+    ret[rank] = bool(ok)
+    dist.destroy_process_group()
+
+
+def test_two_rank_gradient_exchange_and_guard():
+    world = 2
+    port = _free_port()
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker, args=(world, port, ret), nprocs=world, join=True)
+    assert dict(ret) == {0: True, 1: True}
+
+
+def test_flat_params_views_track_module():
+    sys.path.insert(0, REPO)
+    from d3feat_pytorch_amd.train import FlatParams
+    m = torch.nn.Linear(3, 2)
+    f = FlatParams(m)
+    assert f.numel == 8 and m.weight.data_ptr() == f.data.data_ptr()
+    (m(torch.ones(1, 3)).sum()).backward()
+    assert torch.equal(f.grad[:6].view(2, 3), m.weight.grad) and float(f.grad.abs().sum()) > 0
+    f.zero_grad()
+    assert float(m.weight.grad.abs().sum()) == 0.0
