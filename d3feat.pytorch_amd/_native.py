@@ -11,8 +11,8 @@ _PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 _REPO = os.path.dirname(_PKG_DIR)
 LIB_PATH = os.path.join(_PKG_DIR, "libd3feat_hip.so")
 CSRC = os.path.join(_PKG_DIR, "csrc")
-SOURCES = ["radius_neighbors.hip", "grid_subsample.hip", "kpconv.hip", "kpconv_fused.hip", "pool.hip", "detection.hip", "loss.hip",
-           "matching.hip", "misc.hip"]
+SOURCES = ["radius_neighbors.hip", "grid_subsample.hip", "kpconv.hip", "kpconv_fused.hip", "kpconv_small.hip", "pool.hip", "detection.hip", "loss.hip",
+           "matching.hip", "elementwise.hip", "misc.hip"]
 
 _vp, _i, _f, _sz = C.c_void_p, C.c_int, C.c_float, C.c_size_t
 
@@ -35,6 +35,8 @@ SIGNATURES = {
     "d3f_max_pool_backward": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp]),
     "d3f_closest_pool_forward": (_i, [_vp, _i, _i, _vp, _i, _i, _vp, _vp]),
     "d3f_closest_pool_backward": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp]),
+    "d3f_bias_act_forward": (_i, [_vp, _vp, _vp, _vp, _f, _i, _i, _vp, _vp]),
+    "d3f_bias_act_backward": (_i, [_vp, _vp, _f, _i, _i, _vp, _vp, _vp]),
     "d3f_global_max": (_i, [_vp, _sz, _vp, _vp, _sz, _vp]),
     "d3f_detection_scores_forward": (_i, [_vp, _i, _i, _vp, _i, _vp, _i, _vp, _vp]),
     "d3f_detection_scores_ws_bytes": (_sz, [_i, _i]),

@@ -1,0 +1,115 @@
+// Fused bias / residual / LeakyReLU epilogue of the unary and KPConv blocks, forward and backward.
+//
+// Replaces, per block of the reference network (models/blocks.py): BatchNormBlock's bias add (:473, use_bn=False),
+// nn.LeakyReLU(0.1) (:497,:598,:676), the residual add of the bottleneck (:686) and -- in backward -- the two
+// elementwise kernels plus the column reduction PyTorch runs for the bias gradient.  ~150 tiny launches per training
+// step in the reference graph become one launch forward and one backward per block.
+//
+//   forward : out[n,c] = act( x[n,c] + b1[c] + (add[n,c] + b2[c]) ),  act(v) = v > 0 ? v : slope*v   (slope = 1: identity)
+//   backward: gx[n,c]  = go[n,c] * (out[n,c] > 0 ? 1 : slope)     (also the gradient of `add`)
+//             gb[c]    = sum_n gx[n,c]                               (gradient of b1 and of b2)
+#include "common.hpp"
+
+namespace {
+
+__global__ __launch_bounds__(256) void bias_act_fwd_kernel(const float* __restrict__ x, const float* __restrict__ b1,
+                                                           const float* __restrict__ add,
+                                                           const float* __restrict__ b2, float slope, size_t n4,
+                                                           int C, float* __restrict__ out) {
+  // C % 4 == 0: one float4 per thread, columns of a float4 are c .. c+3
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n4) return;
+  const int c = (int)((i * 4) % (size_t)C);
+  float4 v = ((const float4*)x)[i];
+  if (b1) { const float4 b = *(const float4*)(b1 + c); v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w; }
+  if (add) { const float4 a = ((const float4*)add)[i]; v.x += a.x; v.y += a.y; v.z += a.z; v.w += a.w; }
+  if (b2) { const float4 b = *(const float4*)(b2 + c); v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w; }
+  v.x = v.x > 0.0f ? v.x : v.x * slope;
+  v.y = v.y > 0.0f ? v.y : v.y * slope;
+  v.z = v.z > 0.0f ? v.z : v.z * slope;
+  v.w = v.w > 0.0f ? v.w : v.w * slope;
+  ((float4*)out)[i] = v;
+}
+
+// scalar fallback for C % 4 != 0
+__global__ __launch_bounds__(256) void bias_act_fwd_scalar_kernel(const float* __restrict__ x,
+                                                                  const float* __restrict__ b1,
+                                                                  const float* __restrict__ add,
+                                                                  const float* __restrict__ b2, float slope, size_t n,
+                                                                  int C, float* __restrict__ out) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int c = (int)(i % (size_t)C);
+  float v = x[i];
+  if (b1) v += b1[c];
+  if (add) v += add[i];
+  if (b2) v += b2[c];
+  out[i] = v > 0.0f ? v : v * slope;
+}
+
+// One workgroup owns ROWS rows x all C columns (C <= 2048 via column loop): thread t handles column (t % CT) of
+// row group (t / CT); per-column partial sums are combined in LDS and flushed with one atomic per column.
+constexpr int kRowsPerBlock = 64;
+
+__global__ __launch_bounds__(256) void bias_act_bwd_kernel(const float* __restrict__ go, const float* __restrict__ out,
+                                                           float slope, int N, int C, float* __restrict__ gx,
+                                                           float* __restrict__ gb) {
+  __shared__ float red[256];
+  const int r0 = blockIdx.x * kRowsPerBlock;
+  const int r1 = min(N, r0 + kRowsPerBlock);
+  for (int c0 = 0; c0 < C; c0 += 64) {
+    // 64 columns x 4 row-lanes per pass
+    const int c = c0 + (threadIdx.x & 63);
+    const int rl = threadIdx.x >> 6;
+    float s = 0.0f;
+    if (c < C) {
+      for (int r = r0 + rl; r < r1; r += 4) {
+        const size_t i = (size_t)r * C + c;
+        const float g = go[i] * (out[i] > 0.0f ? 1.0f : slope);
+        if (gx) gx[i] = g;
+        s += g;
+      }
+    }
+    if (gb) {
+      red[threadIdx.x] = s;
+      __syncthreads();
+      if (threadIdx.x < 64 && c < C) atomicAdd(&gb[c], red[threadIdx.x] + red[threadIdx.x + 64] + red[threadIdx.x + 128] +
+                                                            red[threadIdx.x + 192]);
+      __syncthreads();
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+int d3f_bias_act_forward(const float* x, const float* bias1, const float* add, const float* bias2, float slope, int N,
+                         int C, float* out, void* stream) {
+  if (!x || !out || N < 0 || C < 1) return D3F_EINVAL;
+  const size_t n = (size_t)N * C;
+  if (n == 0) return D3F_OK;
+  if (C % 4 == 0)
+    bias_act_fwd_kernel<<<d3f::cdiv((long long)(n / 4), 256), 256, 0, (hipStream_t)stream>>>(x, bias1, add, bias2, slope,
+                                                                                            n / 4, C, out);
+  else
+    bias_act_fwd_scalar_kernel<<<d3f::cdiv((long long)n, 256), 256, 0, (hipStream_t)stream>>>(x, bias1, add, bias2, slope,
+                                                                                             n, C, out);
+  D3F_LAUNCH_CHECK();
+  return D3F_OK;
+}
+
+/* grad_x (optional) [N,C]; grad_bias (optional) [C] is OVERWRITTEN. */
+int d3f_bias_act_backward(const float* grad_out, const float* out, float slope, int N, int C, float* grad_x,
+                          float* grad_bias, void* stream) {
+  if (!grad_out || !out || N < 0 || C < 1 || (!grad_x && !grad_bias)) return D3F_EINVAL;
+  if (grad_bias && hipMemsetAsync(grad_bias, 0, sizeof(float) * (size_t)C, (hipStream_t)stream) != hipSuccess)
+    return D3F_ELAUNCH;
+  if (N == 0) return D3F_OK;
+  bias_act_bwd_kernel<<<d3f::cdiv(N, kRowsPerBlock), 256, 0, (hipStream_t)stream>>>(grad_out, out, slope, N, C, grad_x,
+                                                                                   grad_bias);
+  D3F_LAUNCH_CHECK();
+  return D3F_OK;
+}
+
+}  // extern "C"

@@ -233,6 +233,12 @@ size_t kpconv_fused_ws_bytes(int Ns);
 int kpconv_forward_fused(const float* q_pts, int Nq, const float* s_pts, int Ns, const int32_t* idx, int H,
                          const float* x, int Cin, const float* kp, int K, const float* W, int Cout, float extent,
                          float* out, float* nn_out, void* ws, hipStream_t stream);
+// kpconv_small.hip
+bool kpconv_small_supported(int Cin, int Cout, int K, int H);
+int kpconv_small_dispatch(bool fwd, const float* q_pts, const float* s_pts, const int32_t* idx, const float* x,
+                          const float* kp, const float* W, const float* nn_in, const float* gout, int Nq, int Ns, int H,
+                          int Cin, int Cout, int K, float extent, float* out, float* nn_out, float* gW,
+                          hipStream_t stream);
 int kpconv_backward_fused(const float* q_pts, int Nq, const float* s_pts, int Ns, const int32_t* idx, int H,
                           const float* x, int Cin, const float* kp, int K, const float* W, int Cout, float extent,
                           const float* nn, const float* gout, float* gx, float* gw, void* ws, hipStream_t stream);
@@ -273,6 +279,9 @@ int d3f_kpconv_forward(const float* q_pts, int Nq, const float* s_pts, int Ns, c
   if (ws_bytes < d3f_kpconv_ws_bytes(Nq, Ns, H, K, Cin, Cout)) return D3F_EWORKSPACE;
   if (Nq == 0) return D3F_OK;
   hipStream_t stream = (hipStream_t)stream_;
+  if (kpconv_small_supported(Cin, Cout, K, H))
+    return kpconv_small_dispatch(true, q_pts, s_pts, idx, x, kernel_points, weights, nullptr, nullptr, Nq, Ns, H, Cin,
+                                 Cout, K, extent, out, nn_out, nullptr, stream);
   if (kpconv_fused_supported(Cin, Cout, K, H, Ns))
     return kpconv_forward_fused(q_pts, Nq, s_pts, Ns, idx, H, x, Cin, kernel_points, K, weights, Cout, extent, out,
                                 nn_out, ws, stream);
@@ -309,6 +318,13 @@ int d3f_kpconv_backward(const float* q_pts, int Nq, const float* s_pts, int Ns, 
                                  grad_out, grad_x, grad_w, ws, stream);
   }
   int rc;
+  if (grad_w && kpconv_small_supported(Cin, Cout, K, H)) {
+    if (hipMemsetAsync(grad_w, 0, sizeof(float) * (size_t)KC * Cout, stream) != hipSuccess) return D3F_ELAUNCH;
+    rc = kpconv_small_dispatch(false, q_pts, s_pts, idx, x, kernel_points, weights, nn, grad_out, Nq, Ns, H, Cin, Cout,
+                               K, extent, nullptr, nullptr, grad_w, stream);
+    if (rc) return rc;
+    grad_w = nullptr;  // done; grad_x (rarely needed for the input layer) continues on the general path
+  }
   if (grad_w) {
     // grad_W [KC, Cout] = wf^T [KC, Nq] @ (grad_out / nn) [Nq, Cout]
     rc = launch_wf<false>(q_pts, s_pts, idx, x, kernel_points, Nq, Ns, H, Cin, K, extent, wf, nullptr, stream);

@@ -15,6 +15,7 @@ import math
 
 import torch
 import torch.nn as nn
+import torch.nn.functional as F
 from torch.nn.init import kaiming_uniform_
 from torch.nn.parameter import Parameter
 
@@ -150,6 +151,8 @@ class BatchNormBlock(nn.Module):
     def forward(self, x):
         if self.use_bn:
             return self.batch_norm(x.unsqueeze(2).transpose(0, 2)).transpose(0, 2).squeeze()
+        if x.is_cuda and x.dim() == 2:
+            return ops.bias_act(x, self.bias, slope=1.0)
         return x + self.bias
 
     def __repr__(self):
@@ -172,9 +175,20 @@ class UnaryBlock(nn.Module):
         if not no_relu:
             self.leaky_relu = nn.LeakyReLU(0.1)
 
-    def forward(self, x, batch=None):
+    def forward(self, x, batch=None, residual=None):
+        if not self.use_bn and x.is_cuda and x.dim() == 2:
+            # Linear without its bias; both biases (+ residual) + LeakyReLU go into ONE epilogue launch whose backward
+            # also yields the (shared) bias gradient -- no separate add / leaky / column-reduce kernels
+            return ops.bias_act(F.linear(x, self.mlp.weight), self.mlp.bias, residual, self.batch_norm.bias,
+                                slope=1.0 if (self.no_relu and residual is None) else 0.1)
         x = self.batch_norm(self.mlp(x))
+        if residual is not None:
+            return self.leaky_relu_res(x + residual)
         return x if self.no_relu else self.leaky_relu(x)
+
+    @staticmethod
+    def leaky_relu_res(x):
+        return F.leaky_relu(x, 0.1)
 
     def __repr__(self):
         return 'UnaryBlock(in_feat: {:d}, out_feat: {:d}, BN: {:s}, ReLU: {:s})'.format(
@@ -229,7 +243,10 @@ class SimpleBlock(nn.Module):
 
     def forward(self, x, batch):
         q_pts, s_pts, inds = _layer_inputs(self.block_name, self.layer_ind, batch)
-        return self.leaky_relu(self.batch_norm(self.KPConv(q_pts, s_pts, inds, x)))
+        y = self.KPConv(q_pts, s_pts, inds, x)
+        if not self.use_bn:
+            return ops.bias_act(y, self.batch_norm.bias, slope=0.1)
+        return self.leaky_relu(self.batch_norm(y))
 
 
 class ResnetBottleneckBlock(nn.Module):
@@ -257,10 +274,14 @@ class ResnetBottleneckBlock(nn.Module):
     def forward(self, features, batch):
         q_pts, s_pts, inds = _layer_inputs(self.block_name, self.layer_ind, batch)
         x = self.unary1(features)
-        x = self.leaky_relu(self.batch_norm_conv(self.KPConv(q_pts, s_pts, inds, x)))
-        x = self.unary2(x)
+        x = self.KPConv(q_pts, s_pts, inds, x)
         shortcut = max_pool(features, inds) if 'strided' in self.block_name else features
-        return self.leaky_relu(x + self.unary_shortcut(shortcut))
+        shortcut = self.unary_shortcut(shortcut)
+        if not self.use_bn:
+            x = ops.bias_act(x, self.batch_norm_conv.bias, slope=0.1)
+            return self.unary2(x, residual=shortcut)  # leaky(unary2(x) + shortcut) in the epilogue of unary2
+        x = self.leaky_relu(self.batch_norm_conv(x))
+        return self.leaky_relu(self.unary2(x) + shortcut)
 
 
 class GlobalAverageBlock(nn.Module):

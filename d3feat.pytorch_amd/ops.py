@@ -312,6 +312,58 @@ def closest_pool(x, inds):
 
 
 # ---------------------------------------------------------------------------------------------------------------
+# block epilogue: bias (+ residual) (+ LeakyReLU) (models/blocks.py:473,497,598,676,686)
+# ---------------------------------------------------------------------------------------------------------------
+class _BiasActFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, b1, add, b2, slope):
+        N, C = int(x.shape[0]), int(x.shape[1])
+        out = torch.empty_like(x)
+        _native.check(_native.lib().d3f_bias_act_forward(_p(x), _p(b1), _p(add), _p(b2), float(slope), N, C, _p(out),
+                                                         _stream()), "d3f_bias_act_forward")
+        ctx.save_for_backward(out)
+        ctx.slope = float(slope)
+        ctx.has = (b1 is not None, add is not None, b2 is not None)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        (out,) = ctx.saved_tensors
+        N, C = int(out.shape[0]), int(out.shape[1])
+        go = grad_out.contiguous()
+        need_gx = ctx.needs_input_grad[0] or (ctx.has[1] and ctx.needs_input_grad[2])
+        need_gb = (ctx.has[0] and ctx.needs_input_grad[1]) or (ctx.has[2] and ctx.needs_input_grad[3])
+        identity = ctx.slope == 1.0
+        gx = None
+        gb = torch.empty(C, dtype=torch.float32, device=go.device) if need_gb else None
+        if identity and not need_gb:
+            gx = go
+        elif need_gx or need_gb:
+            if need_gx and not identity:
+                gx = torch.empty_like(go)
+            _native.check(_native.lib().d3f_bias_act_backward(_p(go), _p(out), ctx.slope, N, C, _p(gx), _p(gb),
+                                                              _stream()), "d3f_bias_act_backward")
+            if identity:
+                gx = go
+        return (gx if ctx.needs_input_grad[0] else None, gb if ctx.has[0] and ctx.needs_input_grad[1] else None,
+                gx if ctx.has[1] and ctx.needs_input_grad[2] else None,
+                gb if ctx.has[2] and ctx.needs_input_grad[3] else None, None)
+
+
+def bias_act(x, bias1=None, add=None, bias2=None, slope=0.1):
+    """act(x + bias1 + add + bias2) with act = LeakyReLU(slope) (slope = 1.0: no activation); one launch each way."""
+    x = _f32(x, "x")
+    if x.dim() != 2:
+        raise RuntimeError("bias_act expects [N, C]")
+    b1 = _f32(bias1, "bias1") if bias1 is not None else None
+    b2 = _f32(bias2, "bias2") if bias2 is not None else None
+    a = _f32(add, "add") if add is not None else None
+    if a is not None and a.shape != x.shape:
+        raise RuntimeError("bias_act: residual shape %s != %s" % (tuple(a.shape), tuple(x.shape)))
+    return _BiasActFn.apply(x, b1, a, b2, float(slope))
+
+
+# ---------------------------------------------------------------------------------------------------------------
 # detector score (models/architectures.py:322-368)
 # ---------------------------------------------------------------------------------------------------------------
 def global_max(x):

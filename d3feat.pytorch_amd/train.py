@@ -118,10 +118,37 @@ class TrainStep:
         det = dists._d3f_det[0][1]
         return desc * self.w_desc + det * self.w_det, desc, det, acc
 
-    def step(self, item):
-        """item = (pts0, pts1, feat0, feat1, sel_corr, dist_keypts), host arrays or device tensors."""
-        batch = self.build_batch(item)
-        batch['n0'] = int(item[0].shape[0])
+    # -- pyramid construction on a side stream ---------------------------------------------------------------
+    # build_pyramid reads the level sizes back once; done on the training stream that read-back would wait for the
+    # whole previous step.  prefetch() runs it on its own stream (the host blocks only on that stream), so the 13
+    # searches + 4 voxel levels of pair k+1 overlap the network of pair k.
+    def prefetch(self, item):
+        if getattr(self, '_side', None) is None:
+            self._side = torch.cuda.Stream(device=self.device)
+        with torch.cuda.stream(self._side):  # inputs are long-lived device tensors: no dependency on the main stream
+            batch = self.build_batch(item)
+            batch['n0'] = int(item[0].shape[0])
+            ev = torch.cuda.Event()
+            ev.record(self._side)
+        self._pending = (batch, ev)
+
+    def step(self, item=None, next_item=None):
+        """item = (pts0, pts1, feat0, feat1, sel_corr, dist_keypts), host arrays or device tensors.  With
+        ``next_item`` the following pair's pyramid is started on the side stream before this step's network runs."""
+        pending = getattr(self, '_pending', None)
+        if pending is not None:
+            batch, ev = pending
+            self._pending = None
+            torch.cuda.current_stream(self.device).wait_event(ev)
+            for v in batch.values():  # tensors produced on the side stream are consumed on this one
+                for t in (v if isinstance(v, list) else [v]):
+                    if isinstance(t, torch.Tensor):
+                        t.record_stream(torch.cuda.current_stream(self.device))
+        else:
+            batch = self.build_batch(item)
+            batch['n0'] = int(item[0].shape[0])
+        if next_item is not None:
+            self.prefetch(next_item)
         self.flat.zero_grad()
         loss, desc, det, acc = self.forward_loss(batch)
         loss.backward()

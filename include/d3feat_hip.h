@@ -110,6 +110,18 @@ int d3f_closest_pool_backward(const float* grad_out, const int32_t* idx, int Nq,
                               void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * Block epilogue -- replaces BatchNormBlock's bias add (models/blocks.py:473, use_bn=False), nn.LeakyReLU(0.1)
+ *   (:497,:598,:676), the bottleneck's residual add (:686) and, in backward, PyTorch's bias-gradient reduction.
+ *   out = act(x + bias1 + (add + bias2)), act(v) = v > 0 ? v : slope*v  (slope = 1: identity); bias1/add/bias2 optional.
+ *   backward: grad_x = grad_out * (out > 0 ? 1 : slope)  (also the gradient of `add`);
+ *             grad_bias[c] = sum_n grad_x[n,c]  (gradient of bias1 and bias2; OVERWRITTEN).
+ * ---------------------------------------------------------------------------------------------- */
+int d3f_bias_act_forward(const float* x, const float* bias1, const float* add, const float* bias2, float slope, int N,
+                         int C, float* out, void* stream);
+int d3f_bias_act_backward(const float* grad_out, const float* out, float slope, int N, int C, float* grad_x,
+                          float* grad_bias, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Detector score -- replaces KPFCNN.detection_scores (models/architectures.py:322-368).
  * feat [N,C] un-normalised descriptors, idx = neighbors[0] [N,H].  feat_max [1] is a device scalar holding
  * max(feat) (d3f_global_max computes it).  training != 0: soft score; training == 0 additionally applies the

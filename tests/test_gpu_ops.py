@@ -124,7 +124,8 @@ def _kpconv_case(rng, nq, ns, h, cin, cout, shadow_frac=0.15, k=15):
 @pytest.mark.parametrize("nq,ns,h,cin,cout", [(700, 900, 42, 1, 64), (1000, 1000, 42, 32, 32), (333, 1000, 37, 64, 64),
                                               (257, 300, 45, 128, 128), (97, 154, 23, 512, 512), (500, 500, 9, 16, 8),
                                               (200, 260, 42, 24, 40), (300, 400, 42, 16, 16), (300, 400, 40, 32, 64),
-                                              (150, 160, 42, 256, 128), (2100, 2100, 42, 64, 32), (571, 2053, 42, 128, 128)])
+                                              (150, 160, 42, 256, 128), (2100, 2100, 42, 64, 32), (571, 2053, 42, 128, 128),
+                                              (900, 900, 42, 1, 32), (400, 500, 30, 2, 100), (300, 300, 42, 4, 64), (300, 300, 17, 3, 8)])
 def test_kpconv_forward_backward(nq, ns, h, cin, cout):
     rng = np.random.default_rng(nq + cin)
     q, s, idx, x, kp, w = _kpconv_case(rng, nq, ns, h, cin, cout)
@@ -175,6 +176,31 @@ def test_pools(c):
         out.backward(cu(go))
         assert np.array_equal(out.detach().cpu().numpy(), ref.detach().numpy())
         assert rel_err(gx.grad.cpu().numpy(), tx.grad.numpy()) < 1e-6
+
+
+# ------------------------------------------------------------------------------------------------ block epilogue
+@pytest.mark.parametrize("n,c,slope,with_add", [(1000, 128, 0.1, True), (333, 32, 0.1, False), (77, 6, 1.0, True),
+                                                (4000, 2048, 0.1, True), (50, 64, 1.0, False)])
+def test_bias_act(n, c, slope, with_add):
+    import torch.nn.functional as F
+    rng = np.random.default_rng(n + c)
+    x = rng.normal(size=(n, c)).astype(np.float32)
+    b1, b2 = rng.normal(size=c).astype(np.float32), rng.normal(size=c).astype(np.float32)
+    a = rng.normal(size=(n, c)).astype(np.float32)
+    go = rng.normal(size=(n, c)).astype(np.float32)
+    tx, tb1, tb2, ta = [torch.from_numpy(v).requires_grad_(True) for v in (x, b1, b2, a)]
+    pre = tx + tb1 + tb2 + (ta if with_add else 0)
+    ref = F.leaky_relu(pre, slope) if slope != 1.0 else pre
+    ref.backward(torch.from_numpy(go))
+    gx, gb1, gb2, ga = [cu(v).requires_grad_(True) for v in (x, b1, b2, a)]
+    out = ops.bias_act(gx, gb1, ga if with_add else None, gb2, slope=slope)
+    out.backward(cu(go))
+    assert rel_err(out.detach().cpu().numpy(), ref.detach().numpy()) < 1e-6
+    assert rel_err(gx.grad.cpu().numpy(), tx.grad.numpy()) < 1e-6
+    assert rel_err(gb1.grad.cpu().numpy(), tb1.grad.numpy()) < 2e-5
+    assert rel_err(gb2.grad.cpu().numpy(), tb2.grad.numpy()) < 2e-5
+    if with_add:
+        assert rel_err(ga.grad.cpu().numpy(), ta.grad.numpy()) < 1e-6
 
 
 # ------------------------------------------------------------------------------------------------ detector score
