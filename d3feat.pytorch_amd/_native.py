@@ -12,7 +12,7 @@ _REPO = os.path.dirname(_PKG_DIR)
 LIB_PATH = os.path.join(_PKG_DIR, "libd3feat_hip.so")
 CSRC = os.path.join(_PKG_DIR, "csrc")
 SOURCES = ["radius_neighbors.hip", "grid_subsample.hip", "kpconv.hip", "kpconv_fused.hip", "kpconv_small.hip", "pool.hip", "detection.hip", "loss.hip",
-           "matching.hip", "elementwise.hip", "misc.hip"]
+           "matching.hip", "elementwise.hip", "optimizer.hip", "misc.hip"]
 
 _vp, _i, _f, _sz = C.c_void_p, C.c_int, C.c_float, C.c_size_t
 
@@ -26,7 +26,7 @@ SIGNATURES = {
     "d3f_radius_grid_build": (_i, [_vp, _i, _vp, _i, _f, _vp, _sz, _vp, _vp]),
     "d3f_radius_query": (_i, [_vp, _vp, _i, _vp, _vp, _i, _vp, _i, _f, _i, _vp, _vp, _vp, _vp, _vp]),
     "d3f_grid_subsample_ws_bytes": (_sz, [_i, _i]),
-    "d3f_grid_subsample": (_i, [_vp, _i, _vp, _i, _f, _i, _i, _vp, _vp, _vp, _vp, _sz, _vp, _vp]),
+    "d3f_grid_subsample": (_i, [_vp, _i, _vp, _i, _f, _i, _i, _vp, _i, _vp, _vp, _vp, _sz, _vp, _vp]),
     "d3f_kpconv_ws_bytes": (_sz, [_i, _i, _i, _i, _i, _i]),
     "d3f_kpconv_forward": (_i, [_vp, _i, _vp, _i, _vp, _i, _vp, _i, _vp, _i, _vp, _i, _f, _vp, _vp, _vp, _sz, _vp]),
     "d3f_kpconv_backward": (_i, [_vp, _i, _vp, _i, _vp, _i, _vp, _i, _vp, _i, _vp, _i, _f, _vp, _vp, _vp, _vp, _vp,
@@ -38,6 +38,7 @@ SIGNATURES = {
     "d3f_bias_act_forward": (_i, [_vp, _vp, _vp, _vp, _f, _i, _i, _vp, _vp]),
     "d3f_bias_act_backward": (_i, [_vp, _vp, _f, _i, _i, _vp, _vp, _vp]),
     "d3f_global_max": (_i, [_vp, _sz, _vp, _vp, _sz, _vp]),
+    "d3f_global_max_rows": (_i, [_vp, _i, _i, _vp, _i, _vp, _vp, _sz, _vp]),
     "d3f_detection_scores_forward": (_i, [_vp, _i, _i, _vp, _i, _vp, _i, _vp, _vp]),
     "d3f_detection_scores_ws_bytes": (_sz, [_i, _i]),
     "d3f_detection_scores_backward": (_i, [_vp, _i, _i, _vp, _i, _vp, _vp, _vp, _vp, _sz, _vp]),
@@ -48,12 +49,14 @@ SIGNATURES = {
     "d3f_circle_det_loss_backward": (_i, [_vp, _vp, _i, _i, _vp, _vp, _vp, _f, _f, _f, _f, _vp, _vp, _vp, _vp, _vp,
                                           _vp, _vp, _vp, _vp, _sz, _vp]),
     "d3f_mutual_nn": (_i, [_vp, _i, _vp, _i, _i, _vp, _vp, _vp, _vp]),
+    "d3f_sgd_guarded_step": (_i, [_vp, _vp, _vp, _sz, _f, _f, _f, _vp, _vp]),
 }
 
 ERRORS = {-1: "invalid argument", -2: "workspace too small", -3: "HIP launch failure"}
 STATUS_BITS = {1: "a query has more in-radius candidates than the kernel can rank (512)",
                2: "a point lies outside the addressable cell grid",
-               4: "voxel hash table full"}
+               4: "voxel hash table full",
+               8: "a pyramid level needs more rows than its capacity (raise the capacities)"}
 
 
 def build(verbose=False):
@@ -107,7 +110,16 @@ def lib():
     return _lib
 
 
+_TRACE = bool(os.environ.get("D3F_TRACE"))
+
+
 def check(rc, what):
+    if _TRACE:  # debugging aid: name every C-ABI call and fence it, so a device fault can be attributed
+        import sys
+        import torch
+        sys.stderr.write("[d3f] %s\n" % what)
+        sys.stderr.flush()
+        torch.cuda.synchronize()
     if rc != 0:
         raise RuntimeError("%s failed: %s" % (what, ERRORS.get(rc, "error %d" % rc)))
 

@@ -15,6 +15,20 @@
 
 namespace d3f {
 
+// Zero-fill as an ordinary kernel launch.  hipMemsetAsync nodes were observed NOT to re-execute under hipGraph replay
+// of this library's launches (second replay saw dirty allocators), so every re-initialisation is a kernel.
+__global__ static void zero_fill_kernel(uint32_t* __restrict__ p, size_t n_words) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_words; i += (size_t)gridDim.x * blockDim.x) p[i] = 0u;
+}
+static inline hipError_t zero_async(void* p, size_t bytes, hipStream_t stream) {
+  const size_t words = (bytes + 3) / 4;  // all buffers of this library are 4-byte multiples
+  if (words == 0) return hipSuccess;
+  size_t blocks = (words + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  zero_fill_kernel<<<(unsigned)blocks, 256, 0, stream>>>((uint32_t*)p, words);
+  return hipGetLastError();
+}
+
 static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 static inline int cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
 

@@ -146,6 +146,18 @@ __global__ __launch_bounds__(256) void gmax_partial_kernel(const float* __restri
   m = d3f::wave_max(m);
   if ((threadIdx.x & 63) == 0) atomicMax(enc, f2ord(m));
 }
+__global__ __launch_bounds__(256) void gmax_rows_kernel(const float* __restrict__ x, int cap_rows, int C,
+                                                        const int32_t* __restrict__ len, int B,
+                                                        uint32_t* __restrict__ enc) {
+  int rows = d3f::batch_offset(len, B);
+  if (rows > cap_rows) rows = cap_rows;
+  const size_t n = (size_t)rows * C;
+  float m = -INFINITY;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+    m = fmaxf(m, x[i]);
+  m = d3f::wave_max(m);
+  if ((threadIdx.x & 63) == 0) atomicMax(enc, f2ord(m));
+}
 __global__ void gmax_final_kernel(const uint32_t* __restrict__ enc, float* __restrict__ out) { *out = ord2f(*enc); }
 
 // S = sum(df * f), ties = #{feat == fmax}
@@ -185,10 +197,23 @@ extern "C" {
 int d3f_global_max(const float* x, size_t n, float* out_max, void* ws, size_t ws_bytes, void* stream_) {
   if (!x || !out_max || !ws || ws_bytes < 4 || n == 0) return D3F_EINVAL;
   hipStream_t stream = (hipStream_t)stream_;
-  if (hipMemsetAsync(ws, 0, 4, stream) != hipSuccess) return D3F_ELAUNCH;
+  if (d3f::zero_async(ws, 4, stream) != hipSuccess) return D3F_ELAUNCH;
   int blocks = d3f::cdiv((long long)n, 256 * 8);
   if (blocks > 1024) blocks = 1024;
   gmax_partial_kernel<<<blocks, 256, 0, stream>>>(x, n, (uint32_t*)ws);
+  gmax_final_kernel<<<1, 1, 0, stream>>>((const uint32_t*)ws, out_max);
+  D3F_LAUNCH_CHECK();
+  return D3F_OK;
+}
+
+int d3f_global_max_rows(const float* x, int cap_rows, int C, const int32_t* len, int B, float* out_max, void* ws,
+                        size_t ws_bytes, void* stream_) {
+  if (!x || !out_max || !ws || !len || ws_bytes < 4 || cap_rows < 1 || C < 1 || B < 1) return D3F_EINVAL;
+  hipStream_t stream = (hipStream_t)stream_;
+  if (d3f::zero_async(ws, 4, stream) != hipSuccess) return D3F_ELAUNCH;
+  int blocks = d3f::cdiv((long long)cap_rows * C, 256 * 8);
+  if (blocks > 1024) blocks = 1024;
+  gmax_rows_kernel<<<blocks, 256, 0, stream>>>(x, cap_rows, C, len, B, (uint32_t*)ws);
   gmax_final_kernel<<<1, 1, 0, stream>>>((const uint32_t*)ws, out_max);
   D3F_LAUNCH_CHECK();
   return D3F_OK;
@@ -218,8 +243,8 @@ int d3f_detection_scores_backward(const float* feat, int N, int C, const int32_t
   if (N == 0) return D3F_OK;
   hipStream_t stream = (hipStream_t)stream_;
   const size_t n = (size_t)N * C;
-  if (hipMemsetAsync(grad_feat, 0, sizeof(float) * n, stream) != hipSuccess) return D3F_ELAUNCH;
-  if (hipMemsetAsync(ws, 0, 8, stream) != hipSuccess) return D3F_ELAUNCH;
+  if (d3f::zero_async(grad_feat, sizeof(float) * n, stream) != hipSuccess) return D3F_ELAUNCH;
+  if (d3f::zero_async(ws, 8, stream) != hipSuccess) return D3F_ELAUNCH;
   const int grid = d3f::cdiv(N, 4);
   if (C <= 16) det_bwd_kernel<16><<<grid, 256, 0, stream>>>(feat, N, C, idx, H, feat_max, grad_scores, grad_feat);
   else if (C <= 32) det_bwd_kernel<32><<<grid, 256, 0, stream>>>(feat, N, C, idx, H, feat_max, grad_scores, grad_feat);

@@ -47,36 +47,33 @@ __global__ __launch_bounds__(256) void bias_act_fwd_scalar_kernel(const float* _
   out[i] = v > 0.0f ? v : v * slope;
 }
 
-// One workgroup owns ROWS rows x all C columns (C <= 2048 via column loop): thread t handles column (t % CT) of
-// row group (t / CT); per-column partial sums are combined in LDS and flushed with one atomic per column.
-constexpr int kRowsPerBlock = 64;
-
+// Workgroup (bx, by) owns rows [bx*rows_per_block, ...) x 64 columns [64*by, ...): thread t handles column t & 63 of
+// row lane t >> 6 (4 lanes), so every access is a coalesced 256-B row segment; the 4 lane partials are combined in
+// LDS and flushed with one atomic per column.  rows_per_block is chosen by the host so that the launch has >= ~1000
+// workgroups also for the few-point / 2048-channel layers at the bottom of the U-Net.
 __global__ __launch_bounds__(256) void bias_act_bwd_kernel(const float* __restrict__ go, const float* __restrict__ out,
-                                                           float slope, int N, int C, float* __restrict__ gx,
-                                                           float* __restrict__ gb) {
+                                                           float slope, int N, int C, int rows_per_block,
+                                                           float* __restrict__ gx, float* __restrict__ gb) {
   __shared__ float red[256];
-  const int r0 = blockIdx.x * kRowsPerBlock;
-  const int r1 = min(N, r0 + kRowsPerBlock);
-  for (int c0 = 0; c0 < C; c0 += 64) {
-    // 64 columns x 4 row-lanes per pass
-    const int c = c0 + (threadIdx.x & 63);
-    const int rl = threadIdx.x >> 6;
-    float s = 0.0f;
-    if (c < C) {
-      for (int r = r0 + rl; r < r1; r += 4) {
-        const size_t i = (size_t)r * C + c;
-        const float g = go[i] * (out[i] > 0.0f ? 1.0f : slope);
-        if (gx) gx[i] = g;
-        s += g;
-      }
+  const int r0 = blockIdx.x * rows_per_block;
+  const int r1 = min(N, r0 + rows_per_block);
+  const int c = blockIdx.y * 64 + (threadIdx.x & 63);
+  const int rl = threadIdx.x >> 6;
+  float s = 0.0f;
+  if (c < C) {
+#pragma unroll 4
+    for (int r = r0 + rl; r < r1; r += 4) {
+      const size_t i = (size_t)r * C + c;
+      const float g = go[i] * (out[i] > 0.0f ? 1.0f : slope);
+      if (gx) gx[i] = g;
+      s += g;
     }
-    if (gb) {
-      red[threadIdx.x] = s;
-      __syncthreads();
-      if (threadIdx.x < 64 && c < C) atomicAdd(&gb[c], red[threadIdx.x] + red[threadIdx.x + 64] + red[threadIdx.x + 128] +
-                                                            red[threadIdx.x + 192]);
-      __syncthreads();
-    }
+  }
+  if (gb) {
+    red[threadIdx.x] = s;
+    __syncthreads();
+    if (threadIdx.x < 64 && c < C)
+      atomicAdd(&gb[c], red[threadIdx.x] + red[threadIdx.x + 64] + red[threadIdx.x + 128] + red[threadIdx.x + 192]);
   }
 }
 
@@ -103,11 +100,14 @@ int d3f_bias_act_forward(const float* x, const float* bias1, const float* add, c
 int d3f_bias_act_backward(const float* grad_out, const float* out, float slope, int N, int C, float* grad_x,
                           float* grad_bias, void* stream) {
   if (!grad_out || !out || N < 0 || C < 1 || (!grad_x && !grad_bias)) return D3F_EINVAL;
-  if (grad_bias && hipMemsetAsync(grad_bias, 0, sizeof(float) * (size_t)C, (hipStream_t)stream) != hipSuccess)
+  if (grad_bias && d3f::zero_async(grad_bias, sizeof(float) * (size_t)C, (hipStream_t)stream) != hipSuccess)
     return D3F_ELAUNCH;
   if (N == 0) return D3F_OK;
-  bias_act_bwd_kernel<<<d3f::cdiv(N, kRowsPerBlock), 256, 0, (hipStream_t)stream>>>(grad_out, out, slope, N, C, grad_x,
-                                                                                   grad_bias);
+  const int cblocks = d3f::cdiv(C, 64);
+  int rows = 256;  // fewer atomics per column when there are plenty of rows
+  while (rows > 16 && (long long)d3f::cdiv(N, rows) * cblocks < 1024) rows >>= 1;
+  dim3 grid(d3f::cdiv(N, rows), cblocks);
+  bias_act_bwd_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(grad_out, out, slope, N, C, rows, grad_x, grad_bias);
   D3F_LAUNCH_CHECK();
   return D3F_OK;
 }

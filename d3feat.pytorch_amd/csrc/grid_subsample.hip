@@ -305,7 +305,8 @@ __global__ __launch_bounds__(kOrderThreads) void order_kernel(
     int32_t* __restrict__ seq_slot, int32_t* __restrict__ curA, int32_t* __restrict__ curB,
     int32_t* __restrict__ tmpbk, int32_t* __restrict__ memberT, int32_t* __restrict__ bfirst,
     int32_t* __restrict__ bcnt, int32_t* __restrict__ bcur, int32_t* __restrict__ bbase,
-    float* __restrict__ out_points, int32_t* __restrict__ out_len, int32_t* __restrict__ out_total) {
+    float* __restrict__ out_points, int32_t* __restrict__ out_len, int32_t* __restrict__ out_total, int out_cap,
+    int32_t* __restrict__ status) {
   __shared__ int sh[16];
   const int b = blockIdx.x, tid = threadIdx.x, nthr = blockDim.x;
   const int pstart = d3f::batch_offset(len, b), n = len[b], pend = pstart + n;
@@ -319,8 +320,12 @@ __global__ __launch_bounds__(kOrderThreads) void order_kernel(
   }
   const int emit = min(Mc, limit);
   if (tid == 0) {
-    out_len[b] = emit;
-    if (b == 0) *out_total = total;
+    // lengths handed downstream never exceed the buffer: on overflow the level is truncated AND flagged
+    out_len[b] = max(0, min(emit, out_cap - obase));
+    if (b == 0) {
+      *out_total = total;
+      if (total > out_cap) atomicOr(status, D3F_ST_CAPACITY);
+    }
   }
   if (n <= 0 || Mc <= 0) return;
 
@@ -432,6 +437,7 @@ __global__ __launch_bounds__(kOrderThreads) void order_kernel(
     __syncthreads();
   }
   for (int pos = tid; pos < emit; pos += nthr) {
+    if (obase + pos >= out_cap) continue;  // capacity overflow is reported through the status word
     const float4 v = bary[sslot[cur[pos]]];
     float* o = out_points + 3 * (size_t)(obase + pos);
     o[0] = v.x; o[1] = v.y; o[2] = v.z;
@@ -445,8 +451,9 @@ extern "C" {
 size_t d3f_grid_subsample_ws_bytes(int N, int B) { return layout(nullptr, N, B < 1 ? 1 : B).bytes; }
 
 int d3f_grid_subsample(const float* points, int N, const int32_t* len, int B, float sampleDl, int max_p, int order,
-                       float* out_points, int32_t* out_len, int32_t* out_total, void* ws, size_t ws_bytes,
+                       float* out_points, int out_cap, int32_t* out_len, int32_t* out_total, void* ws, size_t ws_bytes,
                        int32_t* status, void* stream_) {
+  if (out_cap <= 0) out_cap = N;
   if (!points || !len || !out_points || !out_len || !out_total || !ws || !status || N < 1 || B < 1 ||
       B > D3F_MAX_BATCH || !(sampleDl > 0.0f) || (order != D3F_ORDER_REFERENCE && order != D3F_ORDER_FIRST_SEEN))
     return D3F_EINVAL;
@@ -454,8 +461,10 @@ int d3f_grid_subsample(const float* points, int N, const int32_t* len, int B, fl
   Layout L = layout(ws, N, B);
   if (ws_bytes < L.bytes) return D3F_EWORKSPACE;
   const Schedule& sched = host_schedule(N);
-  if (hipMemsetAsync(L.tcount, 0, sizeof(int32_t) * (L.M + 64 + (size_t)B), stream) != hipSuccess) return D3F_ELAUNCH;
-  if (hipMemsetAsync(L.bitmap, 0, sizeof(uint64_t) * ((size_t)N / 64 + 2), stream) != hipSuccess) return D3F_ELAUNCH;
+  if (d3f::zero_async(L.tcount, sizeof(int32_t) * (L.M + 64 + (size_t)B), stream) != hipSuccess) return D3F_ELAUNCH;
+  if (d3f::zero_async(L.bitmap, sizeof(uint64_t) * ((size_t)N / 64 + 2), stream) != hipSuccess) return D3F_ELAUNCH;
+  // rows past the emitted total stay zero: a capacity-shaped consumer never sees uninitialised (NaN) coordinates
+  if (d3f::zero_async(out_points, sizeof(float) * 3 * (size_t)out_cap, stream) != hipSuccess) return D3F_ELAUNCH;
   init_kernel<<<d3f::cdiv(L.M, 256), 256, 0, stream>>>(L.M, L.tkey, L.tfirst);
   bbox_kernel<<<B, 1024, 0, stream>>>(points, len, sampleDl, L.grid);
   insert_kernel<<<d3f::cdiv(N, 256), 256, 0, stream>>>(points, N, len, B, sampleDl, L.grid, L.M - 1, L.tkey, L.tcount,
@@ -467,7 +476,7 @@ int d3f_grid_subsample(const float* points, int N, const int32_t* len, int B, fl
   order_kernel<<<B, kOrderThreads, 0, stream>>>(len, B, max_p, order, sched, L.bitmap, L.wprefix, L.slot_of, L.tkey,
                                                 L.bary, L.ncell, L.seq_key, L.seq_slot, L.curA, L.curB, L.tmpbk,
                                                 L.memberT, L.bfirst, L.bcnt, L.bcur, L.bbase, out_points, out_len,
-                                                out_total);
+                                                out_total, out_cap, status);
   D3F_LAUNCH_CHECK();
   return D3F_OK;
 }

@@ -201,7 +201,7 @@ int launch_gemm(const float* A, long sai, long sak, const float* B, long sbk, lo
   split = cdiv(Kd, kchunk);
   if (split < 1) split = 1;
   if (split > 1) {
-    if (hipMemsetAsync(C, 0, sizeof(float) * (size_t)M * N, stream) != hipSuccess) return D3F_ELAUNCH;
+    if (d3f::zero_async(C, sizeof(float) * (size_t)M * N, stream) != hipSuccess) return D3F_ELAUNCH;
   }
   dim3 grid(cdiv(M, 64), cdiv(N, 64), split);
   gemm_f32_mfma_kernel<<<grid, 256, 0, stream>>>(A, sai, sak, B, sbk, sbj, C, M, N, Kd, rscale, rscale_inv, kchunk,
@@ -305,21 +305,21 @@ int d3f_kpconv_backward(const float* q_pts, int Nq, const float* s_pts, int Ns, 
   const size_t wf_elems = align_up(sizeof(float) * (size_t)(Nq > 0 ? Nq : 1) * KC, 256) / sizeof(float);
   float* wf = (float*)ws;
   float* gW = wf + wf_elems;
-  if (grad_x && hipMemsetAsync(grad_x, 0, sizeof(float) * (size_t)Ns * Cin, stream) != hipSuccess) return D3F_ELAUNCH;
+  if (grad_x && d3f::zero_async(grad_x, sizeof(float) * (size_t)Ns * Cin, stream) != hipSuccess) return D3F_ELAUNCH;
   if (Nq == 0) {
-    if (grad_w && hipMemsetAsync(grad_w, 0, sizeof(float) * (size_t)KC * Cout, stream) != hipSuccess)
+    if (grad_w && d3f::zero_async(grad_w, sizeof(float) * (size_t)KC * Cout, stream) != hipSuccess)
       return D3F_ELAUNCH;
     return D3F_OK;
   }
   if (kpconv_fused_supported(Cin, Cout, K, H, Ns)) {
-    if (grad_w && hipMemsetAsync(grad_w, 0, sizeof(float) * (size_t)KC * Cout, stream) != hipSuccess)
+    if (grad_w && d3f::zero_async(grad_w, sizeof(float) * (size_t)KC * Cout, stream) != hipSuccess)
       return D3F_ELAUNCH;
     return kpconv_backward_fused(q_pts, Nq, s_pts, Ns, idx, H, x, Cin, kernel_points, K, weights, Cout, extent, nn,
                                  grad_out, grad_x, grad_w, ws, stream);
   }
   int rc;
   if (grad_w && kpconv_small_supported(Cin, Cout, K, H)) {
-    if (hipMemsetAsync(grad_w, 0, sizeof(float) * (size_t)KC * Cout, stream) != hipSuccess) return D3F_ELAUNCH;
+    if (d3f::zero_async(grad_w, sizeof(float) * (size_t)KC * Cout, stream) != hipSuccess) return D3F_ELAUNCH;
     rc = kpconv_small_dispatch(false, q_pts, s_pts, idx, x, kernel_points, weights, nn, grad_out, Nq, Ns, H, Cin, Cout,
                                K, extent, nullptr, nullptr, grad_w, stream);
     if (rc) return rc;

@@ -396,7 +396,7 @@ static int launch_fused_cv(const float* q_pts, const float4* spack, const int32_
   int zsplit = 1;
   while (zsplit < nchunks && (long long)tiles * (Cout / slab) * zsplit < 512) zsplit <<= 1;
   if (zsplit > nchunks) zsplit = nchunks;
-  if (zsplit > 1 && hipMemsetAsync(out, 0, sizeof(float) * (size_t)Nq * Cout, stream) != hipSuccess) return D3F_ELAUNCH;
+  if (zsplit > 1 && d3f::zero_async(out, sizeof(float) * (size_t)Nq * Cout, stream) != hipSuccess) return D3F_ELAUNCH;
 #define D3F_LAUNCH(NBW, WK)                                                                                     \
   {                                                                                                             \
     const size_t lds = lds_base + ((WK) > 1 ? sizeof(float) * 16 * (size_t)slab : 0);                           \

@@ -152,15 +152,22 @@ __global__ __launch_bounds__(256) void kpconv_small_dw_kernel(const float* __res
         for (int j = 0; j < OPL; ++j) dw[k][c][j] = fmaf(v, g[j], dw[k][c][j]);
       }
   }
+  // combine the 4 waves of the workgroup in LDS, then one global atomic per weight per workgroup
+  __shared__ float red[16 * CIN * OPL * 64];
+  for (int i = threadIdx.x; i < 16 * CIN * OPL * 64; i += blockDim.x) red[i] = 0.0f;
+  __syncthreads();
 #pragma unroll
   for (int k = 0; k < 16; ++k)
 #pragma unroll
     for (int c = 0; c < CIN; ++c)
 #pragma unroll
-      for (int j = 0; j < OPL; ++j) {
-        const int o = lane + 64 * j;
-        if (k < K && o < Cout) atomicAdd(&gW[((size_t)k * CIN + c) * Cout + o], dw[k][c][j]);
-      }
+      for (int j = 0; j < OPL; ++j) atomicAdd(&red[((k * CIN + c) * OPL + j) * 64 + lane], dw[k][c][j]);
+  __syncthreads();
+  for (int i = threadIdx.x; i < 16 * CIN * OPL * 64; i += blockDim.x) {
+    const int l = i & 63, j = (i >> 6) % OPL, kc = (i >> 6) / OPL;
+    const int k = kc / CIN, c = kc % CIN, o = l + 64 * j;
+    if (k < K && o < Cout) atomicAdd(&gW[((size_t)k * CIN + c) * Cout + o], red[i]);
+  }
 }
 
 bool kpconv_small_supported(int Cin, int Cout, int K, int H) {
@@ -175,6 +182,7 @@ static int launch_small(bool fwd, const float* q_pts, const float* s_pts, const 
   // persistent waves: 4 per workgroup, ~8 workgroups per CU so the per-wave weight registers are loaded once per ~5 queries
   int blocks = cdiv(Nq, 4 * 4);
   if (blocks > 2048) blocks = 2048;
+  if (!fwd && blocks > 512) blocks = 512;  // dW: every workgroup ends with K*Cin*Cout global atomics
   if (blocks < 1) blocks = 1;
   if (fwd)
     kpconv_small_fwd_kernel<CIN, OPL><<<blocks, 256, 0, stream>>>(q_pts, s_pts, idx, x, kp, W, Nq, Ns, H, Cout, K, extent,

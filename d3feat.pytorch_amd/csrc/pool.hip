@@ -73,7 +73,7 @@ int d3f_max_pool_forward(const float* x, int Ns, int C, const int32_t* idx, int 
 int d3f_max_pool_backward(const float* grad_out, const int32_t* argmax, int Nq, int C, int Ns, float* grad_x,
                           void* stream) {
   if (!grad_out || !argmax || !grad_x || Nq < 0 || C < 1 || Ns < 0) return D3F_EINVAL;
-  if (hipMemsetAsync(grad_x, 0, sizeof(float) * (size_t)Ns * C, (hipStream_t)stream) != hipSuccess) return D3F_ELAUNCH;
+  if (d3f::zero_async(grad_x, sizeof(float) * (size_t)Ns * C, (hipStream_t)stream) != hipSuccess) return D3F_ELAUNCH;
   if (Nq == 0) return D3F_OK;
   max_pool_bwd_kernel<<<d3f::cdiv((long long)Nq * C, 256), 256, 0, (hipStream_t)stream>>>(grad_out, argmax, Nq, C, Ns,
                                                                                           grad_x);
@@ -94,7 +94,7 @@ int d3f_closest_pool_forward(const float* x, int Ns, int C, const int32_t* idx, 
 int d3f_closest_pool_backward(const float* grad_out, const int32_t* idx, int Nq, int H, int C, int Ns, float* grad_x,
                               void* stream) {
   if (!grad_out || !idx || !grad_x || Nq < 0 || C < 1 || Ns < 0 || H < 1) return D3F_EINVAL;
-  if (hipMemsetAsync(grad_x, 0, sizeof(float) * (size_t)Ns * C, (hipStream_t)stream) != hipSuccess) return D3F_ELAUNCH;
+  if (d3f::zero_async(grad_x, sizeof(float) * (size_t)Ns * C, (hipStream_t)stream) != hipSuccess) return D3F_ELAUNCH;
   if (Nq == 0) return D3F_OK;
   closest_pool_bwd_kernel<<<d3f::cdiv((long long)Nq * C, 256), 256, 0, (hipStream_t)stream>>>(grad_out, idx, Nq, H, C,
                                                                                               Ns, grad_x);

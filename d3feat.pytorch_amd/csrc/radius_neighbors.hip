@@ -67,7 +67,7 @@ __global__ void grid_count_kernel(const float* __restrict__ s, int Ns, const int
                                   double inv_cell, uint32_t mask, int32_t* __restrict__ cnt,
                                   uint64_t* __restrict__ key_tmp, int32_t* __restrict__ status) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= Ns) return;
+  if (i >= Ns || i >= d3f::batch_offset(s_len, B)) return;  // Ns is a row capacity; sum(s_len) rows are live
   int b, st;
   d3f::locate_batch(s_len, B, i, b, st);
   const int cx = cell_coord(s[3 * i + 0], inv_cell), cy = cell_coord(s[3 * i + 1], inv_cell),
@@ -89,11 +89,11 @@ __global__ void grid_alloc_kernel(uint32_t M, int32_t* __restrict__ cnt, int32_t
   end[b] = s;
 }
 
-__global__ void grid_scatter_kernel(const float* __restrict__ s, int Ns, uint32_t mask,
-                                    const uint64_t* __restrict__ key_tmp, int32_t* __restrict__ end,
+__global__ void grid_scatter_kernel(const float* __restrict__ s, int Ns, const int32_t* __restrict__ s_len, int B,
+                                    uint32_t mask, const uint64_t* __restrict__ key_tmp, int32_t* __restrict__ end,
                                     float4* __restrict__ pts, uint64_t* __restrict__ key) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= Ns) return;
+  if (i >= Ns || i >= d3f::batch_offset(s_len, B)) return;
   const uint64_t k = key_tmp[i];
   const int pos = atomicAdd(&end[bucket_of(k, mask)], 1);
   pts[pos] = make_float4(s[3 * i + 0], s[3 * i + 1], s[3 * i + 2], __int_as_float(i));
@@ -124,6 +124,11 @@ __global__ __launch_bounds__(kQueryWaves * 64) void radius_query_kernel(
   if (qi >= Nq) return;  // no workgroup barrier below: waves are independent
   WaveScratch& ws = scratch[wave];
   volatile uint64_t* cand = ws.cand;
+  if (qi >= d3f::batch_offset(q_len, B)) {  // Nq is a row capacity: rows past sum(q_len) get an all-shadow row
+    for (int c = lane; c < width; c += 64) out_idx[(size_t)qi * width + c] = Ns;
+    if (lane == 0 && out_counts) out_counts[qi] = 0;
+    return;
+  }
 
   int b, qstart;
   d3f::locate_batch(q_len, B, qi, b, qstart);
@@ -240,7 +245,7 @@ int d3f_radius_grid_build(const float* supports, int Ns, const int32_t* s_len, i
   GridLayout g = grid_layout(grid_ws, Ns);
   if (grid_ws_bytes < g.bytes) return D3F_EWORKSPACE;
   const double inv_cell = 1.0 / ((double)radius * kCellSlack);
-  if (hipMemsetAsync(g.cnt, 0, sizeof(int32_t) * (g.M + 64), stream) != hipSuccess) return D3F_ELAUNCH;
+  if (d3f::zero_async(g.cnt, sizeof(int32_t) * (g.M + 64), stream) != hipSuccess) return D3F_ELAUNCH;
   if (Ns > 0) {
     grid_count_kernel<<<d3f::cdiv(Ns, 256), 256, 0, stream>>>(supports, Ns, s_len, B, inv_cell, g.M - 1, g.cnt,
                                                              g.key_tmp, status);
@@ -249,7 +254,8 @@ int d3f_radius_grid_build(const float* supports, int Ns, const int32_t* s_len, i
   grid_alloc_kernel<<<d3f::cdiv(g.M, 256), 256, 0, stream>>>(g.M, g.cnt, g.start, g.end);
   D3F_LAUNCH_CHECK();
   if (Ns > 0) {
-    grid_scatter_kernel<<<d3f::cdiv(Ns, 256), 256, 0, stream>>>(supports, Ns, g.M - 1, g.key_tmp, g.end, g.pts, g.key);
+    grid_scatter_kernel<<<d3f::cdiv(Ns, 256), 256, 0, stream>>>(supports, Ns, s_len, B, g.M - 1, g.key_tmp, g.end, g.pts,
+                                                                g.key);
     D3F_LAUNCH_CHECK();
   }
   return D3F_OK;

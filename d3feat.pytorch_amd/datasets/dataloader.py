@@ -111,6 +111,51 @@ class _Walk:
             layer_blocks = []
 
 
+def build_pyramid_static(points, lengths, config, neighborhood_limits, capacities, order=ops.ORDER_REFERENCE):
+    """Capacity-shaped pyramid: every level l has ``capacities[l]`` rows, the live row counts stay on the device.
+
+    No host synchronisation at all (hipGraph-capturable): voxel levels write into fixed-capacity buffers (rows past
+    the live count are zero), searches give rows past the live count an all-shadow row, and the shadow index of a
+    table is the support CAPACITY, so the operators run unchanged on the padded shapes and padded rows never reach a
+    live row.  A level outgrowing its capacity sets D3F_ST_CAPACITY in the returned status word."""
+    dev = points.device
+    walk = _Walk(config)
+    status = ops.DeviceStatus(dev)
+    pts, lens = [points], [ops._lens(lengths, dev, "lengths")]
+    for e in walk.layers:
+        if e['pool']:
+            out, out_len, _, _ = ops.grid_subsample_raw(pts[-1], lens[-1], e['dl'], order=order, status=status,
+                                                        out_cap=int(capacities[len(pts)]))
+            pts.append(out)
+            lens.append(out_len)
+    grids = {}
+
+    def grid_for(level, radius):
+        key = (level, float(radius))
+        if key not in grids:
+            grids[key] = ops.RadiusGrid(pts[level], lens[level], radius, status=status)
+        return grids[key]
+
+    empty_idx = torch.zeros((0, 1), dtype=torch.int32, device=dev)
+    neighbors, pools, upsamples = [], [], []
+    level = 0
+    for li, e in enumerate(walk.layers):
+        lim = int(neighborhood_limits[li])
+        neighbors.append(grid_for(level, e['conv_r']).query(pts[level], lens[level], lim)
+                         if e['conv_r'] is not None else empty_idx)
+        if e['pool']:
+            pools.append(grid_for(level, e['pool_r']).query(pts[level + 1], lens[level + 1], lim))
+            upsamples.append(grid_for(level + 1, e['up_r']).query(pts[level], lens[level], lim))
+            level += 1
+        else:
+            pools.append(empty_idx)
+            upsamples.append(empty_idx)
+    n_levels = len(neighbors)
+    return {'points': [pts[min(i, len(pts) - 1)] for i in range(n_levels)], 'neighbors': neighbors, 'pools': pools,
+            'upsamples': upsamples, 'stack_lengths': [lens[min(i, len(lens) - 1)] for i in range(n_levels)],
+            '_status': status, '_static': True}
+
+
 def build_pyramid(points, lengths, config, neighborhood_limits, index_dtype=torch.int32, exact_width=False,
                   order=ops.ORDER_REFERENCE):
     """points [N0,3] + stack lengths [B] -> dict(points, neighbors, pools, upsamples, stack_lengths) on the device.

@@ -84,4 +84,5 @@ class KPFCNN(nn.Module):
     def detection_scores(self, inputs, features):
         """Saliency score of every point [N,1] (reference architectures.py:322-368); eval mode adds the
         local-maximum gate."""
-        return ops.detection_scores(features, inputs['neighbors'][0], training=self.training)
+        lens = inputs['stack_lengths'][0] if inputs.get('_static', False) else None  # capacity-shaped batch
+        return ops.detection_scores(features, inputs['neighbors'][0], training=self.training, lens=lens)

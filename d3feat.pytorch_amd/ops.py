@@ -169,7 +169,7 @@ class RadiusGrid:
 # ---------------------------------------------------------------------------------------------------------------
 # grid subsampling (cpp_wrappers/cpp_subsampling; datasets/dataloader.py:12-22)
 # ---------------------------------------------------------------------------------------------------------------
-def grid_subsample_raw(points, lens, sampleDl, max_p=0, order=ORDER_REFERENCE, status=None):
+def grid_subsample_raw(points, lens, sampleDl, max_p=0, order=ORDER_REFERENCE, status=None, out_cap=0):
     """Sync-free form: returns (out_points [capacity,3], out_len [B] int32, out_total [1] int32).
 
     ``points`` may itself be a capacity buffer: only the first sum(lens) rows are read, so pyramid levels chain
@@ -184,12 +184,13 @@ def grid_subsample_raw(points, lens, sampleDl, max_p=0, order=ORDER_REFERENCE, s
     L = _native.lib()
     nbytes = L.d3f_grid_subsample_ws_bytes(N, B)
     ws = _ws(nbytes, dev)
-    out = torch.empty((N, 3), dtype=torch.float32, device=dev)
+    cap = int(out_cap) if out_cap and out_cap > 0 else N
+    out = torch.empty((cap, 3), dtype=torch.float32, device=dev)
     out_len = torch.empty(B, dtype=torch.int32, device=dev)
     total = torch.empty(1, dtype=torch.int32, device=dev)
     with _region("grid_subsample[cap=%d]" % N, 24 * N):
         _native.check(L.d3f_grid_subsample(_p(p), N, _p(lens), B, float(sampleDl), int(max_p), int(order), _p(out),
-                                           _p(out_len), _p(total), _p(ws), nbytes, _p(status.word), _stream()),
+                                           cap, _p(out_len), _p(total), _p(ws), nbytes, _p(status.word), _stream()),
                       "d3f_grid_subsample")
     return out, out_len, total, status
 
@@ -366,19 +367,26 @@ def bias_act(x, bias1=None, add=None, bias2=None, slope=0.1):
 # ---------------------------------------------------------------------------------------------------------------
 # detector score (models/architectures.py:322-368)
 # ---------------------------------------------------------------------------------------------------------------
-def global_max(x):
+def global_max(x, lens=None):
+    """max(x) as a device scalar; with ``lens`` (int32 stack lengths) only the first sum(lens) rows count."""
     x = _f32(x, "x")
     out = torch.empty(1, dtype=torch.float32, device=x.device)
     ws = _ws(256, x.device)
-    _native.check(_native.lib().d3f_global_max(_p(x), x.numel(), _p(out), _p(ws), 256, _stream()), "d3f_global_max")
+    if lens is None:
+        _native.check(_native.lib().d3f_global_max(_p(x), x.numel(), _p(out), _p(ws), 256, _stream()),
+                      "d3f_global_max")
+    else:
+        _native.check(_native.lib().d3f_global_max_rows(_p(x), int(x.shape[0]), int(x.shape[1]), _p(lens),
+                                                        int(lens.numel()), _p(out), _p(ws), 256, _stream()),
+                      "d3f_global_max_rows")
     return out
 
 
 class _DetScoreFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, feat, idx, training):
+    def forward(ctx, feat, idx, training, lens=None):
         N, C, H = int(feat.shape[0]), int(feat.shape[1]), int(idx.shape[1])
-        fmax = global_max(feat)
+        fmax = global_max(feat, lens)
         scores = torch.empty((N, 1), dtype=torch.float32, device=feat.device)
         with _region("detection_fwd[N=%d]" % N, 4 * N * H + 4 * N * H * C + 4 * N * C + 4 * N):
             _native.check(_native.lib().d3f_detection_scores_forward(_p(feat), N, C, _p(idx), H, _p(fmax),
@@ -401,12 +409,13 @@ class _DetScoreFn(torch.autograd.Function):
             _native.check(_native.lib().d3f_detection_scores_backward(_p(feat), N, C, _p(idx), H, _p(fmax), _p(gs),
                                                                       _p(gf), _p(ws), 256, _stream()),
                           "d3f_detection_scores_backward")
-        return gf, None, None
+        return gf, None, None, None
 
 
-def detection_scores(features, neighbors, training=True):
-    """scores [N,1] from un-normalised descriptors [N,C] and the layer-0 neighbor table."""
-    return _DetScoreFn.apply(_f32(features, "features"), _i32(neighbors, "neighbors"), bool(training))
+def detection_scores(features, neighbors, training=True, lens=None):
+    """scores [N,1] from un-normalised descriptors [N,C] and the layer-0 neighbor table.  ``lens`` (device int32
+    stack lengths) restricts the global-max normaliser to the live rows of a capacity-shaped batch."""
+    return _DetScoreFn.apply(_f32(features, "features"), _i32(neighbors, "neighbors"), bool(training), lens)
 
 
 # ---------------------------------------------------------------------------------------------------------------
@@ -478,3 +487,19 @@ def mutual_nn(source_desc, target_desc):
     _native.check(_native.lib().d3f_mutual_nn(_p(s), Ns, _p(t), Nt, C, _p(ra), _p(ca), _p(mu), _stream()),
                   "d3f_mutual_nn")
     return ra, ca, mu
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# guarded SGD step on flat buffers (trainer.py:104-111 + training_3DMatch.py:62-76)
+# ---------------------------------------------------------------------------------------------------------------
+def sgd_guarded_step(grad, params, momentum_buf, lr, momentum, weight_decay, state):
+    """In place: params/momentum_buf updated unless grad holds a non-finite value (then state[1] += 1)."""
+    for t, name in ((grad, "grad"), (params, "params"), (momentum_buf, "momentum_buf")):
+        if not (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous() and t.numel() == grad.numel()):
+            raise ValueError("%s must be a contiguous fp32 device tensor of %d elements" % (name, grad.numel()))
+    if not (state.is_cuda and state.dtype == torch.int32 and state.numel() >= 2):
+        raise ValueError("state must be an int32[2] device tensor")
+    with _region("sgd", 20 * grad.numel()):
+        _native.check(_native.lib().d3f_sgd_guarded_step(_p(grad), _p(params), _p(momentum_buf), grad.numel(),
+                                                         float(lr), float(momentum), float(weight_decay), _p(state),
+                                                         _stream()), "d3f_sgd_guarded_step")

@@ -20,7 +20,11 @@ from .utils.loss import CircleLoss
 
 
 class FlatParams:
-    """All trainable parameters (and their gradients) of a module as views into two flat fp32 buffers."""
+    """All trainable parameters of a module as views into one flat fp32 buffer, plus a flat gradient buffer.
+
+    Gradients are NOT accumulated into the flat buffer by autograd: with ``p.grad = None`` the engine hands each
+    parameter the gradient tensor its backward kernel produced (no per-parameter add launch -- ~100 of them per step
+    at full width), and ``gather_grads`` packs them into ``grad`` with one batched concatenation."""
 
     def __init__(self, module):
         self.params = [p for p in module.parameters() if p.requires_grad]
@@ -33,18 +37,19 @@ class FlatParams:
             k = p.numel()
             self.data[off:off + k].copy_(p.data.reshape(-1))
             p.data = self.data[off:off + k].view_as(p.data)
-            p.grad = self.grad[off:off + k].view_as(p.data)
+            p.grad = None
             off += k
         self.numel = n
 
     def zero_grad(self):
-        self.grad.zero_()
-        off = 0
-        for p in self.params:  # autograd may have replaced .grad; re-point it at the flat buffer
-            k = p.numel()
-            if p.grad is None or p.grad.data_ptr() != self.grad[off:off + k].data_ptr():
-                p.grad = self.grad[off:off + k].view_as(p.data)
-            off += k
+        for p in self.params:
+            p.grad = None
+
+    def gather_grads(self):
+        """Pack the per-parameter gradients of the last backward into ``grad`` (zeros for unused parameters)."""
+        parts = [(p.grad if p.grad is not None else torch.zeros_like(p.data)).reshape(-1) for p in self.params]
+        torch.cat(parts, out=self.grad)
+        return self.grad
 
 
 def allreduce_mean_(flat, world_size, n_buckets=4, group=None):
@@ -67,22 +72,34 @@ def allreduce_mean_(flat, world_size, n_buckets=4, group=None):
 
 class GuardedSGD:
     """SGD with momentum + weight decay on flat buffers; the update is skipped (momentum untouched) when the
-    gradient holds a non-finite value -- the reference's guard (trainer.py:104-111) evaluated on the device."""
+    gradient holds a non-finite value -- the reference's guard (trainer.py:104-111) evaluated on the device.
+    On the GPU this is d3f_sgd_guarded_step (two launches, no host sync); the torch expression below is the same
+    arithmetic for host tensors (the gloo tests of the data-parallel logic)."""
 
     def __init__(self, flat, lr=0.01, momentum=0.98, weight_decay=1e-6):
         self.flat, self.lr, self.momentum, self.weight_decay = flat, lr, momentum, weight_decay
         self.buf = torch.zeros_like(flat.data)
-        self.skipped = torch.zeros(1, dtype=torch.int32, device=flat.data.device)
+        self.state = torch.zeros(2, dtype=torch.int32, device=flat.data.device)
+
+    @property
+    def skipped(self):
+        return self.state[1]
 
     @torch.no_grad()
     def step(self):
+        """Returns a 0-dim bool tensor: True when the update was applied."""
         g = self.flat.grad
+        if g.is_cuda:
+            from . import ops
+            before = self.state[1].clone()
+            ops.sgd_guarded_step(g, self.flat.data, self.buf, self.lr, self.momentum, self.weight_decay, self.state)
+            return self.state[1] == before
         ok = torch.isfinite(g).all()
         d = torch.add(g, self.flat.data, alpha=self.weight_decay)       # g + wd * p
         new_buf = torch.add(d, self.buf, alpha=self.momentum)            # mom * buf + d
         self.buf.copy_(torch.where(ok, new_buf, self.buf))
         self.flat.data.sub_(torch.where(ok, new_buf, torch.zeros_like(new_buf)), alpha=self.lr)
-        self.skipped += (~ok).to(torch.int32)
+        self.state[1] += (~ok).to(torch.int32)
         return ok
 
 
@@ -112,11 +129,90 @@ class TrainStep:
     def forward_loss(self, batch):
         feats, scores = self.model(batch)
         corr = batch['corr'].long()
-        n0 = batch['n0'] if 'n0' in batch else int(batch['stack_lengths'][0][0])
+        n0 = batch['n0'] if 'n0' in batch else batch['stack_lengths'][0][0]  # host int, or a device scalar (no sync)
         ia, ip = corr[:, 0], corr[:, 1] + n0
         desc, acc, fp, an, _, dists = self.circle(feats[ia], feats[ip], batch['dist_keypts'], scores[ia], scores[ip])
         det = dists._d3f_det[0][1]
         return desc * self.w_desc + det * self.w_det, desc, det, acc
+
+    # -- static shapes + hipGraph -----------------------------------------------------------------------------
+    # The eager step costs ~11 ms of host enqueue time (600+ launches) against ~9 ms of GPU work.  In graph mode every
+    # level of the pyramid has a fixed row CAPACITY (live counts stay on the device, see build_pyramid_static), so
+    # the whole step -- 4 voxel levels, 13 searches, network forward, fused loss, backward, optimizer -- has static
+    # shapes and addresses, is captured once into a hipGraph and replayed per pair with ONE launch.
+    @staticmethod
+    def capacities_for(level_sizes, slack=1.06):
+        """Per-level row capacities from observed level sizes [[N0, N1, ...], ...] (rounded up to 64 rows)."""
+        n = len(level_sizes[0])
+        return [int(-(-int(max(s[l] for s in level_sizes) * slack + 32) // 64) * 64) for l in range(n)]
+
+    def enable_graph(self, capacities, num_corr):
+        dev = self.device
+        self.caps = [int(c) for c in capacities]
+        self.s_pts = torch.zeros((self.caps[0], 3), dtype=torch.float32, device=dev)
+        self.s_lens = torch.zeros(2, dtype=torch.int32, device=dev)
+        self.s_feat = torch.ones((self.caps[0], 1), dtype=torch.float32, device=dev)
+        self.s_corr = torch.zeros((num_corr, 2), dtype=torch.int64, device=dev)
+        self.s_dk = torch.zeros((num_corr, num_corr), dtype=torch.float64, device=dev)
+        self.graph = None
+
+    def _load_static(self, item):
+        p0, p1, _, _, corr, dk = item
+        n0, n1 = int(p0.shape[0]), int(p1.shape[0])
+        if n0 + n1 > self.caps[0] or tuple(corr.shape) != tuple(self.s_corr.shape):
+            raise RuntimeError("pair does not fit the captured shapes (%d + %d points, capacity %d; corr %s)" % (
+                n0, n1, self.caps[0], tuple(corr.shape)))
+        self.s_pts[:n0].copy_(p0, non_blocking=True)
+        self.s_pts[n0:n0 + n1].copy_(p1, non_blocking=True)
+        self.s_lens[0] = n0
+        self.s_lens[1] = n1
+        self.s_corr.copy_(corr, non_blocking=True)
+        self.s_dk.copy_(dk, non_blocking=True)
+
+    def _static_step(self):
+        batch = dl.build_pyramid_static(self.s_pts, self.s_lens, self.config, self.limits, self.caps)
+        self._status = batch.pop('_status')
+        batch['features'], batch['corr'], batch['dist_keypts'] = self.s_feat, self.s_corr, self.s_dk
+        self.flat.zero_grad()
+        loss, desc, det, acc = self.forward_loss(batch)
+        loss.backward()
+        self.flat.gather_grads()
+        if self.world == 1:
+            self.opt.step()
+        return loss.detach(), desc.detach(), det.detach(), acc.detach()
+
+    def capture(self, item):
+        """Warm up on a side stream, then record the step into a hipGraph (torch.cuda.CUDAGraph)."""
+        self._load_static(item)
+        side = torch.cuda.Stream(device=self.device)
+        side.wait_stream(torch.cuda.current_stream(self.device))
+        with torch.cuda.stream(side):
+            for _ in range(3):
+                out = self._static_step()
+                if self.world > 1:
+                    allreduce_mean_(self.flat.grad, self.world)
+                    self.opt.step()
+        torch.cuda.current_stream(self.device).wait_stream(side)
+        torch.cuda.synchronize(self.device)
+        self._status.raise_if_set()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            self._graph_out = self._static_step()
+        self.graph = g
+        return out
+
+    def step_graph(self, item):
+        self._load_static(item)
+        self.graph.replay()
+        if self.world > 1:
+            allreduce_mean_(self.flat.grad, self.world)
+            self.opt.step()
+        return self._graph_out
+
+    def check_status(self):
+        """Raise if a device-side condition (capacity overflow, candidate overflow, ...) was flagged (one sync)."""
+        if getattr(self, '_status', None) is not None:
+            self._status.raise_if_set()
 
     # -- pyramid construction on a side stream ---------------------------------------------------------------
     # build_pyramid reads the level sizes back once; done on the training stream that read-back would wait for the
@@ -152,6 +248,6 @@ class TrainStep:
         self.flat.zero_grad()
         loss, desc, det, acc = self.forward_loss(batch)
         loss.backward()
-        allreduce_mean_(self.flat.grad, self.world)
+        allreduce_mean_(self.flat.gather_grads(), self.world)
         self.opt.step()
         return loss.detach(), desc.detach(), det.detach(), acc.detach()

@@ -35,6 +35,7 @@ extern "C" {
 #define D3F_ST_CAND_OVERFLOW 1  /* a query had more in-radius candidates than the kernel can rank */
 #define D3F_ST_CELL_RANGE 2     /* a point fell outside the +-32767-cell addressable grid */
 #define D3F_ST_TABLE_FULL 4     /* voxel hash table full (workspace sized for fewer points) */
+#define D3F_ST_CAPACITY 8       /* an output needed more rows than the caller's capacity */
 
 const char* d3f_version(void);
 int d3f_device_arch_ok(void); /* 1 if the current HIP device is gfx950, 0 otherwise, <0 = -(hipError_t) */
@@ -68,14 +69,15 @@ int d3f_radius_query(const void* grid_ws, const float* queries, int Nq, const in
  *   std::unordered_map<size_t,...> it accumulates into, grid_subsampling.cpp:48,85);
  *   D3F_ORDER_FIRST_SEEN emits cells in order of their first input point (cheaper).
  * N is a row CAPACITY: only the first sum(len) rows are read, so levels can be chained without reading
- * lengths back to the host.  Outputs: out_points [<=N,3] (caller provides N rows), out_len [B], out_total [1].
+ * lengths back to the host.  Outputs: out_points [out_cap,3] (rows past the emitted total are zero-filled; a total
+ * above out_cap sets D3F_ST_CAPACITY), out_len [B], out_total [1].
  * ---------------------------------------------------------------------------------------------- */
 #define D3F_ORDER_REFERENCE 0
 #define D3F_ORDER_FIRST_SEEN 1
 size_t d3f_grid_subsample_ws_bytes(int N, int B);
 int d3f_grid_subsample(const float* points, int N, const int32_t* len, int B, float sampleDl, int max_p, int order,
-                       float* out_points, int32_t* out_len, int32_t* out_total, void* ws, size_t ws_bytes,
-                       int32_t* status, void* stream);
+                       float* out_points, int out_cap /* rows of out_points; <= 0: N */, int32_t* out_len,
+                       int32_t* out_total, void* ws, size_t ws_bytes, int32_t* status, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * KPConv -- replaces models/blocks.py:237-382 (KPConv.forward, rigid / 'linear' / 'sum' path) and its
@@ -128,6 +130,9 @@ int d3f_bias_act_backward(const float* grad_out, const float* out, float slope, 
  * local-maximum gate (:361-366).
  * ---------------------------------------------------------------------------------------------- */
 int d3f_global_max(const float* x, size_t n, float* out_max, void* ws /* >= 4 bytes */, size_t ws_bytes, void* stream);
+/* same over the first sum(len) rows of x [cap_rows, C] (row count read on the device) */
+int d3f_global_max_rows(const float* x, int cap_rows, int C, const int32_t* len, int B, float* out_max, void* ws,
+                        size_t ws_bytes, void* stream);
 int d3f_detection_scores_forward(const float* feat, int N, int C, const int32_t* idx, int H, const float* feat_max,
                                  int training, float* scores, void* stream);
 /* grad_feat [N,C] is OVERWRITTEN.  Includes the gradient through the global max normaliser. */
@@ -169,6 +174,17 @@ int d3f_circle_det_loss_backward(const float* anchor, const float* positive, int
  * ---------------------------------------------------------------------------------------------- */
 int d3f_mutual_nn(const float* src_desc, int Ns, const float* tgt_desc, int Nt, int C, int32_t* row_argmin,
                   int32_t* col_argmin, int32_t* mutual, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Optimizer step with the reference's non-finite-gradient guard -- replaces trainer.py:104-111 (per-parameter
+ * torch.isfinite(...).all() host checks, then optimizer.step()) + torch.optim.SGD(momentum, weight_decay) as
+ * configured in training_3DMatch.py:62-76, on flat fp32 buffers of n elements (16-byte aligned):
+ *   if every grad[i] is finite:  buf = momentum*buf + (grad + weight_decay*params);  params -= lr*buf
+ *   else: nothing is modified and state[1] (skipped-step counter) is incremented.
+ * state: int32[2] on the device; state[0] is scratch.
+ * ---------------------------------------------------------------------------------------------- */
+int d3f_sgd_guarded_step(const float* grad, float* params, float* momentum_buf, size_t n, float lr, float momentum,
+                         float weight_decay, int32_t* state, void* stream);
 
 #ifdef __cplusplus
 }

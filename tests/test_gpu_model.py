@@ -176,3 +176,49 @@ def test_model_forward_backward_s1_full_width(golden_s1):
     with torch.no_grad():
         fe, se = model(batch)
     assert np.abs(fe.cpu().numpy()[g['features_eval.rows']] - g['features_eval.sample']).max() < 1e-4
+
+
+def test_graph_mode_matches_eager_step(golden_s0):
+    """Static-capacity pyramid + hipGraph replay of the whole step == the eager step (same pair, same weights)."""
+    from d3feat_pytorch_amd.train import TrainStep
+    g = golden_s0
+    cfg = cfgmod.default_config(first_features_dim=16, num_node=64)
+    limits = [int(x) for x in g['limits']]
+    item = tuple(torch.from_numpy(np.ascontiguousarray(a)).to(DEV) for a in _item(g))
+    sizes = [[int(g['batch.points.%d' % l].shape[0]) for l in range(5)]]
+
+    def fresh():
+        np.random.seed(0)
+        torch.manual_seed(0)
+        return TrainStep(cfg, limits, torch.device(DEV), seed=0)
+    eager = fresh()
+    losses_e = [float(eager.step(item)[0]) for _ in range(3)]
+    graph = fresh()
+    graph.enable_graph(TrainStep.capacities_for(sizes, slack=1.3), num_corr=item[4].shape[0])
+    assert all(c % 64 == 0 and c > n for c, n in zip(graph.caps, sizes[0]))
+    # capture() itself runs 3 eager warm-up steps in static mode + records; compare a FRESH replay trajectory instead
+    g2 = fresh()
+    g2.enable_graph(graph.caps, num_corr=item[4].shape[0])
+    g2._load_static(item)
+    first = g2._static_step()          # static shapes, no graph: must equal the eager step
+    torch.cuda.synchronize()
+    assert abs(float(first[0]) - losses_e[0]) < 1e-4 * max(1.0, abs(losses_e[0]))
+    graph.capture(item)                # 3 warm-up steps were applied to the parameters
+    l4 = float(graph.step_graph(item)[0])
+    graph.check_status()
+    e2 = fresh()
+    for _ in range(3):
+        e2.step(item)
+    ref4 = float(e2.step(item)[0])
+    assert abs(l4 - ref4) < 2e-3 * max(1.0, abs(ref4)), (l4, ref4)
+    # parameters after the same number of updates agree
+    pa = graph.flat.data
+    pb = e2.flat.data
+    assert float((pa - pb).abs().max()) < 1e-4 * float(pb.abs().max())
+    # a too-small capacity is reported, not silently truncated
+    small = fresh()
+    small.enable_graph([sizes[0][0] + 64, 64, 64, 64, 64], num_corr=item[4].shape[0])
+    small._load_static(item)
+    small._static_step()
+    with pytest.raises(RuntimeError):
+        small.check_status()
