@@ -232,7 +232,10 @@ bool kpconv_fused_supported(int Cin, int Cout, int K, int H, int Ns);
 size_t kpconv_fused_ws_bytes(int Ns);
 int kpconv_forward_fused(const float* q_pts, int Nq, const float* s_pts, int Ns, const int32_t* idx, int H,
                          const float* x, int Cin, const float* kp, int K, const float* W, int Cout, float extent,
-                         float* out, float* nn_out, void* ws, hipStream_t stream);
+                         float* out, float* nn_out, float* wf_save, void* ws, hipStream_t stream);
+size_t atb_ws_bytes(int R, int M, int N);
+int atb_splitk(const float* A, const float* B, const float* row_div, int R, int M, int N, float* C, void* ws,
+               hipStream_t stream);
 // kpconv_small.hip
 bool kpconv_small_supported(int Cin, int Cout, int K, int H);
 int kpconv_small_dispatch(bool fwd, const float* q_pts, const float* s_pts, const int32_t* idx, const float* x,
@@ -241,7 +244,8 @@ int kpconv_small_dispatch(bool fwd, const float* q_pts, const float* s_pts, cons
                           hipStream_t stream);
 int kpconv_backward_fused(const float* q_pts, int Nq, const float* s_pts, int Ns, const int32_t* idx, int H,
                           const float* x, int Cin, const float* kp, int K, const float* W, int Cout, float extent,
-                          const float* nn, const float* gout, float* gx, float* gw, void* ws, hipStream_t stream);
+                          const float* nn, const float* gout, const float* wf_saved, float* gx, float* gw, void* ws,
+                          hipStream_t stream);
 
 }  // namespace d3f
 
@@ -260,7 +264,7 @@ size_t d3f_kpconv_ws_bytes(int Nq, int Ns, int H, int K, int Cin, int Cout) {
   const size_t wf = align_up(sizeof(float) * n * kc, 256);                                  // wf
   const size_t gw = align_up(sizeof(float) * n * (kc > (size_t)Cout ? kc : (size_t)Cout), 256);  // gW / scaled grad
   const size_t generic = wf + gw + 256;
-  const size_t fused = kpconv_fused_ws_bytes(Ns) + 256;
+  const size_t fused = kpconv_fused_ws_bytes(Ns) + atb_ws_bytes(Nq, K * Cin, Cout) + 256;
   return generic > fused ? generic : fused;
 }
 
@@ -270,9 +274,13 @@ static int kp_args_ok(const void* q_pts, int Nq, const void* s_pts, int Ns, cons
          K <= 16 && Cout >= 1 && extent > 0.0f;
 }
 
+// 1 when the forward for these shapes fills wf_save (every path except the tiny-Cin input-layer kernels)
+int d3f_kpconv_saves_wf(int Cin, int Cout, int K, int H) { return kpconv_small_supported(Cin, Cout, K, H) ? 0 : 1; }
+
 int d3f_kpconv_forward(const float* q_pts, int Nq, const float* s_pts, int Ns, const int32_t* idx, int H,
                        const float* x, int Cin, const float* kernel_points, int K, const float* weights, int Cout,
-                       float extent, float* out, float* nn_out, void* ws, size_t ws_bytes, void* stream_) {
+                       float extent, float* out, float* nn_out, float* wf_save, void* ws, size_t ws_bytes,
+                       void* stream_) {
   if (!kp_args_ok(q_pts, Nq, s_pts, Ns, idx, H, x, Cin, kernel_points, K, weights, Cout, extent) || !out || !nn_out ||
       !ws)
     return D3F_EINVAL;
@@ -284,8 +292,8 @@ int d3f_kpconv_forward(const float* q_pts, int Nq, const float* s_pts, int Ns, c
                                  Cout, K, extent, out, nn_out, nullptr, stream);
   if (kpconv_fused_supported(Cin, Cout, K, H, Ns))
     return kpconv_forward_fused(q_pts, Nq, s_pts, Ns, idx, H, x, Cin, kernel_points, K, weights, Cout, extent, out,
-                                nn_out, ws, stream);
-  float* wf = (float*)ws;
+                                nn_out, wf_save, ws, stream);
+  float* wf = wf_save ? wf_save : (float*)ws;
   int rc = launch_wf<true>(q_pts, s_pts, idx, x, kernel_points, Nq, Ns, H, Cin, K, extent, wf, nn_out, stream);
   if (rc) return rc;
   // out = (wf [Nq, K*Cin] @ W [K*Cin, Cout]) / nn
@@ -294,8 +302,8 @@ int d3f_kpconv_forward(const float* q_pts, int Nq, const float* s_pts, int Ns, c
 
 int d3f_kpconv_backward(const float* q_pts, int Nq, const float* s_pts, int Ns, const int32_t* idx, int H,
                         const float* x, int Cin, const float* kernel_points, int K, const float* weights, int Cout,
-                        float extent, const float* nn, const float* grad_out, float* grad_x, float* grad_w, void* ws,
-                        size_t ws_bytes, void* stream_) {
+                        float extent, const float* nn, const float* grad_out, const float* wf_saved, float* grad_x,
+                        float* grad_w, void* ws, size_t ws_bytes, void* stream_) {
   if (!kp_args_ok(q_pts, Nq, s_pts, Ns, idx, H, x, Cin, kernel_points, K, weights, Cout, extent) || !nn || !grad_out ||
       !ws || (!grad_x && !grad_w))
     return D3F_EINVAL;
@@ -311,12 +319,9 @@ int d3f_kpconv_backward(const float* q_pts, int Nq, const float* s_pts, int Ns, 
       return D3F_ELAUNCH;
     return D3F_OK;
   }
-  if (kpconv_fused_supported(Cin, Cout, K, H, Ns)) {
-    if (grad_w && d3f::zero_async(grad_w, sizeof(float) * (size_t)KC * Cout, stream) != hipSuccess)
-      return D3F_ELAUNCH;
+  if (kpconv_fused_supported(Cin, Cout, K, H, Ns))
     return kpconv_backward_fused(q_pts, Nq, s_pts, Ns, idx, H, x, Cin, kernel_points, K, weights, Cout, extent, nn,
-                                 grad_out, grad_x, grad_w, ws, stream);
-  }
+                                 grad_out, wf_saved, grad_x, grad_w, ws, stream);
   int rc;
   if (grad_w && kpconv_small_supported(Cin, Cout, K, H)) {
     if (d3f::zero_async(grad_w, sizeof(float) * (size_t)KC * Cout, stream) != hipSuccess) return D3F_ELAUNCH;
@@ -327,8 +332,12 @@ int d3f_kpconv_backward(const float* q_pts, int Nq, const float* s_pts, int Ns, 
   }
   if (grad_w) {
     // grad_W [KC, Cout] = wf^T [KC, Nq] @ (grad_out / nn) [Nq, Cout]
-    rc = launch_wf<false>(q_pts, s_pts, idx, x, kernel_points, Nq, Ns, H, Cin, K, extent, wf, nullptr, stream);
-    if (rc) return rc;
+    if (wf_saved) {
+      wf = const_cast<float*>(wf_saved);
+    } else {
+      rc = launch_wf<false>(q_pts, s_pts, idx, x, kernel_points, Nq, Ns, H, Cin, K, extent, wf, nullptr, stream);
+      if (rc) return rc;
+    }
     float* gbuf = gW;  // second scratch doubles as the scaled gradient [Nq, Cout] (sized max(KC, Cout) per row)
     row_div_kernel<<<cdiv((long long)Nq * Cout, 256), 256, 0, stream>>>(grad_out, nn, Nq, Cout, gbuf);
     D3F_LAUNCH_CHECK();

@@ -60,7 +60,8 @@ template <int CV, int NBW, int WK>
 __global__ __launch_bounds__(256) void kpconv_fwd_fused_kernel(
     const float* __restrict__ q_pts, const float4* __restrict__ spack, const int32_t* __restrict__ idx,
     const float* __restrict__ x, const float* __restrict__ kp, const float* __restrict__ W, int Nq, int Ns, int H,
-    int Cin, int Cout, int K, float extent, float* __restrict__ out, float* __restrict__ nn_out, int dbg) {
+    int Cin, int Cout, int K, float extent, float* __restrict__ out, float* __restrict__ nn_out,
+    float* __restrict__ wf_save, int dbg) {
   constexpr int CC = 16 * CV;
   constexpr int WN = 4 / WK;
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -108,6 +109,17 @@ __global__ __launch_bounds__(256) void kpconv_fwd_fused_kernel(
     if (first && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x < 16 && q0 + (int)threadIdx.x < Nq)
       nn_out[q0 + threadIdx.x] = nn_l[threadIdx.x];
     first = false;
+    if (wf_save && blockIdx.y == 0) {
+      // training: leave the weighted features behind for the backward pass (grad_W becomes one tall-skinny GEMM and
+      // the aggregation is never recomputed) -- K*Cin*4 bytes per query of HBM, plentiful on this part
+      constexpr int V = CC / 4;
+      for (int t = threadIdx.x; t < 16 * K * V; t += 256) {
+        const int v = t % V, k = (t / V) % K, ql = t / (V * K);
+        if (q0 + ql < Nq)
+          *(float4*)(wf_save + ((size_t)(q0 + ql) * K + k) * Cin + cbase + 4 * v) =
+              *(const float4*)(wf + ql * RS + k * CC + 4 * v);
+      }
+    }
     // ------------------------------------------------------------------ phase B
     const int steps = (K * CC) >> 4;
     // The W fragments stream from L2 and each 16-row step is only 4*NBW MFMAs, so a step-at-a-time loop pays one
@@ -370,6 +382,12 @@ bool kpconv_fused_supported(int Cin, int Cout, int K, int H, int Ns) {
   return cin_ok && cout_ok && addr_ok && K >= 1 && K <= 16 && H >= 1 && H <= 64;  // one index row per wave load
 }
 
+// linear.hip
+bool atb_supported(int R, int M, int N);
+size_t atb_ws_bytes(int R, int M, int N);
+int atb_splitk(const float* A, const float* B, const float* row_div, int R, int M, int N, float* C, void* ws,
+               hipStream_t stream);
+
 size_t kpconv_fused_ws_bytes(int Ns) { return align_up(sizeof(float4) * (size_t)(Ns > 0 ? Ns : 1), 256); }
 
 static int pack_supports(const float* s_pts, const float* x, int Ns, int Cin, float4* spack, hipStream_t stream) {
@@ -383,7 +401,7 @@ static int pack_supports(const float* s_pts, const float* x, int Ns, int Cin, fl
 template <int CV>
 static int launch_fused_cv(const float* q_pts, const float4* spack, const int32_t* idx, const float* x,
                            const float* kp, const float* W, int Nq, int Ns, int H, int Cin, int Cout, int K,
-                           float extent, float* out, float* nn_out, hipStream_t stream) {
+                           float extent, float* out, float* nn_out, float* wf_save, hipStream_t stream) {
   const int tiles = cdiv(Nq, 16);
   const int CC = 16 * CV;
   const int nchunks = Cin / CC;
@@ -402,7 +420,8 @@ static int launch_fused_cv(const float* q_pts, const float4* spack, const int32_
     const size_t lds = lds_base + ((WK) > 1 ? sizeof(float) * 16 * (size_t)slab : 0);                           \
     dim3 grid(tiles, Cout / slab, zsplit);                                                                      \
     kpconv_fwd_fused_kernel<CV, NBW, WK><<<grid, 256, lds, stream>>>(q_pts, spack, idx, x, kp, W, Nq, Ns, H, Cin, \
-                                                                      Cout, K, extent, out, nn_out, g_debug_flags); \
+                                                                      Cout, K, extent, out, nn_out, wf_save,       \
+                                                                      g_debug_flags);                            \
   }
   switch (slab) {
     case 16: D3F_LAUNCH(1, 4) break;
@@ -420,18 +439,19 @@ static int launch_fused_cv(const float* q_pts, const float4* spack, const int32_
 
 int kpconv_forward_fused(const float* q_pts, int Nq, const float* s_pts, int Ns, const int32_t* idx, int H,
                          const float* x, int Cin, const float* kp, int K, const float* W, int Cout, float extent,
-                         float* out, float* nn_out, void* ws, hipStream_t stream) {
+                         float* out, float* nn_out, float* wf_save, void* ws, hipStream_t stream) {
   float4* spack = (float4*)ws;
   int rc = pack_supports(s_pts, x, Ns, Cin, spack, stream);
   if (rc) return rc;
-  if (Cin == 16) return launch_fused_cv<1>(q_pts, spack, idx, x, kp, W, Nq, Ns, H, Cin, Cout, K, extent, out, nn_out, stream);
-  if (Cin == 32) return launch_fused_cv<2>(q_pts, spack, idx, x, kp, W, Nq, Ns, H, Cin, Cout, K, extent, out, nn_out, stream);
-  return launch_fused_cv<4>(q_pts, spack, idx, x, kp, W, Nq, Ns, H, Cin, Cout, K, extent, out, nn_out, stream);
+  if (Cin == 16) return launch_fused_cv<1>(q_pts, spack, idx, x, kp, W, Nq, Ns, H, Cin, Cout, K, extent, out, nn_out, wf_save, stream);
+  if (Cin == 32) return launch_fused_cv<2>(q_pts, spack, idx, x, kp, W, Nq, Ns, H, Cin, Cout, K, extent, out, nn_out, wf_save, stream);
+  return launch_fused_cv<4>(q_pts, spack, idx, x, kp, W, Nq, Ns, H, Cin, Cout, K, extent, out, nn_out, wf_save, stream);
 }
 
 int kpconv_backward_fused(const float* q_pts, int Nq, const float* s_pts, int Ns, const int32_t* idx, int H,
                           const float* x, int Cin, const float* kp, int K, const float* W, int Cout, float extent,
-                          const float* nn, const float* gout, float* gx, float* gw, void* ws, hipStream_t stream) {
+                          const float* nn, const float* gout, const float* wf_saved, float* gx, float* gw, void* ws,
+                          hipStream_t stream) {
   float4* spack = (float4*)ws;
   int rc = pack_supports(s_pts, x, Ns, Cin, spack, stream);
   if (rc) return rc;
@@ -446,7 +466,12 @@ int kpconv_backward_fused(const float* q_pts, int Nq, const float* s_pts, int Ns
     else kpconv_bwd_dx_kernel<4><<<grid, 256, lds, stream>>>(q_pts, spack, idx, kp, W, nn, gout, Nq, Ns, H, Cin, Cout, K, extent, gx);
     D3F_LAUNCH_CHECK();
   }
-  if (gw) {
+  if (gw && wf_saved) {
+    // dW [K*Cin, Cout] = wf^T (g / nn): tall-skinny GEMM over the saved weighted features (linear.hip)
+    rc = atb_splitk(wf_saved, gout, nn, Nq, K * Cin, Cout, gw, (char*)ws + kpconv_fused_ws_bytes(Ns), stream);
+    if (rc) return rc;
+  } else if (gw) {
+    if (d3f::zero_async(gw, sizeof(float) * (size_t)K * Cin * Cout, stream) != hipSuccess) return D3F_ELAUNCH;
     const int CV = Cin == 16 ? 1 : 2;
     const int SB = Cout == 16 ? 1 : 2;
     const int CC = 16 * CV, SLAB = 16 * SB;

@@ -1,0 +1,176 @@
+// C[M,N] = A^T B for tall-skinny operands A [R,M], B [R,N] (R = number of points >> M, N): the weight gradient of
+// every 1x1 "unary" convolution (reference models/blocks.py:481-515, nn.Linear inside UnaryBlock) and -- with the
+// weighted-feature matrix the fused KPConv forward leaves behind -- of every KPConv (blocks.py:375-380).
+//
+// A library GEMM sees M x N = 64 x 128 outputs and a 38 000-long reduction and launches 8 workgroups (measured:
+// ~100 us).  Here the REDUCTION is what is spread over the chip:
+//   workgroup g owns rows [g*rpw, (g+1)*rpw) and one (16*TI) x (16*TJ) block of C; each of its 4 waves accumulates it with
+//   v_mfma_f32_16x16x4_f32 (each lane feeds the MFMA straight from ONE TI-wide and ONE TJ-wide vector load: the
+//   A fragment t of lane (i, k) is A[row k][m0 + TI*i + t], so 16 lanes read 64*TI contiguous bytes of a row), and
+//   the 4 waves are summed through LDS and the partial block goes to a scratch slab; a second launch sums the
+//   slabs in a fixed order.
+// No atomics: the result is bit-reproducible run to run.
+// fp32-MFMA bound when M*N is large, HBM bound (R*(M+N)*4 bytes, each read once per column/row block) otherwise.
+#include "kpconv_tile.hpp"
+
+namespace d3f {
+
+template <int TI, int TJ>
+__global__ __launch_bounds__(256) void atb_partial_kernel(const float* __restrict__ A, const float* __restrict__ B,
+                                                          const float* __restrict__ row_div, int R, int M, int N,
+                                                          int rows_per_wg, float* __restrict__ part) {
+  typedef typename VecT<TI>::type VA;
+  typedef typename VecT<TJ>::type VB;
+  __shared__ float red[3][TI * TJ * 256];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int li = lane & 15, lk = lane >> 4;
+  const int nbj = N / (16 * TJ);
+  const int m0 = (blockIdx.y / nbj) * 16 * TI, n0 = (blockIdx.y % nbj) * 16 * TJ;
+  const int r0 = blockIdx.x * rows_per_wg, r1 = min(R, r0 + rows_per_wg);
+  const float* ap = A + m0 + TI * li;
+  const float* bp = B + n0 + TJ * li;
+  f32x4 acc[TI][TJ];
+#pragma unroll
+  for (int t = 0; t < TI; ++t)
+#pragma unroll
+    for (int u = 0; u < TJ; ++u) acc[t][u] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  constexpr int U = (TI * TJ >= 8) ? 2 : 4;  // k-steps whose loads are issued together
+  // the 4 waves interleave groups of 4*U rows
+  for (int base = r0 + wave * 4 * U; base < r1; base += 16 * U) {
+    VA a[U];
+    VB b[U];
+    float sc[U];
+#pragma unroll
+    for (int s = 0; s < U; ++s) {
+      const int row = base + 4 * s + lk;
+      const bool ok = row < r1;
+      const size_t rr = (size_t)(ok ? row : r0);
+      a[s] = *(const VA*)(ap + rr * M);
+      b[s] = *(const VB*)(bp + rr * N);
+      sc[s] = ok ? (row_div ? 1.0f / row_div[rr] : 1.0f) : 0.0f;
+    }
+#pragma unroll
+    for (int s = 0; s < U; ++s)
+#pragma unroll
+      for (int u = 0; u < TJ; ++u) {
+        const float bv = vget<TJ>(b[s], u) * sc[s];
+#pragma unroll
+        for (int t = 0; t < TI; ++t)
+          acc[t][u] = __builtin_amdgcn_mfma_f32_16x16x4f32(vget<TI>(a[s], t), bv, acc[t][u], 0, 0, 0);
+      }
+  }
+  // combine the 4 waves in a fixed order (wave 0 + 1 + 2 + 3) through LDS
+  if (wave > 0) {
+#pragma unroll
+    for (int t = 0; t < TI; ++t)
+#pragma unroll
+      for (int u = 0; u < TJ; ++u)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) red[wave - 1][((t * TJ + u) * 4 + r) * 64 + lane] = acc[t][u][r];
+  }
+  __syncthreads();
+  if (wave > 0) return;
+  // D[i][j] (i = 4*lk + r, j = li) is C[m0 + TI*i + t][n0 + TJ*j + u]
+  float* pp = part + (size_t)blockIdx.x * M * N;
+#pragma unroll
+  for (int t = 0; t < TI; ++t)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      float* dst = pp + (size_t)(m0 + TI * (4 * lk + r) + t) * N + n0 + TJ * li;
+#pragma unroll
+      for (int u = 0; u < TJ; ++u) {
+        const int e = ((t * TJ + u) * 4 + r) * 64 + lane;
+        dst[u] = ((acc[t][u][r] + red[0][e]) + red[1][e]) + red[2][e];
+      }
+    }
+}
+
+// C[e] = sum_p part[p][e]: 4 threads per element each sum a strided quarter of the slabs, combined in a fixed order
+__global__ __launch_bounds__(256) void atb_reduce_kernel(const float* __restrict__ part, int P, size_t MN,
+                                                         float* __restrict__ C) {
+  const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t e = (t >> 8 << 6) | (t & 63);  // 64 consecutive elements per wave, 4 waves of a block share them
+  const int sub = (int)((t >> 6) & 3);
+  __shared__ float sh[3][64];
+  float s0 = 0.f, s1 = 0.f;
+  if (e < MN) {
+    int p = sub;
+    for (; p + 4 < P; p += 8) {
+      s0 += part[(size_t)p * MN + e];
+      s1 += part[(size_t)(p + 4) * MN + e];
+    }
+    if (p < P) s0 += part[(size_t)p * MN + e];
+  }
+  const float s = s0 + s1;
+  if (sub > 0) sh[sub - 1][threadIdx.x & 63] = s;
+  __syncthreads();
+  if (sub == 0 && e < MN) C[e] = ((s + sh[0][threadIdx.x]) + sh[1][threadIdx.x]) + sh[2][threadIdx.x];
+}
+
+static inline int tile_width(int n) { return n % 64 == 0 ? 4 : (n % 32 == 0 ? 2 : (n % 16 == 0 ? 1 : 0)); }
+
+bool atb_supported(int R, int M, int N) { return R >= 1 && tile_width(M) && tile_width(N); }
+
+// number of row partitions = workgroups along the reduction
+static int atb_partitions(int R, int M, int N) {
+  const long long nblocks = (long long)(M / (16 * tile_width(M))) * (N / (16 * tile_width(N)));
+  long long wgs = (1024 + nblocks - 1) / nblocks;         // ~4 workgroups per CU over the whole launch
+  const long long max_by_rows = (R + 63) / 64;            // >= 16 rows (4 MFMA k-steps) per wave
+  if (wgs > max_by_rows) wgs = max_by_rows;
+  if (wgs > 512) wgs = 512;
+  if (wgs < 1) wgs = 1;
+  return (int)wgs;
+}
+
+size_t atb_ws_bytes(int R, int M, int N) {
+  if (!atb_supported(R, M, N)) return 0;
+  return align_up(sizeof(float) * (size_t)atb_partitions(R, M, N) * M * N, 256);
+}
+
+// C [M,N] = A^T [M,R] (B [R,N] / row_div [R]); ws >= atb_ws_bytes
+int atb_splitk(const float* A, const float* B, const float* row_div, int R, int M, int N, float* C, void* ws,
+               hipStream_t stream) {
+  if (!atb_supported(R, M, N)) return D3F_EINVAL;
+  const int ti = tile_width(M), tj = tile_width(N);
+  const int P = atb_partitions(R, M, N);
+  int rpw = (R + P - 1) / P;
+  rpw = (rpw + 3) / 4 * 4;
+  dim3 grid(P, (M / (16 * ti)) * (N / (16 * tj)));
+  float* part = (float*)ws;
+#define D3F_ATB(I, J) atb_partial_kernel<I, J><<<grid, 256, 0, stream>>>(A, B, row_div, R, M, N, rpw, part)
+  switch (ti * 8 + tj) {
+    case 1 * 8 + 1: D3F_ATB(1, 1); break;
+    case 1 * 8 + 2: D3F_ATB(1, 2); break;
+    case 1 * 8 + 4: D3F_ATB(1, 4); break;
+    case 2 * 8 + 1: D3F_ATB(2, 1); break;
+    case 2 * 8 + 2: D3F_ATB(2, 2); break;
+    case 2 * 8 + 4: D3F_ATB(2, 4); break;
+    case 4 * 8 + 1: D3F_ATB(4, 1); break;
+    case 4 * 8 + 2: D3F_ATB(4, 2); break;
+    default: D3F_ATB(4, 4); break;
+  }
+#undef D3F_ATB
+  D3F_LAUNCH_CHECK();
+  const size_t MN = (size_t)M * N;
+  atb_reduce_kernel<<<cdiv((long long)MN, 64), 256, 0, stream>>>(part, P, MN, C);
+  D3F_LAUNCH_CHECK();
+  return D3F_OK;
+}
+
+}  // namespace d3f
+
+extern "C" {
+
+int d3f_linear_grad_weight_supported(int N, int Cin, int Cout) { return d3f::atb_supported(N, Cout, Cin) ? 1 : 0; }
+
+size_t d3f_linear_grad_weight_ws_bytes(int N, int Cin, int Cout) { return d3f::atb_ws_bytes(N, Cout, Cin); }
+
+/* grad_w [Cout, Cin] (nn.Linear layout) = grad_out^T [Cout, N] @ x [N, Cin] */
+int d3f_linear_grad_weight(const float* x, const float* grad_out, int N, int Cin, int Cout, float* grad_w, void* ws,
+                           size_t ws_bytes, void* stream) {
+  if (!x || !grad_out || !grad_w || !ws || !d3f::atb_supported(N, Cout, Cin)) return D3F_EINVAL;
+  if (ws_bytes < d3f::atb_ws_bytes(N, Cout, Cin)) return D3F_EWORKSPACE;
+  return d3f::atb_splitk(grad_out, x, nullptr, N, Cout, Cin, grad_w, ws, (hipStream_t)stream);
+}
+
+}  // extern "C"

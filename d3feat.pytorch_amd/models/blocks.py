@@ -179,7 +179,7 @@ class UnaryBlock(nn.Module):
         if not self.use_bn and x.is_cuda and x.dim() == 2:
             # Linear without its bias; both biases (+ residual) + LeakyReLU go into ONE epilogue launch whose backward
             # also yields the (shared) bias gradient -- no separate add / leaky / column-reduce kernels
-            return ops.bias_act(F.linear(x, self.mlp.weight), self.mlp.bias, residual, self.batch_norm.bias,
+            return ops.bias_act(ops.linear_nobias(x, self.mlp.weight), self.mlp.bias, residual, self.batch_norm.bias,
                                 slope=1.0 if (self.no_relu and residual is None) else 0.1)
         x = self.batch_norm(self.mlp(x))
         if residual is not None:

@@ -198,6 +198,12 @@ def grid_subsample_raw(points, lens, sampleDl, max_p=0, order=ORDER_REFERENCE, s
 # ---------------------------------------------------------------------------------------------------------------
 # KPConv (models/blocks.py:237-382)
 # ---------------------------------------------------------------------------------------------------------------
+# False: the backward pass recomputes the neighbor aggregation instead of reading it back (saves K*Cin*4 B/query)
+SAVE_WEIGHTED_FEATURES = True
+# below this many rows a weight gradient is a plain GEMM for the library; above, the reduction-parallel kernel
+_SPLITK_MIN_ROWS = 4096
+
+
 class _KPConvFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, q_pts, s_pts, idx, x, kernel_points, weights, extent):
@@ -208,33 +214,47 @@ class _KPConvFn(torch.autograd.Function):
         nn = torch.empty(Nq, dtype=torch.float32, device=x.device)
         nbytes = L.d3f_kpconv_ws_bytes(Nq, Ns, H, K, Cin, Cout)
         ws = _ws(nbytes, x.device)
+        # training: keep the weighted features [Nq, K*Cin] for the backward pass (K*Cin*4 B per query of HBM) so the
+        # weight gradient is one tall-skinny GEMM and the neighbor aggregation is not recomputed
+        wf = None
+        if SAVE_WEIGHTED_FEATURES and ctx.needs_input_grad[5] and Nq > 0 and L.d3f_kpconv_saves_wf(Cin, Cout, K, H):
+            wf = torch.empty((Nq, K * Cin), dtype=torch.float32, device=x.device)
         with _region("kpconv_fwd[Nq=%d,Cin=%d,Cout=%d,H=%d]" % (Nq, Cin, Cout, H),
                      kpconv_fwd_bytes(Nq, Ns, H, K, Cin, Cout)):
             _native.check(L.d3f_kpconv_forward(_p(q_pts), Nq, _p(s_pts), Ns, _p(idx), H, _p(x), Cin,
                                                _p(kernel_points), K, _p(weights), Cout, float(extent), _p(out),
-                                               _p(nn), _p(ws), nbytes, _stream()), "d3f_kpconv_forward")
-        ctx.save_for_backward(q_pts, s_pts, idx, x, kernel_points, weights, nn)
+                                               _p(nn), _p(wf), _p(ws), nbytes, _stream()), "d3f_kpconv_forward")
+        ctx.has_wf = wf is not None
+        ctx.save_for_backward(q_pts, s_pts, idx, x, kernel_points, weights, nn, *([wf] if wf is not None else []))
         ctx.extent = float(extent)
         return out
 
     @staticmethod
     def backward(ctx, grad_out):
-        q_pts, s_pts, idx, x, kernel_points, weights, nn = ctx.saved_tensors
+        q_pts, s_pts, idx, x, kernel_points, weights, nn = ctx.saved_tensors[:7]
+        wf = ctx.saved_tensors[7] if ctx.has_wf else None
         L = _native.lib()
         Nq, Ns, H = int(q_pts.shape[0]), int(s_pts.shape[0]), int(idx.shape[1])
         K, Cin, Cout = int(weights.shape[0]), int(weights.shape[1]), int(weights.shape[2])
         need_x, need_w = ctx.needs_input_grad[3], ctx.needs_input_grad[5]
         gx = torch.empty_like(x) if need_x else None
         gw = torch.empty_like(weights) if need_w else None
-        if need_x or need_w:
-            go = grad_out.contiguous().float()
+        go = grad_out.contiguous().float() if (need_x or need_w) else None
+        gw_native = gw
+        if need_w and wf is not None and Nq < _SPLITK_MIN_ROWS:
+            # few points, wide layers (bottom of the U-Net): grad_W = wf^T (g/nn) is an ordinary GEMM with a short
+            # reduction -- a library call; the reduction-parallel kernel is for the tall-skinny upper levels
+            with _region("kpconv_dw_gemm[Nq=%d,Cin=%d,Cout=%d]" % (Nq, Cin, Cout), 4 * Nq * (K * Cin + Cout)):
+                torch.mm(wf.t(), go / nn.unsqueeze(1), out=gw.view(K * Cin, Cout))
+            gw_native = None
+        if need_x or gw_native is not None:
             nbytes = L.d3f_kpconv_ws_bytes(Nq, Ns, H, K, Cin, Cout)
             ws = _ws(nbytes, x.device)
             with _region("kpconv_bwd[Nq=%d,Cin=%d,Cout=%d,H=%d]" % (Nq, Cin, Cout, H),
                          kpconv_bwd_bytes(Nq, Ns, H, K, Cin, Cout)):
                 _native.check(L.d3f_kpconv_backward(_p(q_pts), Nq, _p(s_pts), Ns, _p(idx), H, _p(x), Cin,
                                                     _p(kernel_points), K, _p(weights), Cout, ctx.extent, _p(nn),
-                                                    _p(go), _p(gx), _p(gw), _p(ws), nbytes, _stream()),
+                                                    _p(go), _p(wf), _p(gx), _p(gw_native), _p(ws), nbytes, _stream()),
                               "d3f_kpconv_backward")
         return None, None, None, gx, None, gw, None
 
@@ -248,6 +268,42 @@ def kpconv(q_pts, s_pts, neighb_inds, x, kernel_points, weights, extent):
         raise RuntimeError("KPConv: inconsistent shapes q%s s%s idx%s x%s W%s" % (
             tuple(q_pts.shape), tuple(s_pts.shape), tuple(idx.shape), tuple(x.shape), tuple(w.shape)))
     return _KPConvFn.apply(q_pts, s_pts, idx, x, kp, w, float(extent))
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# 1x1 convolution of the unary blocks (models/blocks.py:481-515): library GEMMs for y = x W^T and grad_x, own
+# reduction-parallel kernel for grad_W (tall-skinny: the reduction runs over the points)
+# ---------------------------------------------------------------------------------------------------------------
+class _LinearFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight):
+        ctx.save_for_backward(x, weight)
+        return torch.mm(x, weight.t())
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        x, weight = ctx.saved_tensors
+        go = grad_out.contiguous()
+        gx = torch.mm(go, weight) if ctx.needs_input_grad[0] else None
+        gw = None
+        if ctx.needs_input_grad[1]:
+            L = _native.lib()
+            N, Cin, Cout = int(x.shape[0]), int(x.shape[1]), int(weight.shape[0])
+            if N >= _SPLITK_MIN_ROWS and L.d3f_linear_grad_weight_supported(N, Cin, Cout):
+                gw = torch.empty_like(weight)
+                nbytes = L.d3f_linear_grad_weight_ws_bytes(N, Cin, Cout)
+                ws = _ws(nbytes, x.device)
+                with _region("linear_dw[N=%d,Cin=%d,Cout=%d]" % (N, Cin, Cout), 4 * N * (Cin + Cout) + 4 * Cin * Cout):
+                    _native.check(L.d3f_linear_grad_weight(_p(x), _p(go), N, Cin, Cout, _p(gw), _p(ws), nbytes,
+                                                           _stream()), "d3f_linear_grad_weight")
+            else:
+                gw = torch.mm(go.t(), x)
+        return gx, gw
+
+
+def linear_nobias(x, weight):
+    """x [N, Cin] @ weight[Cout, Cin]^T on the device (fp32)."""
+    return _LinearFn.apply(_f32(x, "x"), _f32(weight, "weight"))
 
 
 # ---------------------------------------------------------------------------------------------------------------

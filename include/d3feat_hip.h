@@ -85,16 +85,33 @@ int d3f_grid_subsample(const float* points, int N, const int32_t* len, int B, fl
  *   out[n,:] = ( sum_k ( sum_h w[n,h,k] * x[idx[n,h],:] ) @ W[k] ) / nn[n]
  *   w = max(0, 1 - |(s[idx[n,h]] - q[n]) - kp[k]| / extent),  nn[n] = max(1, #{h : sum_c x[idx[n,h],c] > 0})
  * nn_out [Nq] float32 is saved for the backward pass.
+ * wf_save (optional, [Nq, K*Cin] float32): the weighted features sum_h w[n,h,k] x[idx[n,h],c] are left there for
+ *   the backward pass (what autograd keeps alive in the reference as `weighted_features`, blocks.py:375); whether
+ *   the forward for a given shape fills it is answered by d3f_kpconv_saves_wf.
  * ---------------------------------------------------------------------------------------------- */
 int d3f_kpconv_forward(const float* q_pts, int Nq, const float* s_pts, int Ns, const int32_t* idx, int H,
                        const float* x, int Cin, const float* kernel_points, int K, const float* weights, int Cout,
-                       float extent, float* out, float* nn_out, void* ws, size_t ws_bytes, void* stream);
+                       float extent, float* out, float* nn_out, float* wf_save, void* ws, size_t ws_bytes,
+                       void* stream);
+int d3f_kpconv_saves_wf(int Cin, int Cout, int K, int H);
 size_t d3f_kpconv_ws_bytes(int Nq, int Ns, int H, int K, int Cin, int Cout);
-/* grad_x [Ns,Cin] and grad_w [K,Cin,Cout] are OVERWRITTEN (zeroed inside). */
+/* grad_x [Ns,Cin] and grad_w [K,Cin,Cout] are OVERWRITTEN.  wf_saved (optional): the forward's wf_save; without it
+ * the aggregation is recomputed. */
 int d3f_kpconv_backward(const float* q_pts, int Nq, const float* s_pts, int Ns, const int32_t* idx, int H,
                         const float* x, int Cin, const float* kernel_points, int K, const float* weights, int Cout,
-                        float extent, const float* nn, const float* grad_out, float* grad_x, float* grad_w,
-                        void* ws, size_t ws_bytes, void* stream);
+                        float extent, const float* nn, const float* grad_out, const float* wf_saved, float* grad_x,
+                        float* grad_w, void* ws, size_t ws_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Weight gradient of the 1x1 "unary" convolutions -- replaces autograd's grad_out^T @ x for nn.Linear in
+ * UnaryBlock (models/blocks.py:481-515): grad_w [Cout, Cin] = grad_out^T [Cout, N] @ x [N, Cin], with the
+ * reduction over the N points spread over the chip (deterministic two-pass sum, no atomics).
+ * Supported when Cin and Cout are multiples of 16 (d3f_linear_grad_weight_supported).
+ * ---------------------------------------------------------------------------------------------- */
+int d3f_linear_grad_weight_supported(int N, int Cin, int Cout);
+size_t d3f_linear_grad_weight_ws_bytes(int N, int Cin, int Cout);
+int d3f_linear_grad_weight(const float* x, const float* grad_out, int N, int Cin, int Cout, float* grad_w, void* ws,
+                           size_t ws_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Pools -- replace models/blocks.py:94-110 (max_pool) and :79-91 (closest_pool).

@@ -148,6 +148,55 @@ def test_kpconv_forward_backward(nq, ns, h, cin, cout):
     assert rel_err(out32.cpu().numpy(), out.detach().cpu().numpy()) < 1e-6  # atomically combined partial sums
 
 
+@pytest.mark.parametrize("nq,ns,h,cin,cout", [(1000, 1000, 42, 32, 32), (97, 154, 23, 512, 512), (300, 400, 42, 16, 16),
+                                              (150, 160, 42, 256, 128), (200, 260, 42, 24, 40)])
+@pytest.mark.parametrize("min_rows", [1, 1 << 30])  # reduction-parallel kernel / library GEMM for grad_W
+def test_kpconv_backward_saved_vs_recomputed_aggregation(nq, ns, h, cin, cout, min_rows, monkeypatch):
+    """grad_W from the weighted features the forward leaves behind == grad_W with the aggregation recomputed."""
+    monkeypatch.setattr(ops, "_SPLITK_MIN_ROWS", min_rows)
+    rng = np.random.default_rng(nq * 7 + cin)
+    q, s, idx, x, kp, w = _kpconv_case(rng, nq, ns, h, cin, cout)
+    go = cu(rng.normal(size=(nq, cout)).astype(np.float32))
+    grads = []
+    for save in (True, False):
+        monkeypatch.setattr(ops, "SAVE_WEIGHTED_FEATURES", save)
+        gx, gw = cu(x).requires_grad_(True), cu(w).requires_grad_(True)
+        ops.kpconv(cu(q), cu(s), cu(idx), gx, cu(kp), gw, 0.05).backward(go)
+        grads.append((gx.grad.cpu().numpy(), gw.grad.cpu().numpy()))
+    assert rel_err(grads[0][0], grads[1][0]) < 1e-5
+    assert rel_err(grads[0][1], grads[1][1]) < 1e-5
+    # weight gradient alone (frozen features) and feature gradient alone (frozen weights)
+    monkeypatch.setattr(ops, "SAVE_WEIGHTED_FEATURES", True)
+    gw = cu(w).requires_grad_(True)
+    ops.kpconv(cu(q), cu(s), cu(idx), cu(x), cu(kp), gw, 0.05).backward(go)
+    assert rel_err(gw.grad.cpu().numpy(), grads[0][1]) < 1e-6
+    gx = cu(x).requires_grad_(True)
+    ops.kpconv(cu(q), cu(s), cu(idx), gx, cu(kp), cu(w), 0.05).backward(go)
+    assert rel_err(gx.grad.cpu().numpy(), grads[0][0]) < 1e-5
+
+
+@pytest.mark.parametrize("n,cin,cout", [(38001, 64, 128), (7919, 128, 32), (2050, 32, 128), (159, 1024, 512), (3, 16, 16),
+                                        (1000, 48, 80), (500, 3072, 1024), (601, 24, 40)])
+@pytest.mark.parametrize("min_rows", [1, 4096])
+def test_linear_weight_gradient(n, cin, cout, min_rows, monkeypatch):
+    """y = x W^T: grad_W from the reduction-parallel kernel (or the library GEMM: few rows, odd widths) vs float64."""
+    monkeypatch.setattr(ops, "_SPLITK_MIN_ROWS", min_rows)
+    rng = np.random.default_rng(n + cin)
+    x = rng.normal(size=(n, cin)).astype(np.float32)
+    w = (rng.normal(size=(cout, cin)) / np.sqrt(cin)).astype(np.float32)
+    go = rng.normal(size=(n, cout)).astype(np.float32)
+    tx, tw = cu(x).requires_grad_(True), cu(w).requires_grad_(True)
+    y = ops.linear_nobias(tx, tw)
+    y.backward(cu(go))
+    assert rel_err(y.detach().cpu().numpy(), (x.astype(np.float64) @ w.astype(np.float64).T)) < 1e-5
+    assert rel_err(tw.grad.cpu().numpy(), go.astype(np.float64).T @ x.astype(np.float64)) < 1e-5
+    assert rel_err(tx.grad.cpu().numpy(), go.astype(np.float64) @ w.astype(np.float64)) < 1e-5
+    # deterministic (no atomics): a second backward gives the same bits
+    tw2 = cu(w).requires_grad_(True)
+    ops.linear_nobias(cu(x), tw2).backward(cu(go))
+    assert torch.equal(tw2.grad, tw.grad)
+
+
 def test_kpconv_all_shadow_rows_and_empty():
     rng = np.random.default_rng(0)
     q, s, idx, x, kp, w = _kpconv_case(rng, 64, 80, 10, 32, 32)
