@@ -137,7 +137,8 @@ def main():
     n_total = args.warmup + args.steps
     use_graph = not args.no_graph
     if use_graph:
-        # static-capacity shapes + one hipGraph for the whole step (pyramid, forward, loss, backward, optimizer)
+        # static-capacity shapes + hipGraph replay of the whole step (forward, loss, backward, optimizer of pair k on the
+        # main branch, pyramid of pair k+1 on a side branch)
         sizes = []
         for it in items:
             b = ts.build_batch(it)
@@ -151,10 +152,10 @@ def main():
             use_graph = False
 
     def run(k):
-        if use_graph:
-            return ts.step_graph(items[k % len(items)])
-        # eager: the pyramid of pair k+1 is built on a side stream meanwhile
+        # the pyramid of pair k+1 is built on a side stream / side branch of the graph meanwhile
         nxt = items[(k + 1) % len(items)] if k + 1 < n_total else None
+        if use_graph:
+            return ts.step_graph(items[k % len(items)], nxt)
         return ts.step(items[k % len(items)], next_item=nxt)
 
     for w in range(args.warmup):

@@ -205,6 +205,10 @@ class LastUnaryBlock(nn.Module):
         self.mlp = nn.Linear(in_dim, out_dim, bias=True)
 
     def forward(self, x, batch=None):
+        if x.is_cuda and x.dim() == 2:
+            # same arithmetic as nn.Linear; the bias gradient comes from the fused epilogue's column reduction instead
+            # of a multi-block library reduction (whose memset-initialised semaphores do not survive hipGraph replay)
+            return ops.bias_act(ops.linear_nobias(x, self.mlp.weight), self.mlp.bias, slope=1.0)
         return self.mlp(x)
 
     def __repr__(self):

@@ -135,44 +135,76 @@ class TrainStep:
         det = dists._d3f_det[0][1]
         return desc * self.w_desc + det * self.w_det, desc, det, acc
 
-    # -- static shapes + hipGraph -----------------------------------------------------------------------------
-    # The eager step costs ~11 ms of host enqueue time (600+ launches) against ~9 ms of GPU work.  In graph mode every
-    # level of the pyramid has a fixed row CAPACITY (live counts stay on the device, see build_pyramid_static), so
-    # the whole step -- 4 voxel levels, 13 searches, network forward, fused loss, backward, optimizer -- has static
-    # shapes and addresses, is captured once into a hipGraph and replayed per pair with ONE launch.
+    # -- static shapes + hipGraph ---------------------------------------------------------------------------
+    # The eager step costs ~10 ms of host enqueue time (600+ launches) against ~7 ms of GPU work.  In graph mode
+    # every level of the pyramid has a fixed row CAPACITY (live counts stay on the device, see
+    # build_pyramid_static), so the whole step has static shapes and addresses and is replayed with ONE launch.
+    # The step is software-pipelined over two streams,
+    #     training stream:  zero grads -> network forward -> fused loss -> backward -> optimizer  on pair k   (set i)
+    #     side stream:      4 voxel levels + 13 radius searches                                   of pair k+1 (set 1-i)
+    # so the latency-bound pyramid kernels (2-workgroup voxel ordering, hash builds) run UNDER the network's
+    # MFMA/HBM-bound kernels instead of in front of them.  (Two branches inside ONE graph were measured to execute
+    # back to back, hence separate graphs on separate streams; see step_graph for the ordering.)
     @staticmethod
     def capacities_for(level_sizes, slack=1.06):
         """Per-level row capacities from observed level sizes [[N0, N1, ...], ...] (rounded up to 64 rows)."""
         n = len(level_sizes[0])
         return [int(-(-int(max(s[l] for s in level_sizes) * slack + 32) // 64) * 64) for l in range(n)]
 
+    NSETS = 3
+
+    class _Set:
+        """Inputs of one pair (static addresses) + its capacity-shaped pyramid."""
+
+        def __init__(self, caps, num_corr, dev):
+            self.pts = torch.zeros((caps[0], 3), dtype=torch.float32, device=dev)
+            self.lens = torch.zeros(2, dtype=torch.int32, device=dev)
+            self.corr = torch.zeros((num_corr, 2), dtype=torch.int64, device=dev)
+            self.dk = torch.zeros((num_corr, num_corr), dtype=torch.float64, device=dev)
+            self.batch = None     # persistent pyramid tensors (filled by the side branch of the OTHER graph)
+            self.status = None
+            self.loaded = None    # the item whose pyramid `batch` holds
+
     def enable_graph(self, capacities, num_corr):
         dev = self.device
         self.caps = [int(c) for c in capacities]
-        self.s_pts = torch.zeros((self.caps[0], 3), dtype=torch.float32, device=dev)
-        self.s_lens = torch.zeros(2, dtype=torch.int32, device=dev)
+        self.sets = [TrainStep._Set(self.caps, num_corr, dev) for _ in range(self.NSETS)]
         self.s_feat = torch.ones((self.caps[0], 1), dtype=torch.float32, device=dev)
-        self.s_corr = torch.zeros((num_corr, 2), dtype=torch.int64, device=dev)
-        self.s_dk = torch.zeros((num_corr, num_corr), dtype=torch.float64, device=dev)
-        self.graph = None
+        self.graphs = None
+        self.cur = 0
 
-    def _load_static(self, item):
+    def _load_inputs(self, st, item):
         p0, p1, _, _, corr, dk = item
         n0, n1 = int(p0.shape[0]), int(p1.shape[0])
-        if n0 + n1 > self.caps[0] or tuple(corr.shape) != tuple(self.s_corr.shape):
+        if n0 + n1 > self.caps[0] or tuple(corr.shape) != tuple(st.corr.shape):
             raise RuntimeError("pair does not fit the captured shapes (%d + %d points, capacity %d; corr %s)" % (
                 n0, n1, self.caps[0], tuple(corr.shape)))
-        self.s_pts[:n0].copy_(p0, non_blocking=True)
-        self.s_pts[n0:n0 + n1].copy_(p1, non_blocking=True)
-        self.s_lens[0] = n0
-        self.s_lens[1] = n1
-        self.s_corr.copy_(corr, non_blocking=True)
-        self.s_dk.copy_(dk, non_blocking=True)
+        st.pts[:n0].copy_(p0, non_blocking=True)
+        st.pts[n0:n0 + n1].copy_(p1, non_blocking=True)
+        st.lens[0] = n0
+        st.lens[1] = n1
+        st.corr.copy_(corr, non_blocking=True)
+        st.dk.copy_(dk, non_blocking=True)
 
-    def _static_step(self):
-        batch = dl.build_pyramid_static(self.s_pts, self.s_lens, self.config, self.limits, self.caps)
-        self._status = batch.pop('_status')
-        batch['features'], batch['corr'], batch['dist_keypts'] = self.s_feat, self.s_corr, self.s_dk
+    def _build_set(self, st):
+        """Pyramid of the pair in ``st``'s input buffers -> ``st.batch`` (tensors adopted the first time, then
+        overwritten in place so every graph sees the same addresses)."""
+        batch = dl.build_pyramid_static(st.pts, st.lens, self.config, self.limits, self.caps)
+        status = batch.pop('_status')
+        if st.batch is None:
+            st.batch, st.status = batch, status
+            return
+        st.status.word.copy_(status.word)
+        done = set()
+        for key in ('points', 'neighbors', 'pools', 'upsamples', 'stack_lengths'):
+            for dst, src in zip(st.batch[key], batch[key]):
+                if dst.data_ptr() not in done and dst.numel():
+                    dst.copy_(src)
+                    done.add(dst.data_ptr())
+
+    def _net_step(self, st):
+        batch = dict(st.batch)
+        batch['features'], batch['corr'], batch['dist_keypts'] = self.s_feat, st.corr, st.dk
         self.flat.zero_grad()
         loss, desc, det, acc = self.forward_loss(batch)
         loss.backward()
@@ -181,38 +213,101 @@ class TrainStep:
             self.opt.step()
         return loss.detach(), desc.detach(), det.detach(), acc.detach()
 
+    def _static_step(self, item):
+        """One step on static shapes without a graph (pyramid, then network, on the current stream)."""
+        st = self.sets[0]
+        self._load_inputs(st, item)
+        self._build_set(st)
+        st.loaded = item
+        return self._net_step(st)
+
     def capture(self, item):
-        """Warm up on a side stream, then record the step into a hipGraph (torch.cuda.CUDAGraph)."""
-        self._load_static(item)
-        side = torch.cuda.Stream(device=self.device)
-        side.wait_stream(torch.cuda.current_stream(self.device))
-        with torch.cuda.stream(side):
-            for _ in range(3):
-                out = self._static_step()
+        """Warm up, then record the graphs (torch.cuda.CUDAGraph = hipGraph): one network step and one pyramid build
+        per buffer set.  Network graphs replay on the training stream, pyramid graphs on a side stream."""
+        dev = self.device
+        main = torch.cuda.current_stream(dev)
+        for st in self.sets:
+            self._load_inputs(st, item)
+            self._build_set(st)
+            st.loaded = item
+        warm = torch.cuda.Stream(device=dev)
+        warm.wait_stream(main)
+        with torch.cuda.stream(warm):
+            for k in range(3):
+                self._build_set(self.sets[(k + 1) % self.NSETS])
+                out = self._net_step(self.sets[k % self.NSETS])
                 if self.world > 1:
                     allreduce_mean_(self.flat.grad, self.world)
                     self.opt.step()
-        torch.cuda.current_stream(self.device).wait_stream(side)
-        torch.cuda.synchronize(self.device)
-        self._status.raise_if_set()
-        g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g):
-            self._graph_out = self._static_step()
-        self.graph = g
+        main.wait_stream(warm)
+        torch.cuda.synchronize(dev)
+        self.check_status()
+        self._side = torch.cuda.Stream(device=dev)
+        self.g_net, self.g_pyr, self._graph_out = [], [], []
+        for i in range(self.NSETS):
+            # graphs of one kind never run concurrently and replay in capture order: they share a memory pool
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, pool=self.g_net[0].pool() if self.g_net else None):
+                self._graph_out.append(self._net_step(self.sets[i]))
+            self.g_net.append(g)
+        for i in range(self.NSETS):
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, pool=self.g_pyr[0].pool() if self.g_pyr else None):
+                self._build_set(self.sets[i])
+            self.g_pyr.append(g)
+        torch.cuda.synchronize(dev)
+        self.ev_net = [torch.cuda.Event() for _ in range(self.NSETS)]
+        self.ev_pyr = [torch.cuda.Event() for _ in range(self.NSETS)]
+        for i in range(self.NSETS):
+            self.ev_net[i].record(main)
+            self.ev_pyr[i].record(main)
+        self.cur = 0
         return out
 
-    def step_graph(self, item):
-        self._load_static(item)
-        self.graph.replay()
+    def step_graph(self, item, next_item=None):
+        """Train on ``item``; the pyramid of ``next_item`` (default: ``item`` again) is built on the side stream
+        meanwhile.  When ``item`` was the previous call's ``next_item`` its pyramid is already there (or under way);
+        otherwise it is built first.  ``next_item``'s tensors must be complete when this is called (host arrays or
+        device tensors produced on an already synchronised stream): the side stream does not wait for the training
+        stream.
+
+        Ordering uses HOST waits on events, not stream waits (a graph launch behind a pending cross-stream wait was
+        measured to block the host for the whole step).  With three buffer sets both waits are on work launched at
+        least one step earlier, so the host stays a step ahead of the GPU and the training stream never idles:
+          * the pyramid of pair k+1 overwrites the set last read by the network step of pair k-2,
+          * the network step of pair k needs the pyramid launched during step k-1."""
+        i = self.cur
+        n = (i + 1) % self.NSETS
+        st, nx = self.sets[i], self.sets[n]
+        main = torch.cuda.current_stream(self.device)
+        if st.loaded is not item:
+            self.ev_net[i].synchronize()
+            with torch.cuda.stream(self._side):
+                self._load_inputs(st, item)
+                self.g_pyr[i].replay()
+                self.ev_pyr[i].record(self._side)
+            st.loaded = item
+        nxt = item if next_item is None else next_item
+        self.ev_net[n].synchronize()
+        with torch.cuda.stream(self._side):
+            self._load_inputs(nx, nxt)
+            self.g_pyr[n].replay()
+            self.ev_pyr[n].record(self._side)
+        nx.loaded = nxt
+        self.ev_pyr[i].synchronize()
+        self.g_net[i].replay()
+        self.ev_net[i].record(main)
+        self.cur = n
         if self.world > 1:
             allreduce_mean_(self.flat.grad, self.world)
             self.opt.step()
-        return self._graph_out
+        return self._graph_out[i]
 
     def check_status(self):
         """Raise if a device-side condition (capacity overflow, candidate overflow, ...) was flagged (one sync)."""
-        if getattr(self, '_status', None) is not None:
-            self._status.raise_if_set()
+        for st in getattr(self, 'sets', []):
+            if st.status is not None:
+                st.status.raise_if_set()
 
     # -- pyramid construction on a side stream ---------------------------------------------------------------
     # build_pyramid reads the level sizes back once; done on the training stream that read-back would wait for the

@@ -199,26 +199,80 @@ def test_graph_mode_matches_eager_step(golden_s0):
     # capture() itself runs 3 eager warm-up steps in static mode + records; compare a FRESH replay trajectory instead
     g2 = fresh()
     g2.enable_graph(graph.caps, num_corr=item[4].shape[0])
-    g2._load_static(item)
-    first = g2._static_step()          # static shapes, no graph: must equal the eager step
+    first = g2._static_step(item)      # static shapes, no graph: must equal the eager step
     torch.cuda.synchronize()
     assert abs(float(first[0]) - losses_e[0]) < 1e-4 * max(1.0, abs(losses_e[0]))
-    graph.capture(item)                # 3 warm-up steps were applied to the parameters
-    l4 = float(graph.step_graph(item)[0])
-    graph.check_status()
+    # a second, different pair: the same two fragments in the other order
+    swapped = (item[1], item[0], item[3], item[2], item[4].flip(1).contiguous(), item[5].t().contiguous())
+    graph.capture(item)                # 3 warm-up steps (on `item`) were applied to the parameters
     e2 = fresh()
     for _ in range(3):
         e2.step(item)
-    ref4 = float(e2.step(item)[0])
-    assert abs(l4 - ref4) < 2e-3 * max(1.0, abs(ref4)), (l4, ref4)
+    # pipelined replay: the pyramid of the next pair is built by the side branch of the previous step's graph
+    seq = [item, swapped, item, swapped]
+    trace = []
+    for k, it in enumerate(seq):
+        nxt = seq[k + 1] if k + 1 < len(seq) else None
+        lg = float(graph.step_graph(it, nxt)[0])
+        le = float(e2.step(it)[0])
+        trace.append((lg, le))
+        assert abs(lg - le) < 2e-3 * max(1.0, abs(le)), (k, lg, le)
+    graph.check_status()
+    other = tuple(t.clone() for t in swapped)  # a pair object the pipeline has not seen: built on demand
+    lg = float(graph.step_graph(other)[0])
+    le = float(e2.step(swapped)[0])
+    trace.append((lg, le))
+    assert abs(lg - le) < 2e-3 * max(1.0, abs(le)), (lg, le)
     # parameters after the same number of updates agree
     pa = graph.flat.data
     pb = e2.flat.data
-    assert float((pa - pb).abs().max()) < 1e-4 * float(pb.abs().max())
+    assert float((pa - pb).abs().max()) < 1e-4 * float(pb.abs().max()), trace
     # a too-small capacity is reported, not silently truncated
     small = fresh()
     small.enable_graph([sizes[0][0] + 64, 64, 64, 64, 64], num_corr=item[4].shape[0])
-    small._load_static(item)
-    small._static_step()
+    small._static_step(item)
     with pytest.raises(RuntimeError):
         small.check_status()
+
+
+def test_every_graph_replay_reproduces_the_eager_gradient(golden_s0):
+    """Each captured network graph, replayed twice per pair on alternating pairs from the same parameters, must give
+    the eager gradient of THAT pair every time: nothing may be carried from one replay to the next (a buffer whose
+    initialisation is not part of the replay shows up here as a stale gradient on the first or on the alternate pair).
+    """
+    from d3feat_pytorch_amd.train import TrainStep
+    g = golden_s0
+    cfg = cfgmod.default_config(first_features_dim=16, num_node=64)
+    limits = [int(x) for x in g['limits']]
+    item = tuple(torch.from_numpy(np.ascontiguousarray(a)).to(DEV) for a in _item(g))
+    swapped = (item[1], item[0], item[3], item[2], item[4].flip(1).contiguous(), item[5].t().contiguous())
+    sizes = [[int(g['batch.points.%d' % l].shape[0]) for l in range(5)]]
+    np.random.seed(0)
+    torch.manual_seed(0)
+    t = TrainStep(cfg, limits, torch.device(DEV), seed=0)
+    t.enable_graph(TrainStep.capacities_for(sizes, slack=1.3), num_corr=item[4].shape[0])
+    t.capture(item)
+    torch.cuda.synchronize()
+    p0, b0 = t.flat.data.clone(), t.opt.buf.clone()
+
+    def restore():
+        t.flat.data.copy_(p0)
+        t.opt.buf.copy_(b0)
+    eager = {}
+    for name, it in (("item", item), ("swapped", swapped)):
+        restore()
+        t._static_step(it)
+        torch.cuda.synchronize()
+        eager[name] = (t.flat.grad.clone(), t.flat.data.clone())
+    scale = float(eager["item"][0].abs().max())
+    for gi in range(t.NSETS):
+        for name, it in (("item", item), ("item", item), ("swapped", swapped), ("swapped", swapped), ("item", item)):
+            restore()
+            t._load_inputs(t.sets[gi], it)
+            t.g_pyr[gi].replay()
+            torch.cuda.synchronize()
+            t.g_net[gi].replay()
+            torch.cuda.synchronize()
+            ge, pe = eager[name]
+            assert float((t.flat.grad - ge).abs().max()) < 1e-5 * scale, (gi, name)
+            assert float((t.flat.data - pe).abs().max()) < 1e-6, (gi, name)
