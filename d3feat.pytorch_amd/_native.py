@@ -33,6 +33,8 @@ SIGNATURES = {
     "d3f_kpconv_saves_wf": (_i, [_i, _i, _i, _i]),
     "d3f_kpconv_backward": (_i, [_vp, _i, _vp, _i, _vp, _i, _vp, _i, _vp, _i, _vp, _i, _f, _vp, _vp, _vp, _vp, _vp,
                                  _vp, _sz, _vp]),
+    "d3f_kpconv_grad_input_supported": (_i, [_i, _i, _i, _i]),
+    "d3f_kpconv_grad_input": (_i, [_vp, _i, _vp, _i, _vp, _i, _vp, _i, _vp, _i, _f, _vp, _vp, _vp, _sz, _vp]),
     "d3f_linear_grad_weight_supported": (_i, [_i, _i, _i]),
     "d3f_linear_grad_weight_ws_bytes": (_sz, [_i, _i, _i]),
     "d3f_linear_grad_weight": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _sz, _vp]),

@@ -236,6 +236,9 @@ int kpconv_forward_fused(const float* q_pts, int Nq, const float* s_pts, int Ns,
 size_t atb_ws_bytes(int R, int M, int N);
 int atb_splitk(const float* A, const float* B, const float* row_div, int R, int M, int N, float* C, void* ws,
                hipStream_t stream);
+int kpconv_grad_input_from_gw(const float* q_pts, int Nq, const float* s_pts, int Ns, const int32_t* idx, int H,
+                              const float* x, int Cin, const float* kp, int K, float extent, const float* gwf, float* gx,
+                              void* ws, hipStream_t stream);
 // kpconv_small.hip
 bool kpconv_small_supported(int Cin, int Cout, int K, int H);
 int kpconv_small_dispatch(bool fwd, const float* q_pts, const float* s_pts, const int32_t* idx, const float* x,
@@ -361,6 +364,25 @@ int d3f_kpconv_backward(const float* q_pts, int Nq, const float* s_pts, int Ns, 
     D3F_LAUNCH_CHECK();
   }
   return D3F_OK;
+}
+
+// grad_x [Ns, Cin] (OVERWRITTEN) from gwf = (grad_out / nn) @ W^T  [Nq, K*Cin] computed by the caller (a plain GEMM)
+int d3f_kpconv_grad_input_supported(int Cin, int K, int H, int Ns) {
+  return kpconv_fused_supported(Cin, 64, K, H, Ns) ? 1 : 0;
+}
+
+int d3f_kpconv_grad_input(const float* q_pts, int Nq, const float* s_pts, int Ns, const int32_t* idx, int H,
+                          const float* x, int Cin, const float* kernel_points, int K, float extent, const float* gwf,
+                          float* grad_x, void* ws, size_t ws_bytes, void* stream_) {
+  if (!q_pts || !s_pts || !idx || !x || !kernel_points || !gwf || !grad_x || !ws || Nq < 0 || Ns < 0 || H < 1 ||
+      !(extent > 0.0f) || !kpconv_fused_supported(Cin, 64, K, H, Ns))
+    return D3F_EINVAL;
+  if (ws_bytes < d3f_kpconv_ws_bytes(Nq, Ns, H, K, Cin, 64)) return D3F_EWORKSPACE;
+  hipStream_t stream = (hipStream_t)stream_;
+  if (d3f::zero_async(grad_x, sizeof(float) * (size_t)Ns * Cin, stream) != hipSuccess) return D3F_ELAUNCH;
+  if (Nq == 0) return D3F_OK;
+  return kpconv_grad_input_from_gw(q_pts, Nq, s_pts, Ns, idx, H, x, Cin, kernel_points, K, extent, gwf, grad_x, ws,
+                                   stream);
 }
 
 }  // extern "C"

@@ -35,7 +35,8 @@
 
 namespace d3f {
 
-// ablation switches for profiling (profiles/ablate_kpconv.py): bit0 skip phase A, bit1 skip phase B, bit2 skip stores
+// ablation switches for profiling (profiles/ablate_kpconv*.py): forward bit0 skip phase A, bit1 skip phase B, bit2 skip
+// stores; grad-input bit3 skip the scatter atomics, bit4 skip phase 1 (gW tile), bit5 skip phase 2
 static int g_debug_flags = 0;
 void kpconv_set_debug_flags(int f) { g_debug_flags = f; }
 
@@ -207,7 +208,7 @@ __global__ __launch_bounds__(256) void kpconv_bwd_dx_kernel(
     const float* __restrict__ q_pts, const float4* __restrict__ spack, const int32_t* __restrict__ idx,
     const float* __restrict__ kp, const float* __restrict__ W, const float* __restrict__ nn,
     const float* __restrict__ gout, int Nq, int Ns, int H, int Cin, int Cout, int K, float extent,
-    float* __restrict__ gx) {
+    float* __restrict__ gx, const float* __restrict__ gwf_in, int dbg) {
   constexpr int CC = 16 * CV;
   extern __shared__ __attribute__((aligned(16))) float lds[];
   constexpr int RS = 16 * CC + 4;
@@ -221,15 +222,28 @@ __global__ __launch_bounds__(256) void kpconv_bwd_dx_kernel(
   const int cbase = blockIdx.y * CC;
   const __amdgpu_buffer_rsrc_t rs_sp = make_rsrc(spack, (unsigned)Ns * 16u);
 
-  for (int t = threadIdx.x; t < 16 * Cout; t += 256) {
-    const int r = t / Cout, o = t % Cout;
-    const int q = q0 + r;
-    gl[r * GS + o] = q < Nq ? gout[(size_t)q * Cout + o] / nn[q] : 0.0f;
+  if (gwf_in) {
+    // few-point / wide layers: gW = (g/nn) W^T was produced by a library GEMM over ALL queries (phase 1 below would
+    // run on a handful of workgroups there); just stage this tile's slice
+    constexpr int V = CC / 4;
+    for (int t = threadIdx.x; t < 16 * K * V; t += 256) {
+      const int v = t % V, k = (t / V) % K, ql = t / (V * K);
+      const int q = q0 + ql;
+      const float4 val = q < Nq ? *(const float4*)(gwf_in + ((size_t)q * K + k) * Cin + cbase + 4 * v)
+                                : make_float4(0.f, 0.f, 0.f, 0.f);
+      *(float4*)(gw + ql * RS + k * CC + 4 * v) = val;
+    }
+  } else {
+    for (int t = threadIdx.x; t < 16 * Cout; t += 256) {
+      const int r = t / Cout, o = t % Cout;
+      const int q = q0 + r;
+      gl[r * GS + o] = q < Nq ? gout[(size_t)q * Cout + o] / nn[q] : 0.0f;
+    }
   }
   __syncthreads();
   // ---- phase 1: gW[q, kc] = sum_o g[q, o] * W[kc, o]
   const int nkb = (K * CC) >> 4;
-  for (int kb = wave; kb < nkb; kb += 4) {
+  for (int kb = wave; kb < ((gwf_in || (dbg & 16)) ? 0 : nkb); kb += 4) {
     const int kc0 = kb << 4;
     const int k = kc0 / CC, c0 = kc0 % CC;
     const float* wr = W + (size_t)(k * Cin + cbase + c0 + li) * Cout + 4 * lg;
@@ -263,7 +277,7 @@ __global__ __launch_bounds__(256) void kpconv_bwd_dx_kernel(
   for (int i = 0; i < 4; ++i) {
     const int ql = wave * 4 + i;
     const int q = q0 + ql;
-    if (q >= Nq) continue;
+    if (q >= Nq || (dbg & 32)) continue;
     const float qx = q_pts[3 * (size_t)q + 0], qy = q_pts[3 * (size_t)q + 1], qz = q_pts[3 * (size_t)q + 2];
     float cx[4], cy[4], cz[4];
 #pragma unroll
@@ -291,7 +305,8 @@ __global__ __launch_bounds__(256) void kpconv_bwd_dx_kernel(
         }
 #pragma unroll
         for (int r = 0; r < 4; ++r)
-          if ((unsigned)nrow[r] < (unsigned)Ns) atomicAdd(&gx[(size_t)nrow[r] * Cin + cbase + cb * 16 + li], acc[r]);
+          if ((unsigned)nrow[r] < (unsigned)Ns && !(dbg & 8))
+            atomicAdd(&gx[(size_t)nrow[r] * Cin + cbase + cb * 16 + li], acc[r]);
       }
     }
   }
@@ -461,9 +476,9 @@ int kpconv_backward_fused(const float* q_pts, int Nq, const float* s_pts, int Ns
     const int CC = 16 * CV;
     const size_t lds = sizeof(float) * (size_t)(16 * (16 * CC + 4) + 16 * (Cout + 4));
     dim3 grid(tiles, Cin / CC);
-    if (CV == 1) kpconv_bwd_dx_kernel<1><<<grid, 256, lds, stream>>>(q_pts, spack, idx, kp, W, nn, gout, Nq, Ns, H, Cin, Cout, K, extent, gx);
-    else if (CV == 2) kpconv_bwd_dx_kernel<2><<<grid, 256, lds, stream>>>(q_pts, spack, idx, kp, W, nn, gout, Nq, Ns, H, Cin, Cout, K, extent, gx);
-    else kpconv_bwd_dx_kernel<4><<<grid, 256, lds, stream>>>(q_pts, spack, idx, kp, W, nn, gout, Nq, Ns, H, Cin, Cout, K, extent, gx);
+    if (CV == 1) kpconv_bwd_dx_kernel<1><<<grid, 256, lds, stream>>>(q_pts, spack, idx, kp, W, nn, gout, Nq, Ns, H, Cin, Cout, K, extent, gx, nullptr, g_debug_flags);
+    else if (CV == 2) kpconv_bwd_dx_kernel<2><<<grid, 256, lds, stream>>>(q_pts, spack, idx, kp, W, nn, gout, Nq, Ns, H, Cin, Cout, K, extent, gx, nullptr, g_debug_flags);
+    else kpconv_bwd_dx_kernel<4><<<grid, 256, lds, stream>>>(q_pts, spack, idx, kp, W, nn, gout, Nq, Ns, H, Cin, Cout, K, extent, gx, nullptr, g_debug_flags);
     D3F_LAUNCH_CHECK();
   }
   if (gw && wf_saved) {
@@ -491,6 +506,28 @@ int kpconv_backward_fused(const float* q_pts, int Nq, const float* s_pts, int Ns
 #undef D3F_DW
     D3F_LAUNCH_CHECK();
   }
+  return D3F_OK;
+}
+
+// grad_x from a precomputed gW = (grad_out / nn) @ W^T  [Nq, K*Cin]: staging + phase 2 (scatter) of the kernel above
+int kpconv_grad_input_from_gw(const float* q_pts, int Nq, const float* s_pts, int Ns, const int32_t* idx, int H,
+                              const float* x, int Cin, const float* kp, int K, float extent, const float* gwf, float* gx,
+                              void* ws, hipStream_t stream) {
+  float4* spack = (float4*)ws;
+  int rc = pack_supports(s_pts, x, Ns, Cin, spack, stream);
+  if (rc) return rc;
+  const int CV = Cin == 16 ? 1 : (Cin == 32 ? 2 : 4);
+  const int CC = 16 * CV;
+  const size_t lds = sizeof(float) * (size_t)(16 * (16 * CC + 4));
+  dim3 grid(cdiv(Nq, 16), Cin / CC);
+#define D3F_DXG(CVV)                                                                                                  \
+  kpconv_bwd_dx_kernel<CVV><<<grid, 256, lds, stream>>>(q_pts, spack, idx, kp, nullptr, nullptr, nullptr, Nq, Ns, H, Cin, \
+                                                        0, K, extent, gx, gwf, 0)
+  if (CV == 1) D3F_DXG(1);
+  else if (CV == 2) D3F_DXG(2);
+  else D3F_DXG(4);
+#undef D3F_DXG
+  D3F_LAUNCH_CHECK();
   return D3F_OK;
 }
 

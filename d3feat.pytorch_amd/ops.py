@@ -202,6 +202,8 @@ def grid_subsample_raw(points, lens, sampleDl, max_p=0, order=ORDER_REFERENCE, s
 SAVE_WEIGHTED_FEATURES = True
 # below this many rows a weight gradient is a plain GEMM for the library; above, the reduction-parallel kernel
 _SPLITK_MIN_ROWS = 4096
+# below this many query points grad_x takes gW = (g/nn) W^T from a library GEMM and only scatters
+_GEMM_DX_MAX_ROWS = 1500
 
 
 class _KPConvFn(torch.autograd.Function):
@@ -240,21 +242,36 @@ class _KPConvFn(torch.autograd.Function):
         gx = torch.empty_like(x) if need_x else None
         gw = torch.empty_like(weights) if need_w else None
         go = grad_out.contiguous().float() if (need_x or need_w) else None
-        gw_native = gw
+        gw_native, gx_native = gw, gx
+        gon = None
         if need_w and wf is not None and Nq < _SPLITK_MIN_ROWS:
             # few points, wide layers (bottom of the U-Net): grad_W = wf^T (g/nn) is an ordinary GEMM with a short
             # reduction -- a library call; the reduction-parallel kernel is for the tall-skinny upper levels
+            gon = go / nn.unsqueeze(1)
             with _region("kpconv_dw_gemm[Nq=%d,Cin=%d,Cout=%d]" % (Nq, Cin, Cout), 4 * Nq * (K * Cin + Cout)):
-                torch.mm(wf.t(), go / nn.unsqueeze(1), out=gw.view(K * Cin, Cout))
+                torch.mm(wf.t(), gon, out=gw.view(K * Cin, Cout))
             gw_native = None
-        if need_x or gw_native is not None:
+        if need_x and 0 < Nq < _GEMM_DX_MAX_ROWS and L.d3f_kpconv_grad_input_supported(Cin, K, H, Ns):
+            # same layers: gW = (g/nn) W^T over all queries is one library GEMM; the kernel only scatters
+            if gon is None:
+                gon = go / nn.unsqueeze(1)
+            gwf = torch.mm(gon, weights.view(K * Cin, Cout).t())
+            nbytes = L.d3f_kpconv_ws_bytes(Nq, Ns, H, K, Cin, 64)
+            ws = _ws(nbytes, x.device)
+            with _region("kpconv_dx_scatter[Nq=%d,Cin=%d,H=%d]" % (Nq, Cin, H), 4 * Nq * K * Cin + 4 * Nq * H * (1 + Cin)):
+                _native.check(L.d3f_kpconv_grad_input(_p(q_pts), Nq, _p(s_pts), Ns, _p(idx), H, _p(x), Cin,
+                                                      _p(kernel_points), K, ctx.extent, _p(gwf), _p(gx), _p(ws),
+                                                      nbytes, _stream()), "d3f_kpconv_grad_input")
+            gx_native = None
+        if gx_native is not None or gw_native is not None:
             nbytes = L.d3f_kpconv_ws_bytes(Nq, Ns, H, K, Cin, Cout)
             ws = _ws(nbytes, x.device)
             with _region("kpconv_bwd[Nq=%d,Cin=%d,Cout=%d,H=%d]" % (Nq, Cin, Cout, H),
                          kpconv_bwd_bytes(Nq, Ns, H, K, Cin, Cout)):
                 _native.check(L.d3f_kpconv_backward(_p(q_pts), Nq, _p(s_pts), Ns, _p(idx), H, _p(x), Cin,
                                                     _p(kernel_points), K, _p(weights), Cout, ctx.extent, _p(nn),
-                                                    _p(go), _p(wf), _p(gx), _p(gw_native), _p(ws), nbytes, _stream()),
+                                                    _p(go), _p(wf), _p(gx_native), _p(gw_native), _p(ws), nbytes,
+                                                    _stream()),
                               "d3f_kpconv_backward")
         return None, None, None, gx, None, gw, None
 

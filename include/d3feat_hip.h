@@ -102,6 +102,15 @@ int d3f_kpconv_backward(const float* q_pts, int Nq, const float* s_pts, int Ns, 
                         float extent, const float* nn, const float* grad_out, const float* wf_saved, float* grad_x,
                         float* grad_w, void* ws, size_t ws_bytes, void* stream);
 
+/* grad_x alone, from gwf = (grad_out / nn) @ W^T  [Nq, K*Cin] computed by the caller (an ordinary GEMM: the right
+ * tool for the few-point / 256..512-channel layers at the bottom of the U-Net, where the fused kernel's own gW tile
+ * would run on a handful of workgroups).  Same semantics as the grad_x of d3f_kpconv_backward.
+ * Workspace: d3f_kpconv_ws_bytes(Nq, Ns, H, K, Cin, 64). */
+int d3f_kpconv_grad_input_supported(int Cin, int K, int H, int Ns);
+int d3f_kpconv_grad_input(const float* q_pts, int Nq, const float* s_pts, int Ns, const int32_t* idx, int H,
+                          const float* x, int Cin, const float* kernel_points, int K, float extent, const float* gwf,
+                          float* grad_x, void* ws, size_t ws_bytes, void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Weight gradient of the 1x1 "unary" convolutions -- replaces autograd's grad_out^T @ x for nn.Linear in
  * UnaryBlock (models/blocks.py:481-515): grad_w [Cout, Cin] = grad_out^T [Cout, N] @ x [N, Cin], with the

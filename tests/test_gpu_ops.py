@@ -126,7 +126,9 @@ def _kpconv_case(rng, nq, ns, h, cin, cout, shadow_frac=0.15, k=15):
                                               (200, 260, 42, 24, 40), (300, 400, 42, 16, 16), (300, 400, 40, 32, 64),
                                               (150, 160, 42, 256, 128), (2100, 2100, 42, 64, 32), (571, 2053, 42, 128, 128),
                                               (900, 900, 42, 1, 32), (400, 500, 30, 2, 100), (300, 300, 42, 4, 64), (300, 300, 17, 3, 8)])
-def test_kpconv_forward_backward(nq, ns, h, cin, cout):
+@pytest.mark.parametrize("gemm_dx_rows", [0, 1 << 30])  # grad_x: fused gW tile / library GEMM + scatter kernel
+def test_kpconv_forward_backward(nq, ns, h, cin, cout, gemm_dx_rows, monkeypatch):
+    monkeypatch.setattr(ops, "_GEMM_DX_MAX_ROWS", gemm_dx_rows)
     rng = np.random.default_rng(nq + cin)
     q, s, idx, x, kp, w = _kpconv_case(rng, nq, ns, h, cin, cout)
     ext = 0.05
