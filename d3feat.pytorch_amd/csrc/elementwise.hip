@@ -15,8 +15,11 @@ namespace {
 __global__ __launch_bounds__(256) void bias_act_fwd_kernel(const float* __restrict__ x, const float* __restrict__ b1,
                                                            const float* __restrict__ add,
                                                            const float* __restrict__ b2, float slope, size_t n4,
-                                                           int C, float* __restrict__ out) {
+                                                           int C, float* __restrict__ out, float* __restrict__ zinit,
+                                                           int zn) {
   // C % 4 == 0: one float4 per thread, columns of a float4 are c .. c+3
+  if (zinit && blockIdx.x == 0)
+    for (int t = threadIdx.x; t < zn; t += blockDim.x) zinit[t] = 0.0f;
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n4) return;
   const int c = (int)((i * 4) % (size_t)C);
@@ -36,7 +39,10 @@ __global__ __launch_bounds__(256) void bias_act_fwd_scalar_kernel(const float* _
                                                                   const float* __restrict__ b1,
                                                                   const float* __restrict__ add,
                                                                   const float* __restrict__ b2, float slope, size_t n,
-                                                                  int C, float* __restrict__ out) {
+                                                                  int C, float* __restrict__ out,
+                                                                  float* __restrict__ zinit, int zn) {
+  if (zinit && blockIdx.x == 0)
+    for (int t = threadIdx.x; t < zn; t += blockDim.x) zinit[t] = 0.0f;
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const int c = (int)(i % (size_t)C);
@@ -53,7 +59,8 @@ __global__ __launch_bounds__(256) void bias_act_fwd_scalar_kernel(const float* _
 // workgroups also for the few-point / 2048-channel layers at the bottom of the U-Net.
 __global__ __launch_bounds__(256) void bias_act_bwd_kernel(const float* __restrict__ go, const float* __restrict__ out,
                                                            float slope, int N, int C, int rows_per_block,
-                                                           float* __restrict__ gx, float* __restrict__ gb) {
+                                                           float* __restrict__ gx, float* __restrict__ gb,
+                                                           float* __restrict__ gb2) {
   __shared__ float red[256];
   const int r0 = blockIdx.x * rows_per_block;
   const int r1 = min(N, r0 + rows_per_block);
@@ -72,8 +79,11 @@ __global__ __launch_bounds__(256) void bias_act_bwd_kernel(const float* __restri
   if (gb) {
     red[threadIdx.x] = s;
     __syncthreads();
-    if (threadIdx.x < 64 && c < C)
-      atomicAdd(&gb[c], red[threadIdx.x] + red[threadIdx.x + 64] + red[threadIdx.x + 128] + red[threadIdx.x + 192]);
+    if (threadIdx.x < 64 && c < C) {
+      const float v = red[threadIdx.x] + red[threadIdx.x + 64] + red[threadIdx.x + 128] + red[threadIdx.x + 192];
+      atomicAdd(&gb[c], v);
+      if (gb2) atomicAdd(&gb2[c], v);
+    }
   }
 }
 
@@ -82,32 +92,43 @@ __global__ __launch_bounds__(256) void bias_act_bwd_kernel(const float* __restri
 extern "C" {
 
 int d3f_bias_act_forward(const float* x, const float* bias1, const float* add, const float* bias2, float slope, int N,
-                         int C, float* out, void* stream) {
-  if (!x || !out || N < 0 || C < 1) return D3F_EINVAL;
+                         int C, float* out, float* zero_init, int zero_n, void* stream) {
+  if (!x || !out || N < 0 || C < 1 || (zero_init && zero_n < 1)) return D3F_EINVAL;
   const size_t n = (size_t)N * C;
-  if (n == 0) return D3F_OK;
+  if (n == 0) {
+    if (zero_init && d3f::zero_async(zero_init, sizeof(float) * (size_t)zero_n, (hipStream_t)stream) != hipSuccess)
+      return D3F_ELAUNCH;
+    return D3F_OK;
+  }
   if (C % 4 == 0)
-    bias_act_fwd_kernel<<<d3f::cdiv((long long)(n / 4), 256), 256, 0, (hipStream_t)stream>>>(x, bias1, add, bias2, slope,
-                                                                                            n / 4, C, out);
+    bias_act_fwd_kernel<<<d3f::cdiv((long long)(n / 4), 256), 256, 0, (hipStream_t)stream>>>(
+        x, bias1, add, bias2, slope, n / 4, C, out, zero_init, zero_n);
   else
-    bias_act_fwd_scalar_kernel<<<d3f::cdiv((long long)n, 256), 256, 0, (hipStream_t)stream>>>(x, bias1, add, bias2, slope,
-                                                                                             n, C, out);
+    bias_act_fwd_scalar_kernel<<<d3f::cdiv((long long)n, 256), 256, 0, (hipStream_t)stream>>>(
+        x, bias1, add, bias2, slope, n, C, out, zero_init, zero_n);
   D3F_LAUNCH_CHECK();
   return D3F_OK;
 }
 
-/* grad_x (optional) [N,C]; grad_bias (optional) [C] is OVERWRITTEN. */
+/* grad_x (optional) [N,C]; grad_bias / grad_bias2 (optional) [C] receive the SAME column sums (the two biases of a
+ * unary block are distinct parameters with identical gradients).  With bias_prezeroed = 0 they are zeroed here;
+ * with 1 the caller guarantees zeros (d3f_bias_act_forward's zero_init). */
 int d3f_bias_act_backward(const float* grad_out, const float* out, float slope, int N, int C, float* grad_x,
-                          float* grad_bias, void* stream) {
-  if (!grad_out || !out || N < 0 || C < 1 || (!grad_x && !grad_bias)) return D3F_EINVAL;
-  if (grad_bias && d3f::zero_async(grad_bias, sizeof(float) * (size_t)C, (hipStream_t)stream) != hipSuccess)
-    return D3F_ELAUNCH;
+                          float* grad_bias, float* grad_bias2, int bias_prezeroed, void* stream) {
+  if (!grad_out || !out || N < 0 || C < 1 || (!grad_x && !grad_bias) || (grad_bias2 && !grad_bias)) return D3F_EINVAL;
+  if (!bias_prezeroed) {
+    if (grad_bias && d3f::zero_async(grad_bias, sizeof(float) * (size_t)C, (hipStream_t)stream) != hipSuccess)
+      return D3F_ELAUNCH;
+    if (grad_bias2 && d3f::zero_async(grad_bias2, sizeof(float) * (size_t)C, (hipStream_t)stream) != hipSuccess)
+      return D3F_ELAUNCH;
+  }
   if (N == 0) return D3F_OK;
   const int cblocks = d3f::cdiv(C, 64);
   int rows = 256;  // fewer atomics per column when there are plenty of rows
   while (rows > 16 && (long long)d3f::cdiv(N, rows) * cblocks < 1024) rows >>= 1;
   dim3 grid(d3f::cdiv(N, rows), cblocks);
-  bias_act_bwd_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(grad_out, out, slope, N, C, rows, grad_x, grad_bias);
+  bias_act_bwd_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(grad_out, out, slope, N, C, rows, grad_x, grad_bias,
+                                                             grad_bias2);
   D3F_LAUNCH_CHECK();
   return D3F_OK;
 }

@@ -316,7 +316,9 @@ int d3f_kpconv_backward(const float* q_pts, int Nq, const float* s_pts, int Ns, 
   const size_t wf_elems = align_up(sizeof(float) * (size_t)(Nq > 0 ? Nq : 1) * KC, 256) / sizeof(float);
   float* wf = (float*)ws;
   float* gW = wf + wf_elems;
-  if (grad_x && d3f::zero_async(grad_x, sizeof(float) * (size_t)Ns * Cin, stream) != hipSuccess) return D3F_ELAUNCH;
+  const bool fused = Nq > 0 && Ns > 0 && kpconv_fused_supported(Cin, Cout, K, H, Ns);  // clears grad_x while packing
+  if (grad_x && !fused && d3f::zero_async(grad_x, sizeof(float) * (size_t)Ns * Cin, stream) != hipSuccess)
+    return D3F_ELAUNCH;
   if (Nq == 0) {
     if (grad_w && d3f::zero_async(grad_w, sizeof(float) * (size_t)KC * Cout, stream) != hipSuccess)
       return D3F_ELAUNCH;
@@ -379,8 +381,10 @@ int d3f_kpconv_grad_input(const float* q_pts, int Nq, const float* s_pts, int Ns
     return D3F_EINVAL;
   if (ws_bytes < d3f_kpconv_ws_bytes(Nq, Ns, H, K, Cin, 64)) return D3F_EWORKSPACE;
   hipStream_t stream = (hipStream_t)stream_;
-  if (d3f::zero_async(grad_x, sizeof(float) * (size_t)Ns * Cin, stream) != hipSuccess) return D3F_ELAUNCH;
-  if (Nq == 0) return D3F_OK;
+  if (Nq == 0 || Ns == 0) {
+    if (d3f::zero_async(grad_x, sizeof(float) * (size_t)Ns * Cin, stream) != hipSuccess) return D3F_ELAUNCH;
+    return D3F_OK;
+  }
   return kpconv_grad_input_from_gw(q_pts, Nq, s_pts, Ns, idx, H, x, Cin, kernel_points, K, extent, gwf, grad_x, ws,
                                    stream);
 }

@@ -40,15 +40,19 @@ namespace d3f {
 static int g_debug_flags = 0;
 void kpconv_set_debug_flags(int f) { g_debug_flags = f; }
 
-// spack[n] = {s.x, s.y, s.z, (sum_c x[n,c] > 0) ? 1 : 0}; 16 lanes cooperate on one support row
+// spack[n] = {s.x, s.y, s.z, (sum_c x[n,c] > 0) ? 1 : 0}; 16 lanes cooperate on one support row.
+// In backward the same lanes clear row n of grad_x (the scatter target) -- no separate fill launch.
 __global__ __launch_bounds__(256) void pack_supports_kernel(const float* __restrict__ s_pts,
                                                             const float* __restrict__ x, int Ns, int Cin,
-                                                            float4* __restrict__ spack) {
+                                                            float4* __restrict__ spack, float* __restrict__ zero_rows) {
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
   const int n = t >> 4, l = t & 15;
   float s = 0.0f;
   if (n < Ns)
-    for (int c = l; c < Cin; c += 16) s += x[(size_t)n * Cin + c];
+    for (int c = l; c < Cin; c += 16) {
+      s += x[(size_t)n * Cin + c];
+      if (zero_rows) zero_rows[(size_t)n * Cin + c] = 0.0f;
+    }
 #pragma unroll
   for (int o = 8; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
   if (n < Ns && l == 0)
@@ -405,9 +409,10 @@ int atb_splitk(const float* A, const float* B, const float* row_div, int R, int 
 
 size_t kpconv_fused_ws_bytes(int Ns) { return align_up(sizeof(float4) * (size_t)(Ns > 0 ? Ns : 1), 256); }
 
-static int pack_supports(const float* s_pts, const float* x, int Ns, int Cin, float4* spack, hipStream_t stream) {
+static int pack_supports(const float* s_pts, const float* x, int Ns, int Cin, float4* spack, hipStream_t stream,
+                         float* zero_rows = nullptr) {
   if (Ns > 0) {
-    pack_supports_kernel<<<cdiv((long long)Ns * 16, 256), 256, 0, stream>>>(s_pts, x, Ns, Cin, spack);
+    pack_supports_kernel<<<cdiv((long long)Ns * 16, 256), 256, 0, stream>>>(s_pts, x, Ns, Cin, spack, zero_rows);
     D3F_LAUNCH_CHECK();
   }
   return D3F_OK;
@@ -468,7 +473,7 @@ int kpconv_backward_fused(const float* q_pts, int Nq, const float* s_pts, int Ns
                           const float* nn, const float* gout, const float* wf_saved, float* gx, float* gw, void* ws,
                           hipStream_t stream) {
   float4* spack = (float4*)ws;
-  int rc = pack_supports(s_pts, x, Ns, Cin, spack, stream);
+  int rc = pack_supports(s_pts, x, Ns, Cin, spack, stream, gx);  // also clears gx
   if (rc) return rc;
   const int tiles = cdiv(Nq, 16);
   if (gx) {
@@ -514,7 +519,7 @@ int kpconv_grad_input_from_gw(const float* q_pts, int Nq, const float* s_pts, in
                               const float* x, int Cin, const float* kp, int K, float extent, const float* gwf, float* gx,
                               void* ws, hipStream_t stream) {
   float4* spack = (float4*)ws;
-  int rc = pack_supports(s_pts, x, Ns, Cin, spack, stream);
+  int rc = pack_supports(s_pts, x, Ns, Cin, spack, stream, gx);  // also clears gx
   if (rc) return rc;
   const int CV = Cin == 16 ? 1 : (Cin == 32 ? 2 : 4);
   const int CC = 16 * CV;

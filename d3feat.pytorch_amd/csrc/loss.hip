@@ -37,17 +37,17 @@ __device__ __forceinline__ void terms(float d, bool negm, const LossParams& P, f
   tneg = P.s * (P.neg_margin - neg) * nw;
 }
 
-// wave-cooperative statistics of one row (stride 1) or one column (stride M) of D
-__device__ void line_stats(const float* __restrict__ D, const uint8_t* __restrict__ negm, int M, long base, long stride,
-                           int self, const LossParams& P, float& lse_p, float& lse_n, float& sumd, float& cmin,
-                           int& carg) {
+// wave-cooperative statistics of one line of D: element t of the line is D[base + t*stride] (mask alike)
+__device__ void line_stats(const float* __restrict__ D, long dbase, long dstride, const uint8_t* __restrict__ negm,
+                           long nbase, long nstride, int M, int self, const LossParams& P, float& lse_p, float& lse_n,
+                           float& sumd, float& cmin, int& carg) {
   const int lane = threadIdx.x & 63;
   float mp = -INFINITY, mn = -INFINITY, sd = 0.0f, cm = INFINITY;
   int ca = 0x7fffffff;
   for (int t = lane; t < M; t += 64) {
-    const float d = D[base + t * stride];
+    const float d = D[dbase + t * dstride];
     float tp, pw, tn, nw;
-    terms(d, negm[base + t * stride] != 0, P, tp, pw, tn, nw);
+    terms(d, negm[nbase + t * nstride] != 0, P, tp, pw, tn, nw);
     mp = fmaxf(mp, tp);
     mn = fmaxf(mn, tn);
     sd += d;
@@ -65,9 +65,9 @@ __device__ void line_stats(const float* __restrict__ D, const uint8_t* __restric
   }
   float ep = 0.0f, en = 0.0f;
   for (int t = lane; t < M; t += 64) {
-    const float d = D[base + t * stride];
+    const float d = D[dbase + t * dstride];
     float tp, pw, tn, nw;
-    terms(d, negm[base + t * stride] != 0, P, tp, pw, tn, nw);
+    terms(d, negm[nbase + t * nstride] != 0, P, tp, pw, tn, nw);
     ep += expf(tp - mp);
     en += expf(tn - mn);
   }
@@ -90,41 +90,73 @@ __device__ float block_sum(float v, float* sh) {
   return t;
 }
 
+// LDS plan of the cached variants (M <= 128, C <= 64; everything the workgroup touches more than once):
+//   fwd: region0 = descriptors a, p as [M][C+1] each (later reused for the mask bytes), region1 = D as [M][M+1]
+//   bwd: region0 = a, p as [M][C+1] each, region1 = G as [M][M+1]
+// Without CACHE (larger problems) the same code runs on the global buffers.
+__host__ __device__ inline size_t cached_lds_bytes(int M, int C) {
+  return sizeof(float) * ((size_t)2 * M * (C + 1) + (size_t)M * (M + 1));
+}
+static bool cache_ok(int M, int C) { return M <= 128 && C <= 64; }
+
 // stats layout (floats): [0,M) lse_pr  [M,2M) lse_nr  [2M,3M) lse_pc  [3M,4M) lse_nc  [4M,5M) cn  [5M,6M) cnarg(int)
+template <bool CACHE>
 __global__ __launch_bounds__(kThreads) void loss_fwd_kernel(
     const float* __restrict__ a, const float* __restrict__ p, int M, int C, const uint8_t* __restrict__ negm,
     const float* __restrict__ sa, const float* __restrict__ sp, LossParams P, float* __restrict__ D,
     float* __restrict__ fp_out, float* __restrict__ avgneg_out, float* __restrict__ scalars,
     float* __restrict__ stats) {
   __shared__ float sh[16];
+  extern __shared__ __attribute__((aligned(16))) float lds[];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, nw = blockDim.x >> 6;
+  const int CS = C + 1, DS = M + 1;
+  float* al = lds;
+  float* pl = lds + (size_t)M * CS;
+  float* Dl = lds + (size_t)2 * M * CS;
+  uint8_t* nl = (uint8_t*)lds;  // overlays al/pl once the distances exist
+  if (CACHE) {
+    for (int t = tid; t < M * C; t += blockDim.x) {
+      al[(t / C) * CS + t % C] = a[t];
+      pl[(t / C) * CS + t % C] = p[t];
+    }
+    __syncthreads();
+  }
   for (int t = tid; t < M * M; t += blockDim.x) {
     const int i = t / M, j = t % M;
     float acc = 0.0f;
     for (int c = 0; c < C; ++c) {
-      const float df = a[(size_t)i * C + c] - p[(size_t)j * C + c];
+      const float df = CACHE ? al[i * CS + c] - pl[j * CS + c] : a[(size_t)i * C + c] - p[(size_t)j * C + c];
       acc += df * df;
     }
-    D[t] = sqrtf(acc + 1e-12f);
+    const float d = sqrtf(acc + 1e-12f);
+    D[t] = d;
+    if (CACHE) Dl[i * DS + j] = d;
   }
   __threadfence_block();
   __syncthreads();
+  if (CACHE) {
+    for (int t = tid; t < M * M; t += blockDim.x) nl[t] = negm[t];
+    __syncthreads();
+  }
+  const float* Dr = CACHE ? Dl : D;
+  const long ld = CACHE ? DS : M;
+  const uint8_t* nr = CACHE ? nl : negm;
   for (int i = wave; i < M; i += nw) {
     float lp, ln, sd, cm; int ca;
-    line_stats(D, negm, M, (long)i * M, 1, i, P, lp, ln, sd, cm, ca);
+    line_stats(Dr, (long)i * ld, 1, nr, (long)i * M, 1, M, i, P, lp, ln, sd, cm, ca);
     if (lane == 0) {
       stats[i] = lp;
       stats[M + i] = ln;
       stats[4 * M + i] = cm;
       ((int*)stats)[5 * M + i] = ca;
-      const float fp = D[(size_t)i * M + i];  // max_j D*I = D_ii (D > 0)
+      const float fp = Dr[(long)i * ld + i];  // max_j D*I = D_ii (D > 0)
       fp_out[i] = fp;
       avgneg_out[i] = (sd - fp) / (float)(M - 1);
     }
   }
   for (int j = wave; j < M; j += nw) {
     float lp, ln, sd, cm; int ca;
-    line_stats(D, negm, M, (long)j, M, j, P, lp, ln, sd, cm, ca);
+    line_stats(Dr, (long)j, ld, nr, (long)j, M, M, j, P, lp, ln, sd, cm, ca);
     if (lane == 0) {
       stats[2 * M + j] = lp;
       stats[3 * M + j] = ln;
@@ -156,15 +188,26 @@ __global__ __launch_bounds__(kThreads) void loss_fwd_kernel(
   }
 }
 
+template <bool CACHE>
 __global__ __launch_bounds__(kThreads) void loss_bwd_kernel(
     const float* __restrict__ a, const float* __restrict__ p, int M, int C, const uint8_t* __restrict__ negm,
     const float* __restrict__ sa, const float* __restrict__ sp, LossParams P, const float* __restrict__ D,
     const float* __restrict__ stats, const float* __restrict__ g_desc, const float* __restrict__ g_det,
     float* __restrict__ G, float* __restrict__ ga, float* __restrict__ gp, float* __restrict__ gsa,
     float* __restrict__ gsp) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
   const int tid = threadIdx.x;
+  const int CS = C + 1, DS = M + 1;
+  float* al = lds;
+  float* pl = lds + (size_t)M * CS;
+  float* Gl = lds + (size_t)2 * M * CS;
   const float gd = g_desc ? *g_desc : 0.0f, gt = g_det ? *g_det : 0.0f;
   const float invM = 1.0f / (float)M;
+  if (CACHE)
+    for (int t = tid; t < M * C; t += blockDim.x) {
+      al[(t / C) * CS + t % C] = a[t];
+      pl[(t / C) * CS + t % C] = p[t];
+    }
   for (int t = tid; t < M * M; t += blockDim.x) {
     const int i = t / M, j = t % M;
     const float d = D[t];
@@ -177,22 +220,33 @@ __global__ __launch_bounds__(kThreads) void loss_bwd_kernel(
     const float w = gt * invM * (sa[i] + sp[i]);
     if (j == i) g += w;
     if (j == ((const int*)stats)[5 * M + i]) g -= w;
-    G[t] = g / d;
+    if (CACHE) Gl[i * DS + j] = g / d;
+    else G[t] = g / d;
   }
   __threadfence_block();
   __syncthreads();
   for (int t = tid; t < M * C; t += blockDim.x) {
     const int i = t / C, c = t % C;
-    const float ai = a[t];
     float acc = 0.0f;
-    for (int j = 0; j < M; ++j) acc += G[(size_t)i * M + j] * (ai - p[(size_t)j * C + c]);
+    if (CACHE) {
+      const float ai = al[i * CS + c];
+      for (int j = 0; j < M; ++j) acc += Gl[i * DS + j] * (ai - pl[j * CS + c]);
+    } else {
+      const float ai = a[t];
+      for (int j = 0; j < M; ++j) acc += G[(size_t)i * M + j] * (ai - p[(size_t)j * C + c]);
+    }
     ga[t] = acc;
   }
   for (int t = tid; t < M * C; t += blockDim.x) {
     const int j = t / C, c = t % C;
-    const float pj = p[t];
     float acc = 0.0f;
-    for (int i = 0; i < M; ++i) acc += G[(size_t)i * M + j] * (pj - a[(size_t)i * C + c]);
+    if (CACHE) {
+      const float pj = pl[j * CS + c];
+      for (int i = 0; i < M; ++i) acc += Gl[i * DS + j] * (pj - al[i * CS + c]);
+    } else {
+      const float pj = p[t];
+      for (int i = 0; i < M; ++i) acc += G[(size_t)i * M + j] * (pj - a[(size_t)i * C + c]);
+    }
     gp[t] = acc;
   }
   for (int i = tid; i < M; i += blockDim.x) {
@@ -217,9 +271,14 @@ int d3f_circle_det_loss_forward(const float* anchor, const float* positive, int 
       !average_negative || !out_scalars || !stats || M < 2 || M > kMaxM || C < 1)
     return D3F_EINVAL;
   LossParams P = {log_scale, safe_radius, pos_margin, neg_margin};
-  loss_fwd_kernel<<<1, kThreads, 0, (hipStream_t)stream>>>(anchor, positive, M, C, neg_mask, anc_score, pos_score, P,
-                                                            dists, furthest_positive, average_negative, out_scalars,
-                                                            stats);
+  if (cache_ok(M, C))
+    loss_fwd_kernel<true><<<1, kThreads, cached_lds_bytes(M, C), (hipStream_t)stream>>>(
+        anchor, positive, M, C, neg_mask, anc_score, pos_score, P, dists, furthest_positive, average_negative,
+        out_scalars, stats);
+  else
+    loss_fwd_kernel<false><<<1, kThreads, 0, (hipStream_t)stream>>>(anchor, positive, M, C, neg_mask, anc_score,
+                                                                     pos_score, P, dists, furthest_positive,
+                                                                     average_negative, out_scalars, stats);
   D3F_LAUNCH_CHECK();
   return D3F_OK;
 }
@@ -235,9 +294,15 @@ int d3f_circle_det_loss_backward(const float* anchor, const float* positive, int
     return D3F_EINVAL;
   if (ws_bytes < d3f_circle_det_loss_ws_bytes(M)) return D3F_EWORKSPACE;
   LossParams P = {log_scale, safe_radius, pos_margin, neg_margin};
-  loss_bwd_kernel<<<1, kThreads, 0, (hipStream_t)stream>>>(anchor, positive, M, C, neg_mask, anc_score, pos_score, P,
-                                                            dists, stats, grad_desc, grad_det, (float*)ws, grad_anchor,
-                                                            grad_positive, grad_anc_score, grad_pos_score);
+  if (cache_ok(M, C))
+    loss_bwd_kernel<true><<<1, kThreads, cached_lds_bytes(M, C), (hipStream_t)stream>>>(
+        anchor, positive, M, C, neg_mask, anc_score, pos_score, P, dists, stats, grad_desc, grad_det, (float*)ws,
+        grad_anchor, grad_positive, grad_anc_score, grad_pos_score);
+  else
+    loss_bwd_kernel<false><<<1, kThreads, 0, (hipStream_t)stream>>>(anchor, positive, M, C, neg_mask, anc_score,
+                                                                     pos_score, P, dists, stats, grad_desc, grad_det,
+                                                                     (float*)ws, grad_anchor, grad_positive,
+                                                                     grad_anc_score, grad_pos_score);
   D3F_LAUNCH_CHECK();
   return D3F_OK;
 }

@@ -393,9 +393,14 @@ class _BiasActFn(torch.autograd.Function):
     def forward(ctx, x, b1, add, b2, slope):
         N, C = int(x.shape[0]), int(x.shape[1])
         out = torch.empty_like(x)
+        # the backward's bias-gradient accumulators [2, C] are cleared by the forward kernel on the side: no fill
+        # launch in backward, and the two bias parameters get separate buffers (autograd would clone a shared one)
+        nb = int(b1 is not None and ctx.needs_input_grad[1]) + int(b2 is not None and ctx.needs_input_grad[3])
+        gbuf = torch.empty((nb, C), dtype=torch.float32, device=x.device) if nb else None
         _native.check(_native.lib().d3f_bias_act_forward(_p(x), _p(b1), _p(add), _p(b2), float(slope), N, C, _p(out),
-                                                         _stream()), "d3f_bias_act_forward")
+                                                         _p(gbuf), nb * C, _stream()), "d3f_bias_act_forward")
         ctx.save_for_backward(out)
+        ctx.gbuf = gbuf
         ctx.slope = float(slope)
         ctx.has = (b1 is not None, add is not None, b2 is not None)
         return out
@@ -406,22 +411,31 @@ class _BiasActFn(torch.autograd.Function):
         N, C = int(out.shape[0]), int(out.shape[1])
         go = grad_out.contiguous()
         need_gx = ctx.needs_input_grad[0] or (ctx.has[1] and ctx.needs_input_grad[2])
-        need_gb = (ctx.has[0] and ctx.needs_input_grad[1]) or (ctx.has[2] and ctx.needs_input_grad[3])
+        want1 = ctx.has[0] and ctx.needs_input_grad[1]
+        want2 = ctx.has[2] and ctx.needs_input_grad[3]
         identity = ctx.slope == 1.0
-        gx = None
-        gb = torch.empty(C, dtype=torch.float32, device=go.device) if need_gb else None
-        if identity and not need_gb:
+        gx = g1 = g2 = None
+        if want1 or want2:
+            gbuf, pre = ctx.gbuf, 1
+            ctx.gbuf = None
+            if gbuf is None:  # a second backward through the same node: fresh, not pre-cleared accumulators
+                gbuf, pre = torch.empty((int(want1) + int(want2), C), dtype=torch.float32, device=go.device), 0
+            rows = list(gbuf.unbind(0))
+            g1 = rows.pop(0) if want1 else None
+            g2 = rows.pop(0) if want2 else None
+        if identity and not (want1 or want2):
             gx = go
-        elif need_gx or need_gb:
+        elif need_gx or want1 or want2:
             if need_gx and not identity:
                 gx = torch.empty_like(go)
-            _native.check(_native.lib().d3f_bias_act_backward(_p(go), _p(out), ctx.slope, N, C, _p(gx), _p(gb),
-                                                              _stream()), "d3f_bias_act_backward")
+            first, second = (g1, g2) if g1 is not None else (g2, None)
+            _native.check(_native.lib().d3f_bias_act_backward(_p(go), _p(out), ctx.slope, N, C, _p(gx), _p(first),
+                                                              _p(second), pre if first is not None else 0, _stream()),
+                          "d3f_bias_act_backward")
             if identity:
                 gx = go
-        return (gx if ctx.needs_input_grad[0] else None, gb if ctx.has[0] and ctx.needs_input_grad[1] else None,
-                gx if ctx.has[1] and ctx.needs_input_grad[2] else None,
-                gb if ctx.has[2] and ctx.needs_input_grad[3] else None, None)
+        return (gx if ctx.needs_input_grad[0] else None, g1, gx if ctx.has[1] and ctx.needs_input_grad[2] else None,
+                g2, None)
 
 
 def bias_act(x, bias1=None, add=None, bias2=None, slope=0.1):

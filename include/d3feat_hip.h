@@ -142,12 +142,15 @@ int d3f_closest_pool_backward(const float* grad_out, const int32_t* idx, int Nq,
  *   (:497,:598,:676), the bottleneck's residual add (:686) and, in backward, PyTorch's bias-gradient reduction.
  *   out = act(x + bias1 + (add + bias2)), act(v) = v > 0 ? v : slope*v  (slope = 1: identity); bias1/add/bias2 optional.
  *   backward: grad_x = grad_out * (out > 0 ? 1 : slope)  (also the gradient of `add`);
- *             grad_bias[c] = sum_n grad_x[n,c]  (gradient of bias1 and bias2; OVERWRITTEN).
+ *             grad_bias[c] = sum_n grad_x[n,c]  (gradient of bias1 and bias2; OVERWRITTEN); grad_bias2 (optional)
+ *             receives the same sums in a second buffer (two parameters, identical gradients).
+ * zero_init (optional, zero_n floats): scratch the forward kernel clears on the side -- the backward's bias-gradient
+ *   accumulators, so that backward (bias_prezeroed = 1) needs no separate fill launch.
  * ---------------------------------------------------------------------------------------------- */
 int d3f_bias_act_forward(const float* x, const float* bias1, const float* add, const float* bias2, float slope, int N,
-                         int C, float* out, void* stream);
+                         int C, float* out, float* zero_init, int zero_n, void* stream);
 int d3f_bias_act_backward(const float* grad_out, const float* out, float slope, int N, int C, float* grad_x,
-                          float* grad_bias, void* stream);
+                          float* grad_bias, float* grad_bias2, int bias_prezeroed, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Detector score -- replaces KPFCNN.detection_scores (models/architectures.py:322-368).
