@@ -27,6 +27,43 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s spec, ~6.3 TB/s achievable)
+F32_MFMA_PEAK_TFLOPS = 157.3  # dense fp32 matrix peak (v_mfma_f32_16x16x4_f32), same guide
+
+
+def dx_kernel_cost(Nq, Ns, H, Cin, Cout, K):
+    """Algorithmic (gather/scatter-expanded, SURVEY.md 8d convention) bytes and flops of ONE launch of the KPConv
+    grad-input kernel.  Cout == 0 marks the variant that reads gW = (g/nn) W^T from a library GEMM."""
+    common = 12 * Nq + 4 * Nq * H + 16 * Nq * H + 4 * Nq * H * Cin       # queries, index rows, packed supports, scatter rows
+    if Cout == 0:
+        return common + 4 * Nq * K * Cin, 2 * Nq * H * K * Cin
+    return common + 4 * Nq * Cout + 4 * Nq + 4 * K * Cin * Cout, 2 * Nq * K * Cin * Cout + 2 * Nq * H * K * Cin
+
+
+def fwd_kernel_cost(Nq, Ns, H, Cin, Cout, K):
+    return kpconv_fwd_bytes(Nq, Ns, H, K, Cin, Cout), 2 * Nq * H * K * Cin + 2 * Nq * K * Cin * Cout
+
+
+def timed_kernel(lib, which, run_steps, cost):
+    """HIP events on the launch stream around every launch of one library kernel (d3f_debug_kernel_timing_*)."""
+    import ctypes
+    cap = 1024
+    if lib.d3f_debug_kernel_timing_begin(which, cap) != 0:
+        return None
+    run_steps()
+    torch.cuda.synchronize()
+    ms = (ctypes.c_float * cap)()
+    sh = (ctypes.c_int32 * (6 * cap))()
+    n = min(lib.d3f_debug_kernel_timing_end(ms, sh, cap), cap)
+    if n <= 0:
+        return None
+    tot_ms = tot_b = tot_f = 0.0
+    for i in range(n):
+        b, f = cost(*[int(sh[6 * i + j]) for j in range(6)])
+        tot_ms += ms[i]
+        tot_b += b
+        tot_f += f
+    return {"launches": n, "avg_us": tot_ms / n * 1e3, "bytes_per_launch": tot_b / n, "flops_per_launch": tot_f / n,
+            "gbs": tot_b / (tot_ms * 1e-3) / 1e9, "tflops": tot_f / (tot_ms * 1e-3) / 1e12}
 
 
 def kpconv_fwd_bytes(Nq, Ns, H, K, Cin, Cout):
@@ -190,21 +227,50 @@ def main():
         dist.all_reduce(elapsed, op=dist.ReduceOp.MAX)
     elapsed = float(elapsed.item())
 
+    # Roofline leg: the dominant kernel of the training stream (profiles/r01*_kernel_stats*.txt) is the KPConv
+    # grad-input kernel; every launch of it in 3 eager steps is bracketed by HIP events inside the library, on the
+    # stream it is launched on.  The fused forward kernel is timed the same way for reference.
+    def _three_steps():
+        ts._pending = None
+        for k in range(3):
+            ts.step(items[k % len(items)])
+    dx_t = timed_kernel(_native.lib(), 2, _three_steps, dx_kernel_cost)
+    fw_t = timed_kernel(_native.lib(), 1, _three_steps, fwd_kernel_cost)
+
     if rank == 0:
         n_pts = [int(it[0].shape[0] + it[1].shape[0]) for it in items]
         summary = prof.summary()
-        dom = max(summary.items(), key=lambda kv: kv[1]["total_ms"]) if summary else None
         roofline = None
-        if dom is not None:
-            label, st = dom
-            achieved = st["bytes_per_call"] / (st["avg_ms"] * 1e-3) / 1e9
-            roofline = {"bound": "hbm", "kernel": label, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
-                        "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
-                        "avg_us": round(st["avg_ms"] * 1e3, 2), "calls": st["calls"],
-                        "algorithmic_bytes_per_launch": int(st["bytes_per_call"]),
-                        "share_of_step": round(st["total_ms"] / prof_steps / (elapsed / args.steps * 1e3), 4),
-                        "measured": "HIP events around the operator's launches, %d eager steps run right after the "
-                                    "timed region (events cannot be recorded inside graph replay)" % prof_steps}
+        if dx_t is not None:
+            traffic = None
+            tpath = os.path.join(REPO, "profiles", "pmc_traffic.json")
+            if os.path.exists(tpath):
+                with open(tpath) as f:
+                    traffic = json.load(f).get("kpconv_bwd_dx_kernel", {}).get("hbm_bytes_per_launch")
+            f_hbm = dx_t["gbs"] / HBM_PEAK_GBS
+            f_mfma = dx_t["tflops"] / F32_MFMA_PEAK_TFLOPS
+            mfma_bound = f_mfma > f_hbm
+            roofline = {
+                "bound": "mfma" if mfma_bound else "hbm",
+                "kernel": "kpconv_bwd_dx_kernel (KPConv grad-input: gW tile on f32 MFMA + influence-weighted scatter; "
+                          "all channel-width instantiations, every layer)",
+                "achieved": round(dx_t["tflops"] if mfma_bound else dx_t["gbs"], 2),
+                "peak": F32_MFMA_PEAK_TFLOPS if mfma_bound else HBM_PEAK_GBS,
+                "unit": "TFLOP/s" if mfma_bound else "GB/s",
+                "frac": round(max(f_mfma, f_hbm), 4),
+                "traffic": traffic,
+                "avg_us": round(dx_t["avg_us"], 2), "launches_timed": dx_t["launches"],
+                "algorithmic_bytes_per_launch": int(dx_t["bytes_per_launch"]),
+                "algorithmic_flops_per_launch": int(dx_t["flops_per_launch"]),
+                "hbm": {"achieved_GBs": round(dx_t["gbs"], 1), "frac": round(f_hbm, 4)},
+                "mfma_f32": {"achieved_TFLOPs": round(dx_t["tflops"], 2), "frac": round(f_mfma, 4)},
+                "also_timed": None if fw_t is None else {
+                    "kernel": "kpconv_fwd_fused_kernel", "avg_us": round(fw_t["avg_us"], 2),
+                    "launches_timed": fw_t["launches"], "achieved_GBs": round(fw_t["gbs"], 1),
+                    "achieved_TFLOPs": round(fw_t["tflops"], 2)},
+                "measured": "hipEventRecord on the launch stream immediately before/after each launch of the kernel "
+                            "(d3f_debug_kernel_timing_*), 3 eager steps after the timed region; averages are "
+                            "time-weighted over all launches (13 KPConv layers per step)"}
         res = {
             "metric": "fragment-pairs/sec (fwd+bwd) on 3DMatch-shaped pairs",
             "value": round(args.steps * world / elapsed, 3),

@@ -254,12 +254,24 @@ int kpconv_backward_fused(const float* q_pts, int Nq, const float* s_pts, int Ns
 
 using namespace d3f;
 
-namespace d3f { void kpconv_set_debug_flags(int f); }
+namespace d3f {
+void kpconv_set_debug_flags(int f);
+int kpconv_timing_begin(int which, int max_launches);
+int kpconv_timing_end(float* ms_out, int* shapes_out, int cap);
+}
 
 extern "C" {
 
 // profiling aid (not part of the operator contract): run-time ablation switches of the fused forward kernel
 void d3f_debug_set_flags(int flags) { d3f::kpconv_set_debug_flags(flags); }
+
+// measurement aid: HIP events on the launch stream around every launch of one kernel (which = 1: fused KPConv
+// forward kernel, 2: KPConv grad-input kernel) between begin and end; end (after a device synchronisation by the
+// caller) returns the launch count and fills per-launch milliseconds + {Nq, Ns, H, Cin, Cout, K}
+int d3f_debug_kernel_timing_begin(int which, int max_launches) { return d3f::kpconv_timing_begin(which, max_launches); }
+int d3f_debug_kernel_timing_end(float* ms_out, int32_t* shapes_out, int cap) {
+  return d3f::kpconv_timing_end(ms_out, shapes_out, cap);
+}
 
 size_t d3f_kpconv_ws_bytes(int Nq, int Ns, int H, int K, int Cin, int Cout) {
   (void)Ns; (void)H;

@@ -40,6 +40,53 @@ namespace d3f {
 static int g_debug_flags = 0;
 void kpconv_set_debug_flags(int f) { g_debug_flags = f; }
 
+// Measurement aid (bench.py's roofline leg): HIP events recorded on the launch stream right around ONE kernel of
+// this file (1 = fused forward, 2 = grad input), one event pair per launch, read back after a synchronisation.
+struct TimedLaunch { hipEvent_t e0, e1; int shape[6]; };
+static TimedLaunch* g_timed = nullptr;
+static int g_timed_which = 0, g_timed_cap = 0, g_timed_n = 0;
+
+struct TimingScope {
+  hipStream_t st;
+  TimedLaunch* t;
+  TimingScope(int which, hipStream_t stream, int Nq, int Ns, int H, int Cin, int Cout, int K) : st(stream), t(nullptr) {
+    if (which != g_timed_which || g_timed_n >= g_timed_cap) return;
+    t = &g_timed[g_timed_n++];
+    const int sh[6] = {Nq, Ns, H, Cin, Cout, K};
+    for (int i = 0; i < 6; ++i) t->shape[i] = sh[i];
+    (void)hipEventRecord(t->e0, st);
+  }
+  ~TimingScope() { if (t) (void)hipEventRecord(t->e1, st); }
+};
+
+int kpconv_timing_begin(int which, int max_launches) {
+  if (g_timed || which < 1 || which > 2 || max_launches < 1) return D3F_EINVAL;
+  g_timed = new TimedLaunch[max_launches];
+  for (int i = 0; i < max_launches; ++i)
+    if (hipEventCreate(&g_timed[i].e0) != hipSuccess || hipEventCreate(&g_timed[i].e1) != hipSuccess) return D3F_ELAUNCH;
+  g_timed_cap = max_launches;
+  g_timed_n = 0;
+  g_timed_which = which;
+  return D3F_OK;
+}
+
+// the caller has synchronised the device; returns the number of launches recorded (<= cap written)
+int kpconv_timing_end(float* ms_out, int* shapes_out, int cap) {
+  if (!g_timed) return D3F_EINVAL;
+  const int n = g_timed_n;
+  for (int i = 0; i < n && i < cap; ++i) {
+    float ms = 0.0f;
+    (void)hipEventElapsedTime(&ms, g_timed[i].e0, g_timed[i].e1);
+    ms_out[i] = ms;
+    for (int j = 0; j < 6; ++j) shapes_out[6 * i + j] = g_timed[i].shape[j];
+  }
+  for (int i = 0; i < g_timed_cap; ++i) { (void)hipEventDestroy(g_timed[i].e0); (void)hipEventDestroy(g_timed[i].e1); }
+  delete[] g_timed;
+  g_timed = nullptr;
+  g_timed_which = g_timed_cap = g_timed_n = 0;
+  return n;
+}
+
 // spack[n] = {s.x, s.y, s.z, (sum_c x[n,c] > 0) ? 1 : 0}; 16 lanes cooperate on one support row.
 // In backward the same lanes clear row n of grad_x (the scatter target) -- no separate fill launch.
 __global__ __launch_bounds__(256) void pack_supports_kernel(const float* __restrict__ s_pts,
@@ -443,6 +490,7 @@ static int launch_fused_cv(const float* q_pts, const float4* spack, const int32_
                                                                       Cout, K, extent, out, nn_out, wf_save,       \
                                                                       g_debug_flags);                            \
   }
+  TimingScope timing(1, stream, Nq, Ns, H, Cin, Cout, K);
   switch (slab) {
     case 16: D3F_LAUNCH(1, 4) break;
     case 32: D3F_LAUNCH(1, 2) break;
@@ -481,6 +529,7 @@ int kpconv_backward_fused(const float* q_pts, int Nq, const float* s_pts, int Ns
     const int CC = 16 * CV;
     const size_t lds = sizeof(float) * (size_t)(16 * (16 * CC + 4) + 16 * (Cout + 4));
     dim3 grid(tiles, Cin / CC);
+    TimingScope timing(2, stream, Nq, Ns, H, Cin, Cout, K);
     if (CV == 1) kpconv_bwd_dx_kernel<1><<<grid, 256, lds, stream>>>(q_pts, spack, idx, kp, W, nn, gout, Nq, Ns, H, Cin, Cout, K, extent, gx, nullptr, g_debug_flags);
     else if (CV == 2) kpconv_bwd_dx_kernel<2><<<grid, 256, lds, stream>>>(q_pts, spack, idx, kp, W, nn, gout, Nq, Ns, H, Cin, Cout, K, extent, gx, nullptr, g_debug_flags);
     else kpconv_bwd_dx_kernel<4><<<grid, 256, lds, stream>>>(q_pts, spack, idx, kp, W, nn, gout, Nq, Ns, H, Cin, Cout, K, extent, gx, nullptr, g_debug_flags);
@@ -525,6 +574,7 @@ int kpconv_grad_input_from_gw(const float* q_pts, int Nq, const float* s_pts, in
   const int CC = 16 * CV;
   const size_t lds = sizeof(float) * (size_t)(16 * (16 * CC + 4));
   dim3 grid(cdiv(Nq, 16), Cin / CC);
+  TimingScope timing(2, stream, Nq, Ns, H, Cin, 0, K);  // Cout = 0: gW comes from the caller's GEMM
 #define D3F_DXG(CVV)                                                                                                  \
   kpconv_bwd_dx_kernel<CVV><<<grid, 256, lds, stream>>>(q_pts, spack, idx, kp, nullptr, nullptr, nullptr, Nq, Ns, H, Cin, \
                                                         0, K, extent, gx, gwf, 0)

@@ -40,7 +40,13 @@ extern "C" {
 const char* d3f_version(void);
 int d3f_device_arch_ok(void); /* 1 if the current HIP device is gfx950, 0 otherwise, <0 = -(hipError_t) */
 int d3f_device_arch_name(char* out, int n); /* gcnArchName of the current device */
-void d3f_debug_set_flags(int flags);      /* profiling aid: ablation switches of the fused KPConv forward (0 = off) */
+void d3f_debug_set_flags(int flags);      /* profiling aid: ablation switches of the fused KPConv kernels (0 = off) */
+/* measurement aid (bench.py roofline leg): HIP events on the launch stream around every launch of ONE kernel
+ * (which = 1 fused KPConv forward kernel, 2 KPConv grad-input kernel) between begin and end.  end -- after the caller
+ * synchronised the device -- returns the number of launches seen and fills ms_out[i] and shapes_out[6*i .. 6*i+5] =
+ * {Nq, Ns, H, Cin, Cout, K} for the first `cap` of them. */
+int d3f_debug_kernel_timing_begin(int which, int max_launches);
+int d3f_debug_kernel_timing_end(float* ms_out, int32_t* shapes_out, int cap);
 
 /* ------------------------------------------------------------------------------------------------
  * Radius neighbors -- replaces radius_neighbors.batch_query
