@@ -571,8 +571,10 @@ def mutual_nn(source_desc, target_desc):
     ra = torch.empty(Ns, dtype=torch.int32, device=s.device)
     ca = torch.empty(Nt, dtype=torch.int32, device=s.device)
     mu = torch.empty(Ns, dtype=torch.int32, device=s.device)
-    _native.check(_native.lib().d3f_mutual_nn(_p(s), Ns, _p(t), Nt, C, _p(ra), _p(ca), _p(mu), _stream()),
-                  "d3f_mutual_nn")
+    nbytes = _native.lib().d3f_mutual_nn_ws_bytes(Ns, Nt)
+    ws = _ws(nbytes, s.device)
+    _native.check(_native.lib().d3f_mutual_nn(_p(s), Ns, _p(t), Nt, C, _p(ra), _p(ca), _p(mu), _p(ws), nbytes,
+                                              _stream()), "d3f_mutual_nn")
     return ra, ca, mu
 
 

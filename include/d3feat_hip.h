@@ -203,12 +203,14 @@ int d3f_circle_det_loss_backward(const float* anchor, const float* positive, int
 /* ------------------------------------------------------------------------------------------------
  * Dense matching -- replaces build_correspondence (geometric_registration/common.py:5-21): the
  * [Ns,Nt] distance matrix sqrt(2 - 2 S.T^T) is never materialised; an f32 MFMA tile kernel keeps a running
- * row arg-min (and, with the operands swapped, the column arg-min).  row_argmin [Ns], col_argmin [Nt] int32
+ * row arg-min (and, with the operands swapped, the column arg-min); the target range is split over workgroups and
+ * merged with one 64-bit atomicMin per row on (distance bits, column).  row_argmin [Ns], col_argmin [Nt] int32
  * (lowest index on ties, like np.argmin), mutual [Ns] int32 (optional) = 1 where col_argmin[row_argmin[i]] == i.
  * C in {16, 32, 64, 128}.
  * ---------------------------------------------------------------------------------------------- */
+size_t d3f_mutual_nn_ws_bytes(int Ns, int Nt);
 int d3f_mutual_nn(const float* src_desc, int Ns, const float* tgt_desc, int Nt, int C, int32_t* row_argmin,
-                  int32_t* col_argmin, int32_t* mutual, void* stream);
+                  int32_t* col_argmin, int32_t* mutual, void* ws, size_t ws_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Optimizer step with the reference's non-finite-gradient guard -- replaces trainer.py:104-111 (per-parameter
