@@ -138,13 +138,22 @@ __device__ __forceinline__ float ord2f(uint32_t o) {
   return __uint_as_float((o & 0x80000000u) ? (o & 0x7fffffffu) : ~o);
 }
 
+// one contended atomic per WORKGROUP (a per-wave atomic on a single word serialises: ~8 ns each, 4096 of them)
+__device__ __forceinline__ float block_max256(float m) {
+  __shared__ float sh[4];
+  m = d3f::wave_max(m);
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = m;
+  __syncthreads();
+  return fmaxf(fmaxf(sh[0], sh[1]), fmaxf(sh[2], sh[3]));
+}
+
 __global__ __launch_bounds__(256) void gmax_partial_kernel(const float* __restrict__ x, size_t n,
                                                            uint32_t* __restrict__ enc) {
   float m = -INFINITY;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
     m = fmaxf(m, x[i]);
-  m = d3f::wave_max(m);
-  if ((threadIdx.x & 63) == 0) atomicMax(enc, f2ord(m));
+  m = block_max256(m);
+  if (threadIdx.x == 0) atomicMax(enc, f2ord(m));
 }
 __global__ __launch_bounds__(256) void gmax_rows_kernel(const float* __restrict__ x, int cap_rows, int C,
                                                         const int32_t* __restrict__ len, int B,
@@ -155,8 +164,8 @@ __global__ __launch_bounds__(256) void gmax_rows_kernel(const float* __restrict_
   float m = -INFINITY;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
     m = fmaxf(m, x[i]);
-  m = d3f::wave_max(m);
-  if ((threadIdx.x & 63) == 0) atomicMax(enc, f2ord(m));
+  m = block_max256(m);
+  if (threadIdx.x == 0) atomicMax(enc, f2ord(m));
 }
 __global__ void gmax_final_kernel(const uint32_t* __restrict__ enc, float* __restrict__ out) { *out = ord2f(*enc); }
 
@@ -171,11 +180,17 @@ __global__ __launch_bounds__(256) void det_reduce_kernel(const float* __restrict
     s += df[i] * (v / denom);
     t += v == mx ? 1.0f : 0.0f;
   }
+  __shared__ float sh[2][4];
   s = d3f::wave_sum(s);
   t = d3f::wave_sum(t);
   if ((threadIdx.x & 63) == 0) {
-    atomicAdd(&acc[0], s);
-    atomicAdd(&acc[1], t);
+    sh[0][threadIdx.x >> 6] = s;
+    sh[1][threadIdx.x >> 6] = t;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    atomicAdd(&acc[0], (sh[0][0] + sh[0][1]) + (sh[0][2] + sh[0][3]));
+    atomicAdd(&acc[1], (sh[1][0] + sh[1][1]) + (sh[1][2] + sh[1][3]));
   }
 }
 
@@ -199,7 +214,7 @@ int d3f_global_max(const float* x, size_t n, float* out_max, void* ws, size_t ws
   hipStream_t stream = (hipStream_t)stream_;
   if (d3f::zero_async(ws, 4, stream) != hipSuccess) return D3F_ELAUNCH;
   int blocks = d3f::cdiv((long long)n, 256 * 8);
-  if (blocks > 1024) blocks = 1024;
+  if (blocks > 512) blocks = 512;
   gmax_partial_kernel<<<blocks, 256, 0, stream>>>(x, n, (uint32_t*)ws);
   gmax_final_kernel<<<1, 1, 0, stream>>>((const uint32_t*)ws, out_max);
   D3F_LAUNCH_CHECK();
@@ -212,7 +227,7 @@ int d3f_global_max_rows(const float* x, int cap_rows, int C, const int32_t* len,
   hipStream_t stream = (hipStream_t)stream_;
   if (d3f::zero_async(ws, 4, stream) != hipSuccess) return D3F_ELAUNCH;
   int blocks = d3f::cdiv((long long)cap_rows * C, 256 * 8);
-  if (blocks > 1024) blocks = 1024;
+  if (blocks > 512) blocks = 512;
   gmax_rows_kernel<<<blocks, 256, 0, stream>>>(x, cap_rows, C, len, B, (uint32_t*)ws);
   gmax_final_kernel<<<1, 1, 0, stream>>>((const uint32_t*)ws, out_max);
   D3F_LAUNCH_CHECK();
@@ -250,7 +265,7 @@ int d3f_detection_scores_backward(const float* feat, int N, int C, const int32_t
   else if (C <= 32) det_bwd_kernel<32><<<grid, 256, 0, stream>>>(feat, N, C, idx, H, feat_max, grad_scores, grad_feat);
   else det_bwd_kernel<64><<<grid, 256, 0, stream>>>(feat, N, C, idx, H, feat_max, grad_scores, grad_feat);
   int blocks = d3f::cdiv((long long)n, 256 * 8);
-  if (blocks > 1024) blocks = 1024;
+  if (blocks > 512) blocks = 512;
   det_reduce_kernel<<<blocks, 256, 0, stream>>>(feat, grad_feat, n, feat_max, (float*)ws);
   det_finalize_kernel<<<d3f::cdiv((long long)n, 256), 256, 0, stream>>>(feat, n, feat_max, (const float*)ws, grad_feat);
   D3F_LAUNCH_CHECK();

@@ -223,19 +223,35 @@ __global__ void insert_kernel(const float* __restrict__ p, int N, const int32_t*
   slot_of[i] = (int32_t)s;
 }
 
-__global__ void alloc_kernel(uint32_t M, const uint64_t* __restrict__ tkey, int32_t* __restrict__ tcount,
+// member-list ranges: the total is one word, so the reservation is aggregated per wave (inclusive scan of the counts,
+// ONE atomic by the last lane) -- a per-cell atomic on a single word serialises (46 us for 12k cells)
+__global__ void alloc_kernel(uint32_t M, int B, const uint64_t* __restrict__ tkey, int32_t* __restrict__ tcount,
                              const int32_t* __restrict__ tfirst, int32_t* __restrict__ tstart,
                              int32_t* __restrict__ tfill, uint64_t* __restrict__ bitmap, int32_t* __restrict__ ncell) {
   const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
-  if (s >= M) return;
-  const int c = tcount[s];
+  const int lane = threadIdx.x & 63;
+  const int c = s < M ? tcount[s] : 0;
+  int incl = c;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const int t = __shfl_up(incl, o, 64);
+    if (lane >= o) incl += t;
+  }
+  const int total = __shfl(incl, 63, 64);
+  int base = 0;
+  if (lane == 63 && total > 0) base = atomicAdd(&tcount[M], total);
+  base = __shfl(base, 63, 64);
+  const int b = c > 0 ? (int)(tkey[s] >> 56) : -1;
+  for (int k = 0; k < B; ++k) {
+    const unsigned long long m = __ballot(b == k);
+    if (lane == 0 && m) atomicAdd(&ncell[k], __popcll(m));
+  }
   if (c == 0) return;
-  const int st = atomicAdd(&tcount[M], c);
+  const int st = base + incl - c;
   tstart[s] = st;
   tfill[s] = st;
   const int f = tfirst[s];
   atomicOr((unsigned long long*)&bitmap[f >> 6], 1ull << (f & 63));
-  atomicAdd(&ncell[(int)(tkey[s] >> 56)], 1);
 }
 
 __global__ void scatter_kernel(int N, const int32_t* __restrict__ len, int B, const int32_t* __restrict__ slot_of,
@@ -469,7 +485,7 @@ int d3f_grid_subsample(const float* points, int N, const int32_t* len, int B, fl
   bbox_kernel<<<B, 1024, 0, stream>>>(points, len, sampleDl, L.grid);
   insert_kernel<<<d3f::cdiv(N, 256), 256, 0, stream>>>(points, N, len, B, sampleDl, L.grid, L.M - 1, L.tkey, L.tcount,
                                                        L.tfirst, L.slot_of, status);
-  alloc_kernel<<<d3f::cdiv(L.M, 256), 256, 0, stream>>>(L.M, L.tkey, L.tcount, L.tfirst, L.tstart, L.tfill, L.bitmap,
+  alloc_kernel<<<d3f::cdiv(L.M, 256), 256, 0, stream>>>(L.M, B, L.tkey, L.tcount, L.tfirst, L.tstart, L.tfill, L.bitmap,
                                                         L.ncell);
   scatter_kernel<<<d3f::cdiv(N, 256), 256, 0, stream>>>(N, len, B, L.slot_of, L.tfill, L.members);
   cell_sum_kernel<<<d3f::cdiv(L.M, 256), 256, 0, stream>>>(L.M, points, L.tcount, L.tstart, L.members, L.bary);
