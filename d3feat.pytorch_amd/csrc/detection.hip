@@ -130,6 +130,120 @@ __global__ __launch_bounds__(256) void det_bwd_kernel(const float* __restrict__ 
   }
 }
 
+// ---- 16-byte gathers: lane = (4 channels, neighbor group); LP = C/4 lanes serve one neighbor row, 64/LP rows per step.
+// Training additionally leaves 8 scalars per point behind (aux) so that the backward pass needs no feature gather:
+//   {f*, alpha*, beta*, u*, dmax, num, c* (int bits), c' (int bits)}   (* = winning channel, ' = channel of max_c f)
+template <int LP>
+__global__ __launch_bounds__(256) void det_fwd_v4_kernel(const float* __restrict__ feat, int N,
+                                                         const int32_t* __restrict__ idx, int H,
+                                                         const float* __restrict__ fmax, int training,
+                                                         float* __restrict__ scores, float* __restrict__ aux) {
+  constexpr int C = 4 * LP, G = 64 / LP;
+  const int lane = threadIdx.x & 63;
+  const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (n >= N) return;
+  const int c4 = lane % LP, g = lane / LP;
+  const float denom = fmaxf(*fmax, 0.0f) + 1e-6f;  // the reference's max includes its zero shadow row (:336-342)
+  const int32_t* row = idx + (size_t)n * H;
+  float4 msum = make_float4(0.f, 0.f, 0.f, 0.f), lmax = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+  int cnt = 0;
+  for (int h0 = 0; h0 < H; h0 += G) {
+    const int h = h0 + g;
+    const int m = h < H ? row[h] : N;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (m >= 0 && m < N) {
+      const float4 t = *(const float4*)(feat + (size_t)m * C + 4 * c4);
+      v = make_float4(t.x / denom, t.y / denom, t.z / denom, t.w / denom);
+    }
+    const float rs = group_sum<LP>((v.x + v.y) + (v.z + v.w));
+    if (h < H) {
+      cnt += rs != 0.0f;
+      msum.x += v.x; msum.y += v.y; msum.z += v.z; msum.w += v.w;
+      lmax.x = fmaxf(lmax.x, v.x); lmax.y = fmaxf(lmax.y, v.y); lmax.z = fmaxf(lmax.z, v.z); lmax.w = fmaxf(lmax.w, v.w);
+    }
+  }
+#pragma unroll
+  for (int o = LP; o < 64; o <<= 1) {
+    msum.x += __shfl_xor(msum.x, o, 64); msum.y += __shfl_xor(msum.y, o, 64);
+    msum.z += __shfl_xor(msum.z, o, 64); msum.w += __shfl_xor(msum.w, o, 64);
+    cnt += __shfl_xor(cnt, o, 64);
+    lmax.x = fmaxf(lmax.x, __shfl_xor(lmax.x, o, 64)); lmax.y = fmaxf(lmax.y, __shfl_xor(lmax.y, o, 64));
+    lmax.z = fmaxf(lmax.z, __shfl_xor(lmax.z, o, 64)); lmax.w = fmaxf(lmax.w, __shfl_xor(lmax.w, o, 64));
+  }
+  const float num = (float)(cnt > 1 ? cnt : 1);
+  const float4 t = *(const float4*)(feat + (size_t)n * C + 4 * c4);
+  const float fs[4] = {t.x / denom, t.y / denom, t.z / denom, t.w / denom};
+  const float mean[4] = {msum.x / num, msum.y / num, msum.z / num, msum.w / num};
+  const float lm[4] = {lmax.x, lmax.y, lmax.z, lmax.w};
+  const float dmax = group_max<LP>(fmaxf(fmaxf(fs[0], fs[1]), fmaxf(fs[2], fs[3])));
+  float u[4], al[4], be[4], sc[4];
+  float best = -INFINITY;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    u[k] = fs[k] - mean[k];
+    al[k] = softplus_t(u[k]);
+    be[k] = fs[k] / (1e-6f + dmax);
+    sc[k] = al[k] * be[k];
+    best = fmaxf(best, sc[k]);
+  }
+  best = group_max<LP>(best);
+  float score = best;
+  if (!training) {
+    float is = 0.0f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) is = fmaxf(is, fs[k] == lm[k] ? 1.0f : 0.0f);
+    score *= group_max<LP>(is);
+  }
+  if (lane == 0) scores[n] = score;
+  if (aux) {
+    // first channel attaining the max (torch.max returns the first maximal index), and first channel of max_c f
+    int cs = 0x7fffffff, cp = 0x7fffffff;
+#pragma unroll
+    for (int k = 3; k >= 0; --k) {
+      if (sc[k] == best) cs = 4 * c4 + k;
+      if (fs[k] == dmax) cp = 4 * c4 + k;
+    }
+#pragma unroll
+    for (int o = LP >> 1; o > 0; o >>= 1) {
+      cs = min(cs, __shfl_xor(cs, o, 64));
+      cp = min(cp, __shfl_xor(cp, o, 64));
+    }
+    // the lane that owns channel c* publishes its values
+    if (g == 0 && (cs >> 2) == c4) {
+      const int k = cs & 3;
+      float* a = aux + (size_t)n * 8;
+      a[0] = fs[k]; a[1] = al[k]; a[2] = be[k]; a[3] = u[k];
+      a[4] = dmax; a[5] = num; a[6] = __int_as_float(cs); a[7] = __int_as_float(cp);
+    }
+  }
+}
+
+// backward from aux: no feature gather, one wave per point (self terms + one atomic per neighbor)
+__global__ __launch_bounds__(256) void det_bwd_aux_kernel(const float* __restrict__ aux, int N, int C,
+                                                          const int32_t* __restrict__ idx, int H,
+                                                          const float* __restrict__ gscore, float* __restrict__ df) {
+  const int lane = threadIdx.x & 63;
+  const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (n >= N) return;
+  const float* a = aux + (size_t)n * 8;
+  const float f_star = a[0], a_star = a[1], b_star = a[2], u_star = a[3], dmax = a[4], num = a[5];
+  const int cstar = __float_as_int(a[6]), cprime = __float_as_int(a[7]);
+  const float ds = gscore[n];
+  const float sig = u_star > 20.0f ? 1.0f : 1.0f / (1.0f + expf(-u_star));
+  const float du = ds * b_star * sig;
+  const float inv = 1.0f / (1e-6f + dmax);
+  if (lane == 0) {
+    atomicAdd(&df[(size_t)n * C + cstar], du + ds * a_star * inv);
+    atomicAdd(&df[(size_t)n * C + cprime], -ds * a_star * f_star * inv * inv);
+  }
+  const float gn = -du / num;
+  const int32_t* row = idx + (size_t)n * H;
+  for (int h = lane; h < H; h += 64) {
+    const int m = row[h];
+    if (m >= 0 && m < N) atomicAdd(&df[(size_t)m * C + cstar], gn);
+  }
+}
+
 __device__ __forceinline__ uint32_t f2ord(float f) {
   const uint32_t b = __float_as_uint(f);
   return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
@@ -234,12 +348,22 @@ int d3f_global_max_rows(const float* x, int cap_rows, int C, const int32_t* len,
   return D3F_OK;
 }
 
+int d3f_detection_scores_aux_floats(int C) { return (C == 16 || C == 32 || C == 64) ? 8 : 0; }
+
 int d3f_detection_scores_forward(const float* feat, int N, int C, const int32_t* idx, int H, const float* feat_max,
-                                 int training, float* scores, void* stream_) {
+                                 int training, float* scores, float* aux, void* stream_) {
   if (!feat || !idx || !feat_max || !scores || N < 0 || C < 1 || C > 64 || H < 1) return D3F_EINVAL;
+  if (aux && (!training || !d3f_detection_scores_aux_floats(C))) return D3F_EINVAL;
   if (N == 0) return D3F_OK;
   hipStream_t stream = (hipStream_t)stream_;
   const int grid = d3f::cdiv(N, 4);
+  if (C == 16 || C == 32 || C == 64) {
+    if (C == 16) det_fwd_v4_kernel<4><<<grid, 256, 0, stream>>>(feat, N, idx, H, feat_max, training, scores, aux);
+    else if (C == 32) det_fwd_v4_kernel<8><<<grid, 256, 0, stream>>>(feat, N, idx, H, feat_max, training, scores, aux);
+    else det_fwd_v4_kernel<16><<<grid, 256, 0, stream>>>(feat, N, idx, H, feat_max, training, scores, aux);
+    D3F_LAUNCH_CHECK();
+    return D3F_OK;
+  }
   if (C <= 16) det_fwd_kernel<16><<<grid, 256, 0, stream>>>(feat, N, C, idx, H, feat_max, training, scores);
   else if (C <= 32) det_fwd_kernel<32><<<grid, 256, 0, stream>>>(feat, N, C, idx, H, feat_max, training, scores);
   else det_fwd_kernel<64><<<grid, 256, 0, stream>>>(feat, N, C, idx, H, feat_max, training, scores);
@@ -250,8 +374,8 @@ int d3f_detection_scores_forward(const float* feat, int N, int C, const int32_t*
 size_t d3f_detection_scores_ws_bytes(int N, int C) { (void)N; (void)C; return 256; }
 
 int d3f_detection_scores_backward(const float* feat, int N, int C, const int32_t* idx, int H, const float* feat_max,
-                                  const float* grad_scores, float* grad_feat, void* ws, size_t ws_bytes,
-                                  void* stream_) {
+                                  const float* grad_scores, const float* aux, float* grad_feat, void* ws,
+                                  size_t ws_bytes, void* stream_) {
   if (!feat || !idx || !feat_max || !grad_scores || !grad_feat || !ws || ws_bytes < 8 || N < 0 || C < 1 || C > 64 ||
       H < 1)
     return D3F_EINVAL;
@@ -261,7 +385,8 @@ int d3f_detection_scores_backward(const float* feat, int N, int C, const int32_t
   if (d3f::zero_async(grad_feat, sizeof(float) * n, stream) != hipSuccess) return D3F_ELAUNCH;
   if (d3f::zero_async(ws, 8, stream) != hipSuccess) return D3F_ELAUNCH;
   const int grid = d3f::cdiv(N, 4);
-  if (C <= 16) det_bwd_kernel<16><<<grid, 256, 0, stream>>>(feat, N, C, idx, H, feat_max, grad_scores, grad_feat);
+  if (aux) det_bwd_aux_kernel<<<grid, 256, 0, stream>>>(aux, N, C, idx, H, grad_scores, grad_feat);
+  else if (C <= 16) det_bwd_kernel<16><<<grid, 256, 0, stream>>>(feat, N, C, idx, H, feat_max, grad_scores, grad_feat);
   else if (C <= 32) det_bwd_kernel<32><<<grid, 256, 0, stream>>>(feat, N, C, idx, H, feat_max, grad_scores, grad_feat);
   else det_bwd_kernel<64><<<grid, 256, 0, stream>>>(feat, N, C, idx, H, feat_max, grad_scores, grad_feat);
   int blocks = d3f::cdiv((long long)n, 256 * 8);

@@ -168,12 +168,16 @@ int d3f_global_max(const float* x, size_t n, float* out_max, void* ws /* >= 4 by
 /* same over the first sum(len) rows of x [cap_rows, C] (row count read on the device) */
 int d3f_global_max_rows(const float* x, int cap_rows, int C, const int32_t* len, int B, float* out_max, void* ws,
                         size_t ws_bytes, void* stream);
+/* aux (optional, training only, [N, d3f_detection_scores_aux_floats(C)]): per-point scalars of the winning channel,
+ * left behind so that the backward pass does not gather features again. */
+int d3f_detection_scores_aux_floats(int C); /* 8 for C in {16, 32, 64}, 0 (aux unsupported) otherwise */
 int d3f_detection_scores_forward(const float* feat, int N, int C, const int32_t* idx, int H, const float* feat_max,
-                                 int training, float* scores, void* stream);
-/* grad_feat [N,C] is OVERWRITTEN.  Includes the gradient through the global max normaliser. */
+                                 int training, float* scores, float* aux, void* stream);
+/* grad_feat [N,C] is OVERWRITTEN.  Includes the gradient through the global max normaliser.  aux: the forward's
+ * (optional; without it the neighborhood statistics are recomputed). */
 int d3f_detection_scores_backward(const float* feat, int N, int C, const int32_t* idx, int H, const float* feat_max,
-                                  const float* grad_scores, float* grad_feat, void* ws, size_t ws_bytes,
-                                  void* stream);
+                                  const float* grad_scores, const float* aux, float* grad_feat, void* ws,
+                                  size_t ws_bytes, void* stream);
 size_t d3f_detection_scores_ws_bytes(int N, int C);
 
 /* ------------------------------------------------------------------------------------------------

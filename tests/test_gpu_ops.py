@@ -255,7 +255,7 @@ def test_bias_act(n, c, slope, with_add):
 
 
 # ------------------------------------------------------------------------------------------------ detector score
-@pytest.mark.parametrize("c", [32, 16, 48])
+@pytest.mark.parametrize("c", [32, 16, 48, 64])
 def test_detection_scores(c):
     rng = np.random.default_rng(c)
     n, h = 1500, 30
