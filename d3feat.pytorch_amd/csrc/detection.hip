@@ -147,19 +147,31 @@ __global__ __launch_bounds__(256) void det_fwd_v4_kernel(const float* __restrict
   const int32_t* row = idx + (size_t)n * H;
   float4 msum = make_float4(0.f, 0.f, 0.f, 0.f), lmax = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
   int cnt = 0;
-  for (int h0 = 0; h0 < H; h0 += G) {
-    const int h = h0 + g;
-    const int m = h < H ? row[h] : N;
-    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (m >= 0 && m < N) {
-      const float4 t = *(const float4*)(feat + (size_t)m * C + 4 * c4);
-      v = make_float4(t.x / denom, t.y / denom, t.z / denom, t.w / denom);
+  // the whole index row in one coalesced load (H <= 64), then all gathers of a batch of steps issued back to back:
+  // one memory latency per batch instead of two dependent ones per step
+  const int mrow = lane < H ? row[lane] : N;
+  constexpr int SB = 4;  // steps per batch
+  for (int h0 = 0; h0 < H; h0 += G * SB) {
+    float4 raw[SB];
+    bool live[SB];
+#pragma unroll
+    for (int s = 0; s < SB; ++s) {
+      const int h = h0 + s * G + g;
+      const int m = __shfl(mrow, h & 63, 64);
+      live[s] = h < H && m >= 0 && m < N;
+      raw[s] = live[s] ? *(const float4*)(feat + (size_t)m * C + 4 * c4) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
-    const float rs = group_sum<LP>((v.x + v.y) + (v.z + v.w));
-    if (h < H) {
-      cnt += rs != 0.0f;
-      msum.x += v.x; msum.y += v.y; msum.z += v.z; msum.w += v.w;
-      lmax.x = fmaxf(lmax.x, v.x); lmax.y = fmaxf(lmax.y, v.y); lmax.z = fmaxf(lmax.z, v.z); lmax.w = fmaxf(lmax.w, v.w);
+#pragma unroll
+    for (int s = 0; s < SB; ++s) {
+      const int h = h0 + s * G + g;
+      const float4 v = live[s] ? make_float4(raw[s].x / denom, raw[s].y / denom, raw[s].z / denom, raw[s].w / denom)
+                               : make_float4(0.f, 0.f, 0.f, 0.f);
+      const float rs = group_sum<LP>((v.x + v.y) + (v.z + v.w));
+      if (h < H) {
+        cnt += rs != 0.0f;
+        msum.x += v.x; msum.y += v.y; msum.z += v.z; msum.w += v.w;
+        lmax.x = fmaxf(lmax.x, v.x); lmax.y = fmaxf(lmax.y, v.y); lmax.z = fmaxf(lmax.z, v.z); lmax.w = fmaxf(lmax.w, v.w);
+      }
     }
   }
 #pragma unroll
@@ -218,30 +230,27 @@ __global__ __launch_bounds__(256) void det_fwd_v4_kernel(const float* __restrict
   }
 }
 
-// backward from aux: no feature gather, one wave per point (self terms + one atomic per neighbor)
+// backward from aux: no feature gather; one THREAD per (point, neighbor slot) -- the index table is read fully
+// coalesced and a wave's 64 atomics belong to 1-2 points (one wave per point is dispatch-rate bound: 80 us)
 __global__ __launch_bounds__(256) void det_bwd_aux_kernel(const float* __restrict__ aux, int N, int C,
                                                           const int32_t* __restrict__ idx, int H,
                                                           const float* __restrict__ gscore, float* __restrict__ df) {
-  const int lane = threadIdx.x & 63;
-  const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (n >= N) return;
-  const float* a = aux + (size_t)n * 8;
-  const float f_star = a[0], a_star = a[1], b_star = a[2], u_star = a[3], dmax = a[4], num = a[5];
-  const int cstar = __float_as_int(a[6]), cprime = __float_as_int(a[7]);
+  const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= (size_t)N * H) return;
+  const int n = (int)(t / H), h = (int)(t % H);
+  const float4 a0 = *(const float4*)(aux + (size_t)n * 8);      // f*, alpha*, beta*, u*
+  const float4 a1 = *(const float4*)(aux + (size_t)n * 8 + 4);  // dmax, num, c*, c'
+  const int cstar = __float_as_int(a1.z);
   const float ds = gscore[n];
-  const float sig = u_star > 20.0f ? 1.0f : 1.0f / (1.0f + expf(-u_star));
-  const float du = ds * b_star * sig;
-  const float inv = 1.0f / (1e-6f + dmax);
-  if (lane == 0) {
-    atomicAdd(&df[(size_t)n * C + cstar], du + ds * a_star * inv);
-    atomicAdd(&df[(size_t)n * C + cprime], -ds * a_star * f_star * inv * inv);
+  const float sig = a0.w > 20.0f ? 1.0f : 1.0f / (1.0f + expf(-a0.w));
+  const float du = ds * a0.z * sig;
+  if (h == 0) {
+    const float inv = 1.0f / (1e-6f + a1.x);
+    atomicAdd(&df[(size_t)n * C + cstar], du + ds * a0.y * inv);
+    atomicAdd(&df[(size_t)n * C + __float_as_int(a1.w)], -ds * a0.y * a0.x * inv * inv);
   }
-  const float gn = -du / num;
-  const int32_t* row = idx + (size_t)n * H;
-  for (int h = lane; h < H; h += 64) {
-    const int m = row[h];
-    if (m >= 0 && m < N) atomicAdd(&df[(size_t)m * C + cstar], gn);
-  }
+  const int m = idx[t];
+  if (m >= 0 && m < N) atomicAdd(&df[(size_t)m * C + cstar], -du / a1.y);
 }
 
 __device__ __forceinline__ uint32_t f2ord(float f) {
@@ -348,16 +357,16 @@ int d3f_global_max_rows(const float* x, int cap_rows, int C, const int32_t* len,
   return D3F_OK;
 }
 
-int d3f_detection_scores_aux_floats(int C) { return (C == 16 || C == 32 || C == 64) ? 8 : 0; }
+int d3f_detection_scores_aux_floats(int C) { return (C == 16 || C == 32 || C == 64) ? 8 : 0; }  /* and H <= 64 */
 
 int d3f_detection_scores_forward(const float* feat, int N, int C, const int32_t* idx, int H, const float* feat_max,
                                  int training, float* scores, float* aux, void* stream_) {
   if (!feat || !idx || !feat_max || !scores || N < 0 || C < 1 || C > 64 || H < 1) return D3F_EINVAL;
-  if (aux && (!training || !d3f_detection_scores_aux_floats(C))) return D3F_EINVAL;
+  if (aux && (!training || !d3f_detection_scores_aux_floats(C) || H > 64)) return D3F_EINVAL;
   if (N == 0) return D3F_OK;
   hipStream_t stream = (hipStream_t)stream_;
   const int grid = d3f::cdiv(N, 4);
-  if (C == 16 || C == 32 || C == 64) {
+  if ((C == 16 || C == 32 || C == 64) && H <= 64) {
     if (C == 16) det_fwd_v4_kernel<4><<<grid, 256, 0, stream>>>(feat, N, idx, H, feat_max, training, scores, aux);
     else if (C == 32) det_fwd_v4_kernel<8><<<grid, 256, 0, stream>>>(feat, N, idx, H, feat_max, training, scores, aux);
     else det_fwd_v4_kernel<16><<<grid, 256, 0, stream>>>(feat, N, idx, H, feat_max, training, scores, aux);
@@ -385,7 +394,7 @@ int d3f_detection_scores_backward(const float* feat, int N, int C, const int32_t
   if (d3f::zero_async(grad_feat, sizeof(float) * n, stream) != hipSuccess) return D3F_ELAUNCH;
   if (d3f::zero_async(ws, 8, stream) != hipSuccess) return D3F_ELAUNCH;
   const int grid = d3f::cdiv(N, 4);
-  if (aux) det_bwd_aux_kernel<<<grid, 256, 0, stream>>>(aux, N, C, idx, H, grad_scores, grad_feat);
+  if (aux) det_bwd_aux_kernel<<<d3f::cdiv((long long)N * H, 256), 256, 0, stream>>>(aux, N, C, idx, H, grad_scores, grad_feat);
   else if (C <= 16) det_bwd_kernel<16><<<grid, 256, 0, stream>>>(feat, N, C, idx, H, feat_max, grad_scores, grad_feat);
   else if (C <= 32) det_bwd_kernel<32><<<grid, 256, 0, stream>>>(feat, N, C, idx, H, feat_max, grad_scores, grad_feat);
   else det_bwd_kernel<64><<<grid, 256, 0, stream>>>(feat, N, C, idx, H, feat_max, grad_scores, grad_feat);

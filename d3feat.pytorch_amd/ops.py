@@ -475,7 +475,7 @@ class _DetScoreFn(torch.autograd.Function):
         N, C, H = int(feat.shape[0]), int(feat.shape[1]), int(idx.shape[1])
         fmax = global_max(feat, lens)
         scores = torch.empty((N, 1), dtype=torch.float32, device=feat.device)
-        na = _native.lib().d3f_detection_scores_aux_floats(C) if (training and ctx.needs_input_grad[0]) else 0
+        na = _native.lib().d3f_detection_scores_aux_floats(C) if (training and ctx.needs_input_grad[0] and H <= 64) else 0
         aux = torch.empty((N, na), dtype=torch.float32, device=feat.device) if na else None
         with _region("detection_fwd[N=%d]" % N, 4 * N * H + 4 * N * H * C + 4 * N * C + 4 * N):
             _native.check(_native.lib().d3f_detection_scores_forward(_p(feat), N, C, _p(idx), H, _p(fmax),
