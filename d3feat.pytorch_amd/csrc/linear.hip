@@ -157,6 +157,104 @@ int atb_splitk(const float* A, const float* B, const float* row_div, int R, int 
   return D3F_OK;
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// Y [N,M] = epilogue( X [N,K] . B [K,M] ) for MANY rows and a SMALL weight matrix (unary blocks of the upper pyramid
+// levels: N = 8k..38k points, K, M <= 256).  A library GEMM is launch/latency bound there (6-20 us for 15-30 MB of
+// streaming) and needs a separate bias/activation pass.  Here a wave owns 16*RT rows and ALL M columns:
+//   A fragments = one float4 of the row per 16 reduction indices (x is streamed from HBM exactly once),
+//   B fragments straight from the weight matrix in L2 (WT: B[k][m] = W[m][k], the forward of nn.Linear -- 4 reduction
+//   indices are one contiguous float4 of W's row m; !WT: B = W as stored, grad_x = g W),
+//   RT*M/16 accumulators in registers, and the epilogue out = act(acc + b1 + add + b2) is applied before the only store.
+template <int MBW, int CS, bool WT, bool EPI>
+__global__ __launch_bounds__(256) void rowgemm_kernel(const float* __restrict__ X, const float* __restrict__ W, int N,
+                                                      int K, const float* __restrict__ b1,
+                                                      const float* __restrict__ add, const float* __restrict__ b2,
+                                                      float slope, float* __restrict__ Y, float* __restrict__ zinit,
+                                                      int zn) {
+  // wave w of the workgroup: row tile w / CS (16 rows), column group w % CS (16*MBW columns); M = 16*MBW*CS.
+  // Splitting the columns over waves keeps >= 8 workgroups per CU in flight at 38k rows (one wave per 16 rows and all
+  // columns left the chip at ~1 wave per SIMD and was slower than the library GEMM).
+  constexpr int M = 16 * MBW * CS;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int li = lane & 15, lk = lane >> 4;
+  if (zinit && blockIdx.x == 0)
+    for (int t = threadIdx.x; t < zn; t += blockDim.x) zinit[t] = 0.0f;
+  const int row0 = (blockIdx.x * (4 / CS) + wave / CS) * 16;
+  const int c0 = (wave % CS) * 16 * MBW;
+  if (row0 >= N) return;
+  f32x4 acc[MBW];
+#pragma unroll
+  for (int nb = 0; nb < MBW; ++nb) acc[nb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  const float* xr = X + (size_t)min(row0 + li, N - 1) * K + 4 * lk;
+  for (int k0 = 0; k0 < K; k0 += 16) {
+    const float4 a = *(const float4*)(xr + k0);
+    float bq[MBW][4];
+#pragma unroll
+    for (int nb = 0; nb < MBW; ++nb) {
+      if (WT) {
+        const float4 b = *(const float4*)(W + (size_t)(c0 + nb * 16 + li) * K + k0 + 4 * lk);
+        bq[nb][0] = b.x; bq[nb][1] = b.y; bq[nb][2] = b.z; bq[nb][3] = b.w;
+      } else {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) bq[nb][t] = W[(size_t)(k0 + 4 * lk + t) * M + c0 + nb * 16 + li];
+      }
+    }
+#pragma unroll
+    for (int nb = 0; nb < MBW; ++nb) {
+      acc[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, bq[nb][0], acc[nb], 0, 0, 0);
+      acc[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, bq[nb][1], acc[nb], 0, 0, 0);
+      acc[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, bq[nb][2], acc[nb], 0, 0, 0);
+      acc[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, bq[nb][3], acc[nb], 0, 0, 0);
+    }
+  }
+  // D[i][j]: row = row0 + 4 lk + r, column = c0 + 16 nb + li
+#pragma unroll
+  for (int nb = 0; nb < MBW; ++nb) {
+    const int col = c0 + nb * 16 + li;
+    float bias1 = 0.0f, bias2 = 0.0f;
+    if (EPI) {
+      if (b1) bias1 = b1[col];
+      if (b2) bias2 = b2[col];
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = row0 + 4 * lk + r;
+      if (row < N) {
+        float v = acc[nb][r];
+        if (EPI) {
+          if (b1) v += bias1;
+          if (add) v += add[(size_t)row * M + col];
+          if (b2) v += bias2;
+          v = v > 0.0f ? v : v * slope;
+        }
+        Y[(size_t)row * M + col] = v;
+      }
+    }
+  }
+}
+
+bool rowgemm_supported(int N, int K, int M) {
+  return N >= 1 && K >= 16 && K % 16 == 0 && K <= 1024 && (M == 32 || M == 64 || M == 128 || M == 256);
+}
+
+template <bool WT, bool EPI>
+static int rowgemm_launch(const float* X, const float* W, int N, int K, int M, const float* b1, const float* add,
+                          const float* b2, float slope, float* Y, float* zinit, int zn, hipStream_t stream) {
+#define D3F_RG(MBW, CS)                                                                                  \
+  rowgemm_kernel<MBW, CS, WT, EPI><<<cdiv(N, 16 * (4 / CS)), 256, 0, stream>>>(X, W, N, K, b1, add, b2, slope, Y, \
+                                                                               zinit, zn)
+  switch (M) {
+    case 32: D3F_RG(1, 2); break;
+    case 64: D3F_RG(2, 2); break;
+    case 128: D3F_RG(2, 4); break;
+    case 256: D3F_RG(4, 4); break;
+    default: return D3F_EINVAL;
+  }
+#undef D3F_RG
+  D3F_LAUNCH_CHECK();
+  return D3F_OK;
+}
+
 }  // namespace d3f
 
 extern "C" {
@@ -171,6 +269,28 @@ int d3f_linear_grad_weight(const float* x, const float* grad_out, int N, int Cin
   if (!x || !grad_out || !grad_w || !ws || !d3f::atb_supported(N, Cout, Cin)) return D3F_EINVAL;
   if (ws_bytes < d3f::atb_ws_bytes(N, Cout, Cin)) return D3F_EWORKSPACE;
   return d3f::atb_splitk(grad_out, x, nullptr, N, Cout, Cin, grad_w, ws, (hipStream_t)stream);
+}
+
+int d3f_linear_fused_supported(int N, int Cin, int Cout) {
+  return (d3f::rowgemm_supported(N, Cin, Cout) && d3f::rowgemm_supported(N, Cout, Cin)) ? 1 : 0;
+}
+
+/* out [N,Cout] = act(x [N,Cin] @ weight[Cout,Cin]^T + bias1 + add + bias2), act = LeakyReLU(slope) (slope = 1: none);
+ * bias1 / add [N,Cout] / bias2 optional.  zero_init as in d3f_bias_act_forward. */
+int d3f_linear_bias_act_forward(const float* x, const float* weight, int N, int Cin, int Cout, const float* bias1,
+                                const float* add, const float* bias2, float slope, float* out, float* zero_init,
+                                int zero_n, void* stream) {
+  if (!x || !weight || !out || !d3f::rowgemm_supported(N, Cin, Cout) || (zero_init && zero_n < 1)) return D3F_EINVAL;
+  return d3f::rowgemm_launch<true, true>(x, weight, N, Cin, Cout, bias1, add, bias2, slope, out, zero_init, zero_n,
+                                         (hipStream_t)stream);
+}
+
+/* grad_x [N,Cin] = grad_out [N,Cout] @ weight [Cout,Cin] */
+int d3f_linear_grad_input(const float* grad_out, const float* weight, int N, int Cin, int Cout, float* grad_x,
+                          void* stream) {
+  if (!grad_out || !weight || !grad_x || !d3f::rowgemm_supported(N, Cout, Cin)) return D3F_EINVAL;
+  return d3f::rowgemm_launch<false, false>(grad_out, weight, N, Cout, Cin, nullptr, nullptr, nullptr, 1.0f, grad_x,
+                                           nullptr, 0, (hipStream_t)stream);
 }
 
 }  // extern "C"

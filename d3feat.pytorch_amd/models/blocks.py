@@ -179,8 +179,8 @@ class UnaryBlock(nn.Module):
         if not self.use_bn and x.is_cuda and x.dim() == 2:
             # Linear without its bias; both biases (+ residual) + LeakyReLU go into ONE epilogue launch whose backward
             # also yields the (shared) bias gradient -- no separate add / leaky / column-reduce kernels
-            return ops.bias_act(ops.linear_nobias(x, self.mlp.weight), self.mlp.bias, residual, self.batch_norm.bias,
-                                slope=1.0 if (self.no_relu and residual is None) else 0.1)
+            return ops.linear_bias_act(x, self.mlp.weight, self.mlp.bias, residual, self.batch_norm.bias,
+                                       slope=1.0 if (self.no_relu and residual is None) else 0.1)
         x = self.batch_norm(self.mlp(x))
         if residual is not None:
             return self.leaky_relu_res(x + residual)
@@ -208,7 +208,7 @@ class LastUnaryBlock(nn.Module):
         if x.is_cuda and x.dim() == 2:
             # same arithmetic as nn.Linear; the bias gradient comes from the fused epilogue's column reduction instead
             # of a multi-block library reduction (whose memset-initialised semaphores do not survive hipGraph replay)
-            return ops.bias_act(ops.linear_nobias(x, self.mlp.weight), self.mlp.bias, slope=1.0)
+            return ops.linear_bias_act(x, self.mlp.weight, self.mlp.bias, slope=1.0)
         return self.mlp(x)
 
     def __repr__(self):

@@ -318,6 +318,92 @@ class _LinearFn(torch.autograd.Function):
         return gx, gw
 
 
+class _LinearBiasActFn(torch.autograd.Function):
+    """act(x W^T + b1 + add + b2) in ONE launch (d3f_linear_bias_act_forward) for the many-row / narrow layers; the
+    backward is the epilogue's backward kernel followed by grad_x = g W (row-streaming kernel) and grad_W = g^T x
+    (reduction-parallel kernel)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, b1, add, b2, slope):
+        L = _native.lib()
+        N, Cin, Cout = int(x.shape[0]), int(x.shape[1]), int(weight.shape[0])
+        out = torch.empty((N, Cout), dtype=torch.float32, device=x.device)
+        nb = int(b1 is not None and ctx.needs_input_grad[2]) + int(b2 is not None and ctx.needs_input_grad[4])
+        gbuf = torch.empty((nb, Cout), dtype=torch.float32, device=x.device) if nb else None
+        with _region("linear_fused_fwd[N=%d,Cin=%d,Cout=%d]" % (N, Cin, Cout), 4 * N * (Cin + Cout) + 4 * Cin * Cout):
+            _native.check(L.d3f_linear_bias_act_forward(_p(x), _p(weight), N, Cin, Cout, _p(b1), _p(add), _p(b2),
+                                                        float(slope), _p(out), _p(gbuf), nb * Cout, _stream()),
+                          "d3f_linear_bias_act_forward")
+        ctx.save_for_backward(x, weight, out)
+        ctx.gbuf = gbuf
+        ctx.slope = float(slope)
+        ctx.has = (b1 is not None, add is not None, b2 is not None)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        x, weight, out = ctx.saved_tensors
+        L = _native.lib()
+        N, Cin, Cout = int(x.shape[0]), int(x.shape[1]), int(weight.shape[0])
+        go = grad_out.contiguous()
+        want1 = ctx.has[0] and ctx.needs_input_grad[2]
+        want2 = ctx.has[2] and ctx.needs_input_grad[4]
+        g1 = g2 = None
+        pre = 0
+        if want1 or want2:
+            gbuf, pre = ctx.gbuf, 1
+            ctx.gbuf = None
+            if gbuf is None:
+                gbuf, pre = torch.empty((int(want1) + int(want2), Cout), dtype=torch.float32, device=go.device), 0
+            rows = list(gbuf.unbind(0))
+            g1 = rows.pop(0) if want1 else None
+            g2 = rows.pop(0) if want2 else None
+        if ctx.slope == 1.0 and not (want1 or want2):
+            gm = go
+        else:
+            gm = go if ctx.slope == 1.0 else torch.empty_like(go)
+            first, second = (g1, g2) if g1 is not None else (g2, None)
+            _native.check(L.d3f_bias_act_backward(_p(go), _p(out), ctx.slope, N, Cout,
+                                                  _p(gm) if ctx.slope != 1.0 else None, _p(first), _p(second),
+                                                  pre if first is not None else 0, _stream()),
+                          "d3f_bias_act_backward")
+        gx = gw = None
+        if ctx.needs_input_grad[0]:
+            gx = torch.empty_like(x)
+            with _region("linear_dx[N=%d,Cin=%d,Cout=%d]" % (N, Cin, Cout), 4 * N * (Cin + Cout) + 4 * Cin * Cout):
+                _native.check(L.d3f_linear_grad_input(_p(gm), _p(weight), N, Cin, Cout, _p(gx), _stream()),
+                              "d3f_linear_grad_input")
+        if ctx.needs_input_grad[1]:
+            if L.d3f_linear_grad_weight_supported(N, Cin, Cout):
+                gw = torch.empty_like(weight)
+                nbytes = L.d3f_linear_grad_weight_ws_bytes(N, Cin, Cout)
+                ws = _ws(nbytes, x.device)
+                with _region("linear_dw[N=%d,Cin=%d,Cout=%d]" % (N, Cin, Cout), 4 * N * (Cin + Cout) + 4 * Cin * Cout):
+                    _native.check(L.d3f_linear_grad_weight(_p(x), _p(gm), N, Cin, Cout, _p(gw), _p(ws), nbytes,
+                                                           _stream()), "d3f_linear_grad_weight")
+            else:
+                gw = torch.mm(gm.t(), x)
+        return gx, gw, g1, gm if ctx.has[1] and ctx.needs_input_grad[3] else None, g2, None
+
+
+# rows from which the unary blocks use the fused row-streaming kernels instead of library GEMM + epilogue launch
+_FUSED_LINEAR_MIN_ROWS = 4096
+
+
+def linear_bias_act(x, weight, bias1=None, add=None, bias2=None, slope=0.1):
+    """act(x @ weight^T + bias1 + add + bias2) -- the whole unary block (reference blocks.py:481-541,686)."""
+    x, weight = _f32(x, "x"), _f32(weight, "weight")
+    N, Cin, Cout = int(x.shape[0]), int(x.shape[1]), int(weight.shape[0])
+    # measured (profiles/unary_gemm_microbench.py): the fused kernel beats library GEMM + epilogue launch for
+    # Cin <= 64 (7-21 us vs 10-27 us at 38k rows), not for Cin >= 128 where the library's deeper tiling wins
+    if N >= _FUSED_LINEAR_MIN_ROWS and Cin <= 64 and _native.lib().d3f_linear_fused_supported(N, Cin, Cout):
+        b1 = _f32(bias1, "bias1") if bias1 is not None else None
+        b2 = _f32(bias2, "bias2") if bias2 is not None else None
+        a = _f32(add, "add") if add is not None else None
+        return _LinearBiasActFn.apply(x, weight, b1, a, b2, float(slope))
+    return bias_act(linear_nobias(x, weight), bias1, add, bias2, slope=slope)
+
+
 def linear_nobias(x, weight):
     """x [N, Cin] @ weight[Cout, Cin]^T on the device (fp32)."""
     return _LinearFn.apply(_f32(x, "x"), _f32(weight, "weight"))

@@ -124,6 +124,16 @@ int d3f_kpconv_grad_input(const float* q_pts, int Nq, const float* s_pts, int Ns
  * Supported when Cin and Cout are multiples of 16 (d3f_linear_grad_weight_supported).
  * ---------------------------------------------------------------------------------------------- */
 int d3f_linear_grad_weight_supported(int N, int Cin, int Cout);
+/* The same blocks at the upper pyramid levels (many rows, Cin/Cout <= 256): x W^T with the epilogue
+ * act(. + bias1 + add + bias2) applied before the only store, and grad_x = grad_out W, as row-streaming f32-MFMA
+ * kernels (a library GEMM is launch-bound on these shapes).  Supported: Cin, Cout in {32, 64, 128, 256} on the output
+ * side, a multiple of 16 up to 1024 on the reduction side (d3f_linear_fused_supported checks both directions). */
+int d3f_linear_fused_supported(int N, int Cin, int Cout);
+int d3f_linear_bias_act_forward(const float* x, const float* weight, int N, int Cin, int Cout, const float* bias1,
+                                const float* add, const float* bias2, float slope, float* out, float* zero_init,
+                                int zero_n, void* stream);
+int d3f_linear_grad_input(const float* grad_out, const float* weight, int N, int Cin, int Cout, float* grad_x,
+                          void* stream);
 size_t d3f_linear_grad_weight_ws_bytes(int N, int Cin, int Cout);
 int d3f_linear_grad_weight(const float* x, const float* grad_out, int N, int Cin, int Cout, float* grad_w, void* ws,
                            size_t ws_bytes, void* stream);

@@ -37,3 +37,19 @@ for n, cin, cout in SHAPES:
     td += d
     print("%-20s %9.1f %9.1f %12.1f" % ("%d,%d,%d" % (n, cin, cout), f, d, 4 * (n * (cin + cout) + cin * cout) / 5e6))
 print("sum fwd %.1f us, sum dx %.1f us" % (tf, td))
+
+# fused row-streaming kernels of this library on the same shapes
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from d3feat_pytorch_amd import _native
+L = _native.lib()
+print("%-20s %9s %9s   (fused forward incl. bias+act epilogue / grad_x; 0 = shape not supported)" % ("N,Cin,Cout", "fwd_us", "dx_us"))
+for n, cin, cout in SHAPES:
+    if not L.d3f_linear_fused_supported(n, cin, cout):
+        continue
+    x = torch.randn(n, cin, device=dev); w = torch.randn(cout, cin, device=dev); g = torch.randn(n, cout, device=dev)
+    b = torch.randn(cout, device=dev); y = torch.empty(n, cout, device=dev); gx = torch.empty(n, cin, device=dev)
+    st = torch.cuda.current_stream().cuda_stream
+    f = timeit(lambda: L.d3f_linear_bias_act_forward(x.data_ptr(), w.data_ptr(), n, cin, cout, b.data_ptr(), None, b.data_ptr(), 0.1, y.data_ptr(), None, 0, st))
+    d = timeit(lambda: L.d3f_linear_grad_input(g.data_ptr(), w.data_ptr(), n, cin, cout, gx.data_ptr(), st))
+    print("%-20s %9.1f %9.1f" % ("%d,%d,%d" % (n, cin, cout), f, d))

@@ -199,6 +199,33 @@ def test_linear_weight_gradient(n, cin, cout, min_rows, monkeypatch):
     assert torch.equal(tw2.grad, tw.grad)
 
 
+@pytest.mark.parametrize("n,cin,cout,with_add,slope", [(5000, 64, 32, False, 0.1), (4133, 32, 128, True, 0.1),
+                                                       (8200, 64, 256, True, 0.1), (33000, 64, 128, False, 0.1),
+                                                       (4097, 32, 64, False, 1.0), (70, 128, 128, True, 0.1),
+                                                       (4500, 48, 64, False, 0.1)])
+def test_fused_unary_block_matches_unfused(n, cin, cout, with_add, slope, monkeypatch):
+    """act(x W^T + b1 + add + b2): row-streaming fused kernels (forward, grad_x) == library GEMM + epilogue path."""
+    rng = np.random.default_rng(n + cin)
+    x = rng.normal(size=(n, cin)).astype(np.float32)
+    w = (rng.normal(size=(cout, cin)) / np.sqrt(cin)).astype(np.float32)
+    b1, b2 = rng.normal(size=cout).astype(np.float32), rng.normal(size=cout).astype(np.float32)
+    add = rng.normal(size=(n, cout)).astype(np.float32) if with_add else None
+    go = rng.normal(size=(n, cout)).astype(np.float32)
+    res = []
+    for min_rows in (1, 1 << 30):
+        monkeypatch.setattr(ops, "_FUSED_LINEAR_MIN_ROWS", min_rows)
+        t = [cu(a).requires_grad_(True) if a is not None else None for a in (x, w, b1, add, b2)]
+        y = ops.linear_bias_act(t[0], t[1], t[2], t[3], t[4], slope=slope)
+        y.backward(cu(go))
+        res.append([y.detach().cpu().numpy()] + [a.grad.cpu().numpy() if a is not None else None for a in t])
+    ref = x.astype(np.float64) @ w.astype(np.float64).T + b1 + b2 + (add if with_add else 0.0)
+    ref = np.where(ref > 0, ref, ref * slope)
+    assert rel_err(res[0][0], ref) < 1e-5
+    for a, b in zip(res[0], res[1]):
+        if a is not None:
+            assert rel_err(a, b) < 2e-5
+
+
 def test_kpconv_all_shadow_rows_and_empty():
     rng = np.random.default_rng(0)
     q, s, idx, x, kp, w = _kpconv_case(rng, 64, 80, 10, 32, 32)
