@@ -11,6 +11,8 @@ Differences that are the point of this build:
     NaN/Inf guard is decided from the REDUCED gradients so every rank takes the same decision without a host sync.
 One process per GPU; `torch.distributed` backend "nccl" is RCCL on ROCm.
 """
+import os
+
 import torch
 import torch.distributed as dist
 
@@ -45,11 +47,15 @@ class FlatParams:
         for p in self.params:
             p.grad = None
 
-    def gather_grads(self):
-        """Pack the per-parameter gradients of the last backward into ``grad`` (zeros for unused parameters)."""
-        parts = [(p.grad if p.grad is not None else torch.zeros_like(p.data)).reshape(-1) for p in self.params]
-        torch.cat(parts, out=self.grad)
-        return self.grad
+    def gather_grads(self, first=0, last=None):
+        """Pack the per-parameter gradients of the last backward into ``grad`` (zeros for unused parameters);
+        ``first:last`` restricts it to a contiguous range of parameters (a gradient bucket)."""
+        ps = self.params[first:last]
+        parts = [(p.grad if p.grad is not None else torch.zeros_like(p.data)).reshape(-1) for p in ps]
+        a = sum(p.numel() for p in self.params[:first])
+        out = self.grad[a:a + sum(p.numel() for p in ps)]
+        torch.cat(parts, out=out)
+        return out
 
 
 def allreduce_mean_(flat, world_size, n_buckets=4, group=None):
@@ -122,6 +128,17 @@ class TrainStep:
         self.circle = CircleLoss(dist_type='euclidean', log_scale=config.log_scale, safe_radius=config.safe_radius,
                                  pos_margin=config.pos_margin, neg_margin=config.neg_margin)
         self.w_desc, self.w_det = float(config.desc_loss_weight), float(config.det_loss_weight)
+        # Gradient buckets for the data-parallel exchange.  Backward visits decoder -> coarse encoder levels -> fine
+        # encoder levels; 97% of the gradient BYTES belong to the first two, while the fine levels (encoder blocks
+        # 0..CUT-1, 38k/8k points) still have ~1/3 of the backward's run time ahead of them.  With split_backward the
+        # network is cut at the input of encoder block CUT: the "deep" bucket (blocks CUT.. + decoder) is all-reduced
+        # over xGMI while the backward of the fine levels runs.
+        self.split_backward = world_size > 1 or os.environ.get("D3F_SPLIT_BACKWARD") == "1"  # env: measure it on 1 GPU
+        self.CUT = 5
+        shallow = [p for b in list(self.model.encoder_blocks)[:self.CUT] for p in b.parameters() if p.requires_grad]
+        self.n_shallow = len(shallow)
+        assert all(a is b for a, b in zip(shallow, self.flat.params[:self.n_shallow])), "parameter order"
+        self.numel_shallow = sum(p.numel() for p in shallow)
 
     def build_batch(self, item):
         return dl.collate_fn_descriptor([item], self.config, self.limits, device=self.device, exact_width=False)
@@ -134,6 +151,76 @@ class TrainStep:
         desc, acc, fp, an, _, dists = self.circle(feats[ia], feats[ip], batch['dist_keypts'], scores[ia], scores[ip])
         det = dists._d3f_det[0][1]
         return desc * self.w_desc + det * self.w_det, desc, det, acc
+
+    def _forward_loss_cut(self, batch):
+        """forward_loss with the autograd graph cut at the input of encoder block CUT: everything downstream (coarse
+        encoder, decoder, loss) hangs off detached leaves.  Returns the loss tuple and [(tensor, leaf), ...]."""
+        m = self.model
+        x = batch['features'].clone().detach()
+        skips, cuts = [], []
+        for i, op in enumerate(m.encoder_blocks):
+            if i == self.CUT:
+                def leaf_of(t):
+                    leaf = t.detach().requires_grad_(True)
+                    cuts.append((t, leaf))
+                    return leaf
+                x = leaf_of(x)
+                skips = [leaf_of(t) for t in skips]
+            if i in m.encoder_skips:
+                skips.append(x)
+            x = op(x, batch)
+        for j, op in enumerate(m.decoder_blocks):
+            if j in m.decoder_concats:
+                x = torch.cat([x, skips.pop()], dim=1)
+            x = op(x, batch)
+        scores = m.detection_scores(batch, x)
+        feats = torch.nn.functional.normalize(x, p=2, dim=-1)
+        corr = batch['corr'].long()
+        n0 = batch['n0'] if 'n0' in batch else batch['stack_lengths'][0][0]
+        ia, ip = corr[:, 0], corr[:, 1] + n0
+        desc, acc, fp, an, _, dists = self.circle(feats[ia], feats[ip], batch['dist_keypts'], scores[ia], scores[ip])
+        det = dists._d3f_det[0][1]
+        return (desc * self.w_desc + det * self.w_det, desc, det, acc), cuts
+
+    def _backward_deep(self, batch):
+        """Stage 1: forward + backward of the deep bucket; leaves the cut gradients in self._cuts."""
+        self.flat.zero_grad()
+        (loss, desc, det, acc), cuts = self._forward_loss_cut(batch)
+        deep = self.flat.params[self.n_shallow:]
+        torch.autograd.backward(loss, inputs=deep + [leaf for _, leaf in cuts])
+        self._cuts = cuts
+        self.flat.gather_grads(self.n_shallow, None)
+        return loss.detach(), desc.detach(), det.detach(), acc.detach()
+
+    def _backward_shallow(self):
+        """Stage 2: backward of the fine encoder levels from the cut gradients."""
+        cuts, self._cuts = self._cuts, None
+        torch.autograd.backward([t for t, _ in cuts], [leaf.grad for _, leaf in cuts],
+                                inputs=self.flat.params[:self.n_shallow])
+        self.flat.gather_grads(0, self.n_shallow)
+
+    def _exchange_and_step(self, after_deep, after_shallow):
+        """after_deep(): runs/launches stage 1; after_shallow(): stage 2.  The deep bucket's all-reduce is in flight
+        while stage 2 executes."""
+        out = after_deep()
+        g = self.flat.grad
+        works = []
+        if self.world > 1:
+            deep = g[self.numel_shallow:]
+            nb = 3
+            step = (deep.numel() + nb - 1) // nb
+            for b in range(nb):
+                chunk = deep[b * step:min(deep.numel(), (b + 1) * step)]
+                if chunk.numel():
+                    works.append(dist.all_reduce(chunk, op=dist.ReduceOp.SUM, async_op=True))
+        after_shallow()
+        if self.world > 1:
+            works.append(dist.all_reduce(g[:self.numel_shallow], op=dist.ReduceOp.SUM, async_op=True))
+            for w in works:
+                w.wait()
+            g.mul_(1.0 / self.world)
+        self.opt.step()
+        return out
 
     # -- static shapes + hipGraph ---------------------------------------------------------------------------
     # The eager step costs ~10 ms of host enqueue time (600+ launches) against ~7 ms of GPU work.  In graph mode
@@ -202,15 +289,18 @@ class TrainStep:
                     dst.copy_(src)
                     done.add(dst.data_ptr())
 
-    def _net_step(self, st):
+    def _set_batch(self, st):
         batch = dict(st.batch)
         batch['features'], batch['corr'], batch['dist_keypts'] = self.s_feat, st.corr, st.dk
+        return batch
+
+    def _net_step(self, st):
+        batch = self._set_batch(st)
         self.flat.zero_grad()
         loss, desc, det, acc = self.forward_loss(batch)
         loss.backward()
         self.flat.gather_grads()
-        if self.world == 1:
-            self.opt.step()
+        self.opt.step()
         return loss.detach(), desc.detach(), det.detach(), acc.detach()
 
     def _static_step(self, item):
@@ -235,21 +325,30 @@ class TrainStep:
         with torch.cuda.stream(warm):
             for k in range(3):
                 self._build_set(self.sets[(k + 1) % self.NSETS])
-                out = self._net_step(self.sets[k % self.NSETS])
-                if self.world > 1:
-                    allreduce_mean_(self.flat.grad, self.world)
-                    self.opt.step()
+                if self.split_backward:
+                    batch = self._set_batch(self.sets[k % self.NSETS])
+                    out = self._exchange_and_step(lambda: self._backward_deep(batch), self._backward_shallow)
+                else:
+                    out = self._net_step(self.sets[k % self.NSETS])
         main.wait_stream(warm)
         torch.cuda.synchronize(dev)
         self.check_status()
         self._side = torch.cuda.Stream(device=dev)
-        self.g_net, self.g_pyr, self._graph_out = [], [], []
+        self.g_net, self.g_net_b, self.g_pyr, self._graph_out = [], [], [], []
         for i in range(self.NSETS):
             # graphs of one kind never run concurrently and replay in capture order: they share a memory pool
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g, pool=self.g_net[0].pool() if self.g_net else None):
-                self._graph_out.append(self._net_step(self.sets[i]))
+                if self.split_backward:
+                    self._graph_out.append(self._backward_deep(self._set_batch(self.sets[i])))
+                else:
+                    self._graph_out.append(self._net_step(self.sets[i]))
             self.g_net.append(g)
+            if self.split_backward:  # stage 2 of the same step: continues in the same pool
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, pool=self.g_net[0].pool()):
+                    self._backward_shallow()
+                self.g_net_b.append(g)
         for i in range(self.NSETS):
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g, pool=self.g_pyr[0].pool() if self.g_pyr else None):
@@ -295,12 +394,19 @@ class TrainStep:
             self.ev_pyr[n].record(self._side)
         nx.loaded = nxt
         self.ev_pyr[i].synchronize()
-        self.g_net[i].replay()
-        self.ev_net[i].record(main)
+        if self.split_backward:
+            def stage1():
+                self.g_net[i].replay()
+                return self._graph_out[i]
+
+            def stage2():
+                self.g_net_b[i].replay()
+                self.ev_net[i].record(main)
+            self._exchange_and_step(stage1, stage2)
+        else:
+            self.g_net[i].replay()
+            self.ev_net[i].record(main)
         self.cur = n
-        if self.world > 1:
-            allreduce_mean_(self.flat.grad, self.world)
-            self.opt.step()
         return self._graph_out[i]
 
     def check_status(self):
@@ -340,6 +446,8 @@ class TrainStep:
             batch['n0'] = int(item[0].shape[0])
         if next_item is not None:
             self.prefetch(next_item)
+        if self.split_backward:
+            return self._exchange_and_step(lambda: self._backward_deep(batch), self._backward_shallow)
         self.flat.zero_grad()
         loss, desc, det, acc = self.forward_loss(batch)
         loss.backward()
