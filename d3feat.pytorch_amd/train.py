@@ -333,6 +333,8 @@ class TrainStep:
         main.wait_stream(warm)
         torch.cuda.synchronize(dev)
         self.check_status()
+        # (stream priorities were tried: the range here is {0, -1}; replaying the network graphs on a priority -1 stream
+        # made the step 3x slower, so both streams stay at the default priority)
         self._side = torch.cuda.Stream(device=dev)
         self.g_net, self.g_net_b, self.g_pyr, self._graph_out = [], [], [], []
         for i in range(self.NSETS):
