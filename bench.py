@@ -264,6 +264,37 @@ def main():
                     "frac": round(mfl / (mms * 1e-3) / 1e12 / F32_MFMA_PEAK_TFLOPS, 4),
                     "flops": int(mfl), "pairs_per_s": round(1e3 / mms, 1)}
 
+    # evaluation pass of one pair -- pyramid + eval-mode forward (descriptors, gated scores), top-k
+    # keypoints by score, mutual-NN matching of the selected descriptors (build_correspondence); eager launches.
+    evaluation = None
+    if rank == 0:
+        from d3feat_pytorch_amd.geometric_registration.common import build_correspondence, select_keypoints
+        ts.model.eval()
+        ev_item = items[0]
+        n0e = int(ev_item[0].shape[0])
+
+        def eval_pass(k):
+            with torch.no_grad():
+                b = ts.build_batch(ev_item)
+                feats, scores = ts.model(b)
+                si = select_keypoints(scores[:n0e], k)
+                ti = select_keypoints(scores[n0e:], k)
+                return build_correspondence(feats[:n0e][si], feats[n0e:][ti])
+        evaluation = {}
+        for k in (250, 5000):
+            for _ in range(2):
+                corr_k = eval_pass(k)
+            torch.cuda.synchronize()
+            t_e0 = time.perf_counter()
+            for _ in range(5):
+                corr_k = eval_pass(k)
+            torch.cuda.synchronize()
+            evaluation["top%d" % k] = {"ms_per_pair": round((time.perf_counter() - t_e0) / 5 * 1e3, 3),
+                                       "mutual_matches": int(corr_k.shape[0])}
+        evaluation["note"] = ("pyramid + eval forward + top-k + mutual-NN per pair, eager launches (host-bound), random-init "
+                              "weights")
+        ts.model.train()
+
     if rank == 0:
         n_pts = [int(it[0].shape[0] + it[1].shape[0]) for it in items]
         summary = prof.summary()
@@ -317,6 +348,7 @@ def main():
                                  if use_graph else "eager launches, pyramid on a side stream"},
             "roofline": roofline,
             "matching": matching,
+            "evaluation": evaluation,
             "kernels": {k: {"avg_us": round(v["avg_ms"] * 1e3, 2), "calls": v["calls"],
                             "total_ms": round(v["total_ms"], 3)} for k, v in
                         sorted(summary.items(), key=lambda kv: -kv[1]["total_ms"])[:12]},
