@@ -256,6 +256,78 @@ __global__ __launch_bounds__(kThreads) void loss_bwd_kernel(
   }
 }
 
+// ---- keypoint selection + L2 normalisation of the selected descriptors -------------------------------------------
+// The reference normalises ALL N descriptors (architectures.py:318, F.normalize) and then indexes the M sampled
+// correspondences out of them and out of the scores (trainer.py:91-94): ~10 PyTorch launches forward and ~15 backward
+// (two zero-filled [N,C] scatter targets, their sum, the normalisation's backward over all N rows).  Training only
+// ever looks at the 2M selected rows, so one launch gathers and normalises them and one scatters the gradient back.
+//   out[m,:] = x[idx[m],:] / max(||x[idx[m],:]||, 1e-12)          (torch F.normalize semantics)
+__global__ __launch_bounds__(256) void select_normalize_fwd_kernel(const float* __restrict__ x,
+                                                                   const float* __restrict__ scores, int N, int C,
+                                                                   const int64_t* __restrict__ idx_a,
+                                                                   const int64_t* __restrict__ idx_p, int M,
+                                                                   const int32_t* __restrict__ p_offset,
+                                                                   float* __restrict__ out_a, float* __restrict__ out_p,
+                                                                   float* __restrict__ sa, float* __restrict__ sp) {
+  const int lane = threadIdx.x & 63;
+  const int m2 = blockIdx.x * 4 + (threadIdx.x >> 6);  // 0..2M-1: anchors then positives
+  if (m2 >= 2 * M) return;
+  const bool pos = m2 >= M;
+  const int m = pos ? m2 - M : m2;
+  long row = pos ? idx_p[m] + (p_offset ? (long)*p_offset : 0) : idx_a[m];
+  row = row < 0 ? 0 : (row >= N ? N - 1 : row);
+  float ss = 0.0f;
+  for (int c = lane; c < C; c += 64) {
+    const float v = x[row * C + c];
+    ss += v * v;
+  }
+  ss = d3f::wave_sum(ss);
+  const float denom = fmaxf(sqrtf(ss), 1e-12f);
+  float* o = (pos ? out_p : out_a) + (size_t)m * C;
+  for (int c = lane; c < C; c += 64) o[c] = x[row * C + c] / denom;
+  if (lane == 0) (pos ? sp : sa)[m] = scores[row];
+}
+
+// grad_x[row,:] += g/n - y (y.g)/n  with y = x/n the normalised row (n > eps); grad_scores[row] += g_s
+__global__ __launch_bounds__(256) void select_normalize_bwd_kernel(const float* __restrict__ x, int N, int C,
+                                                                   const int64_t* __restrict__ idx_a,
+                                                                   const int64_t* __restrict__ idx_p, int M,
+                                                                   const int32_t* __restrict__ p_offset,
+                                                                   const float* __restrict__ g_a,
+                                                                   const float* __restrict__ g_p,
+                                                                   const float* __restrict__ g_sa,
+                                                                   const float* __restrict__ g_sp,
+                                                                   float* __restrict__ grad_x,
+                                                                   float* __restrict__ grad_s) {
+  const int lane = threadIdx.x & 63;
+  const int m2 = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (m2 >= 2 * M) return;
+  const bool pos = m2 >= M;
+  const int m = pos ? m2 - M : m2;
+  long row = pos ? idx_p[m] + (p_offset ? (long)*p_offset : 0) : idx_a[m];
+  row = row < 0 ? 0 : (row >= N ? N - 1 : row);
+  const float* g = (pos ? g_p : g_a) + (size_t)m * C;
+  float ss = 0.0f, dot = 0.0f;
+  for (int c = lane; c < C; c += 64) {
+    const float v = x[row * C + c];
+    ss += v * v;
+    dot += v * (g ? g[c] : 0.0f);
+  }
+  ss = d3f::wave_sum(ss);
+  dot = d3f::wave_sum(dot);
+  const float n = sqrtf(ss);
+  if (g) {
+    for (int c = lane; c < C; c += 64) {
+      const float v = x[row * C + c];
+      // n <= eps: the forward divided by the constant eps
+      const float gv = n > 1e-12f ? (g[c] - v * dot / ss) / n : g[c] / 1e-12f;
+      atomicAdd(&grad_x[row * C + c], gv);
+    }
+  }
+  const float* gs = pos ? g_sp : g_sa;
+  if (lane == 0 && gs && grad_s) atomicAdd(&grad_s[row], gs[m]);
+}
+
 }  // namespace
 
 extern "C" {
@@ -303,6 +375,37 @@ int d3f_circle_det_loss_backward(const float* anchor, const float* positive, int
                                                                      pos_score, P, dists, stats, grad_desc, grad_det,
                                                                      (float*)ws, grad_anchor, grad_positive,
                                                                      grad_anc_score, grad_pos_score);
+  D3F_LAUNCH_CHECK();
+  return D3F_OK;
+}
+
+/* Sampled-correspondence front end of the loss -- replaces F.normalize over all N descriptors
+ * (models/architectures.py:318) followed by the four index selections of trainer.py:91-94.
+ * idx_a / idx_p: int64 [M] row indices (idx_p is offset by *p_offset, a device int32 = points of the first cloud, or
+ * NULL).  out_a/out_p [M,C] normalised descriptors, sa/sp [M] scores. */
+int d3f_select_normalize_forward(const float* x, const float* scores, int N, int C, const int64_t* idx_a,
+                                 const int64_t* idx_p, int M, const int32_t* p_offset, float* out_a, float* out_p,
+                                 float* sa, float* sp, void* stream) {
+  if (!x || !scores || !idx_a || !idx_p || !out_a || !out_p || !sa || !sp || N < 1 || C < 1 || M < 1) return D3F_EINVAL;
+  select_normalize_fwd_kernel<<<d3f::cdiv(2 * M, 4), 256, 0, (hipStream_t)stream>>>(x, scores, N, C, idx_a, idx_p, M,
+                                                                                      p_offset, out_a, out_p, sa, sp);
+  D3F_LAUNCH_CHECK();
+  return D3F_OK;
+}
+
+/* grad_x [N,C] and grad_scores [N] must be ONE allocation of N*(C+1) floats starting at grad_x (cleared here with a
+ * single fill); g_* may be NULL for outputs that received no gradient. */
+int d3f_select_normalize_backward(const float* x, int N, int C, const int64_t* idx_a, const int64_t* idx_p, int M,
+                                  const int32_t* p_offset, const float* g_a, const float* g_p, const float* g_sa,
+                                  const float* g_sp, float* grad_x, float* grad_scores, void* stream) {
+  if (!x || !idx_a || !idx_p || !grad_x || !grad_scores || N < 1 || C < 1 || M < 1 ||
+      grad_scores != grad_x + (size_t)N * C)
+    return D3F_EINVAL;
+  if (d3f::zero_async(grad_x, sizeof(float) * (size_t)N * (C + 1), (hipStream_t)stream) != hipSuccess)
+    return D3F_ELAUNCH;
+  select_normalize_bwd_kernel<<<d3f::cdiv(2 * M, 4), 256, 0, (hipStream_t)stream>>>(x, N, C, idx_a, idx_p, M, p_offset,
+                                                                                      g_a, g_p, g_sa, g_sp, grad_x,
+                                                                                      grad_scores);
   D3F_LAUNCH_CHECK();
   return D3F_OK;
 }

@@ -66,7 +66,9 @@ class KPFCNN(nn.Module):
         if verbose:
             print(self)
 
-    def forward(self, batch):
+    def forward_raw(self, batch):
+        """(un-normalised descriptors [N,C], scores [N,1]) -- `forward` without the final F.normalize, for callers
+        that only need a few normalised rows (the training step: ops.select_normalize)."""
         x = batch['features'].clone().detach()
         skips = []
         for i, op in enumerate(self.encoder_blocks):
@@ -77,9 +79,11 @@ class KPFCNN(nn.Module):
             if j in self.decoder_concats:
                 x = torch.cat([x, skips.pop()], dim=1)
             x = op(x, batch)
-        scores = self.detection_scores(batch, x)
-        features = F.normalize(x, p=2, dim=-1)
-        return features, scores
+        return x, self.detection_scores(batch, x)
+
+    def forward(self, batch):
+        x, scores = self.forward_raw(batch)
+        return F.normalize(x, p=2, dim=-1), scores
 
     def detection_scores(self, inputs, features):
         """Saliency score of every point [N,1] (reference architectures.py:322-368); eval mode adds the

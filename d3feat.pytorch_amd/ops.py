@@ -650,6 +650,51 @@ def circle_det_loss(anchor, positive, dist_keypts, anc_score, pos_score, log_sca
     return _CircleDetFn.apply(anchor, positive, neg_mask, sa, sp, log_scale, safe_radius, pos_margin, neg_margin)
 
 
+class _SelectNormalizeFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, scores, idx_a, idx_p, p_offset):
+        N, C, M = int(x.shape[0]), int(x.shape[1]), int(idx_a.shape[0])
+        dev = x.device
+        oa = torch.empty((M, C), dtype=torch.float32, device=dev)
+        op = torch.empty((M, C), dtype=torch.float32, device=dev)
+        sa = torch.empty(M, dtype=torch.float32, device=dev)
+        sp = torch.empty(M, dtype=torch.float32, device=dev)
+        _native.check(_native.lib().d3f_select_normalize_forward(_p(x), _p(scores), N, C, _p(idx_a), _p(idx_p), M,
+                                                                 _p(p_offset), _p(oa), _p(op), _p(sa), _p(sp),
+                                                                 _stream()), "d3f_select_normalize_forward")
+        ctx.save_for_backward(x, idx_a, idx_p, p_offset if p_offset is not None else idx_a.new_empty(0))
+        ctx.has_off = p_offset is not None
+        return oa, op, sa, sp
+
+    @staticmethod
+    def backward(ctx, g_a, g_p, g_sa, g_sp):
+        x, idx_a, idx_p, p_off = ctx.saved_tensors
+        N, C, M = int(x.shape[0]), int(x.shape[1]), int(idx_a.shape[0])
+        buf = torch.empty(N * (C + 1), dtype=torch.float32, device=x.device)
+        gx, gs = buf[:N * C].view(N, C), buf[N * C:].view(N, 1)
+        cont = [g.contiguous() if g is not None else None for g in (g_a, g_p, g_sa, g_sp)]
+        _native.check(_native.lib().d3f_select_normalize_backward(_p(x), N, C, _p(idx_a), _p(idx_p), M,
+                                                                  _p(p_off) if ctx.has_off else None, _p(cont[0]),
+                                                                  _p(cont[1]), _p(cont[2]), _p(cont[3]), _p(gx),
+                                                                  _p(gs), _stream()), "d3f_select_normalize_backward")
+        return gx, gs, None, None, None
+
+
+def select_normalize(x, scores, idx_a, idx_p, p_offset=None):
+    """(normalize(x)[idx_a], normalize(x)[idx_p + p_offset], scores[idx_a], scores[idx_p + p_offset]) without
+    normalising or differentiating through the other N - 2M rows.  idx_*: int64 [M]; p_offset: device int32 scalar."""
+    x = _f32(x, "x")
+    sc = _f32(scores, "scores").reshape(-1, 1)
+    ia, ip = idx_a.contiguous(), idx_p.contiguous()
+    if ia.dtype != torch.int64 or ip.dtype != torch.int64:
+        ia, ip = ia.long(), ip.long()
+    off = None
+    if p_offset is not None:
+        off = p_offset if isinstance(p_offset, torch.Tensor) else torch.tensor([int(p_offset)], device=x.device)
+        off = off.reshape(-1)[:1].to(torch.int32).contiguous()
+    return _SelectNormalizeFn.apply(x, sc, ia, ip, off)
+
+
 # ---------------------------------------------------------------------------------------------------------------
 # dense mutual-NN matching (geometric_registration/common.py:5-21)
 # ---------------------------------------------------------------------------------------------------------------

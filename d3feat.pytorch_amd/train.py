@@ -16,6 +16,7 @@ import os
 import torch
 import torch.distributed as dist
 
+from . import ops
 from .datasets import dataloader as dl
 from .models.architectures import KPFCNN
 from .utils.loss import CircleLoss
@@ -92,14 +93,14 @@ class GuardedSGD:
         return self.state[1]
 
     @torch.no_grad()
-    def step(self):
-        """Returns a 0-dim bool tensor: True when the update was applied."""
+    def step(self, want_ok=True):
+        """Returns a 0-dim bool tensor: True when the update was applied (None with want_ok=False: the training
+        step only consults the skipped-step counter)."""
         g = self.flat.grad
         if g.is_cuda:
-            from . import ops
-            before = self.state[1].clone()
+            before = self.state[1].clone() if want_ok else None
             ops.sgd_guarded_step(g, self.flat.data, self.buf, self.lr, self.momentum, self.weight_decay, self.state)
-            return self.state[1] == before
+            return (self.state[1] == before) if want_ok else None
         ok = torch.isfinite(g).all()
         d = torch.add(g, self.flat.data, alpha=self.weight_decay)       # g + wd * p
         new_buf = torch.add(d, self.buf, alpha=self.momentum)            # mom * buf + d
@@ -143,14 +144,20 @@ class TrainStep:
     def build_batch(self, item):
         return dl.collate_fn_descriptor([item], self.config, self.limits, device=self.device, exact_width=False)
 
-    def forward_loss(self, batch):
-        feats, scores = self.model(batch)
-        corr = batch['corr'].long()
-        n0 = batch['n0'] if 'n0' in batch else batch['stack_lengths'][0][0]  # host int, or a device scalar (no sync)
-        ia, ip = corr[:, 0], corr[:, 1] + n0
-        desc, acc, fp, an, _, dists = self.circle(feats[ia], feats[ip], batch['dist_keypts'], scores[ia], scores[ip])
+    def _loss_from_raw(self, x, scores, batch):
+        """Reference trainer.py:91-98 on the un-normalised descriptors: the 2M sampled rows are gathered and
+        normalised by one launch (the other rows never enter the loss)."""
+        corr = batch['corr']
+        n0 = batch['n0'] if 'n0' in batch else batch['stack_lengths'][0][:1]  # host int, or a device scalar (no sync)
+        ia, ip = corr[:, 0].contiguous(), corr[:, 1].contiguous()
+        fa, fp_, sa, sp = ops.select_normalize(x, scores, ia, ip, n0)
+        desc, acc, fp, an, _, dists = self.circle(fa, fp_, batch['dist_keypts'], sa, sp)
         det = dists._d3f_det[0][1]
         return desc * self.w_desc + det * self.w_det, desc, det, acc
+
+    def forward_loss(self, batch):
+        x, scores = self.model.forward_raw(batch)
+        return self._loss_from_raw(x, scores, batch)
 
     def _forward_loss_cut(self, batch):
         """forward_loss with the autograd graph cut at the input of encoder block CUT: everything downstream (coarse
@@ -174,13 +181,7 @@ class TrainStep:
                 x = torch.cat([x, skips.pop()], dim=1)
             x = op(x, batch)
         scores = m.detection_scores(batch, x)
-        feats = torch.nn.functional.normalize(x, p=2, dim=-1)
-        corr = batch['corr'].long()
-        n0 = batch['n0'] if 'n0' in batch else batch['stack_lengths'][0][0]
-        ia, ip = corr[:, 0], corr[:, 1] + n0
-        desc, acc, fp, an, _, dists = self.circle(feats[ia], feats[ip], batch['dist_keypts'], scores[ia], scores[ip])
-        det = dists._d3f_det[0][1]
-        return (desc * self.w_desc + det * self.w_det, desc, det, acc), cuts
+        return self._loss_from_raw(x, scores, batch), cuts
 
     def _backward_deep(self, batch):
         """Stage 1: forward + backward of the deep bucket; leaves the cut gradients in self._cuts."""
@@ -219,7 +220,7 @@ class TrainStep:
             for w in works:
                 w.wait()
             g.mul_(1.0 / self.world)
-        self.opt.step()
+        self.opt.step(want_ok=False)
         return out
 
     # -- static shapes + hipGraph ---------------------------------------------------------------------------
@@ -300,7 +301,7 @@ class TrainStep:
         loss, desc, det, acc = self.forward_loss(batch)
         loss.backward()
         self.flat.gather_grads()
-        self.opt.step()
+        self.opt.step(want_ok=False)
         return loss.detach(), desc.detach(), det.detach(), acc.detach()
 
     def _static_step(self, item):
@@ -454,5 +455,5 @@ class TrainStep:
         loss, desc, det, acc = self.forward_loss(batch)
         loss.backward()
         allreduce_mean_(self.flat.gather_grads(), self.world)
-        self.opt.step()
+        self.opt.step(want_ok=False)
         return loss.detach(), desc.detach(), det.detach(), acc.detach()

@@ -339,6 +339,39 @@ def test_circle_det_loss(m):
     assert rel_err(gsp.grad.cpu().numpy(), tsp.grad.numpy()) < 1e-5
 
 
+@pytest.mark.parametrize("n,c,m", [(5000, 32, 128), (300, 16, 64), (77, 48, 20)])
+def test_select_normalize(n, c, m):
+    """normalize(x)[ia], normalize(x)[ip + n0], scores[...] in one launch each way == F.normalize + indexing."""
+    rng = np.random.default_rng(n)
+    x = rng.normal(size=(n, c)).astype(np.float32)
+    x[3] = 0.0  # a zero row: divided by eps like F.normalize
+    sc = rng.normal(size=(n, 1)).astype(np.float32)
+    n0 = n // 2
+    ia = rng.integers(0, n0, size=m)
+    ip = rng.integers(0, n - n0, size=m)
+    ia[0], ip[1] = 3, ip[0]  # the zero row, and a repeated positive
+    ga, gp = rng.normal(size=(m, c)).astype(np.float32), rng.normal(size=(m, c)).astype(np.float32)
+    gsa, gsp = rng.normal(size=m).astype(np.float32), rng.normal(size=m).astype(np.float32)
+    tx, ts = torch.from_numpy(x).requires_grad_(True), torch.from_numpy(sc).requires_grad_(True)
+    f = torch.nn.functional.normalize(tx, p=2, dim=-1)
+    ref = (f[ia], f[ip + n0], ts[ia].reshape(-1), ts[ip + n0].reshape(-1))
+    torch.autograd.backward(ref, [torch.from_numpy(a) for a in (ga, gp, gsa, gsp)])
+    gx, gs = cu(x).requires_grad_(True), cu(sc).requires_grad_(True)
+    off = torch.tensor([n0, n - n0], dtype=torch.int32, device=DEV)[:1]
+    out = ops.select_normalize(gx, gs, cu(ia), cu(ip), off)
+    torch.autograd.backward(out, [cu(a) for a in (ga, gp, gsa, gsp)])
+    for a, b in zip(out, ref):
+        assert rel_err(a.detach().cpu().numpy(), b.detach().numpy()) < 1e-6
+    mask = np.ones(n, bool)
+    mask[3] = False  # d(x/eps)/dx = 1/eps = 1e12: compared separately
+    assert rel_err(gx.grad.cpu().numpy()[mask], tx.grad.numpy()[mask]) < 1e-5
+    assert rel_err(gx.grad.cpu().numpy()[3], tx.grad.numpy()[3]) < 1e-5
+    assert rel_err(gs.grad.cpu().numpy(), ts.grad.numpy()) < 1e-6
+    # host-int offset gives the same selection
+    out2 = ops.select_normalize(cu(x), cu(sc), cu(ia), cu(ip), n0)
+    assert torch.equal(out2[1], out[1].detach())
+
+
 def test_loss_modules_follow_reference_call_order():
     from d3feat_pytorch_amd.utils.loss import CircleLoss, DetLoss
     rng = np.random.default_rng(9)
