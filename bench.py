@@ -125,6 +125,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--pairs", type=int, default=4, help="distinct synthetic pairs per rank (cycled)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-tuned-gemm", action="store_true", help="library-default GEMM kernels instead of the shipped "
+                                                                 "TunableOp table (d3feat.pytorch_amd/tuned/)")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
     ap.add_argument("--cpu-budget", type=float, default=20.0)
     args = ap.parse_args()
@@ -144,6 +146,10 @@ def main():
     from d3feat_pytorch_amd.datasets import dataloader as dl
     from d3feat_pytorch_amd.train import TrainStep
     _native.lib()  # fail loudly if the HIP library is missing
+    import d3feat_pytorch_amd as d3f
+    tuned = False
+    if not args.no_tuned_gemm and not os.environ.get("PYTORCH_TUNABLEOP_ENABLED"):
+        tuned = d3f.enable_tuned_gemms()
 
     cfg = cfgmod.default_config()
 
@@ -343,6 +349,7 @@ def main():
                                    "on-device radius search + grid subsample, SGD step)" % int(np.mean(n_pts)),
                        "points_per_pair": n_pts, "neighbor_limits": limits, "pairs_per_rank": len(items),
                        "parallelism": "dp%d" % world, "final_loss": round(loss_val, 5),
+                       "library_gemms": "TunableOp table tuned/tunableop_gfx950.csv" if tuned else "library default",
                        "launch": "hipGraph replay: network step on the training stream, next pair's pyramid graph on a side stream "
                                  "(static level capacities %s)" % ts.caps
                                  if use_graph else "eager launches, pyramid on a side stream"},

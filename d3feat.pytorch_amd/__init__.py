@@ -33,3 +33,32 @@ def install_reference_aliases(names=None, overwrite=False):
 
 def build(verbose=False):
     return _native.build(verbose=verbose)
+
+
+def enable_tuned_gemms(path=None, tune_missing=False):
+    """Library-GEMM kernel selection for the network's shapes (PyTorch TunableOp over rocBLAS / hipBLASLt).
+
+    About 95 library GEMMs remain in a training step (unary blocks of the coarse levels, the few-point KPConv weight /
+    input gradients); their shapes are odd for a BLAS heuristic (160..2000 rows against 512..7680 reduction or output
+    columns) and the default pick is 6 % of the step slower than the best solution.  ``tuned/tunableop_gfx950.csv``
+    holds the winners for the static-capacity shapes of S1-class pairs, produced by
+    ``PYTORCH_TUNABLEOP_ENABLED=1 PYTORCH_TUNABLEOP_TUNING=1 python bench.py``; it carries validators (PyTorch, HIP,
+    rocBLAS / hipBLASLt versions, gfx arch) and is ignored by PyTorch when they do not match.  Shapes that are not in
+    the table use the library default unless ``tune_missing``.  Returns True when the table was loaded."""
+    import os
+    import torch
+    tunable = torch.cuda.tunable
+    if path is None:
+        path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tuned", "tunableop_gfx950.csv")
+    if not os.path.exists(path):
+        return False
+    tunable.enable(True)
+    tunable.tuning_enable(bool(tune_missing))
+    try:
+        import tempfile
+        # anything PyTorch decides to write back at exit goes to a scratch file, never into the package
+        tunable.set_filename(os.path.join(tempfile.gettempdir(), "d3f_tunableop_%d.csv" % os.getpid()))
+        return bool(tunable.read_file(path))
+    except Exception:  # pragma: no cover - an unreadable table must not take the training step down
+        tunable.enable(False)
+        return False

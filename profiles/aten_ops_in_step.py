@@ -1,0 +1,43 @@
+"""Which ATen ops (PyTorch glue around the library calls) still run inside one training step, and how often?
+Run on the GPU box: python profiles/aten_ops_in_step.py"""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+from torch.profiler import profile, ProfilerActivity
+from d3feat_pytorch_amd import config as cfgmod, synthetic
+from d3feat_pytorch_amd.datasets import dataloader as dl
+from d3feat_pytorch_amd.train import TrainStep
+
+dev = torch.device("cuda:0")
+cfg = cfgmod.default_config()
+
+
+def sub(p, l, d):
+    a, b = dl.batch_grid_subsampling_kpconv(torch.as_tensor(p).to(dev), torch.as_tensor(l).to(dev), sampleDl=d)
+    return a.cpu().numpy(), b.cpu().numpy()
+
+
+it = synthetic.make_pair(1, 2, sub)
+item = tuple(torch.from_numpy(np.ascontiguousarray(a)).to(dev) for a in it)
+ts = TrainStep(cfg, [42] * 5, dev, seed=0)
+b = ts.build_batch(item)
+sizes = [[int(t.shape[0]) for t in b['points']]]
+ts.enable_graph(TrainStep.capacities_for(sizes, slack=1.0), num_corr=int(item[4].shape[0]))
+st = ts.sets[0]
+ts._load_inputs(st, item)
+ts._build_set(st)
+for _ in range(2):
+    ts._net_step(st)
+torch.cuda.synchronize()
+with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA]) as prof:
+    ts._net_step(st)
+    torch.cuda.synchronize()
+rows = [(e.key, e.count, e.device_time_total if hasattr(e, "device_time_total") else e.cuda_time_total)
+        for e in prof.key_averages()]
+rows = [r for r in rows if r[0].startswith("aten::") and r[2] > 0]
+rows.sort(key=lambda r: -r[2])
+print("%-40s %6s %12s" % ("op", "calls", "device_us"))
+for k, c, t in rows[:40]:
+    print("%-40s %6d %12.1f" % (k, c, t))
+print("total aten device time: %.1f us in %d op calls" % (sum(r[2] for r in rows), sum(r[1] for r in rows)))
