@@ -36,6 +36,7 @@ SIGNATURES = {
     "d3f_kpconv_backward": (_i, [_vp, _i, _vp, _i, _vp, _i, _vp, _i, _vp, _i, _vp, _i, _f, _vp, _vp, _vp, _vp, _vp,
                                  _vp, _sz, _vp]),
     "d3f_kpconv_grad_input_supported": (_i, [_i, _i, _i, _i]),
+    "d3f_kpconv_aggregate": (_i, [_vp, _i, _vp, _i, _vp, _i, _vp, _i, _vp, _i, _f, _vp, _vp, _vp, _sz, _vp]),
     "d3f_kpconv_grad_input": (_i, [_vp, _i, _vp, _i, _vp, _i, _vp, _i, _vp, _i, _f, _vp, _vp, _vp, _sz, _vp]),
     "d3f_linear_grad_weight_supported": (_i, [_i, _i, _i]),
     "d3f_linear_fused_supported": (_i, [_i, _i, _i]),
@@ -47,8 +48,8 @@ SIGNATURES = {
     "d3f_max_pool_backward": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp]),
     "d3f_closest_pool_forward": (_i, [_vp, _i, _i, _vp, _i, _i, _vp, _vp]),
     "d3f_closest_pool_backward": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp]),
-    "d3f_bias_act_forward": (_i, [_vp, _vp, _vp, _vp, _f, _i, _i, _vp, _vp, _i, _vp]),
-    "d3f_bias_act_backward": (_i, [_vp, _vp, _f, _i, _i, _vp, _vp, _vp, _i, _vp]),
+    "d3f_bias_act_forward": (_i, [_vp, _vp, _vp, _vp, _f, _i, _i, _vp, _vp, _i, _vp, _vp]),
+    "d3f_bias_act_backward": (_i, [_vp, _vp, _f, _i, _i, _vp, _vp, _vp, _i, _vp, _vp]),
     "d3f_global_max": (_i, [_vp, _sz, _vp, _vp, _sz, _vp]),
     "d3f_global_max_rows": (_i, [_vp, _i, _i, _vp, _i, _vp, _vp, _sz, _vp]),
     "d3f_detection_scores_aux_floats": (_i, [_i]),

@@ -5,7 +5,8 @@
 // elementwise kernels plus the column reduction PyTorch runs for the bias gradient.  ~150 tiny launches per training
 // step in the reference graph become one launch forward and one backward per block.
 //
-//   forward : out[n,c] = act( x[n,c] + b1[c] + (add[n,c] + b2[c]) ),  act(v) = v > 0 ? v : slope*v   (slope = 1: identity)
+//   forward : out[n,c] = act( x[n,c]/d[n] + b1[c] + (add[n,c] + b2[c]) ),  act(v) = v > 0 ? v : slope*v   (slope = 1: identity;
+//             d = optional per-row divisor: the KPConv neighbor count when x is the raw (wf @ W) product)
 //   backward: gx[n,c]  = go[n,c] * (out[n,c] > 0 ? 1 : slope)     (also the gradient of `add`)
 //             gb[c]    = sum_n gx[n,c]                               (gradient of b1 and of b2)
 #include "common.hpp"
@@ -16,7 +17,7 @@ __global__ __launch_bounds__(256) void bias_act_fwd_kernel(const float* __restri
                                                            const float* __restrict__ add,
                                                            const float* __restrict__ b2, float slope, size_t n4,
                                                            int C, float* __restrict__ out, float* __restrict__ zinit,
-                                                           int zn) {
+                                                           int zn, const float* __restrict__ row_div) {
   // C % 4 == 0: one float4 per thread, columns of a float4 are c .. c+3
   if (zinit && blockIdx.x == 0)
     for (int t = threadIdx.x; t < zn; t += blockDim.x) zinit[t] = 0.0f;
@@ -24,6 +25,7 @@ __global__ __launch_bounds__(256) void bias_act_fwd_kernel(const float* __restri
   if (i >= n4) return;
   const int c = (int)((i * 4) % (size_t)C);
   float4 v = ((const float4*)x)[i];
+  if (row_div) { const float d = row_div[(i * 4) / (size_t)C]; v.x /= d; v.y /= d; v.z /= d; v.w /= d; }
   if (b1) { const float4 b = *(const float4*)(b1 + c); v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w; }
   if (add) { const float4 a = ((const float4*)add)[i]; v.x += a.x; v.y += a.y; v.z += a.z; v.w += a.w; }
   if (b2) { const float4 b = *(const float4*)(b2 + c); v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w; }
@@ -40,13 +42,15 @@ __global__ __launch_bounds__(256) void bias_act_fwd_scalar_kernel(const float* _
                                                                   const float* __restrict__ add,
                                                                   const float* __restrict__ b2, float slope, size_t n,
                                                                   int C, float* __restrict__ out,
-                                                                  float* __restrict__ zinit, int zn) {
+                                                                  float* __restrict__ zinit, int zn,
+                                                                  const float* __restrict__ row_div) {
   if (zinit && blockIdx.x == 0)
     for (int t = threadIdx.x; t < zn; t += blockDim.x) zinit[t] = 0.0f;
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const int c = (int)(i % (size_t)C);
   float v = x[i];
+  if (row_div) v /= row_div[i / (size_t)C];
   if (b1) v += b1[c];
   if (add) v += add[i];
   if (b2) v += b2[c];
@@ -60,7 +64,8 @@ __global__ __launch_bounds__(256) void bias_act_fwd_scalar_kernel(const float* _
 __global__ __launch_bounds__(256) void bias_act_bwd_kernel(const float* __restrict__ go, const float* __restrict__ out,
                                                            float slope, int N, int C, int rows_per_block,
                                                            float* __restrict__ gx, float* __restrict__ gb,
-                                                           float* __restrict__ gb2) {
+                                                           float* __restrict__ gb2,
+                                                           const float* __restrict__ row_div) {
   __shared__ float red[256];
   const int r0 = blockIdx.x * rows_per_block;
   const int r1 = min(N, r0 + rows_per_block);
@@ -72,7 +77,7 @@ __global__ __launch_bounds__(256) void bias_act_bwd_kernel(const float* __restri
     for (int r = r0 + rl; r < r1; r += 4) {
       const size_t i = (size_t)r * C + c;
       const float g = go[i] * (out[i] > 0.0f ? 1.0f : slope);
-      if (gx) gx[i] = g;
+      if (gx) gx[i] = row_div ? g / row_div[r] : g;  // the bias sums stay undivided
       s += g;
     }
   }
@@ -92,7 +97,7 @@ __global__ __launch_bounds__(256) void bias_act_bwd_kernel(const float* __restri
 extern "C" {
 
 int d3f_bias_act_forward(const float* x, const float* bias1, const float* add, const float* bias2, float slope, int N,
-                         int C, float* out, float* zero_init, int zero_n, void* stream) {
+                         int C, float* out, float* zero_init, int zero_n, const float* row_div, void* stream) {
   if (!x || !out || N < 0 || C < 1 || (zero_init && zero_n < 1)) return D3F_EINVAL;
   const size_t n = (size_t)N * C;
   if (n == 0) {
@@ -102,10 +107,10 @@ int d3f_bias_act_forward(const float* x, const float* bias1, const float* add, c
   }
   if (C % 4 == 0)
     bias_act_fwd_kernel<<<d3f::cdiv((long long)(n / 4), 256), 256, 0, (hipStream_t)stream>>>(
-        x, bias1, add, bias2, slope, n / 4, C, out, zero_init, zero_n);
+        x, bias1, add, bias2, slope, n / 4, C, out, zero_init, zero_n, row_div);
   else
     bias_act_fwd_scalar_kernel<<<d3f::cdiv((long long)n, 256), 256, 0, (hipStream_t)stream>>>(
-        x, bias1, add, bias2, slope, n, C, out, zero_init, zero_n);
+        x, bias1, add, bias2, slope, n, C, out, zero_init, zero_n, row_div);
   D3F_LAUNCH_CHECK();
   return D3F_OK;
 }
@@ -114,7 +119,8 @@ int d3f_bias_act_forward(const float* x, const float* bias1, const float* add, c
  * unary block are distinct parameters with identical gradients).  With bias_prezeroed = 0 they are zeroed here;
  * with 1 the caller guarantees zeros (d3f_bias_act_forward's zero_init). */
 int d3f_bias_act_backward(const float* grad_out, const float* out, float slope, int N, int C, float* grad_x,
-                          float* grad_bias, float* grad_bias2, int bias_prezeroed, void* stream) {
+                          float* grad_bias, float* grad_bias2, int bias_prezeroed, const float* row_div,
+                          void* stream) {
   if (!grad_out || !out || N < 0 || C < 1 || (!grad_x && !grad_bias) || (grad_bias2 && !grad_bias)) return D3F_EINVAL;
   if (!bias_prezeroed) {
     if (grad_bias && d3f::zero_async(grad_bias, sizeof(float) * (size_t)C, (hipStream_t)stream) != hipSuccess)
@@ -128,7 +134,7 @@ int d3f_bias_act_backward(const float* grad_out, const float* out, float slope, 
   while (rows > 16 && (long long)d3f::cdiv(N, rows) * cblocks < 1024) rows >>= 1;
   dim3 grid(d3f::cdiv(N, rows), cblocks);
   bias_act_bwd_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(grad_out, out, slope, N, C, rows, grad_x, grad_bias,
-                                                             grad_bias2);
+                                                             grad_bias2, row_div);
   D3F_LAUNCH_CHECK();
   return D3F_OK;
 }

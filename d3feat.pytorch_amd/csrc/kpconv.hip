@@ -239,6 +239,9 @@ int atb_splitk(const float* A, const float* B, const float* row_div, int R, int 
 int kpconv_grad_input_from_gw(const float* q_pts, int Nq, const float* s_pts, int Ns, const int32_t* idx, int H,
                               const float* x, int Cin, const float* kp, int K, float extent, const float* gwf, float* gx,
                               void* ws, hipStream_t stream);
+int kpconv_aggregate(const float* q_pts, int Nq, const float* s_pts, int Ns, const int32_t* idx, int H, const float* x,
+                     int Cin, const float* kp, int K, float extent, float* wf_out, float* nn_out, void* ws,
+                     hipStream_t stream);
 // kpconv_small.hip
 bool kpconv_small_supported(int Cin, int Cout, int K, int H);
 int kpconv_small_dispatch(bool fwd, const float* q_pts, const float* s_pts, const int32_t* idx, const float* x,
@@ -378,6 +381,19 @@ int d3f_kpconv_backward(const float* q_pts, int Nq, const float* s_pts, int Ns, 
     D3F_LAUNCH_CHECK();
   }
   return D3F_OK;
+}
+
+// wf [Nq, K*Cin] and nn [Nq] only (the caller contracts wf with W by a GEMM and divides by nn); shapes as
+// d3f_kpconv_grad_input_supported
+int d3f_kpconv_aggregate(const float* q_pts, int Nq, const float* s_pts, int Ns, const int32_t* idx, int H,
+                         const float* x, int Cin, const float* kernel_points, int K, float extent, float* wf_out,
+                         float* nn_out, void* ws, size_t ws_bytes, void* stream_) {
+  if (!q_pts || !s_pts || !idx || !x || !kernel_points || !wf_out || !nn_out || !ws || Nq < 1 || Ns < 1 || H < 1 ||
+      !(extent > 0.0f) || !kpconv_fused_supported(Cin, 64, K, H, Ns))
+    return D3F_EINVAL;
+  if (ws_bytes < d3f_kpconv_ws_bytes(Nq, Ns, H, K, Cin, 64)) return D3F_EWORKSPACE;
+  return kpconv_aggregate(q_pts, Nq, s_pts, Ns, idx, H, x, Cin, kernel_points, K, extent, wf_out, nn_out, ws,
+                          (hipStream_t)stream_);
 }
 
 // grad_x [Ns, Cin] (OVERWRITTEN) from gwf = (grad_out / nn) @ W^T  [Nq, K*Cin] computed by the caller (a plain GEMM)

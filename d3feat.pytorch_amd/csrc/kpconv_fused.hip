@@ -563,6 +563,30 @@ int kpconv_backward_fused(const float* q_pts, int Nq, const float* s_pts, int Ns
   return D3F_OK;
 }
 
+// Aggregation only: wf [Nq, K*Cin] = sum_h w[q,h,k] x[idx[q,h], c] and the neighbor count nn -- phase A of the fused
+// kernel, one workgroup per (16-query tile, channel chunk); the contraction with W is left to a GEMM (few-point layers)
+int kpconv_aggregate(const float* q_pts, int Nq, const float* s_pts, int Ns, const int32_t* idx, int H, const float* x,
+                     int Cin, const float* kp, int K, float extent, float* wf_out, float* nn_out, void* ws,
+                     hipStream_t stream) {
+  float4* spack = (float4*)ws;
+  int rc = pack_supports(s_pts, x, Ns, Cin, spack, stream);
+  if (rc) return rc;
+  const int CV = Cin == 16 ? 1 : (Cin == 32 ? 2 : 4);
+  const int CC = 16 * CV;
+  const size_t lds = sizeof(float) * (size_t)(16 * (16 * CC + 4) + 16);
+  dim3 grid(cdiv(Nq, 16), 1, Cin / CC);
+  const int dbg = 2 | 4;  // no contraction, no output store
+#define D3F_AGG(CVV)                                                                                                  \
+  kpconv_fwd_fused_kernel<CVV, 1, 1><<<grid, 256, lds, stream>>>(q_pts, spack, idx, x, kp, nullptr, Nq, Ns, H, Cin, 64, K, \
+                                                                 extent, nullptr, nn_out, wf_out, dbg)
+  if (CV == 1) D3F_AGG(1);
+  else if (CV == 2) D3F_AGG(2);
+  else D3F_AGG(4);
+#undef D3F_AGG
+  D3F_LAUNCH_CHECK();
+  return D3F_OK;
+}
+
 // grad_x from a precomputed gW = (grad_out / nn) @ W^T  [Nq, K*Cin]: staging + phase 2 (scatter) of the kernel above
 int kpconv_grad_input_from_gw(const float* q_pts, int Nq, const float* s_pts, int Ns, const int32_t* idx, int H,
                               const float* x, int Cin, const float* kp, int K, float extent, const float* gwf, float* gx,

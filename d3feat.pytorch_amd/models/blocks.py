@@ -247,9 +247,10 @@ class SimpleBlock(nn.Module):
 
     def forward(self, x, batch):
         q_pts, s_pts, inds = _layer_inputs(self.block_name, self.layer_ind, batch)
+        if not self.use_bn and x.is_cuda:
+            return ops.kpconv_bias_act(q_pts, s_pts, inds, x, self.KPConv.kernel_points, self.KPConv.weights,
+                                       self.KPConv.KP_extent, self.batch_norm.bias, slope=0.1)
         y = self.KPConv(q_pts, s_pts, inds, x)
-        if not self.use_bn:
-            return ops.bias_act(y, self.batch_norm.bias, slope=0.1)
         return self.leaky_relu(self.batch_norm(y))
 
 
@@ -278,11 +279,14 @@ class ResnetBottleneckBlock(nn.Module):
     def forward(self, features, batch):
         q_pts, s_pts, inds = _layer_inputs(self.block_name, self.layer_ind, batch)
         x = self.unary1(features)
-        x = self.KPConv(q_pts, s_pts, inds, x)
+        if not self.use_bn and x.is_cuda:
+            x = ops.kpconv_bias_act(q_pts, s_pts, inds, x, self.KPConv.kernel_points, self.KPConv.weights,
+                                    self.KPConv.KP_extent, self.batch_norm_conv.bias, slope=0.1)
+        else:
+            x = self.KPConv(q_pts, s_pts, inds, x)
         shortcut = max_pool(features, inds) if 'strided' in self.block_name else features
         shortcut = self.unary_shortcut(shortcut)
         if not self.use_bn:
-            x = ops.bias_act(x, self.batch_norm_conv.bias, slope=0.1)
             return self.unary2(x, residual=shortcut)  # leaky(unary2(x) + shortcut) in the epilogue of unary2
         x = self.leaky_relu(self.batch_norm_conv(x))
         return self.leaky_relu(self.unary2(x) + shortcut)

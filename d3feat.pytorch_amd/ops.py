@@ -276,6 +276,88 @@ class _KPConvFn(torch.autograd.Function):
         return None, None, None, gx, None, gw, None
 
 
+class _KPConvGemmBiasActFn(torch.autograd.Function):
+    """act(KPConv(x) + bias) for the few-point / wide layers (bottom of the U-Net), as
+        aggregation kernel -> wf [Nq, K*Cin], nn      library GEMM  raw = wf @ W       epilogue  act(raw/nn + bias)
+    and backward   epilogue backward -> g/nn, bias gradient      GEMMs  grad_W = wf^T (g/nn),  gW = (g/nn) W^T
+                   scatter kernel -> grad_x.
+    The fused forward kernel would run its contraction on 10..40 workgroups there (58-71 us); this is ~40 us and the
+    backward saves the separate g/nn pass."""
+
+    @staticmethod
+    def forward(ctx, q_pts, s_pts, idx, x, kernel_points, weights, bias, extent, slope):
+        L = _native.lib()
+        Nq, Ns, H = int(q_pts.shape[0]), int(s_pts.shape[0]), int(idx.shape[1])
+        K, Cin, Cout = int(weights.shape[0]), int(weights.shape[1]), int(weights.shape[2])
+        dev = x.device
+        wf = torch.empty((Nq, K * Cin), dtype=torch.float32, device=dev)
+        nn = torch.empty(Nq, dtype=torch.float32, device=dev)
+        nbytes = L.d3f_kpconv_ws_bytes(Nq, Ns, H, K, Cin, 64)
+        ws = _ws(nbytes, dev)
+        with _region("kpconv_aggregate[Nq=%d,Cin=%d,H=%d]" % (Nq, Cin, H), 4 * Nq * H * (4 + Cin) + 4 * Nq * K * Cin):
+            _native.check(L.d3f_kpconv_aggregate(_p(q_pts), Nq, _p(s_pts), Ns, _p(idx), H, _p(x), Cin,
+                                                 _p(kernel_points), K, float(extent), _p(wf), _p(nn), _p(ws), nbytes,
+                                                 _stream()), "d3f_kpconv_aggregate")
+        raw = torch.mm(wf, weights.view(K * Cin, Cout))
+        out = torch.empty_like(raw)
+        want_b = bias is not None and ctx.needs_input_grad[6]
+        gbuf = torch.empty((1, Cout), dtype=torch.float32, device=dev) if want_b else None
+        _native.check(L.d3f_bias_act_forward(_p(raw), _p(bias), None, None, float(slope), Nq, Cout, _p(out), _p(gbuf),
+                                             Cout if want_b else 0, _p(nn), _stream()), "d3f_bias_act_forward")
+        ctx.save_for_backward(q_pts, s_pts, idx, x, kernel_points, weights, nn, wf, out)
+        ctx.gbuf, ctx.extent, ctx.slope, ctx.want_b = gbuf, float(extent), float(slope), want_b
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        q_pts, s_pts, idx, x, kernel_points, weights, nn, wf, out = ctx.saved_tensors
+        L = _native.lib()
+        Nq, Ns, H = int(q_pts.shape[0]), int(s_pts.shape[0]), int(idx.shape[1])
+        K, Cin, Cout = int(weights.shape[0]), int(weights.shape[1]), int(weights.shape[2])
+        go = grad_out.contiguous()
+        gb, pre = None, 0
+        if ctx.want_b:
+            gb, pre = ctx.gbuf, 1
+            ctx.gbuf = None
+            if gb is None:
+                gb, pre = torch.empty((1, Cout), dtype=torch.float32, device=go.device), 0
+        gon = torch.empty_like(go)  # masked gradient / nn
+        _native.check(L.d3f_bias_act_backward(_p(go), _p(out), ctx.slope, Nq, Cout, _p(gon), _p(gb), None, pre, _p(nn),
+                                              _stream()), "d3f_bias_act_backward")
+        gx = gw = None
+        if ctx.needs_input_grad[5]:
+            gw = torch.empty_like(weights)
+            torch.mm(wf.t(), gon, out=gw.view(K * Cin, Cout))
+        if ctx.needs_input_grad[3]:
+            gx = torch.empty_like(x)
+            gwf = torch.mm(gon, weights.view(K * Cin, Cout).t())
+            nbytes = L.d3f_kpconv_ws_bytes(Nq, Ns, H, K, Cin, 64)
+            ws = _ws(nbytes, x.device)
+            with _region("kpconv_dx_scatter[Nq=%d,Cin=%d,H=%d]" % (Nq, Cin, H), 4 * Nq * K * Cin + 4 * Nq * H * (1 + Cin)):
+                _native.check(L.d3f_kpconv_grad_input(_p(q_pts), Nq, _p(s_pts), Ns, _p(idx), H, _p(x), Cin,
+                                                      _p(kernel_points), K, ctx.extent, _p(gwf), _p(gx), _p(ws),
+                                                      nbytes, _stream()), "d3f_kpconv_grad_input")
+        return None, None, None, gx, None, gw, (gb.view(-1) if gb is not None else None), None, None
+
+
+def kpconv_bias_act(q_pts, s_pts, neighb_inds, x, kernel_points, weights, extent, bias, slope=0.1):
+    """LeakyReLU(KPConv(x) + bias): KPConv + the bias/activation that follows it in every block
+    (reference blocks.py:594-598, 668-676)."""
+    q_pts, s_pts, x = _f32(q_pts, "q_pts"), _f32(s_pts, "s_pts"), _f32(x, "x")
+    Nq, H = int(q_pts.shape[0]), int(neighb_inds.shape[1])
+    K, Cin = int(weights.shape[0]), int(weights.shape[1])
+    if 0 < Nq < _GEMM_DX_MAX_ROWS and s_pts.shape[0] > 0 and \
+            _native.lib().d3f_kpconv_grad_input_supported(Cin, K, H, int(s_pts.shape[0])):
+        idx = _i32(neighb_inds, "neighb_inds")
+        kp, w = _f32(kernel_points, "kernel_points"), _f32(weights, "weights")
+        if x.shape[0] != s_pts.shape[0] or x.shape[1] != w.shape[1] or idx.shape[0] != q_pts.shape[0]:
+            raise RuntimeError("KPConv: inconsistent shapes q%s s%s idx%s x%s W%s" % (
+                tuple(q_pts.shape), tuple(s_pts.shape), tuple(idx.shape), tuple(x.shape), tuple(w.shape)))
+        b = _f32(bias, "bias") if bias is not None else None
+        return _KPConvGemmBiasActFn.apply(q_pts, s_pts, idx, x, kp, w, b, float(extent), float(slope))
+    return bias_act(kpconv(q_pts, s_pts, neighb_inds, x, kernel_points, weights, extent), bias, slope=slope)
+
+
 def kpconv(q_pts, s_pts, neighb_inds, x, kernel_points, weights, extent):
     """Rigid KPConv, 'linear' influence, 'sum' aggregation.  Shapes as KPConv.forward (blocks.py:237)."""
     q_pts, s_pts, x = _f32(q_pts, "q_pts"), _f32(s_pts, "s_pts"), _f32(x, "x")
@@ -365,7 +447,7 @@ class _LinearBiasActFn(torch.autograd.Function):
             first, second = (g1, g2) if g1 is not None else (g2, None)
             _native.check(L.d3f_bias_act_backward(_p(go), _p(out), ctx.slope, N, Cout,
                                                   _p(gm) if ctx.slope != 1.0 else None, _p(first), _p(second),
-                                                  pre if first is not None else 0, _stream()),
+                                                  pre if first is not None else 0, None, _stream()),
                           "d3f_bias_act_backward")
         gx = gw = None
         if ctx.needs_input_grad[0]:
@@ -484,7 +566,7 @@ class _BiasActFn(torch.autograd.Function):
         nb = int(b1 is not None and ctx.needs_input_grad[1]) + int(b2 is not None and ctx.needs_input_grad[3])
         gbuf = torch.empty((nb, C), dtype=torch.float32, device=x.device) if nb else None
         _native.check(_native.lib().d3f_bias_act_forward(_p(x), _p(b1), _p(add), _p(b2), float(slope), N, C, _p(out),
-                                                         _p(gbuf), nb * C, _stream()), "d3f_bias_act_forward")
+                                                         _p(gbuf), nb * C, None, _stream()), "d3f_bias_act_forward")
         ctx.save_for_backward(out)
         ctx.gbuf = gbuf
         ctx.slope = float(slope)
@@ -516,8 +598,8 @@ class _BiasActFn(torch.autograd.Function):
                 gx = torch.empty_like(go)
             first, second = (g1, g2) if g1 is not None else (g2, None)
             _native.check(_native.lib().d3f_bias_act_backward(_p(go), _p(out), ctx.slope, N, C, _p(gx), _p(first),
-                                                              _p(second), pre if first is not None else 0, _stream()),
-                          "d3f_bias_act_backward")
+                                                              _p(second), pre if first is not None else 0, None,
+                                                              _stream()), "d3f_bias_act_backward")
             if identity:
                 gx = go
         return (gx if ctx.needs_input_grad[0] else None, g1, gx if ctx.has[1] and ctx.needs_input_grad[2] else None,

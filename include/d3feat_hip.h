@@ -113,6 +113,11 @@ int d3f_kpconv_backward(const float* q_pts, int Nq, const float* s_pts, int Ns, 
  * would run on a handful of workgroups).  Same semantics as the grad_x of d3f_kpconv_backward.
  * Workspace: d3f_kpconv_ws_bytes(Nq, Ns, H, K, Cin, 64). */
 int d3f_kpconv_grad_input_supported(int Cin, int K, int H, int Ns);
+/* forward counterpart for the same layers: only the neighbor aggregation wf [Nq, K*Cin] and nn [Nq]; the caller
+ * computes out = (wf @ W) / nn with a GEMM (and d3f_bias_act_forward's row_div). */
+int d3f_kpconv_aggregate(const float* q_pts, int Nq, const float* s_pts, int Ns, const int32_t* idx, int H,
+                         const float* x, int Cin, const float* kernel_points, int K, float extent, float* wf_out,
+                         float* nn_out, void* ws, size_t ws_bytes, void* stream);
 int d3f_kpconv_grad_input(const float* q_pts, int Nq, const float* s_pts, int Ns, const int32_t* idx, int H,
                           const float* x, int Cin, const float* kernel_points, int K, float extent, const float* gwf,
                           float* grad_x, void* ws, size_t ws_bytes, void* stream);
@@ -162,11 +167,14 @@ int d3f_closest_pool_backward(const float* grad_out, const int32_t* idx, int Nq,
  *             receives the same sums in a second buffer (two parameters, identical gradients).
  * zero_init (optional, zero_n floats): scratch the forward kernel clears on the side -- the backward's bias-gradient
  *   accumulators, so that backward (bias_prezeroed = 1) needs no separate fill launch.
+ * row_div (optional, [N]): out = act(x[n,:]/row_div[n] + ...) and grad_x[n,:] = masked gradient / row_div[n] (the bias
+ *   sums use the undivided masked gradient) -- the KPConv neighbor-count normalisation when x is a raw wf @ W product.
  * ---------------------------------------------------------------------------------------------- */
 int d3f_bias_act_forward(const float* x, const float* bias1, const float* add, const float* bias2, float slope, int N,
-                         int C, float* out, float* zero_init, int zero_n, void* stream);
+                         int C, float* out, float* zero_init, int zero_n, const float* row_div, void* stream);
 int d3f_bias_act_backward(const float* grad_out, const float* out, float slope, int N, int C, float* grad_x,
-                          float* grad_bias, float* grad_bias2, int bias_prezeroed, void* stream);
+                          float* grad_bias, float* grad_bias2, int bias_prezeroed, const float* row_div,
+                          void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Detector score -- replaces KPFCNN.detection_scores (models/architectures.py:322-368).

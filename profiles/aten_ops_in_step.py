@@ -9,6 +9,9 @@ from d3feat_pytorch_amd import config as cfgmod, synthetic
 from d3feat_pytorch_amd.datasets import dataloader as dl
 from d3feat_pytorch_amd.train import TrainStep
 
+import d3feat_pytorch_amd as d3f
+if "--tuned" in sys.argv:
+    print("tuned GEMM table loaded:", d3f.enable_tuned_gemms())
 dev = torch.device("cuda:0")
 cfg = cfgmod.default_config()
 

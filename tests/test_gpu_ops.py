@@ -226,6 +226,29 @@ def test_fused_unary_block_matches_unfused(n, cin, cout, with_add, slope, monkey
             assert rel_err(a, b) < 2e-5
 
 
+@pytest.mark.parametrize("nq,ns,h,cin,cout", [(97, 154, 23, 512, 512), (150, 160, 42, 256, 128), (300, 400, 42, 16, 16),
+                                              (257, 300, 45, 128, 128), (571, 2053, 42, 64, 256)])
+def test_kpconv_bias_act_gemm_path_matches_fused_path(nq, ns, h, cin, cout, monkeypatch):
+    """LeakyReLU(KPConv(x) + b): aggregation kernel + library GEMMs + row-divided epilogue (few-point layers) ==
+    fused KPConv kernel + epilogue, values and all three gradients."""
+    rng = np.random.default_rng(nq + cout)
+    q, s, idx, x, kp, w = _kpconv_case(rng, nq, ns, h, cin, cout)
+    b = rng.normal(size=cout).astype(np.float32)
+    go = rng.normal(size=(nq, cout)).astype(np.float32)
+    res = []
+    for rows in (1 << 30, 0):
+        monkeypatch.setattr(ops, "_GEMM_DX_MAX_ROWS", rows)
+        tx, tw, tb = cu(x).requires_grad_(True), cu(w).requires_grad_(True), cu(b).requires_grad_(True)
+        y = ops.kpconv_bias_act(cu(q), cu(s), cu(idx), tx, cu(kp), tw, 0.05, tb, slope=0.1)
+        y.backward(cu(go))
+        res.append([t.detach().cpu().numpy() for t in (y, tx.grad, tw.grad, tb.grad)])
+    ref = ops_ref.kpconv(*[torch.from_numpy(a) for a in (q, s, idx, x, kp, w)], 0.05).numpy() + b
+    ref = np.where(ref > 0, ref, 0.1 * ref)
+    assert rel_err(res[0][0], ref) < FWD_TOL
+    for a, c in zip(res[0], res[1]):
+        assert rel_err(a, c) < 2e-5
+
+
 def test_kpconv_all_shadow_rows_and_empty():
     rng = np.random.default_rng(0)
     q, s, idx, x, kp, w = _kpconv_case(rng, 64, 80, 10, 32, 32)
