@@ -30,14 +30,15 @@ SIGNATURES = {
     "d3f_grid_subsample_ws_bytes": (_sz, [_i, _i]),
     "d3f_grid_subsample": (_i, [_vp, _i, _vp, _i, _f, _i, _i, _vp, _i, _vp, _vp, _vp, _sz, _vp, _vp]),
     "d3f_kpconv_ws_bytes": (_sz, [_i, _i, _i, _i, _i, _i]),
-    "d3f_kpconv_forward": (_i, [_vp, _i, _vp, _i, _vp, _i, _vp, _i, _vp, _i, _vp, _i, _f, _vp, _vp, _vp, _vp, _sz,
-                                _vp]),
+    "d3f_kpconv_forward": (_i, [_vp, _i, _vp, _i, _vp, _i, _vp, _i, _vp, _i, _vp, _i, _f, _vp, _vp, _vp, _vp, _vp,
+                                _vp, _sz, _vp]),
+    "d3f_kpconv_packs_supports": (_i, [_i, _i, _i, _i, _i]),
     "d3f_kpconv_saves_wf": (_i, [_i, _i, _i, _i]),
-    "d3f_kpconv_backward": (_i, [_vp, _i, _vp, _i, _vp, _i, _vp, _i, _vp, _i, _vp, _i, _f, _vp, _vp, _vp, _vp, _vp,
-                                 _vp, _sz, _vp]),
+    "d3f_kpconv_backward": (_i, [_vp, _i, _vp, _i, _vp, _i, _vp, _i, _vp, _i, _vp, _i, _f, _vp, _vp, _vp, _vp, _i,
+                                 _vp, _vp, _vp, _sz, _vp]),
     "d3f_kpconv_grad_input_supported": (_i, [_i, _i, _i, _i]),
-    "d3f_kpconv_aggregate": (_i, [_vp, _i, _vp, _i, _vp, _i, _vp, _i, _vp, _i, _f, _vp, _vp, _vp, _sz, _vp]),
-    "d3f_kpconv_grad_input": (_i, [_vp, _i, _vp, _i, _vp, _i, _vp, _i, _vp, _i, _f, _vp, _vp, _vp, _sz, _vp]),
+    "d3f_kpconv_aggregate": (_i, [_vp, _i, _vp, _i, _vp, _i, _vp, _i, _vp, _i, _f, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "d3f_kpconv_grad_input": (_i, [_vp, _i, _vp, _i, _vp, _i, _vp, _i, _vp, _i, _f, _vp, _vp, _i, _vp, _vp, _sz, _vp]),
     "d3f_linear_grad_weight_supported": (_i, [_i, _i, _i]),
     "d3f_linear_fused_supported": (_i, [_i, _i, _i]),
     "d3f_linear_bias_act_forward": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp, _f, _vp, _vp, _i, _vp]),

@@ -232,16 +232,17 @@ bool kpconv_fused_supported(int Cin, int Cout, int K, int H, int Ns);
 size_t kpconv_fused_ws_bytes(int Ns);
 int kpconv_forward_fused(const float* q_pts, int Nq, const float* s_pts, int Ns, const int32_t* idx, int H,
                          const float* x, int Cin, const float* kp, int K, const float* W, int Cout, float extent,
-                         float* out, float* nn_out, float* wf_save, void* ws, hipStream_t stream);
+                         float* out, float* nn_out, float* wf_save, void* spack_keep, float* grad_x_clear, void* ws,
+                         hipStream_t stream);
 size_t atb_ws_bytes(int R, int M, int N);
 int atb_splitk(const float* A, const float* B, const float* row_div, int R, int M, int N, float* C, void* ws,
                hipStream_t stream);
 int kpconv_grad_input_from_gw(const float* q_pts, int Nq, const float* s_pts, int Ns, const int32_t* idx, int H,
-                              const float* x, int Cin, const float* kp, int K, float extent, const float* gwf, float* gx,
-                              void* ws, hipStream_t stream);
+                              const float* x, int Cin, const float* kp, int K, float extent, const float* gwf,
+                              const void* spack_kept, int gx_precleared, float* gx, void* ws, hipStream_t stream);
 int kpconv_aggregate(const float* q_pts, int Nq, const float* s_pts, int Ns, const int32_t* idx, int H, const float* x,
-                     int Cin, const float* kp, int K, float extent, float* wf_out, float* nn_out, void* ws,
-                     hipStream_t stream);
+                     int Cin, const float* kp, int K, float extent, float* wf_out, float* nn_out, void* spack_keep,
+                     float* grad_x_clear, void* ws, hipStream_t stream);
 // kpconv_small.hip
 bool kpconv_small_supported(int Cin, int Cout, int K, int H);
 int kpconv_small_dispatch(bool fwd, const float* q_pts, const float* s_pts, const int32_t* idx, const float* x,
@@ -250,8 +251,8 @@ int kpconv_small_dispatch(bool fwd, const float* q_pts, const float* s_pts, cons
                           hipStream_t stream);
 int kpconv_backward_fused(const float* q_pts, int Nq, const float* s_pts, int Ns, const int32_t* idx, int H,
                           const float* x, int Cin, const float* kp, int K, const float* W, int Cout, float extent,
-                          const float* nn, const float* gout, const float* wf_saved, float* gx, float* gw, void* ws,
-                          hipStream_t stream);
+                          const float* nn, const float* gout, const float* wf_saved, const void* spack_kept,
+                          int gx_precleared, float* gx, float* gw, void* ws, hipStream_t stream);
 
 }  // namespace d3f
 
@@ -292,25 +293,34 @@ static int kp_args_ok(const void* q_pts, int Nq, const void* s_pts, int Ns, cons
          K <= 16 && Cout >= 1 && extent > 0.0f;
 }
 
+// 1 when forward/backward for these shapes work on packed supports (spack_keep / spack_kept are honoured)
+int d3f_kpconv_packs_supports(int Cin, int Cout, int K, int H, int Ns) {
+  return (!kpconv_small_supported(Cin, Cout, K, H) && kpconv_fused_supported(Cin, Cout, K, H, Ns)) ? 1 : 0;
+}
+
 // 1 when the forward for these shapes fills wf_save (every path except the tiny-Cin input-layer kernels)
 int d3f_kpconv_saves_wf(int Cin, int Cout, int K, int H) { return kpconv_small_supported(Cin, Cout, K, H) ? 0 : 1; }
 
 int d3f_kpconv_forward(const float* q_pts, int Nq, const float* s_pts, int Ns, const int32_t* idx, int H,
                        const float* x, int Cin, const float* kernel_points, int K, const float* weights, int Cout,
-                       float extent, float* out, float* nn_out, float* wf_save, void* ws, size_t ws_bytes,
-                       void* stream_) {
+                       float extent, float* out, float* nn_out, float* wf_save, void* spack_keep, float* grad_x_clear,
+                       void* ws, size_t ws_bytes, void* stream_) {
   if (!kp_args_ok(q_pts, Nq, s_pts, Ns, idx, H, x, Cin, kernel_points, K, weights, Cout, extent) || !out || !nn_out ||
       !ws)
     return D3F_EINVAL;
   if (ws_bytes < d3f_kpconv_ws_bytes(Nq, Ns, H, K, Cin, Cout)) return D3F_EWORKSPACE;
-  if (Nq == 0) return D3F_OK;
   hipStream_t stream = (hipStream_t)stream_;
+  const bool packs = Nq > 0 && Ns > 0 && !kpconv_small_supported(Cin, Cout, K, H) && kpconv_fused_supported(Cin, Cout, K, H, Ns);
+  if (grad_x_clear && !packs &&  // only the fused path clears it while packing
+      d3f::zero_async(grad_x_clear, sizeof(float) * (size_t)Ns * Cin, stream) != hipSuccess)
+    return D3F_ELAUNCH;
+  if (Nq == 0) return D3F_OK;
   if (kpconv_small_supported(Cin, Cout, K, H))
     return kpconv_small_dispatch(true, q_pts, s_pts, idx, x, kernel_points, weights, nullptr, nullptr, Nq, Ns, H, Cin,
                                  Cout, K, extent, out, nn_out, nullptr, stream);
   if (kpconv_fused_supported(Cin, Cout, K, H, Ns))
     return kpconv_forward_fused(q_pts, Nq, s_pts, Ns, idx, H, x, Cin, kernel_points, K, weights, Cout, extent, out,
-                                nn_out, wf_save, ws, stream);
+                                nn_out, wf_save, spack_keep, grad_x_clear, ws, stream);
   float* wf = wf_save ? wf_save : (float*)ws;
   int rc = launch_wf<true>(q_pts, s_pts, idx, x, kernel_points, Nq, Ns, H, Cin, K, extent, wf, nn_out, stream);
   if (rc) return rc;
@@ -320,8 +330,9 @@ int d3f_kpconv_forward(const float* q_pts, int Nq, const float* s_pts, int Ns, c
 
 int d3f_kpconv_backward(const float* q_pts, int Nq, const float* s_pts, int Ns, const int32_t* idx, int H,
                         const float* x, int Cin, const float* kernel_points, int K, const float* weights, int Cout,
-                        float extent, const float* nn, const float* grad_out, const float* wf_saved, float* grad_x,
-                        float* grad_w, void* ws, size_t ws_bytes, void* stream_) {
+                        float extent, const float* nn, const float* grad_out, const float* wf_saved,
+                        const void* spack_kept, int grad_x_precleared, float* grad_x, float* grad_w, void* ws,
+                        size_t ws_bytes, void* stream_) {
   if (!kp_args_ok(q_pts, Nq, s_pts, Ns, idx, H, x, Cin, kernel_points, K, weights, Cout, extent) || !nn || !grad_out ||
       !ws || (!grad_x && !grad_w))
     return D3F_EINVAL;
@@ -332,7 +343,8 @@ int d3f_kpconv_backward(const float* q_pts, int Nq, const float* s_pts, int Ns, 
   float* wf = (float*)ws;
   float* gW = wf + wf_elems;
   const bool fused = Nq > 0 && Ns > 0 && kpconv_fused_supported(Cin, Cout, K, H, Ns);  // clears grad_x while packing
-  if (grad_x && !fused && d3f::zero_async(grad_x, sizeof(float) * (size_t)Ns * Cin, stream) != hipSuccess)
+  if (grad_x && !fused && !grad_x_precleared &&
+      d3f::zero_async(grad_x, sizeof(float) * (size_t)Ns * Cin, stream) != hipSuccess)
     return D3F_ELAUNCH;
   if (Nq == 0) {
     if (grad_w && d3f::zero_async(grad_w, sizeof(float) * (size_t)KC * Cout, stream) != hipSuccess)
@@ -341,7 +353,7 @@ int d3f_kpconv_backward(const float* q_pts, int Nq, const float* s_pts, int Ns, 
   }
   if (kpconv_fused_supported(Cin, Cout, K, H, Ns))
     return kpconv_backward_fused(q_pts, Nq, s_pts, Ns, idx, H, x, Cin, kernel_points, K, weights, Cout, extent, nn,
-                                 grad_out, wf_saved, grad_x, grad_w, ws, stream);
+                                 grad_out, wf_saved, spack_kept, grad_x_precleared, grad_x, grad_w, ws, stream);
   int rc;
   if (grad_w && kpconv_small_supported(Cin, Cout, K, H)) {
     if (d3f::zero_async(grad_w, sizeof(float) * (size_t)KC * Cout, stream) != hipSuccess) return D3F_ELAUNCH;
@@ -387,13 +399,14 @@ int d3f_kpconv_backward(const float* q_pts, int Nq, const float* s_pts, int Ns, 
 // d3f_kpconv_grad_input_supported
 int d3f_kpconv_aggregate(const float* q_pts, int Nq, const float* s_pts, int Ns, const int32_t* idx, int H,
                          const float* x, int Cin, const float* kernel_points, int K, float extent, float* wf_out,
-                         float* nn_out, void* ws, size_t ws_bytes, void* stream_) {
+                         float* nn_out, void* spack_keep, float* grad_x_clear, void* ws, size_t ws_bytes,
+                         void* stream_) {
   if (!q_pts || !s_pts || !idx || !x || !kernel_points || !wf_out || !nn_out || !ws || Nq < 1 || Ns < 1 || H < 1 ||
       !(extent > 0.0f) || !kpconv_fused_supported(Cin, 64, K, H, Ns))
     return D3F_EINVAL;
   if (ws_bytes < d3f_kpconv_ws_bytes(Nq, Ns, H, K, Cin, 64)) return D3F_EWORKSPACE;
-  return kpconv_aggregate(q_pts, Nq, s_pts, Ns, idx, H, x, Cin, kernel_points, K, extent, wf_out, nn_out, ws,
-                          (hipStream_t)stream_);
+  return kpconv_aggregate(q_pts, Nq, s_pts, Ns, idx, H, x, Cin, kernel_points, K, extent, wf_out, nn_out, spack_keep,
+                          grad_x_clear, ws, (hipStream_t)stream_);
 }
 
 // grad_x [Ns, Cin] (OVERWRITTEN) from gwf = (grad_out / nn) @ W^T  [Nq, K*Cin] computed by the caller (a plain GEMM)
@@ -403,18 +416,20 @@ int d3f_kpconv_grad_input_supported(int Cin, int K, int H, int Ns) {
 
 int d3f_kpconv_grad_input(const float* q_pts, int Nq, const float* s_pts, int Ns, const int32_t* idx, int H,
                           const float* x, int Cin, const float* kernel_points, int K, float extent, const float* gwf,
-                          float* grad_x, void* ws, size_t ws_bytes, void* stream_) {
+                          const void* spack_kept, int grad_x_precleared, float* grad_x, void* ws, size_t ws_bytes,
+                          void* stream_) {
   if (!q_pts || !s_pts || !idx || !x || !kernel_points || !gwf || !grad_x || !ws || Nq < 0 || Ns < 0 || H < 1 ||
       !(extent > 0.0f) || !kpconv_fused_supported(Cin, 64, K, H, Ns))
     return D3F_EINVAL;
   if (ws_bytes < d3f_kpconv_ws_bytes(Nq, Ns, H, K, Cin, 64)) return D3F_EWORKSPACE;
   hipStream_t stream = (hipStream_t)stream_;
   if (Nq == 0 || Ns == 0) {
-    if (d3f::zero_async(grad_x, sizeof(float) * (size_t)Ns * Cin, stream) != hipSuccess) return D3F_ELAUNCH;
+    if (!grad_x_precleared && d3f::zero_async(grad_x, sizeof(float) * (size_t)Ns * Cin, stream) != hipSuccess)
+      return D3F_ELAUNCH;
     return D3F_OK;
   }
-  return kpconv_grad_input_from_gw(q_pts, Nq, s_pts, Ns, idx, H, x, Cin, kernel_points, K, extent, gwf, grad_x, ws,
-                                   stream);
+  return kpconv_grad_input_from_gw(q_pts, Nq, s_pts, Ns, idx, H, x, Cin, kernel_points, K, extent, gwf, spack_kept,
+                                   grad_x_precleared, grad_x, ws, stream);
 }
 
 }  // extern "C"

@@ -507,9 +507,12 @@ static int launch_fused_cv(const float* q_pts, const float4* spack, const int32_
 
 int kpconv_forward_fused(const float* q_pts, int Nq, const float* s_pts, int Ns, const int32_t* idx, int H,
                          const float* x, int Cin, const float* kp, int K, const float* W, int Cout, float extent,
-                         float* out, float* nn_out, float* wf_save, void* ws, hipStream_t stream) {
-  float4* spack = (float4*)ws;
-  int rc = pack_supports(s_pts, x, Ns, Cin, spack, stream);
+                         float* out, float* nn_out, float* wf_save, void* spack_keep, float* grad_x_clear, void* ws,
+                         hipStream_t stream) {
+  // spack_keep: the packed supports are written to the caller's buffer (kept for the backward pass, which then skips
+  // its own packing launch); grad_x_clear: the backward's scatter target, cleared here on the side
+  float4* spack = (float4*)(spack_keep ? spack_keep : ws);
+  int rc = pack_supports(s_pts, x, Ns, Cin, spack, stream, grad_x_clear);
   if (rc) return rc;
   if (Cin == 16) return launch_fused_cv<1>(q_pts, spack, idx, x, kp, W, Nq, Ns, H, Cin, Cout, K, extent, out, nn_out, wf_save, stream);
   if (Cin == 32) return launch_fused_cv<2>(q_pts, spack, idx, x, kp, W, Nq, Ns, H, Cin, Cout, K, extent, out, nn_out, wf_save, stream);
@@ -518,11 +521,17 @@ int kpconv_forward_fused(const float* q_pts, int Nq, const float* s_pts, int Ns,
 
 int kpconv_backward_fused(const float* q_pts, int Nq, const float* s_pts, int Ns, const int32_t* idx, int H,
                           const float* x, int Cin, const float* kp, int K, const float* W, int Cout, float extent,
-                          const float* nn, const float* gout, const float* wf_saved, float* gx, float* gw, void* ws,
-                          hipStream_t stream) {
-  float4* spack = (float4*)ws;
-  int rc = pack_supports(s_pts, x, Ns, Cin, spack, stream, gx);  // also clears gx
-  if (rc) return rc;
+                          const float* nn, const float* gout, const float* wf_saved, const void* spack_kept,
+                          int gx_precleared, float* gx, float* gw, void* ws, hipStream_t stream) {
+  const float4* spack = (const float4*)spack_kept;
+  int rc = D3F_OK;
+  if (!spack) {
+    rc = pack_supports(s_pts, x, Ns, Cin, (float4*)ws, stream, gx_precleared ? nullptr : gx);  // also clears gx
+    if (rc) return rc;
+    spack = (const float4*)ws;
+  } else if (gx && !gx_precleared) {
+    if (d3f::zero_async(gx, sizeof(float) * (size_t)Ns * Cin, stream) != hipSuccess) return D3F_ELAUNCH;
+  }
   const int tiles = cdiv(Nq, 16);
   if (gx) {
     const int CV = Cin == 16 ? 1 : (Cin == 32 ? 2 : 4);
@@ -566,10 +575,10 @@ int kpconv_backward_fused(const float* q_pts, int Nq, const float* s_pts, int Ns
 // Aggregation only: wf [Nq, K*Cin] = sum_h w[q,h,k] x[idx[q,h], c] and the neighbor count nn -- phase A of the fused
 // kernel, one workgroup per (16-query tile, channel chunk); the contraction with W is left to a GEMM (few-point layers)
 int kpconv_aggregate(const float* q_pts, int Nq, const float* s_pts, int Ns, const int32_t* idx, int H, const float* x,
-                     int Cin, const float* kp, int K, float extent, float* wf_out, float* nn_out, void* ws,
-                     hipStream_t stream) {
-  float4* spack = (float4*)ws;
-  int rc = pack_supports(s_pts, x, Ns, Cin, spack, stream);
+                     int Cin, const float* kp, int K, float extent, float* wf_out, float* nn_out, void* spack_keep,
+                     float* grad_x_clear, void* ws, hipStream_t stream) {
+  float4* spack = (float4*)(spack_keep ? spack_keep : ws);
+  int rc = pack_supports(s_pts, x, Ns, Cin, spack, stream, grad_x_clear);
   if (rc) return rc;
   const int CV = Cin == 16 ? 1 : (Cin == 32 ? 2 : 4);
   const int CC = 16 * CV;
@@ -589,11 +598,17 @@ int kpconv_aggregate(const float* q_pts, int Nq, const float* s_pts, int Ns, con
 
 // grad_x from a precomputed gW = (grad_out / nn) @ W^T  [Nq, K*Cin]: staging + phase 2 (scatter) of the kernel above
 int kpconv_grad_input_from_gw(const float* q_pts, int Nq, const float* s_pts, int Ns, const int32_t* idx, int H,
-                              const float* x, int Cin, const float* kp, int K, float extent, const float* gwf, float* gx,
-                              void* ws, hipStream_t stream) {
-  float4* spack = (float4*)ws;
-  int rc = pack_supports(s_pts, x, Ns, Cin, spack, stream, gx);  // also clears gx
-  if (rc) return rc;
+                              const float* x, int Cin, const float* kp, int K, float extent, const float* gwf,
+                              const void* spack_kept, int gx_precleared, float* gx, void* ws, hipStream_t stream) {
+  const float4* spack = (const float4*)spack_kept;
+  int rc = D3F_OK;
+  if (!spack) {
+    rc = pack_supports(s_pts, x, Ns, Cin, (float4*)ws, stream, gx_precleared ? nullptr : gx);  // also clears gx
+    if (rc) return rc;
+    spack = (const float4*)ws;
+  } else if (!gx_precleared) {
+    if (d3f::zero_async(gx, sizeof(float) * (size_t)Ns * Cin, stream) != hipSuccess) return D3F_ELAUNCH;
+  }
   const int CV = Cin == 16 ? 1 : (Cin == 32 ? 2 : 4);
   const int CC = 16 * CV;
   const size_t lds = sizeof(float) * (size_t)(16 * (16 * CC + 4));

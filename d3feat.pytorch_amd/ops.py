@@ -221,11 +221,20 @@ class _KPConvFn(torch.autograd.Function):
         wf = None
         if SAVE_WEIGHTED_FEATURES and ctx.needs_input_grad[5] and Nq > 0 and L.d3f_kpconv_saves_wf(Cin, Cout, K, H):
             wf = torch.empty((Nq, K * Cin), dtype=torch.float32, device=x.device)
+        # training: the packed supports are kept for the backward pass and its scatter target is cleared on the side
+        keep = gx_buf = None
+        if (ctx.needs_input_grad[3] or ctx.needs_input_grad[5]) and Nq > 0 and Ns > 0 and \
+                L.d3f_kpconv_packs_supports(Cin, Cout, K, H, Ns):
+            keep = torch.empty(16 * Ns, dtype=torch.uint8, device=x.device)
+            if ctx.needs_input_grad[3]:
+                gx_buf = torch.empty_like(x)
         with _region("kpconv_fwd[Nq=%d,Cin=%d,Cout=%d,H=%d]" % (Nq, Cin, Cout, H),
                      kpconv_fwd_bytes(Nq, Ns, H, K, Cin, Cout)):
             _native.check(L.d3f_kpconv_forward(_p(q_pts), Nq, _p(s_pts), Ns, _p(idx), H, _p(x), Cin,
                                                _p(kernel_points), K, _p(weights), Cout, float(extent), _p(out),
-                                               _p(nn), _p(wf), _p(ws), nbytes, _stream()), "d3f_kpconv_forward")
+                                               _p(nn), _p(wf), _p(keep), _p(gx_buf), _p(ws), nbytes, _stream()),
+                          "d3f_kpconv_forward")
+        ctx.keep, ctx.gx_buf = keep, gx_buf
         ctx.has_wf = wf is not None
         ctx.save_for_backward(q_pts, s_pts, idx, x, kernel_points, weights, nn, *([wf] if wf is not None else []))
         ctx.extent = float(extent)
@@ -239,7 +248,13 @@ class _KPConvFn(torch.autograd.Function):
         Nq, Ns, H = int(q_pts.shape[0]), int(s_pts.shape[0]), int(idx.shape[1])
         K, Cin, Cout = int(weights.shape[0]), int(weights.shape[1]), int(weights.shape[2])
         need_x, need_w = ctx.needs_input_grad[3], ctx.needs_input_grad[5]
-        gx = torch.empty_like(x) if need_x else None
+        keep, pre = ctx.keep, 0
+        gx = None
+        if need_x:
+            gx, ctx.gx_buf = ctx.gx_buf, None  # cleared by the forward; a second backward gets a fresh buffer
+            pre = 1 if gx is not None else 0
+            if gx is None:
+                gx = torch.empty_like(x)
         gw = torch.empty_like(weights) if need_w else None
         go = grad_out.contiguous().float() if (need_x or need_w) else None
         gw_native, gx_native = gw, gx
@@ -260,8 +275,8 @@ class _KPConvFn(torch.autograd.Function):
             ws = _ws(nbytes, x.device)
             with _region("kpconv_dx_scatter[Nq=%d,Cin=%d,H=%d]" % (Nq, Cin, H), 4 * Nq * K * Cin + 4 * Nq * H * (1 + Cin)):
                 _native.check(L.d3f_kpconv_grad_input(_p(q_pts), Nq, _p(s_pts), Ns, _p(idx), H, _p(x), Cin,
-                                                      _p(kernel_points), K, ctx.extent, _p(gwf), _p(gx), _p(ws),
-                                                      nbytes, _stream()), "d3f_kpconv_grad_input")
+                                                      _p(kernel_points), K, ctx.extent, _p(gwf), _p(keep), pre, _p(gx),
+                                                      _p(ws), nbytes, _stream()), "d3f_kpconv_grad_input")
             gx_native = None
         if gx_native is not None or gw_native is not None:
             nbytes = L.d3f_kpconv_ws_bytes(Nq, Ns, H, K, Cin, Cout)
@@ -270,8 +285,8 @@ class _KPConvFn(torch.autograd.Function):
                          kpconv_bwd_bytes(Nq, Ns, H, K, Cin, Cout)):
                 _native.check(L.d3f_kpconv_backward(_p(q_pts), Nq, _p(s_pts), Ns, _p(idx), H, _p(x), Cin,
                                                     _p(kernel_points), K, _p(weights), Cout, ctx.extent, _p(nn),
-                                                    _p(go), _p(wf), _p(gx_native), _p(gw_native), _p(ws), nbytes,
-                                                    _stream()),
+                                                    _p(go), _p(wf), _p(keep), pre, _p(gx_native), _p(gw_native),
+                                                    _p(ws), nbytes, _stream()),
                               "d3f_kpconv_backward")
         return None, None, None, gx, None, gw, None
 
@@ -294,10 +309,15 @@ class _KPConvGemmBiasActFn(torch.autograd.Function):
         nn = torch.empty(Nq, dtype=torch.float32, device=dev)
         nbytes = L.d3f_kpconv_ws_bytes(Nq, Ns, H, K, Cin, 64)
         ws = _ws(nbytes, dev)
+        keep = gx_buf = None
+        if ctx.needs_input_grad[3]:
+            keep = torch.empty(16 * Ns, dtype=torch.uint8, device=dev)
+            gx_buf = torch.empty_like(x)
         with _region("kpconv_aggregate[Nq=%d,Cin=%d,H=%d]" % (Nq, Cin, H), 4 * Nq * H * (4 + Cin) + 4 * Nq * K * Cin):
             _native.check(L.d3f_kpconv_aggregate(_p(q_pts), Nq, _p(s_pts), Ns, _p(idx), H, _p(x), Cin,
-                                                 _p(kernel_points), K, float(extent), _p(wf), _p(nn), _p(ws), nbytes,
-                                                 _stream()), "d3f_kpconv_aggregate")
+                                                 _p(kernel_points), K, float(extent), _p(wf), _p(nn), _p(keep),
+                                                 _p(gx_buf), _p(ws), nbytes, _stream()), "d3f_kpconv_aggregate")
+        ctx.keep, ctx.gx_buf = keep, gx_buf
         raw = torch.mm(wf, weights.view(K * Cin, Cout))
         out = torch.empty_like(raw)
         want_b = bias is not None and ctx.needs_input_grad[6]
@@ -329,14 +349,17 @@ class _KPConvGemmBiasActFn(torch.autograd.Function):
             gw = torch.empty_like(weights)
             torch.mm(wf.t(), gon, out=gw.view(K * Cin, Cout))
         if ctx.needs_input_grad[3]:
-            gx = torch.empty_like(x)
+            gx, ctx.gx_buf = ctx.gx_buf, None
+            pre = 1 if gx is not None else 0
+            if gx is None:
+                gx = torch.empty_like(x)
             gwf = torch.mm(gon, weights.view(K * Cin, Cout).t())
             nbytes = L.d3f_kpconv_ws_bytes(Nq, Ns, H, K, Cin, 64)
             ws = _ws(nbytes, x.device)
             with _region("kpconv_dx_scatter[Nq=%d,Cin=%d,H=%d]" % (Nq, Cin, H), 4 * Nq * K * Cin + 4 * Nq * H * (1 + Cin)):
                 _native.check(L.d3f_kpconv_grad_input(_p(q_pts), Nq, _p(s_pts), Ns, _p(idx), H, _p(x), Cin,
-                                                      _p(kernel_points), K, ctx.extent, _p(gwf), _p(gx), _p(ws),
-                                                      nbytes, _stream()), "d3f_kpconv_grad_input")
+                                                      _p(kernel_points), K, ctx.extent, _p(gwf), _p(ctx.keep), pre,
+                                                      _p(gx), _p(ws), nbytes, _stream()), "d3f_kpconv_grad_input")
         return None, None, None, gx, None, gw, (gb.view(-1) if gb is not None else None), None, None
 
 

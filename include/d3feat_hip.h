@@ -94,19 +94,26 @@ int d3f_grid_subsample(const float* points, int N, const int32_t* len, int B, fl
  * wf_save (optional, [Nq, K*Cin] float32): the weighted features sum_h w[n,h,k] x[idx[n,h],c] are left there for
  *   the backward pass (what autograd keeps alive in the reference as `weighted_features`, blocks.py:375); whether
  *   the forward for a given shape fills it is answered by d3f_kpconv_saves_wf.
+ * spack_keep (optional, 16*Ns bytes) / grad_x_clear (optional, [Ns, Cin]): the forward packs the supports as
+ *   float4 {x, y, z, [sum_c feat > 0]}; with spack_keep the packed array is left in the caller's buffer and handed
+ *   back to the backward pass (spack_kept), which then launches no packing kernel of its own; grad_x_clear is the
+ *   backward's scatter target, cleared here on the side (pass grad_x_precleared = 1 to the backward).  Honoured when
+ *   d3f_kpconv_packs_supports says so (otherwise pass NULL / 0).
  * ---------------------------------------------------------------------------------------------- */
 int d3f_kpconv_forward(const float* q_pts, int Nq, const float* s_pts, int Ns, const int32_t* idx, int H,
                        const float* x, int Cin, const float* kernel_points, int K, const float* weights, int Cout,
-                       float extent, float* out, float* nn_out, float* wf_save, void* ws, size_t ws_bytes,
-                       void* stream);
+                       float extent, float* out, float* nn_out, float* wf_save, void* spack_keep, float* grad_x_clear,
+                       void* ws, size_t ws_bytes, void* stream);
 int d3f_kpconv_saves_wf(int Cin, int Cout, int K, int H);
+int d3f_kpconv_packs_supports(int Cin, int Cout, int K, int H, int Ns);
 size_t d3f_kpconv_ws_bytes(int Nq, int Ns, int H, int K, int Cin, int Cout);
 /* grad_x [Ns,Cin] and grad_w [K,Cin,Cout] are OVERWRITTEN.  wf_saved (optional): the forward's wf_save; without it
  * the aggregation is recomputed. */
 int d3f_kpconv_backward(const float* q_pts, int Nq, const float* s_pts, int Ns, const int32_t* idx, int H,
                         const float* x, int Cin, const float* kernel_points, int K, const float* weights, int Cout,
-                        float extent, const float* nn, const float* grad_out, const float* wf_saved, float* grad_x,
-                        float* grad_w, void* ws, size_t ws_bytes, void* stream);
+                        float extent, const float* nn, const float* grad_out, const float* wf_saved,
+                        const void* spack_kept, int grad_x_precleared, float* grad_x, float* grad_w, void* ws,
+                        size_t ws_bytes, void* stream);
 
 /* grad_x alone, from gwf = (grad_out / nn) @ W^T  [Nq, K*Cin] computed by the caller (an ordinary GEMM: the right
  * tool for the few-point / 256..512-channel layers at the bottom of the U-Net, where the fused kernel's own gW tile
@@ -117,10 +124,12 @@ int d3f_kpconv_grad_input_supported(int Cin, int K, int H, int Ns);
  * computes out = (wf @ W) / nn with a GEMM (and d3f_bias_act_forward's row_div). */
 int d3f_kpconv_aggregate(const float* q_pts, int Nq, const float* s_pts, int Ns, const int32_t* idx, int H,
                          const float* x, int Cin, const float* kernel_points, int K, float extent, float* wf_out,
-                         float* nn_out, void* ws, size_t ws_bytes, void* stream);
+                         float* nn_out, void* spack_keep, float* grad_x_clear, void* ws, size_t ws_bytes,
+                         void* stream);
 int d3f_kpconv_grad_input(const float* q_pts, int Nq, const float* s_pts, int Ns, const int32_t* idx, int H,
                           const float* x, int Cin, const float* kernel_points, int K, float extent, const float* gwf,
-                          float* grad_x, void* ws, size_t ws_bytes, void* stream);
+                          const void* spack_kept, int grad_x_precleared, float* grad_x, void* ws, size_t ws_bytes,
+                          void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Weight gradient of the 1x1 "unary" convolutions -- replaces autograd's grad_out^T @ x for nn.Linear in

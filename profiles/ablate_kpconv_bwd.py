@@ -48,7 +48,7 @@ for L, C in ((0, 32), (1, 64), (2, 128), (3, 256), (4, 512)):
 
     def call(want_x=True, want_w=False):
         rc = L_.d3f_kpconv_backward(s.data_ptr(), Nq, s.data_ptr(), Nq, idx.data_ptr(), H, x.data_ptr(), C, kp.data_ptr(), K,
-                                    w.data_ptr(), C, r * 0.8, nn.data_ptr(), go.data_ptr(), None,
+                                    w.data_ptr(), C, r * 0.8, nn.data_ptr(), go.data_ptr(), None, None, 0,
                                     gx.data_ptr() if want_x else None, gw.data_ptr() if want_w else None, ws.data_ptr(), nb, st)
         assert rc == 0, rc
 

@@ -60,7 +60,7 @@ for L, C in ((0, 32), (1, 64)):
         def call():
             rc = L_.d3f_kpconv_backward(q.data_ptr(), Nq, s.data_ptr(), Nq, idx.data_ptr(), H, x.data_ptr(), C,
                                         kp.data_ptr(), K, w.data_ptr(), C, r * 0.8, nn0.data_ptr(), go.data_ptr(), None,
-                                        gx.data_ptr(), None, ws.data_ptr(), nb, st)
+                                        None, 0, gx.data_ptr(), None, ws.data_ptr(), nb, st)
             assert rc == 0
         for _ in range(2):
             call()
