@@ -281,7 +281,8 @@ def test_pools(c):
 
 # ------------------------------------------------------------------------------------------------ block epilogue
 @pytest.mark.parametrize("n,c,slope,with_add", [(1000, 128, 0.1, True), (333, 32, 0.1, False), (77, 6, 1.0, True),
-                                                (4000, 2048, 0.1, True), (50, 64, 1.0, False)])
+                                                (4000, 2048, 0.1, True), (50, 64, 1.0, False), (38001, 32, 0.1, True),
+                                                (5000, 256, 0.1, False), (600, 1024, 0.1, True), (333, 48, 0.1, True)])
 def test_bias_act(n, c, slope, with_add):
     import torch.nn.functional as F
     rng = np.random.default_rng(n + c)
