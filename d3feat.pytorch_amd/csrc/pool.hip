@@ -9,9 +9,14 @@
 namespace {
 
 // argmax convention: first maximal neighbor in row order, like torch.max(dim=1) on CPU/ROCm.
+// `clear` (optional, Ns*C floats): the scatter target of the backward pass, zeroed here on the side so that the
+// backward needs no fill launch of its own.
 __global__ void max_pool_fwd_kernel(const float* __restrict__ x, int Ns, int C, const int32_t* __restrict__ idx,
-                                    int Nq, int H, float* __restrict__ out, int32_t* __restrict__ argmax) {
+                                    int Nq, int H, float* __restrict__ out, int32_t* __restrict__ argmax,
+                                    float* __restrict__ clear) {
   const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (clear)
+    for (size_t i = t; i < (size_t)Ns * C; i += (size_t)gridDim.x * blockDim.x) clear[i] = 0.0f;
   if (t >= (size_t)Nq * C) return;
   const int n = (int)(t / C), c = (int)(t % C);
   const int32_t* row = idx + (size_t)n * H;
@@ -39,21 +44,24 @@ __global__ void max_pool_bwd_kernel(const float* __restrict__ go, const int32_t*
 }
 
 __global__ void closest_pool_fwd_kernel(const float* __restrict__ x, int Ns, int C, const int32_t* __restrict__ idx,
-                                        int Nq, int H, float* __restrict__ out) {
+                                        int Nq, int H, float* __restrict__ out, float* __restrict__ clear) {
   const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (clear)
+    for (size_t i = t; i < (size_t)Ns * C; i += (size_t)gridDim.x * blockDim.x) clear[i] = 0.0f;
   if (t >= (size_t)Nq * C) return;
   const int n = (int)(t / C), c = (int)(t % C);
   const int m = idx[(size_t)n * H];
   out[t] = (m >= 0 && m < Ns) ? x[(size_t)m * C + c] : 0.0f;
 }
 
-__global__ void closest_pool_bwd_kernel(const float* __restrict__ go, const int32_t* __restrict__ idx, int Nq, int H,
-                                        int C, int Ns, float* __restrict__ gx) {
+// go has row stride ld >= C (the gradient of a concatenation arrives as a column slice: no contiguous copy needed)
+__global__ void closest_pool_bwd_kernel(const float* __restrict__ go, int ld, const int32_t* __restrict__ idx, int Nq,
+                                        int H, int C, int Ns, float* __restrict__ gx) {
   const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= (size_t)Nq * C) return;
   const int n = (int)(t / C), c = (int)(t % C);
   const int m = idx[(size_t)n * H];
-  if (m >= 0 && m < Ns) atomicAdd(&gx[(size_t)m * C + c], go[t]);
+  if (m >= 0 && m < Ns) atomicAdd(&gx[(size_t)m * C + c], go[(size_t)n * ld + c]);
 }
 
 }  // namespace
@@ -61,19 +69,25 @@ __global__ void closest_pool_bwd_kernel(const float* __restrict__ go, const int3
 extern "C" {
 
 int d3f_max_pool_forward(const float* x, int Ns, int C, const int32_t* idx, int Nq, int H, float* out,
-                         int32_t* argmax_out, void* stream) {
+                         int32_t* argmax_out, float* grad_x_clear, void* stream) {
   if (!x || !idx || !out || Ns < 0 || C < 1 || Nq < 0 || H < 1) return D3F_EINVAL;
-  if (Nq == 0) return D3F_OK;
+  if (Nq == 0) {
+    if (grad_x_clear && d3f::zero_async(grad_x_clear, sizeof(float) * (size_t)Ns * C, (hipStream_t)stream) != hipSuccess)
+      return D3F_ELAUNCH;
+    return D3F_OK;
+  }
   max_pool_fwd_kernel<<<d3f::cdiv((long long)Nq * C, 256), 256, 0, (hipStream_t)stream>>>(x, Ns, C, idx, Nq, H, out,
-                                                                                          argmax_out);
+                                                                                          argmax_out, grad_x_clear);
   D3F_LAUNCH_CHECK();
   return D3F_OK;
 }
 
 int d3f_max_pool_backward(const float* grad_out, const int32_t* argmax, int Nq, int C, int Ns, float* grad_x,
-                          void* stream) {
+                          int grad_x_precleared, void* stream) {
   if (!grad_out || !argmax || !grad_x || Nq < 0 || C < 1 || Ns < 0) return D3F_EINVAL;
-  if (d3f::zero_async(grad_x, sizeof(float) * (size_t)Ns * C, (hipStream_t)stream) != hipSuccess) return D3F_ELAUNCH;
+  if (!grad_x_precleared &&
+      d3f::zero_async(grad_x, sizeof(float) * (size_t)Ns * C, (hipStream_t)stream) != hipSuccess)
+    return D3F_ELAUNCH;
   if (Nq == 0) return D3F_OK;
   max_pool_bwd_kernel<<<d3f::cdiv((long long)Nq * C, 256), 256, 0, (hipStream_t)stream>>>(grad_out, argmax, Nq, C, Ns,
                                                                                           grad_x);
@@ -82,22 +96,28 @@ int d3f_max_pool_backward(const float* grad_out, const int32_t* argmax, int Nq, 
 }
 
 int d3f_closest_pool_forward(const float* x, int Ns, int C, const int32_t* idx, int Nq, int H, float* out,
-                             void* stream) {
+                             float* grad_x_clear, void* stream) {
   if (!x || !idx || !out || Ns < 0 || C < 1 || Nq < 0 || H < 1) return D3F_EINVAL;
-  if (Nq == 0) return D3F_OK;
+  if (Nq == 0) {
+    if (grad_x_clear && d3f::zero_async(grad_x_clear, sizeof(float) * (size_t)Ns * C, (hipStream_t)stream) != hipSuccess)
+      return D3F_ELAUNCH;
+    return D3F_OK;
+  }
   closest_pool_fwd_kernel<<<d3f::cdiv((long long)Nq * C, 256), 256, 0, (hipStream_t)stream>>>(x, Ns, C, idx, Nq, H,
-                                                                                              out);
+                                                                                              out, grad_x_clear);
   D3F_LAUNCH_CHECK();
   return D3F_OK;
 }
 
-int d3f_closest_pool_backward(const float* grad_out, const int32_t* idx, int Nq, int H, int C, int Ns, float* grad_x,
-                              void* stream) {
-  if (!grad_out || !idx || !grad_x || Nq < 0 || C < 1 || Ns < 0 || H < 1) return D3F_EINVAL;
-  if (d3f::zero_async(grad_x, sizeof(float) * (size_t)Ns * C, (hipStream_t)stream) != hipSuccess) return D3F_ELAUNCH;
+int d3f_closest_pool_backward(const float* grad_out, int ld, const int32_t* idx, int Nq, int H, int C, int Ns,
+                              float* grad_x, int grad_x_precleared, void* stream) {
+  if (!grad_out || !idx || !grad_x || Nq < 0 || C < 1 || Ns < 0 || H < 1 || ld < C) return D3F_EINVAL;
+  if (!grad_x_precleared &&
+      d3f::zero_async(grad_x, sizeof(float) * (size_t)Ns * C, (hipStream_t)stream) != hipSuccess)
+    return D3F_ELAUNCH;
   if (Nq == 0) return D3F_OK;
-  closest_pool_bwd_kernel<<<d3f::cdiv((long long)Nq * C, 256), 256, 0, (hipStream_t)stream>>>(grad_out, idx, Nq, H, C,
-                                                                                              Ns, grad_x);
+  closest_pool_bwd_kernel<<<d3f::cdiv((long long)Nq * C, 256), 256, 0, (hipStream_t)stream>>>(grad_out, ld, idx, Nq, H,
+                                                                                              C, Ns, grad_x);
   D3F_LAUNCH_CHECK();
   return D3F_OK;
 }

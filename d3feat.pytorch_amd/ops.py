@@ -524,11 +524,13 @@ class _MaxPoolFn(torch.autograd.Function):
         Nq, H = int(idx.shape[0]), int(idx.shape[1])
         out = torch.empty((Nq, C), dtype=torch.float32, device=x.device)
         arg = torch.empty((Nq, C), dtype=torch.int32, device=x.device)
+        gx_buf = torch.empty_like(x) if ctx.needs_input_grad[0] else None  # cleared by the forward launch
         with _region("max_pool_fwd[Nq=%d,C=%d]" % (Nq, C), 4 * Nq * H + 4 * Nq * H * C + 4 * Nq * C):
             _native.check(_native.lib().d3f_max_pool_forward(_p(x), Ns, C, _p(idx), Nq, H, _p(out), _p(arg),
-                                                             _stream()), "d3f_max_pool_forward")
+                                                             _p(gx_buf), _stream()), "d3f_max_pool_forward")
         ctx.save_for_backward(arg)
         ctx.shape = (Ns, C)
+        ctx.gx_buf = gx_buf
         return out
 
     @staticmethod
@@ -536,9 +538,12 @@ class _MaxPoolFn(torch.autograd.Function):
         (arg,) = ctx.saved_tensors
         Ns, C = ctx.shape
         go = grad_out.contiguous().float()
-        gx = torch.empty((Ns, C), dtype=torch.float32, device=go.device)
-        _native.check(_native.lib().d3f_max_pool_backward(_p(go), _p(arg), int(arg.shape[0]), C, Ns, _p(gx), _stream()),
-                      "d3f_max_pool_backward")
+        gx, ctx.gx_buf = ctx.gx_buf, None
+        pre = 1 if gx is not None else 0
+        if gx is None:
+            gx = torch.empty((Ns, C), dtype=torch.float32, device=go.device)
+        _native.check(_native.lib().d3f_max_pool_backward(_p(go), _p(arg), int(arg.shape[0]), C, Ns, _p(gx), pre,
+                                                          _stream()), "d3f_max_pool_backward")
         return gx, None
 
 
@@ -552,20 +557,30 @@ class _ClosestPoolFn(torch.autograd.Function):
         Ns, C = int(x.shape[0]), int(x.shape[1])
         Nq, H = int(idx.shape[0]), int(idx.shape[1])
         out = torch.empty((Nq, C), dtype=torch.float32, device=x.device)
-        _native.check(_native.lib().d3f_closest_pool_forward(_p(x), Ns, C, _p(idx), Nq, H, _p(out), _stream()),
-                      "d3f_closest_pool_forward")
+        gx_buf = torch.empty_like(x) if ctx.needs_input_grad[0] else None  # cleared by the forward launch
+        _native.check(_native.lib().d3f_closest_pool_forward(_p(x), Ns, C, _p(idx), Nq, H, _p(out), _p(gx_buf),
+                                                             _stream()), "d3f_closest_pool_forward")
         ctx.save_for_backward(idx)
         ctx.shape = (Ns, C)
+        ctx.gx_buf = gx_buf
         return out
 
     @staticmethod
     def backward(ctx, grad_out):
         (idx,) = ctx.saved_tensors
         Ns, C = ctx.shape
-        go = grad_out.contiguous().float()
-        gx = torch.empty((Ns, C), dtype=torch.float32, device=go.device)
-        _native.check(_native.lib().d3f_closest_pool_backward(_p(go), _p(idx), int(idx.shape[0]), int(idx.shape[1]),
-                                                              C, Ns, _p(gx), _stream()), "d3f_closest_pool_backward")
+        go = grad_out if grad_out.dtype == torch.float32 else grad_out.float()
+        # a column slice of a wider row-major matrix (gradient of the decoder's concatenation) is read in place
+        if not (go.dim() == 2 and go.stride(1) == 1 and go.stride(0) >= C and go.storage_offset() % 1 == 0):
+            go = go.contiguous()
+        ld = int(go.stride(0)) if go.shape[0] > 1 else C
+        gx, ctx.gx_buf = ctx.gx_buf, None
+        pre = 1 if gx is not None else 0
+        if gx is None:
+            gx = torch.empty((Ns, C), dtype=torch.float32, device=go.device)
+        _native.check(_native.lib().d3f_closest_pool_backward(_p(go), ld, _p(idx), int(idx.shape[0]),
+                                                              int(idx.shape[1]), C, Ns, _p(gx), pre, _stream()),
+                      "d3f_closest_pool_backward")
         return gx, None
 
 

@@ -156,16 +156,19 @@ int d3f_linear_grad_weight(const float* x, const float* grad_out, int N, int Cin
  * Pools -- replace models/blocks.py:94-110 (max_pool) and :79-91 (closest_pool).
  * ---------------------------------------------------------------------------------------------- */
 /* out[n,c] = max_h x'[idx[n,h],c], x' = x plus a zero shadow row; argmax_out [Nq,C] int32 = winning support row
- * (Ns if the shadow won), saved for backward. */
+ * (Ns if the shadow won), saved for backward.
+ * grad_x_clear (optional, [Ns,C]): the backward's scatter target, zeroed by the forward launch on the side; the backward
+ * is then called with grad_x_precleared = 1 and launches no fill. */
 int d3f_max_pool_forward(const float* x, int Ns, int C, const int32_t* idx, int Nq, int H, float* out,
-                         int32_t* argmax_out, void* stream);
+                         int32_t* argmax_out, float* grad_x_clear, void* stream);
 int d3f_max_pool_backward(const float* grad_out, const int32_t* argmax, int Nq, int C, int Ns, float* grad_x,
-                          void* stream);
-/* out[n,:] = x'[idx[n,0],:]  (idx has row stride H) */
+                          int grad_x_precleared, void* stream);
+/* out[n,:] = x'[idx[n,0],:]  (idx has row stride H); backward: grad_out has row stride ld >= C (a column slice of
+ * the gradient of the decoder's concatenation is consumed in place) */
 int d3f_closest_pool_forward(const float* x, int Ns, int C, const int32_t* idx, int Nq, int H, float* out,
-                             void* stream);
-int d3f_closest_pool_backward(const float* grad_out, const int32_t* idx, int Nq, int H, int C, int Ns, float* grad_x,
-                              void* stream);
+                             float* grad_x_clear, void* stream);
+int d3f_closest_pool_backward(const float* grad_out, int ld, const int32_t* idx, int Nq, int H, int C, int Ns,
+                              float* grad_x, int grad_x_precleared, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Block epilogue -- replaces BatchNormBlock's bias add (models/blocks.py:473, use_bn=False), nn.LeakyReLU(0.1)

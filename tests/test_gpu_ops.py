@@ -277,6 +277,21 @@ def test_pools(c):
         out.backward(cu(go))
         assert np.array_equal(out.detach().cpu().numpy(), ref.detach().numpy())
         assert rel_err(gx.grad.cpu().numpy(), tx.grad.numpy()) < 1e-6
+        # second backward through the same node (fresh, not pre-cleared scatter target)
+        gx2 = cu(x).requires_grad_(True)
+        out2 = fn(gx2, cu(idx))
+        out2.backward(cu(go), retain_graph=True)
+        out2.backward(cu(go))
+        assert rel_err(gx2.grad.cpu().numpy(), 2 * tx.grad.numpy()) < 1e-6
+    # the decoder's pattern: upsample, concatenate with a skip, and let the gradient arrive as a COLUMN SLICE
+    skip = rng.normal(size=(nq, 24)).astype(np.float32)
+    wgt = rng.normal(size=(nq, c + 24)).astype(np.float32)
+    tx = torch.from_numpy(x).requires_grad_(True)
+    (torch.cat([ops_ref.closest_pool(tx, torch.from_numpy(idx)), torch.from_numpy(skip)], dim=1)
+     * torch.from_numpy(wgt)).sum().backward()
+    gx = cu(x).requires_grad_(True)
+    (torch.cat([ops.closest_pool(gx, cu(idx)), cu(skip)], dim=1) * cu(wgt)).sum().backward()
+    assert rel_err(gx.grad.cpu().numpy(), tx.grad.numpy()) < 1e-6
 
 
 # ------------------------------------------------------------------------------------------------ block epilogue
