@@ -43,15 +43,23 @@ __global__ void max_pool_bwd_kernel(const float* __restrict__ go, const int32_t*
   if (m >= 0 && m < Ns) atomicAdd(&gx[(size_t)m * C + (t % C)], go[t]);
 }
 
+// out has Cs extra columns per row filled from `skip` [Nq, Cs]: the decoder's upsample + concatenation
+// (architectures.py:311-313 after blocks.py:712) written by ONE launch (Cs = 0: plain closest_pool)
 __global__ void closest_pool_fwd_kernel(const float* __restrict__ x, int Ns, int C, const int32_t* __restrict__ idx,
-                                        int Nq, int H, float* __restrict__ out, float* __restrict__ clear) {
+                                        int Nq, int H, const float* __restrict__ skip, int Cs,
+                                        float* __restrict__ out, float* __restrict__ clear) {
   const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (clear)
     for (size_t i = t; i < (size_t)Ns * C; i += (size_t)gridDim.x * blockDim.x) clear[i] = 0.0f;
-  if (t >= (size_t)Nq * C) return;
-  const int n = (int)(t / C), c = (int)(t % C);
-  const int m = idx[(size_t)n * H];
-  out[t] = (m >= 0 && m < Ns) ? x[(size_t)m * C + c] : 0.0f;
+  const int W = C + Cs;
+  if (t >= (size_t)Nq * W) return;
+  const int n = (int)(t / W), c = (int)(t % W);
+  if (c < C) {
+    const int m = idx[(size_t)n * H];
+    out[t] = (m >= 0 && m < Ns) ? x[(size_t)m * C + c] : 0.0f;
+  } else {
+    out[t] = skip[(size_t)n * Cs + (c - C)];
+  }
 }
 
 // go has row stride ld >= C (the gradient of a concatenation arrives as a column slice: no contiguous copy needed)
@@ -95,16 +103,16 @@ int d3f_max_pool_backward(const float* grad_out, const int32_t* argmax, int Nq, 
   return D3F_OK;
 }
 
-int d3f_closest_pool_forward(const float* x, int Ns, int C, const int32_t* idx, int Nq, int H, float* out,
-                             float* grad_x_clear, void* stream) {
-  if (!x || !idx || !out || Ns < 0 || C < 1 || Nq < 0 || H < 1) return D3F_EINVAL;
+int d3f_closest_pool_forward(const float* x, int Ns, int C, const int32_t* idx, int Nq, int H, const float* skip,
+                             int Cs, float* out, float* grad_x_clear, void* stream) {
+  if (!x || !idx || !out || Ns < 0 || C < 1 || Nq < 0 || H < 1 || Cs < 0 || (Cs > 0 && !skip)) return D3F_EINVAL;
   if (Nq == 0) {
     if (grad_x_clear && d3f::zero_async(grad_x_clear, sizeof(float) * (size_t)Ns * C, (hipStream_t)stream) != hipSuccess)
       return D3F_ELAUNCH;
     return D3F_OK;
   }
-  closest_pool_fwd_kernel<<<d3f::cdiv((long long)Nq * C, 256), 256, 0, (hipStream_t)stream>>>(x, Ns, C, idx, Nq, H,
-                                                                                              out, grad_x_clear);
+  closest_pool_fwd_kernel<<<d3f::cdiv((long long)Nq * (C + Cs), 256), 256, 0, (hipStream_t)stream>>>(
+      x, Ns, C, idx, Nq, H, skip, Cs, out, grad_x_clear);
   D3F_LAUNCH_CHECK();
   return D3F_OK;
 }

@@ -12,7 +12,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from .. import ops
-from .blocks import KPConv, block_decider  # noqa: F401
+from .blocks import KPConv, NearestUpsampleBlock, block_decider  # noqa: F401
 
 
 def _moves_level(block):
@@ -75,11 +75,24 @@ class KPFCNN(nn.Module):
             if i in self.encoder_skips:
                 skips.append(x)
             x = op(x, batch)
+        x = self._decode(x, skips, batch)
+        return x, self.detection_scores(batch, x)
+
+    def _decode(self, x, skips, batch):
+        """Decoder blocks with the skip concatenations of the reference (architectures.py:309-314)."""
+        pending = None  # an upsampling block whose output is concatenated right away: one launch does both
         for j, op in enumerate(self.decoder_blocks):
             if j in self.decoder_concats:
-                x = torch.cat([x, skips.pop()], dim=1)
+                if pending is not None:
+                    x = ops.closest_pool(x, batch['upsamples'][pending.layer_ind - 1], skip=skips.pop())
+                    pending = None
+                else:
+                    x = torch.cat([x, skips.pop()], dim=1)
+            if isinstance(op, NearestUpsampleBlock) and (j + 1) in self.decoder_concats and x.is_cuda:
+                pending = op
+                continue
             x = op(x, batch)
-        return x, self.detection_scores(batch, x)
+        return x
 
     def forward(self, batch):
         x, scores = self.forward_raw(batch)

@@ -552,43 +552,53 @@ def max_pool(x, inds):
 
 
 class _ClosestPoolFn(torch.autograd.Function):
+    """closest_pool, optionally concatenated with a skip tensor ([upsampled | skip]) by the same launch."""
+
     @staticmethod
-    def forward(ctx, x, idx):
+    def forward(ctx, x, idx, skip):
         Ns, C = int(x.shape[0]), int(x.shape[1])
         Nq, H = int(idx.shape[0]), int(idx.shape[1])
-        out = torch.empty((Nq, C), dtype=torch.float32, device=x.device)
+        Cs = int(skip.shape[1]) if skip is not None else 0
+        out = torch.empty((Nq, C + Cs), dtype=torch.float32, device=x.device)
         gx_buf = torch.empty_like(x) if ctx.needs_input_grad[0] else None  # cleared by the forward launch
-        _native.check(_native.lib().d3f_closest_pool_forward(_p(x), Ns, C, _p(idx), Nq, H, _p(out), _p(gx_buf),
-                                                             _stream()), "d3f_closest_pool_forward")
+        _native.check(_native.lib().d3f_closest_pool_forward(_p(x), Ns, C, _p(idx), Nq, H, _p(skip), Cs, _p(out),
+                                                             _p(gx_buf), _stream()), "d3f_closest_pool_forward")
         ctx.save_for_backward(idx)
-        ctx.shape = (Ns, C)
+        ctx.shape = (Ns, C, Cs)
         ctx.gx_buf = gx_buf
         return out
 
     @staticmethod
     def backward(ctx, grad_out):
         (idx,) = ctx.saved_tensors
-        Ns, C = ctx.shape
+        Ns, C, Cs = ctx.shape
         go = grad_out if grad_out.dtype == torch.float32 else grad_out.float()
-        # a column slice of a wider row-major matrix (gradient of the decoder's concatenation) is read in place
-        if not (go.dim() == 2 and go.stride(1) == 1 and go.stride(0) >= C and go.storage_offset() % 1 == 0):
+        # a column slice of a wider row-major matrix (the [upsampled | skip] gradient) is read in place
+        if not (go.dim() == 2 and go.stride(1) == 1 and go.stride(0) >= C + Cs):
             go = go.contiguous()
-        ld = int(go.stride(0)) if go.shape[0] > 1 else C
-        gx, ctx.gx_buf = ctx.gx_buf, None
-        pre = 1 if gx is not None else 0
-        if gx is None:
-            gx = torch.empty((Ns, C), dtype=torch.float32, device=go.device)
-        _native.check(_native.lib().d3f_closest_pool_backward(_p(go), ld, _p(idx), int(idx.shape[0]),
-                                                              int(idx.shape[1]), C, Ns, _p(gx), pre, _stream()),
-                      "d3f_closest_pool_backward")
-        return gx, None
+        ld = int(go.stride(0)) if go.shape[0] > 1 else C + Cs
+        gx = None
+        if ctx.needs_input_grad[0]:
+            gx, ctx.gx_buf = ctx.gx_buf, None
+            pre = 1 if gx is not None else 0
+            if gx is None:
+                gx = torch.empty((Ns, C), dtype=torch.float32, device=go.device)
+            _native.check(_native.lib().d3f_closest_pool_backward(_p(go), ld, _p(idx), int(idx.shape[0]),
+                                                                  int(idx.shape[1]), C, Ns, _p(gx), pre, _stream()),
+                          "d3f_closest_pool_backward")
+        g_skip = go[:, C:] if (Cs and ctx.needs_input_grad[2]) else None
+        return gx, None, g_skip
 
 
-def closest_pool(x, inds):
+def closest_pool(x, inds, skip=None):
+    """x'[inds[:, 0]] (reference blocks.py:79-91); with ``skip`` [Nq, Cs] the result is torch.cat([pooled, skip], 1)."""
     idx = _i32(inds, "inds")
     if idx.dim() == 1:
         idx = idx.view(-1, 1)
-    return _ClosestPoolFn.apply(_f32(x, "x"), idx)
+    sk = _f32(skip, "skip") if skip is not None else None
+    if sk is not None and (sk.dim() != 2 or sk.shape[0] != idx.shape[0]):
+        raise RuntimeError("closest_pool: skip %s does not match %d query rows" % (tuple(sk.shape), idx.shape[0]))
+    return _ClosestPoolFn.apply(_f32(x, "x"), idx, sk)
 
 
 # ---------------------------------------------------------------------------------------------------------------

@@ -176,10 +176,7 @@ class TrainStep:
             if i in m.encoder_skips:
                 skips.append(x)
             x = op(x, batch)
-        for j, op in enumerate(m.decoder_blocks):
-            if j in m.decoder_concats:
-                x = torch.cat([x, skips.pop()], dim=1)
-            x = op(x, batch)
+        x = m._decode(x, skips, batch)
         scores = m.detection_scores(batch, x)
         return self._loss_from_raw(x, scores, batch), cuts
 

@@ -165,8 +165,10 @@ int d3f_max_pool_backward(const float* grad_out, const int32_t* argmax, int Nq, 
                           int grad_x_precleared, void* stream);
 /* out[n,:] = x'[idx[n,0],:]  (idx has row stride H); backward: grad_out has row stride ld >= C (a column slice of
  * the gradient of the decoder's concatenation is consumed in place) */
-int d3f_closest_pool_forward(const float* x, int Ns, int C, const int32_t* idx, int Nq, int H, float* out,
-                             float* grad_x_clear, void* stream);
+/* skip (optional, [Nq, Cs]): out is [Nq, C + Cs] = [upsampled | skip], the decoder's torch.cat([x, skip], dim=1)
+ * (models/architectures.py:311-313) done by the same launch; Cs = 0: plain closest_pool. */
+int d3f_closest_pool_forward(const float* x, int Ns, int C, const int32_t* idx, int Nq, int H, const float* skip,
+                             int Cs, float* out, float* grad_x_clear, void* stream);
 int d3f_closest_pool_backward(const float* grad_out, int ld, const int32_t* idx, int Nq, int H, int C, int Ns,
                               float* grad_x, int grad_x_precleared, void* stream);
 

@@ -292,6 +292,15 @@ def test_pools(c):
     gx = cu(x).requires_grad_(True)
     (torch.cat([ops.closest_pool(gx, cu(idx)), cu(skip)], dim=1) * cu(wgt)).sum().backward()
     assert rel_err(gx.grad.cpu().numpy(), tx.grad.numpy()) < 1e-6
+    # ... and the same with the concatenation done by the pooling launch itself
+    gx, gsk = cu(x).requires_grad_(True), cu(skip).requires_grad_(True)
+    y = ops.closest_pool(gx, cu(idx), skip=gsk)
+    assert y.shape == (nq, c + 24)
+    ref_y = torch.cat([ops_ref.closest_pool(torch.from_numpy(x), torch.from_numpy(idx)), torch.from_numpy(skip)], dim=1)
+    assert np.array_equal(y.detach().cpu().numpy(), ref_y.numpy())
+    (y * cu(wgt)).sum().backward()
+    assert rel_err(gx.grad.cpu().numpy(), tx.grad.numpy()) < 1e-6
+    assert np.array_equal(gsk.grad.cpu().numpy(), wgt[:, c:])
 
 
 # ------------------------------------------------------------------------------------------------ block epilogue
