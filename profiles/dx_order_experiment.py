@@ -1,7 +1,17 @@
 #!/usr/bin/env python
 """Does the ORDER in which queries are processed matter for the scatter-bound KPConv grad-input kernel?
 Level-0/1 shapes of the S1 pair, queries in storage order vs Morton (Z-curve) order; also reports how many distinct
-support rows the 16 queries of a tile touch (the factor an LDS pre-combination could save)."""
+support rows the 16 queries of a tile touch (the factor an LDS pre-combination could save).
+
+Round-1 findings (MI355X):
+  * order alone does not help: L0 174 us (storage order) vs 195 us (Morton), L1 79 vs 78 us -- although a Morton tile
+    touches only ~116 distinct support rows for its 672 (query, neighbor) slots (629 in storage order);
+  * an LDS pre-combination was built and measured (open-addressing table support row -> slot, ds_add_f32 into one row
+    of CC floats per slot, one set of global atomics per distinct row): correct, but 377 us at L0 -- the LDS float
+    atomics serialise (384 ds_add_f32 per tile, 4-way same-bank) and cost more than the global atomics they replace
+    (ablation: table + flush without accumulation 175 us, kernel without any atomics 71 us).  Not kept.
+  * profiles/experiments/atomic_width.hip: the L2 float-atomic rate is ~320 G floats/s chip-wide whatever the width
+    of the contiguous segment (64 / 128 / 256 B per row), and ~20 G requests/s for single-float requests."""
 import os
 import sys
 
