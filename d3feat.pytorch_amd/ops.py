@@ -342,8 +342,9 @@ class _KPConvGemmBiasActFn(torch.autograd.Function):
             if gb is None:
                 gb, pre = torch.empty((1, Cout), dtype=torch.float32, device=go.device), 0
         gon = torch.empty_like(go)  # masked gradient / nn
+        wsb, nws = _bias_bwd_ws(Nq, Cout, go.device) if gb is not None else (None, 0)
         _native.check(L.d3f_bias_act_backward(_p(go), _p(out), ctx.slope, Nq, Cout, _p(gon), _p(gb), None, pre, _p(nn),
-                                              _stream()), "d3f_bias_act_backward")
+                                              _p(wsb), nws, _stream()), "d3f_bias_act_backward")
         gx = gw = None
         if ctx.needs_input_grad[5]:
             gw = torch.empty_like(weights)
@@ -468,9 +469,10 @@ class _LinearBiasActFn(torch.autograd.Function):
         else:
             gm = go if ctx.slope == 1.0 else torch.empty_like(go)
             first, second = (g1, g2) if g1 is not None else (g2, None)
+            wsb, nws = _bias_bwd_ws(N, Cout, go.device) if first is not None else (None, 0)
             _native.check(L.d3f_bias_act_backward(_p(go), _p(out), ctx.slope, N, Cout,
                                                   _p(gm) if ctx.slope != 1.0 else None, _p(first), _p(second),
-                                                  pre if first is not None else 0, None, _stream()),
+                                                  pre if first is not None else 0, None, _p(wsb), nws, _stream()),
                           "d3f_bias_act_backward")
         gx = gw = None
         if ctx.needs_input_grad[0]:
@@ -604,6 +606,11 @@ def closest_pool(x, inds, skip=None):
 # ---------------------------------------------------------------------------------------------------------------
 # block epilogue: bias (+ residual) (+ LeakyReLU) (models/blocks.py:473,497,598,676,686)
 # ---------------------------------------------------------------------------------------------------------------
+def _bias_bwd_ws(N, C, device):
+    nb = int(_native.lib().d3f_bias_act_backward_ws_bytes(N, C))
+    return (_ws(nb, device), nb) if nb else (None, 0)
+
+
 class _BiasActFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, b1, add, b2, slope):
@@ -645,9 +652,10 @@ class _BiasActFn(torch.autograd.Function):
             if need_gx and not identity:
                 gx = torch.empty_like(go)
             first, second = (g1, g2) if g1 is not None else (g2, None)
+            wsb, nws = _bias_bwd_ws(N, C, go.device) if first is not None else (None, 0)
             _native.check(_native.lib().d3f_bias_act_backward(_p(go), _p(out), ctx.slope, N, C, _p(gx), _p(first),
                                                               _p(second), pre if first is not None else 0, None,
-                                                              _stream()), "d3f_bias_act_backward")
+                                                              _p(wsb), nws, _stream()), "d3f_bias_act_backward")
             if identity:
                 gx = go
         return (gx if ctx.needs_input_grad[0] else None, g1, gx if ctx.has[1] and ctx.needs_input_grad[2] else None,

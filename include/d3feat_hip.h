@@ -186,9 +186,12 @@ int d3f_closest_pool_backward(const float* grad_out, int ld, const int32_t* idx,
  * ---------------------------------------------------------------------------------------------- */
 int d3f_bias_act_forward(const float* x, const float* bias1, const float* add, const float* bias2, float slope, int N,
                          int C, float* out, float* zero_init, int zero_n, const float* row_div, void* stream);
+/* ws (optional, d3f_bias_act_backward_ws_bytes): with it, N >= 4096 uses per-block partial sums + a second tiny
+ * launch for the bias gradient instead of atomics on C addresses (which serialise: 32 us at 38k x 32), deterministic. */
+size_t d3f_bias_act_backward_ws_bytes(int N, int C);
 int d3f_bias_act_backward(const float* grad_out, const float* out, float slope, int N, int C, float* grad_x,
-                          float* grad_bias, float* grad_bias2, int bias_prezeroed, const float* row_div,
-                          void* stream);
+                          float* grad_bias, float* grad_bias2, int bias_prezeroed, const float* row_div, void* ws,
+                          size_t ws_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Detector score -- replaces KPFCNN.detection_scores (models/architectures.py:322-368).
