@@ -337,7 +337,7 @@ int d3f_global_max(const float* x, size_t n, float* out_max, void* ws, size_t ws
   hipStream_t stream = (hipStream_t)stream_;
   if (d3f::zero_async(ws, 4, stream) != hipSuccess) return D3F_ELAUNCH;
   int blocks = d3f::cdiv((long long)n, 256 * 8);
-  if (blocks > 512) blocks = 512;
+  if (blocks > 128) blocks = 128;  // one same-address atomic per block: ~14 ns each when they pile up
   gmax_partial_kernel<<<blocks, 256, 0, stream>>>(x, n, (uint32_t*)ws);
   gmax_final_kernel<<<1, 1, 0, stream>>>((const uint32_t*)ws, out_max);
   D3F_LAUNCH_CHECK();
@@ -350,7 +350,7 @@ int d3f_global_max_rows(const float* x, int cap_rows, int C, const int32_t* len,
   hipStream_t stream = (hipStream_t)stream_;
   if (d3f::zero_async(ws, 4, stream) != hipSuccess) return D3F_ELAUNCH;
   int blocks = d3f::cdiv((long long)cap_rows * C, 256 * 8);
-  if (blocks > 512) blocks = 512;
+  if (blocks > 128) blocks = 128;
   gmax_rows_kernel<<<blocks, 256, 0, stream>>>(x, cap_rows, C, len, B, (uint32_t*)ws);
   gmax_final_kernel<<<1, 1, 0, stream>>>((const uint32_t*)ws, out_max);
   D3F_LAUNCH_CHECK();
@@ -399,7 +399,7 @@ int d3f_detection_scores_backward(const float* feat, int N, int C, const int32_t
   else if (C <= 32) det_bwd_kernel<32><<<grid, 256, 0, stream>>>(feat, N, C, idx, H, feat_max, grad_scores, grad_feat);
   else det_bwd_kernel<64><<<grid, 256, 0, stream>>>(feat, N, C, idx, H, feat_max, grad_scores, grad_feat);
   int blocks = d3f::cdiv((long long)n, 256 * 8);
-  if (blocks > 512) blocks = 512;
+  if (blocks > 128) blocks = 128;
   det_reduce_kernel<<<blocks, 256, 0, stream>>>(feat, grad_feat, n, feat_max, (float*)ws);
   det_finalize_kernel<<<d3f::cdiv((long long)n, 256), 256, 0, stream>>>(feat, n, feat_max, (const float*)ws, grad_feat);
   D3F_LAUNCH_CHECK();

@@ -81,10 +81,23 @@ __global__ void grid_count_kernel(const float* __restrict__ s, int Ns, const int
 
 __global__ void grid_alloc_kernel(uint32_t M, int32_t* __restrict__ cnt, int32_t* __restrict__ start,
                                   int32_t* __restrict__ end) {
+  // ranges need to be disjoint, not ordered; the running total is ONE word, so a wave reserves its buckets together
+  // (inclusive scan of the counts, one atomic by the last lane) -- per-bucket atomics on it serialise
   const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+  const int lane = threadIdx.x & 63;
+  const int c = b < M ? cnt[b] : 0;
+  int incl = c;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const int t = __shfl_up(incl, o, 64);
+    if (lane >= o) incl += t;
+  }
+  const int total = __shfl(incl, 63, 64);
+  int base = 0;
+  if (lane == 63 && total > 0) base = atomicAdd(&cnt[M], total);
+  base = __shfl(base, 63, 64);
   if (b >= M) return;
-  const int c = cnt[b];
-  const int s = c ? atomicAdd(&cnt[M], c) : 0;  // ranges need to be disjoint, not ordered
+  const int s = c ? base + incl - c : 0;
   start[b] = s;
   end[b] = s;
 }
