@@ -198,6 +198,18 @@ def grid_subsample_raw(points, lens, sampleDl, max_p=0, order=ORDER_REFERENCE, s
 # ---------------------------------------------------------------------------------------------------------------
 # KPConv (models/blocks.py:237-382)
 # ---------------------------------------------------------------------------------------------------------------
+def _adoptable(t, slot):
+    """autograd adopts an incoming gradient as ``p.grad`` without a copy only when nobody else holds the tensor
+    object: hand it a fresh view of the slot."""
+    return t.view_as(t) if (slot is not None and t is slot) else t
+
+
+def _grad_slot(param):
+    """Where the weight gradient of ``param`` is to be written, when its owner (train.FlatParams) reserved a place for
+    it in a flat gradient buffer; None otherwise (a fresh tensor is allocated)."""
+    return getattr(param, "_d3f_grad_slot", None)
+
+
 # False: the backward pass recomputes the neighbor aggregation instead of reading it back (saves K*Cin*4 B/query)
 SAVE_WEIGHTED_FEATURES = True
 # below this many rows a weight gradient is a plain GEMM for the library; above, the reduction-parallel kernel
@@ -235,6 +247,7 @@ class _KPConvFn(torch.autograd.Function):
                                                _p(nn), _p(wf), _p(keep), _p(gx_buf), _p(ws), nbytes, _stream()),
                           "d3f_kpconv_forward")
         ctx.keep, ctx.gx_buf = keep, gx_buf
+        ctx.gw_slot = _grad_slot(weights)
         ctx.has_wf = wf is not None
         ctx.save_for_backward(q_pts, s_pts, idx, x, kernel_points, weights, nn, *([wf] if wf is not None else []))
         ctx.extent = float(extent)
@@ -255,7 +268,7 @@ class _KPConvFn(torch.autograd.Function):
             pre = 1 if gx is not None else 0
             if gx is None:
                 gx = torch.empty_like(x)
-        gw = torch.empty_like(weights) if need_w else None
+        gw = (ctx.gw_slot if ctx.gw_slot is not None else torch.empty_like(weights)) if need_w else None
         go = grad_out.contiguous().float() if (need_x or need_w) else None
         gw_native, gx_native = gw, gx
         gon = None
@@ -288,7 +301,7 @@ class _KPConvFn(torch.autograd.Function):
                                                     _p(go), _p(wf), _p(keep), pre, _p(gx_native), _p(gw_native),
                                                     _p(ws), nbytes, _stream()),
                               "d3f_kpconv_backward")
-        return None, None, None, gx, None, gw, None
+        return None, None, None, gx, None, (_adoptable(gw, ctx.gw_slot) if gw is not None else None), None
 
 
 class _KPConvGemmBiasActFn(torch.autograd.Function):
@@ -326,6 +339,7 @@ class _KPConvGemmBiasActFn(torch.autograd.Function):
                                              Cout if want_b else 0, _p(nn), _stream()), "d3f_bias_act_forward")
         ctx.save_for_backward(q_pts, s_pts, idx, x, kernel_points, weights, nn, wf, out)
         ctx.gbuf, ctx.extent, ctx.slope, ctx.want_b = gbuf, float(extent), float(slope), want_b
+        ctx.gw_slot = _grad_slot(weights)
         return out
 
     @staticmethod
@@ -347,7 +361,7 @@ class _KPConvGemmBiasActFn(torch.autograd.Function):
                                               _p(wsb), nws, _stream()), "d3f_bias_act_backward")
         gx = gw = None
         if ctx.needs_input_grad[5]:
-            gw = torch.empty_like(weights)
+            gw = ctx.gw_slot if ctx.gw_slot is not None else torch.empty_like(weights)
             torch.mm(wf.t(), gon, out=gw.view(K * Cin, Cout))
         if ctx.needs_input_grad[3]:
             gx, ctx.gx_buf = ctx.gx_buf, None
@@ -361,7 +375,8 @@ class _KPConvGemmBiasActFn(torch.autograd.Function):
                 _native.check(L.d3f_kpconv_grad_input(_p(q_pts), Nq, _p(s_pts), Ns, _p(idx), H, _p(x), Cin,
                                                       _p(kernel_points), K, ctx.extent, _p(gwf), _p(ctx.keep), pre,
                                                       _p(gx), _p(ws), nbytes, _stream()), "d3f_kpconv_grad_input")
-        return None, None, None, gx, None, gw, (gb.view(-1) if gb is not None else None), None, None
+        return (None, None, None, gx, None, (_adoptable(gw, ctx.gw_slot) if gw is not None else None),
+                (gb.view(-1) if gb is not None else None), None, None)
 
 
 def kpconv_bias_act(q_pts, s_pts, neighb_inds, x, kernel_points, weights, extent, bias, slope=0.1):
@@ -401,6 +416,7 @@ class _LinearFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight):
         ctx.save_for_backward(x, weight)
+        ctx.gw_slot = _grad_slot(weight)
         return torch.mm(x, weight.t())
 
     @staticmethod
@@ -412,16 +428,19 @@ class _LinearFn(torch.autograd.Function):
         if ctx.needs_input_grad[1]:
             L = _native.lib()
             N, Cin, Cout = int(x.shape[0]), int(x.shape[1]), int(weight.shape[0])
+            slot = ctx.gw_slot
             if N >= _SPLITK_MIN_ROWS and L.d3f_linear_grad_weight_supported(N, Cin, Cout):
-                gw = torch.empty_like(weight)
+                gw = slot if slot is not None else torch.empty_like(weight)
                 nbytes = L.d3f_linear_grad_weight_ws_bytes(N, Cin, Cout)
                 ws = _ws(nbytes, x.device)
                 with _region("linear_dw[N=%d,Cin=%d,Cout=%d]" % (N, Cin, Cout), 4 * N * (Cin + Cout) + 4 * Cin * Cout):
                     _native.check(L.d3f_linear_grad_weight(_p(x), _p(go), N, Cin, Cout, _p(gw), _p(ws), nbytes,
                                                            _stream()), "d3f_linear_grad_weight")
+            elif slot is not None:
+                gw = torch.mm(go.t(), x, out=slot)
             else:
                 gw = torch.mm(go.t(), x)
-        return gx, gw
+        return gx, (_adoptable(gw, ctx.gw_slot) if gw is not None else None)
 
 
 class _LinearBiasActFn(torch.autograd.Function):
@@ -442,6 +461,7 @@ class _LinearBiasActFn(torch.autograd.Function):
                           "d3f_linear_bias_act_forward")
         ctx.save_for_backward(x, weight, out)
         ctx.gbuf = gbuf
+        ctx.gw_slot = _grad_slot(weight)
         ctx.slope = float(slope)
         ctx.has = (b1 is not None, add is not None, b2 is not None)
         return out
@@ -481,16 +501,18 @@ class _LinearBiasActFn(torch.autograd.Function):
                 _native.check(L.d3f_linear_grad_input(_p(gm), _p(weight), N, Cin, Cout, _p(gx), _stream()),
                               "d3f_linear_grad_input")
         if ctx.needs_input_grad[1]:
+            slot = ctx.gw_slot
             if L.d3f_linear_grad_weight_supported(N, Cin, Cout):
-                gw = torch.empty_like(weight)
+                gw = slot if slot is not None else torch.empty_like(weight)
                 nbytes = L.d3f_linear_grad_weight_ws_bytes(N, Cin, Cout)
                 ws = _ws(nbytes, x.device)
                 with _region("linear_dw[N=%d,Cin=%d,Cout=%d]" % (N, Cin, Cout), 4 * N * (Cin + Cout) + 4 * Cin * Cout):
                     _native.check(L.d3f_linear_grad_weight(_p(x), _p(gm), N, Cin, Cout, _p(gw), _p(ws), nbytes,
                                                            _stream()), "d3f_linear_grad_weight")
             else:
-                gw = torch.mm(gm.t(), x)
-        return gx, gw, g1, gm if ctx.has[1] and ctx.needs_input_grad[3] else None, g2, None
+                gw = torch.mm(gm.t(), x, out=slot) if slot is not None else torch.mm(gm.t(), x)
+        return (gx, (_adoptable(gw, ctx.gw_slot) if gw is not None else None), g1,
+                gm if ctx.has[1] and ctx.needs_input_grad[3] else None, g2, None)
 
 
 # rows from which the unary blocks use the fused row-streaming kernels instead of library GEMM + epilogue launch

@@ -315,3 +315,33 @@ def test_split_backward_matches_single_backward(golden_s0):
         assert abs(lc - ld) < 1e-4 * max(1.0, abs(ld)), (k, lc, ld)
     c.check_status()
     assert float((c.flat.data - d.flat.data).abs().max()) < 1e-4 * float(d.flat.data.abs().max())
+
+
+def test_weight_gradients_land_in_the_flat_buffer_without_copies(golden_s0):
+    """FlatParams hands every weight matrix / KPConv kernel its place in the flat gradient buffer; the backward
+    kernels write there and autograd adopts the view (no clone, no concatenation); values equal a plain backward."""
+    from d3feat_pytorch_amd.train import TrainStep
+    g = golden_s0
+    cfg = cfgmod.default_config(first_features_dim=16, num_node=64)
+    limits = [int(x) for x in g['limits']]
+    item = tuple(torch.from_numpy(np.ascontiguousarray(a)).to(DEV) for a in _item(g))
+    np.random.seed(0)
+    torch.manual_seed(0)
+    t = TrainStep(cfg, limits, torch.device(DEV), seed=0)
+    batch = t.build_batch(item)
+    batch['n0'] = int(item[0].shape[0])
+    t.flat.zero_grad()
+    loss = t.forward_loss(batch)[0]
+    loss.backward()
+    in_place = [p.grad is not None and p.grad.data_ptr() == s.data_ptr() for p, s in zip(t.flat.params, t.flat.slots)]
+    weights = [p.dim() >= 2 for p in t.flat.params]
+    assert all(ip for ip, w in zip(in_place, weights) if w), "a weight gradient was cloned instead of adopted"
+    flat = t.flat.gather_grads().clone()
+    # reference: the same backward with ordinary gradient tensors
+    for p in t.flat.params:
+        if hasattr(p, "_d3f_grad_slot"):
+            del p._d3f_grad_slot
+    t.flat.zero_grad()
+    t.forward_loss(batch)[0].backward()
+    ref = torch.cat([p.grad.reshape(-1) for p in t.flat.params])
+    assert float((flat - ref).abs().max()) < 1e-6 * float(ref.abs().max())
