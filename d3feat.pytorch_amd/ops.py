@@ -214,8 +214,9 @@ def _grad_slot(param):
 SAVE_WEIGHTED_FEATURES = True
 # below this many rows a weight gradient is a plain GEMM for the library; above, the reduction-parallel kernel
 _SPLITK_MIN_ROWS = 4096
-# below this many query points grad_x takes gW = (g/nn) W^T from a library GEMM and only scatters
-_GEMM_DX_MAX_ROWS = 1500
+# below this many query points KPConv goes through library GEMMs (aggregate + wf@W forward; gW = (g/nn) W^T + scatter
+# backward): measured better than the fused kernels up to the 2k-point level, not at 8k points
+_GEMM_DX_MAX_ROWS = 4096
 
 
 class _KPConvFn(torch.autograd.Function):
