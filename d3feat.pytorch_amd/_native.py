@@ -49,7 +49,7 @@ SIGNATURES = {
     "d3f_max_pool_backward": (_i, [_vp, _vp, _i, _i, _i, _vp, _i, _vp]),
     "d3f_closest_pool_forward": (_i, [_vp, _i, _i, _vp, _i, _i, _vp, _i, _vp, _vp, _vp]),
     "d3f_closest_pool_backward": (_i, [_vp, _i, _vp, _i, _i, _i, _i, _vp, _i, _vp]),
-    "d3f_bias_act_forward": (_i, [_vp, _vp, _vp, _vp, _f, _i, _i, _vp, _vp, _i, _vp, _vp]),
+    "d3f_bias_act_forward": (_i, [_vp, _vp, _vp, _vp, _f, _i, _i, _vp, _vp, _i, _vp, _vp, _i, _i, _vp]),
     "d3f_bias_act_backward_ws_bytes": (_sz, [_i, _i]),
     "d3f_bias_act_backward": (_i, [_vp, _vp, _f, _i, _i, _vp, _vp, _vp, _i, _vp, _vp, _sz, _vp]),
     "d3f_global_max": (_i, [_vp, _sz, _vp, _vp, _sz, _vp]),

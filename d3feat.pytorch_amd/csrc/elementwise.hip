@@ -17,7 +17,9 @@ __global__ __launch_bounds__(256) void bias_act_fwd_kernel(const float* __restri
                                                            const float* __restrict__ add,
                                                            const float* __restrict__ b2, float slope, size_t n4,
                                                            int C, float* __restrict__ out, float* __restrict__ zinit,
-                                                           int zn, const float* __restrict__ row_div) {
+                                                           int zn, const float* __restrict__ row_div,
+                                                           const int32_t* __restrict__ add_idx, int idx_stride,
+                                                           int add_rows) {
   // C % 4 == 0: one float4 per thread, columns of a float4 are c .. c+3
   if (zinit && blockIdx.x == 0)
     for (int t = threadIdx.x; t < zn; t += blockDim.x) zinit[t] = 0.0f;
@@ -27,7 +29,16 @@ __global__ __launch_bounds__(256) void bias_act_fwd_kernel(const float* __restri
   float4 v = ((const float4*)x)[i];
   if (row_div) { const float d = row_div[(i * 4) / (size_t)C]; v.x /= d; v.y /= d; v.z /= d; v.w /= d; }
   if (b1) { const float4 b = *(const float4*)(b1 + c); v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w; }
-  if (add) { const float4 a = ((const float4*)add)[i]; v.x += a.x; v.y += a.y; v.z += a.z; v.w += a.w; }
+  if (add) {
+    float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (add_idx) {  // add is a COARSE matrix, row n takes the row of its nearest coarse point (shadow -> zeros)
+      const int m = add_idx[((i * 4) / (size_t)C) * (size_t)idx_stride];
+      if (m >= 0 && m < add_rows) a = *(const float4*)(add + (size_t)m * C + c);
+    } else {
+      a = ((const float4*)add)[i];
+    }
+    v.x += a.x; v.y += a.y; v.z += a.z; v.w += a.w;
+  }
   if (b2) { const float4 b = *(const float4*)(b2 + c); v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w; }
   v.x = v.x > 0.0f ? v.x : v.x * slope;
   v.y = v.y > 0.0f ? v.y : v.y * slope;
@@ -43,7 +54,9 @@ __global__ __launch_bounds__(256) void bias_act_fwd_scalar_kernel(const float* _
                                                                   const float* __restrict__ b2, float slope, size_t n,
                                                                   int C, float* __restrict__ out,
                                                                   float* __restrict__ zinit, int zn,
-                                                                  const float* __restrict__ row_div) {
+                                                                  const float* __restrict__ row_div,
+                                                                  const int32_t* __restrict__ add_idx,
+                                                                  int idx_stride, int add_rows) {
   if (zinit && blockIdx.x == 0)
     for (int t = threadIdx.x; t < zn; t += blockDim.x) zinit[t] = 0.0f;
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -52,7 +65,14 @@ __global__ __launch_bounds__(256) void bias_act_fwd_scalar_kernel(const float* _
   float v = x[i];
   if (row_div) v /= row_div[i / (size_t)C];
   if (b1) v += b1[c];
-  if (add) v += add[i];
+  if (add) {
+    if (add_idx) {
+      const int m = add_idx[(i / (size_t)C) * (size_t)idx_stride];
+      if (m >= 0 && m < add_rows) v += add[(size_t)m * C + c];
+    } else {
+      v += add[i];
+    }
+  }
   if (b2) v += b2[c];
   out[i] = v > 0.0f ? v : v * slope;
 }
@@ -132,7 +152,8 @@ __global__ __launch_bounds__(1024) void bias_sum_kernel(const float* __restrict_
 extern "C" {
 
 int d3f_bias_act_forward(const float* x, const float* bias1, const float* add, const float* bias2, float slope, int N,
-                         int C, float* out, float* zero_init, int zero_n, const float* row_div, void* stream) {
+                         int C, float* out, float* zero_init, int zero_n, const float* row_div, const int32_t* add_idx,
+                         int idx_stride, int add_rows, void* stream) {
   if (!x || !out || N < 0 || C < 1 || (zero_init && zero_n < 1)) return D3F_EINVAL;
   const size_t n = (size_t)N * C;
   if (n == 0) {
@@ -142,10 +163,10 @@ int d3f_bias_act_forward(const float* x, const float* bias1, const float* add, c
   }
   if (C % 4 == 0)
     bias_act_fwd_kernel<<<d3f::cdiv((long long)(n / 4), 256), 256, 0, (hipStream_t)stream>>>(
-        x, bias1, add, bias2, slope, n / 4, C, out, zero_init, zero_n, row_div);
+        x, bias1, add, bias2, slope, n / 4, C, out, zero_init, zero_n, row_div, add_idx, idx_stride, add_rows);
   else
     bias_act_fwd_scalar_kernel<<<d3f::cdiv((long long)n, 256), 256, 0, (hipStream_t)stream>>>(
-        x, bias1, add, bias2, slope, n, C, out, zero_init, zero_n, row_div);
+        x, bias1, add, bias2, slope, n, C, out, zero_init, zero_n, row_div, add_idx, idx_stride, add_rows);
   D3F_LAUNCH_CHECK();
   return D3F_OK;
 }

@@ -12,7 +12,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from .. import ops
-from .blocks import KPConv, NearestUpsampleBlock, block_decider  # noqa: F401
+from .blocks import KPConv, NearestUpsampleBlock, UnaryBlock, block_decider  # noqa: F401
 
 
 def _moves_level(block):
@@ -84,8 +84,15 @@ class KPFCNN(nn.Module):
         for j, op in enumerate(self.decoder_blocks):
             if j in self.decoder_concats:
                 if pending is not None:
-                    x = ops.closest_pool(x, batch['upsamples'][pending.layer_ind - 1], skip=skips.pop())
+                    inds = batch['upsamples'][pending.layer_ind - 1]
                     pending = None
+                    if isinstance(op, UnaryBlock) and not op.use_bn and (x.shape[1] * 4) % 16 == 0:
+                        # unary block right after upsample + concat: the upsampled half of the product is computed
+                        # on the coarse rows and upsampled in the epilogue (ops.upsample_linear_bias_act)
+                        x = ops.upsample_linear_bias_act(x, inds, skips.pop(), op.mlp.weight, op.mlp.bias,
+                                                         op.batch_norm.bias, slope=1.0 if op.no_relu else 0.1)
+                        continue
+                    x = ops.closest_pool(x, inds, skip=skips.pop())
                 else:
                     x = torch.cat([x, skips.pop()], dim=1)
             if isinstance(op, NearestUpsampleBlock) and (j + 1) in self.decoder_concats and x.is_cuda:

@@ -337,7 +337,8 @@ class _KPConvGemmBiasActFn(torch.autograd.Function):
         want_b = bias is not None and ctx.needs_input_grad[6]
         gbuf = torch.empty((1, Cout), dtype=torch.float32, device=dev) if want_b else None
         _native.check(L.d3f_bias_act_forward(_p(raw), _p(bias), None, None, float(slope), Nq, Cout, _p(out), _p(gbuf),
-                                             Cout if want_b else 0, _p(nn), _stream()), "d3f_bias_act_forward")
+                                             Cout if want_b else 0, _p(nn), None, 0, 0, _stream()),
+                      "d3f_bias_act_forward")
         ctx.save_for_backward(q_pts, s_pts, idx, x, kernel_points, weights, nn, wf, out)
         ctx.gbuf, ctx.extent, ctx.slope, ctx.want_b = gbuf, float(extent), float(slope), want_b
         ctx.gw_slot = _grad_slot(weights)
@@ -516,6 +517,103 @@ class _LinearBiasActFn(torch.autograd.Function):
                 gm if ctx.has[1] and ctx.needs_input_grad[3] else None, g2, None)
 
 
+class _UpsampleLinearFn(torch.autograd.Function):
+    """Decoder unary block on [nearest_upsample(x_coarse) | skip] (reference architectures.py:311-314 + blocks.py:481):
+        act( [x_c[idx] | skip] W^T + b )  =  act( (x_c W1^T)[idx] + skip W2^T + b ),   W = [W1 | W2].
+    A row gather commutes with a row-wise linear map, so the wide half of the product (the 2048/1024/512-channel
+    upsampled features) is computed on the COARSE rows -- 3.3x .. 4.8x fewer -- and upsampled inside the epilogue; the
+    backward pools the masked gradient back to the coarse rows before the two GEMMs that involve W1."""
+
+    @staticmethod
+    def forward(ctx, xc, idx, skip, weight, b1, b2, slope):
+        L = _native.lib()
+        Nc, Cc = int(xc.shape[0]), int(xc.shape[1])
+        N, Cs = int(skip.shape[0]), int(skip.shape[1])
+        Cout, H = int(weight.shape[0]), int(idx.shape[1])
+        w1, w2 = weight[:, :Cc], weight[:, Cc:]
+        t = torch.mm(xc, w1.t())                      # [Nc, Cout] on the coarse rows
+        y = torch.mm(skip, w2.t())                    # [N, Cout]
+        out = torch.empty_like(y)
+        nb = int(b1 is not None and ctx.needs_input_grad[4]) + int(b2 is not None and ctx.needs_input_grad[5])
+        gbuf = torch.empty((nb, Cout), dtype=torch.float32, device=xc.device) if nb else None
+        gt_buf = torch.empty((Nc, Cout), dtype=torch.float32, device=xc.device)  # pooled gradient, cleared below
+        _native.check(L.d3f_bias_act_forward(_p(y), _p(b1), _p(t), _p(b2), float(slope), N, Cout, _p(out), _p(gbuf),
+                                             nb * Cout, None, _p(idx), H, Nc, _stream()), "d3f_bias_act_forward")
+        gt_buf.zero_()
+        ctx.save_for_backward(xc, idx, skip, weight, out)
+        ctx.gbuf, ctx.gt_buf, ctx.slope = gbuf, gt_buf, float(slope)
+        ctx.has = (b1 is not None, b2 is not None)
+        ctx.gw_slot = _grad_slot(weight)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        xc, idx, skip, weight, out = ctx.saved_tensors
+        L = _native.lib()
+        Nc, Cc = int(xc.shape[0]), int(xc.shape[1])
+        N, Cs = int(skip.shape[0]), int(skip.shape[1])
+        Cout, H = int(weight.shape[0]), int(idx.shape[1])
+        go = grad_out.contiguous()
+        want1 = ctx.has[0] and ctx.needs_input_grad[4]
+        want2 = ctx.has[1] and ctx.needs_input_grad[5]
+        g1 = g2 = None
+        pre = 0
+        if want1 or want2:
+            gbuf, pre = ctx.gbuf, 1
+            ctx.gbuf = None
+            if gbuf is None:
+                gbuf, pre = torch.empty((int(want1) + int(want2), Cout), dtype=torch.float32, device=go.device), 0
+            rows = list(gbuf.unbind(0))
+            g1 = rows.pop(0) if want1 else None
+            g2 = rows.pop(0) if want2 else None
+        gm = torch.empty_like(go)
+        first, second = (g1, g2) if g1 is not None else (g2, None)
+        wsb, nws = _bias_bwd_ws(N, Cout, go.device) if first is not None else (None, 0)
+        _native.check(L.d3f_bias_act_backward(_p(go), _p(out), ctx.slope, N, Cout, _p(gm), _p(first), _p(second),
+                                              pre if first is not None else 0, None, _p(wsb), nws, _stream()),
+                      "d3f_bias_act_backward")
+        # pooled gradient of the coarse product: g_t[m] = sum_{n: idx[n,0] = m} gm[n]
+        gt, ctx.gt_buf = ctx.gt_buf, None
+        pre_t = 1 if gt is not None else 0
+        if gt is None:
+            gt = torch.empty((Nc, Cout), dtype=torch.float32, device=go.device)
+        _native.check(L.d3f_closest_pool_backward(_p(gm), Cout, _p(idx), N, H, Cout, Nc, _p(gt), pre_t, _stream()),
+                      "d3f_closest_pool_backward")
+        w1, w2 = weight[:, :Cc], weight[:, Cc:]
+        gxc = torch.mm(gt, w1) if ctx.needs_input_grad[0] else None
+        gskip = torch.mm(gm, w2) if ctx.needs_input_grad[2] else None
+        gw = None
+        if ctx.needs_input_grad[3]:
+            slot = ctx.gw_slot
+            gw = slot if slot is not None else torch.empty_like(weight)
+            gw[:, :Cc].copy_(torch.mm(gt.t(), xc))
+            if N >= _SPLITK_MIN_ROWS and L.d3f_linear_grad_weight_supported(N, Cs, Cout):
+                tmp = torch.empty((Cout, Cs), dtype=torch.float32, device=go.device)
+                nbytes = L.d3f_linear_grad_weight_ws_bytes(N, Cs, Cout)
+                ws = _ws(nbytes, go.device)
+                _native.check(L.d3f_linear_grad_weight(_p(skip), _p(gm), N, Cs, Cout, _p(tmp), _p(ws), nbytes,
+                                                       _stream()), "d3f_linear_grad_weight")
+            else:
+                tmp = torch.mm(gm.t(), skip)
+            gw[:, Cc:].copy_(tmp)
+            gw = _adoptable(gw, slot)
+        return gxc, None, gskip, gw, g1, g2, None
+
+
+def upsample_linear_bias_act(x_coarse, inds, skip, weight, bias1=None, bias2=None, slope=0.1):
+    """act([x_coarse[inds[:,0]] | skip] @ weight^T + bias1 + bias2) without forming the upsampled matrix."""
+    xc, sk, w = _f32(x_coarse, "x_coarse"), _f32(skip, "skip"), _f32(weight, "weight")
+    idx = _i32(inds, "inds")
+    if idx.dim() == 1:
+        idx = idx.view(-1, 1)
+    if w.shape[1] != xc.shape[1] + sk.shape[1] or idx.shape[0] != sk.shape[0]:
+        raise RuntimeError("upsample_linear: shapes x_c%s skip%s W%s idx%s" % (
+            tuple(xc.shape), tuple(sk.shape), tuple(w.shape), tuple(idx.shape)))
+    b1 = _f32(bias1, "bias1") if bias1 is not None else None
+    b2 = _f32(bias2, "bias2") if bias2 is not None else None
+    return _UpsampleLinearFn.apply(xc, idx, sk, w, b1, b2, float(slope))
+
+
 # rows from which the unary blocks use the fused row-streaming kernels instead of library GEMM + epilogue launch
 _FUSED_LINEAR_MIN_ROWS = 4096
 
@@ -644,7 +742,8 @@ class _BiasActFn(torch.autograd.Function):
         nb = int(b1 is not None and ctx.needs_input_grad[1]) + int(b2 is not None and ctx.needs_input_grad[3])
         gbuf = torch.empty((nb, C), dtype=torch.float32, device=x.device) if nb else None
         _native.check(_native.lib().d3f_bias_act_forward(_p(x), _p(b1), _p(add), _p(b2), float(slope), N, C, _p(out),
-                                                         _p(gbuf), nb * C, None, _stream()), "d3f_bias_act_forward")
+                                                         _p(gbuf), nb * C, None, None, 0, 0, _stream()),
+                      "d3f_bias_act_forward")
         ctx.save_for_backward(out)
         ctx.gbuf = gbuf
         ctx.slope = float(slope)

@@ -183,9 +183,12 @@ int d3f_closest_pool_backward(const float* grad_out, int ld, const int32_t* idx,
  *   accumulators, so that backward (bias_prezeroed = 1) needs no separate fill launch.
  * row_div (optional, [N]): out = act(x[n,:]/row_div[n] + ...) and grad_x[n,:] = masked gradient / row_div[n] (the bias
  *   sums use the undivided masked gradient) -- the KPConv neighbor-count normalisation when x is a raw wf @ W product.
+ * add_idx (optional, int32 with row stride idx_stride): `add` is then a COARSE matrix [add_rows, C] and row n receives
+ *   add[add_idx[n*idx_stride]] (zeros for a shadow index) -- nearest upsampling folded into the epilogue.
  * ---------------------------------------------------------------------------------------------- */
 int d3f_bias_act_forward(const float* x, const float* bias1, const float* add, const float* bias2, float slope, int N,
-                         int C, float* out, float* zero_init, int zero_n, const float* row_div, void* stream);
+                         int C, float* out, float* zero_init, int zero_n, const float* row_div, const int32_t* add_idx,
+                         int idx_stride, int add_rows, void* stream);
 /* ws (optional, d3f_bias_act_backward_ws_bytes): with it, N >= 4096 uses per-block partial sums + a second tiny
  * launch for the bias gradient instead of atomics on C addresses (which serialise: 32 us at 38k x 32), deterministic. */
 size_t d3f_bias_act_backward_ws_bytes(int N, int C);

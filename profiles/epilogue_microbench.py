@@ -31,7 +31,7 @@ for n, c in ((38272, 32), (38272, 64), (38272, 128), (8000, 64), (8000, 256), (2
     go = torch.randn(n, c, device=dev); gx = torch.empty_like(x); gb = torch.zeros(2, c, device=dev)
     st = torch.cuda.current_stream().cuda_stream
     f = timeit(lambda: L.d3f_bias_act_forward(x.data_ptr(), b.data_ptr(), None, b.data_ptr(), 0.1, n, c, out.data_ptr(),
-                                              None, 0, None, st))
+                                              None, 0, None, None, 0, 0, st))
     nb = L.d3f_bias_act_backward_ws_bytes(n, c)
     ws = torch.empty(max(nb, 256), dtype=torch.uint8, device=dev)
     w = timeit(lambda: L.d3f_bias_act_backward(go.data_ptr(), out.data_ptr(), 0.1, n, c, gx.data_ptr(), gb.data_ptr(),

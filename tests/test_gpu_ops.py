@@ -249,6 +249,31 @@ def test_kpconv_bias_act_gemm_path_matches_fused_path(nq, ns, h, cin, cout, monk
         assert rel_err(a, c) < 2e-5
 
 
+@pytest.mark.parametrize("nc,n,cc,cs,cout,slope", [(192, 640, 2048, 1024, 1024, 0.1), (640, 2112, 64, 32, 128, 0.1),
+                                                   (300, 5000, 128, 64, 64, 0.1), (50, 177, 48, 16, 32, 1.0)])
+def test_upsample_linear_commutes_with_gather(nc, n, cc, cs, cout, slope):
+    """act([x_c[idx] | skip] W^T + b1 + b2) with the upsampled half of the product computed on the coarse rows ==
+    nearest upsample + concatenation + linear + epilogue, values and all five gradients."""
+    rng = np.random.default_rng(n + cc)
+    xc = rng.normal(size=(nc, cc)).astype(np.float32)
+    skip = rng.normal(size=(n, cs)).astype(np.float32)
+    w = (rng.normal(size=(cout, cc + cs)) / np.sqrt(cc + cs)).astype(np.float32)
+    b1, b2 = rng.normal(size=cout).astype(np.float32), rng.normal(size=cout).astype(np.float32)
+    idx = rng.integers(0, nc + 1, size=(n, 5)).astype(np.int64)  # nc = shadow -> zero row
+    go = rng.normal(size=(n, cout)).astype(np.float32)
+    txc, tsk, tw, tb1, tb2 = [torch.from_numpy(a).double().requires_grad_(True) for a in (xc, skip, w, b1, b2)]
+    up = torch.cat([txc, torch.zeros(1, cc, dtype=torch.float64)], 0)[torch.from_numpy(idx[:, 0])]
+    ref = torch.cat([up, tsk], 1) @ tw.t() + tb1 + tb2
+    ref = torch.where(ref > 0, ref, ref * slope)
+    ref.backward(torch.from_numpy(go).double())
+    g = [cu(a).requires_grad_(True) for a in (xc, skip, w, b1, b2)]
+    out = ops.upsample_linear_bias_act(g[0], cu(idx), g[1], g[2], g[3], g[4], slope=slope)
+    out.backward(cu(go))
+    assert rel_err(out.detach().cpu().numpy(), ref.detach().numpy()) < 1e-5
+    for a, b in zip(g, (txc, tsk, tw, tb1, tb2)):
+        assert rel_err(a.grad.cpu().numpy(), b.grad.numpy()) < 2e-5
+
+
 def test_kpconv_all_shadow_rows_and_empty():
     rng = np.random.default_rng(0)
     q, s, idx, x, kp, w = _kpconv_case(rng, 64, 80, 10, 32, 32)
