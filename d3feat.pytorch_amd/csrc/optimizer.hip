@@ -32,11 +32,16 @@ __device__ __forceinline__ void sgd1(float g, float& p, float& b, float lr, floa
 
 __global__ __launch_bounds__(256) void sgd_kernel(const float* __restrict__ g, float* __restrict__ p,
                                                   float* __restrict__ buf, size_t n, float lr, float mom, float wd,
-                                                  int* __restrict__ state) {
+                                                  const float* __restrict__ hyper, int* __restrict__ state) {
   const bool skip = __builtin_nontemporal_load(state) != 0;
   if (skip) {
     if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(state + 1, 1);
     return;
+  }
+  if (hyper) {  // device-resident {lr, momentum, weight_decay}: a schedule can change them under a captured graph
+    lr = hyper[0];
+    mom = hyper[1];
+    wd = hyper[2];
   }
   const size_t n4 = n / 4;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
@@ -60,9 +65,10 @@ __global__ __launch_bounds__(256) void sgd_kernel(const float* __restrict__ g, f
 extern "C" {
 
 /* grad, params, momentum_buf: [n] fp32, 16-byte aligned.  state: int32[2] on the device = {scratch flag, number of
- * skipped steps so far}; state[0] is reset here, state[1] only ever incremented. */
+ * skipped steps so far}; state[0] is reset here, state[1] only ever incremented.  hyper_device: NULL, or float[3] on
+ * the device = {lr, momentum, weight_decay} read at execution time instead of the three scalar arguments. */
 int d3f_sgd_guarded_step(const float* grad, float* params, float* momentum_buf, size_t n, float lr, float momentum,
-                         float weight_decay, int32_t* state, void* stream) {
+                         float weight_decay, const float* hyper_device, int32_t* state, void* stream) {
   if (!grad || !params || !momentum_buf || !state) return D3F_EINVAL;
   if ((((uintptr_t)grad | (uintptr_t)params | (uintptr_t)momentum_buf) & 15) != 0) return D3F_EINVAL;
   hipStream_t st = (hipStream_t)stream;
@@ -71,7 +77,7 @@ int d3f_sgd_guarded_step(const float* grad, float* params, float* momentum_buf, 
   const int blocks = (int)std::min<size_t>(2048, (size_t)d3f::cdiv((long long)(n / 4 + 1), 256));
   nonfinite_kernel<<<blocks, 256, 0, st>>>(grad, n, state);
   D3F_LAUNCH_CHECK();
-  sgd_kernel<<<blocks, 256, 0, st>>>(grad, params, momentum_buf, n, lr, momentum, weight_decay, state);
+  sgd_kernel<<<blocks, 256, 0, st>>>(grad, params, momentum_buf, n, lr, momentum, weight_decay, hyper_device, state);
   D3F_LAUNCH_CHECK();
   return D3F_OK;
 }

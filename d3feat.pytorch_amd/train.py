@@ -33,7 +33,11 @@ class FlatParams:
     Contract: exactly one backward between ``zero_grad`` calls (the slots are overwritten, not accumulated)."""
 
     def __init__(self, module):
-        self.params = [p for p in module.parameters() if p.requires_grad]
+        every = list(module.parameters())
+        self.params = [p for p in every if p.requires_grad]
+        # position of each trainable parameter in module.parameters() -- the index torch.optim uses in its state_dict
+        self.module_index = [i for i, p in enumerate(every) if p.requires_grad]
+        self.n_module_params = len(every)
         n = sum(p.numel() for p in self.params)
         dev = self.params[0].device
         self.data = torch.empty(n, dtype=torch.float32, device=dev)
@@ -98,9 +102,62 @@ class GuardedSGD:
     arithmetic for host tensors (the gloo tests of the data-parallel logic)."""
 
     def __init__(self, flat, lr=0.01, momentum=0.98, weight_decay=1e-6):
-        self.flat, self.lr, self.momentum, self.weight_decay = flat, lr, momentum, weight_decay
+        self.flat = flat
         self.buf = torch.zeros_like(flat.data)
         self.state = torch.zeros(2, dtype=torch.int32, device=flat.data.device)
+        # {lr, momentum, weight_decay} live on the device: the kernel reads them when it runs, so a schedule changes the
+        # step size of an already captured graph (a scalar argument would be frozen at capture)
+        self.hyper = torch.tensor([lr, momentum, weight_decay], dtype=torch.float32, device=flat.data.device)
+        self._hyper = [float(lr), float(momentum), float(weight_decay)]
+        self.initial_lr = float(lr)
+
+    def _set(self, i, v):
+        self._hyper[i] = float(v)
+        self.hyper[i] = float(v)   # stream-ordered fill, no sync
+
+    lr = property(lambda self: self._hyper[0], lambda self, v: self._set(0, v))
+    momentum = property(lambda self: self._hyper[1], lambda self, v: self._set(1, v))
+    weight_decay = property(lambda self: self._hyper[2], lambda self, v: self._set(2, v))
+
+    @property
+    def param_groups(self):
+        """Read-only view in torch.optim's shape (the reference reads ``param_groups[0]['lr']``, trainer.py:224)."""
+        return [{'lr': self.lr, 'momentum': self.momentum, 'dampening': 0, 'weight_decay': self.weight_decay,
+                 'nesterov': False, 'initial_lr': self.initial_lr, 'params': list(range(self.flat.n_module_params))}]
+
+    def state_dict(self):
+        """Same layout as ``torch.optim.SGD.state_dict()`` over ``model.parameters()`` (what the reference snapshots,
+        trainer.py:196): momentum buffers keyed by the parameter's position in ``model.parameters()``."""
+        state, off = {}, 0
+        for idx, p in zip(self.flat.module_index, self.flat.params):
+            state[idx] = {'momentum_buffer': self.buf[off:off + p.numel()].view_as(p).detach().clone()}
+            off += p.numel()
+        return {'state': state, 'param_groups': self.param_groups}
+
+    def load_state_dict(self, sd):
+        group = sd['param_groups'][0]
+        if len(sd['param_groups']) != 1 or group.get('dampening', 0) != 0 or group.get('nesterov', False):
+            raise ValueError("GuardedSGD loads a single-group torch.optim.SGD state without dampening / nesterov")
+        if len(group['params']) != self.flat.n_module_params:
+            raise ValueError("optimizer state covers %d parameters, the model has %d" % (
+                len(group['params']), self.flat.n_module_params))
+        self.lr, self.momentum, self.weight_decay = group['lr'], group['momentum'], group['weight_decay']
+        self.initial_lr = float(group.get('initial_lr', self.initial_lr))
+        slot, off = {}, 0
+        for idx, p in zip(self.flat.module_index, self.flat.params):
+            slot[idx] = (off, p)
+            off += p.numel()
+        self.buf.zero_()   # a parameter without state has not been stepped yet: first step sets buf = d = 0*m + d
+        for key, st in sd['state'].items():
+            mb = st.get('momentum_buffer')
+            if mb is None:
+                continue
+            if int(key) not in slot:
+                raise ValueError("optimizer state for parameter %s, which is not trainable here" % key)
+            off, p = slot[int(key)]
+            if tuple(mb.shape) != tuple(p.shape):
+                raise ValueError("momentum buffer %s has shape %s, parameter has %s" % (key, tuple(mb.shape), tuple(p.shape)))
+            self.buf[off:off + p.numel()].copy_(mb.reshape(-1))
 
     @property
     def skipped(self):
@@ -113,11 +170,12 @@ class GuardedSGD:
         g = self.flat.grad
         if g.is_cuda:
             before = self.state[1].clone() if want_ok else None
-            ops.sgd_guarded_step(g, self.flat.data, self.buf, self.lr, self.momentum, self.weight_decay, self.state)
+            ops.sgd_guarded_step(g, self.flat.data, self.buf, self.lr, self.momentum, self.weight_decay, self.state,
+                                 hyper=self.hyper)
             return (self.state[1] == before) if want_ok else None
         ok = torch.isfinite(g).all()
         d = torch.add(g, self.flat.data, alpha=self.weight_decay)       # g + wd * p
-        new_buf = torch.add(d, self.buf, alpha=self.momentum)            # mom * buf + d
+        new_buf = torch.add(d, self.buf, alpha=self.momentum)            # d + mom * buf
         self.buf.copy_(torch.where(ok, new_buf, self.buf))
         self.flat.data.sub_(torch.where(ok, new_buf, torch.zeros_like(new_buf)), alpha=self.lr)
         self.state[1] += (~ok).to(torch.int32)
@@ -167,7 +225,25 @@ class TrainStep:
         fa, fp_, sa, sp = ops.select_normalize(x, scores, ia, ip, n0)
         desc, acc, fp, an, _, dists = self.circle(fa, fp_, batch['dist_keypts'], sa, sp)
         det = dists._d3f_det[0][1]
+        # per-row furthest-positive / average-negative distances [M] (trainer.py:99-100 averages them on the host);
+        # kept on the device for whoever wants the statistics -- no extra launches in the step itself
+        self.last_distances = (fp._t, an._t)
         return desc * self.w_desc + det * self.w_det, desc, det, acc
+
+    @torch.no_grad()
+    def evaluate(self, item):
+        """Validation pass on one pair (trainer.py:164-176): eval-mode forward (the detector applies its local-maximum
+        mask, architectures.py:361-366) + both losses, no backward.  Returns device scalars
+        (loss, desc_loss, det_loss, accuracy, d_pos, d_neg)."""
+        self.model.eval()
+        try:
+            batch = self.build_batch(item)
+            batch['n0'] = int(item[0].shape[0])
+            loss, desc, det, acc = self.forward_loss(batch)
+            fp, an = self.last_distances
+            return loss, desc, det, acc, fp.mean(), an.mean()
+        finally:
+            self.model.train()
 
     def forward_loss(self, batch):
         x, scores = self.model.forward_raw(batch)
@@ -272,10 +348,16 @@ class TrainStep:
         self.graphs = None
         self.cur = 0
 
+    def fits(self, item):
+        """Whether the pair can go through the captured graphs (level-0 capacity and correspondence count; deeper
+        levels are checked on the device, D3F_ST_CAPACITY -> check_status)."""
+        return (int(item[0].shape[0]) + int(item[1].shape[0]) <= self.caps[0]
+                and tuple(item[4].shape) == tuple(self.sets[0].corr.shape))
+
     def _load_inputs(self, st, item):
         p0, p1, _, _, corr, dk = item
         n0, n1 = int(p0.shape[0]), int(p1.shape[0])
-        if n0 + n1 > self.caps[0] or tuple(corr.shape) != tuple(st.corr.shape):
+        if not self.fits(item):
             raise RuntimeError("pair does not fit the captured shapes (%d + %d points, capacity %d; corr %s)" % (
                 n0, n1, self.caps[0], tuple(corr.shape)))
         st.pts[:n0].copy_(p0, non_blocking=True)
@@ -348,7 +430,7 @@ class TrainStep:
         # (stream priorities were tried: the range here is {0, -1}; replaying the network graphs on a priority -1 stream
         # made the step 3x slower, so both streams stay at the default priority)
         self._side = torch.cuda.Stream(device=dev)
-        self.g_net, self.g_net_b, self.g_pyr, self._graph_out = [], [], [], []
+        self.g_net, self.g_net_b, self.g_pyr, self._graph_out, self._graph_dist = [], [], [], [], []
         for i in range(self.NSETS):
             # graphs of one kind never run concurrently and replay in capture order: they share a memory pool
             g = torch.cuda.CUDAGraph()
@@ -357,6 +439,7 @@ class TrainStep:
                     self._graph_out.append(self._backward_deep(self._set_batch(self.sets[i])))
                 else:
                     self._graph_out.append(self._net_step(self.sets[i]))
+                self._graph_dist.append(self.last_distances)   # held: the pool keeps these addresses for this graph
             self.g_net.append(g)
             if self.split_backward:  # stage 2 of the same step: continues in the same pool
                 g = torch.cuda.CUDAGraph()
@@ -421,6 +504,7 @@ class TrainStep:
             self.g_net[i].replay()
             self.ev_net[i].record(main)
         self.cur = n
+        self.last_distances = self._graph_dist[i]
         return self._graph_out[i]
 
     def check_status(self):

@@ -1,0 +1,265 @@
+"""Epoch loop around :class:`TrainStep` with the reference ``Trainer``'s semantics (trainer.py:9-225).
+
+What is kept from the reference, by name: ``Trainer(args)`` reading ``max_epoch, training_max_iter, val_max_iter,
+save_dir, verbose, scheduler_interval, snapshot_interval, pretrain, train_loader, val_loader``; ``train()``,
+``train_epoch(epoch)``, ``evaluate(epoch)``, ``_snapshot(epoch, name)``, ``_load_pretrain(path)``, ``_get_lr()``; the
+best-loss / best-accuracy snapshots (trainer.py:48-54), the ExponentialLR step every ``scheduler_interval`` epochs
+(:59-60, training_3DMatch.py:78-81), the non-finite-gradient guard (:104-111, on the device here) and the snapshot
+file layout ``{'epoch', 'state_dict', 'optimizer', 'scheduler', 'best_loss'}`` (:193-206) with torch.optim.SGD /
+ExponentialLR shaped state, so snapshots move between the two code bases in either direction.
+
+What differs: one step is ``TrainStep.step_graph`` (the pipelined hipGraph replay) whenever the pair fits the captured
+capacities, the eager stream-ordered step otherwise; running statistics are accumulated on the device and read back
+every ``log_interval`` iterations (the reference reads five scalars back per step, trainer.py:115-119); scalars go to
+any object with ``add_scalar(tag, value, step)`` (``args.writer``; tensorboardX is not a dependency), by default a
+JSON-lines file under ``args.tboard_dir``.  With ``world_size > 1`` every rank walks the same shuffled order and takes
+every ``world_size``-th pair; rank 0 writes snapshots and logs.
+"""
+import json
+import os
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from .train import TrainStep
+
+
+class ExponentialLR:
+    """``torch.optim.lr_scheduler.ExponentialLR`` on a :class:`GuardedSGD` (same recursion ``lr <- lr * gamma``, same
+    state_dict keys), writing the new rate to the optimizer's device-resident hyper-parameters."""
+
+    def __init__(self, optimizer, gamma, last_epoch=0):
+        self.optimizer, self.gamma, self.last_epoch = optimizer, float(gamma), int(last_epoch)
+        self.base_lrs = [optimizer.initial_lr]
+        self._last_lr = [optimizer.lr]
+
+    def step(self):
+        self.last_epoch += 1
+        self.optimizer.lr = self.optimizer.lr * self.gamma
+        self._last_lr = [self.optimizer.lr]
+
+    def get_last_lr(self):
+        return list(self._last_lr)
+
+    def state_dict(self):
+        return {'gamma': self.gamma, 'base_lrs': list(self.base_lrs), 'last_epoch': self.last_epoch,
+                '_step_count': self.last_epoch + 1, '_get_lr_called_within_step': False,
+                '_last_lr': list(self._last_lr)}
+
+    def load_state_dict(self, sd):
+        self.gamma = float(sd['gamma'])
+        self.base_lrs = [float(x) for x in sd['base_lrs']]
+        self.last_epoch = int(sd['last_epoch'])
+        last = sd.get('_last_lr')
+        self.optimizer.lr = float(last[0]) if last else self.base_lrs[0] * self.gamma ** self.last_epoch
+        self._last_lr = [self.optimizer.lr]
+
+
+class ScalarLog:
+    """``add_scalar`` sink: one JSON object per line in ``<log_dir>/scalars.jsonl``."""
+
+    def __init__(self, log_dir):
+        self.path = None
+        if log_dir:
+            os.makedirs(log_dir, exist_ok=True)
+            self.path = os.path.join(log_dir, 'scalars.jsonl')
+
+    def add_scalar(self, tag, value, step):
+        if self.path is not None:
+            with open(self.path, 'a') as f:
+                f.write(json.dumps({'tag': tag, 'value': float(value), 'step': int(step)}) + '\n')
+
+
+class _Meters:
+    """Running sums of (desc_loss, det_loss, accuracy, d_pos, d_neg) on the device; one read-back per report."""
+    NAMES = ('desc_loss', 'det_loss', 'accuracy', 'd_pos', 'd_neg')
+
+    def __init__(self, device):
+        self.sum = torch.zeros(5, dtype=torch.float64, device=device)
+        self.count = 0
+
+    def update(self, desc, det, acc, d_pos, d_neg):
+        self.sum += torch.stack([desc.double().reshape(()), det.double().reshape(()), acc.double().reshape(()),
+                                 d_pos.double().reshape(()), d_neg.double().reshape(())])
+        self.count += 1
+
+    def averages(self):
+        v = (self.sum / max(1, self.count)).tolist()   # the only synchronisation
+        return dict(zip(self.NAMES, v))
+
+
+def _get(args, name, default):
+    return getattr(args, name, default) if getattr(args, name, None) is not None else default
+
+
+class Trainer(object):
+    def __init__(self, args):
+        self.config = args
+        self.start_epoch = 0
+        self.max_epoch = args.max_epoch
+        self.training_max_iter = _get(args, 'training_max_iter', 3500)
+        self.val_max_iter = _get(args, 'val_max_iter', 500)
+        self.save_dir = _get(args, 'save_dir', None)
+        self.verbose = _get(args, 'verbose', False)
+        self.log_interval = _get(args, 'log_interval', 100)
+        self.scheduler_interval = _get(args, 'scheduler_interval', 1)
+        self.snapshot_interval = _get(args, 'snapshot_interval', 1)
+        self.best_acc = 0
+        self.best_loss = 10000000
+        self.world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+        self.rank = dist.get_rank() if self.world > 1 else 0
+        self.device = torch.device(_get(args, 'device', 'cuda'))
+
+        self.train_loader = args.train_loader
+        self.val_loader = _get(args, 'val_loader', None)
+        limits = _get(args, 'neighborhood_limits', None)
+        if limits is None:
+            limits = self.train_loader.limits
+        self.engine = TrainStep(args, limits, self.device, world_size=self.world, seed=_get(args, 'seed', 0),
+                                model=_get(args, 'model', None))
+        self.model = self.engine.model
+        self.optimizer = self.engine.opt
+        self.scheduler = ExponentialLR(self.optimizer, gamma=args.scheduler_gamma)
+        self.writer = _get(args, 'writer', None) or ScalarLog(_get(args, 'tboard_dir', None) if self.rank == 0 else None)
+        self.use_graph = bool(_get(args, 'graph', self.device.type == 'cuda'))
+        self._captured = False
+        if _get(args, 'pretrain', ''):
+            self._load_pretrain(args.pretrain)
+
+    # ---------------------------------------------------------------------------------------------------------
+    def _capacities(self, dataset, samples=8, slack=1.06):
+        """Static per-level row capacities for the captured graphs: level sizes of a few pairs, with head-room
+        (the device flags an overflow, D3F_ST_CAPACITY; such a pair is re-run on the eager path)."""
+        caps = _get(self.config, 'graph_capacities', None)
+        if caps is not None:
+            return [int(c) for c in caps]
+        sizes = []
+        for i in range(min(samples, len(dataset))):
+            b = self.engine.build_batch(dataset[i])
+            sizes.append([int(t.shape[0]) for t in b['points']])
+        return TrainStep.capacities_for(sizes, slack=slack)
+
+    def _order(self, loader, epoch):
+        n = len(loader.dataset)
+        if getattr(loader, 'shuffle', False):
+            return np.random.RandomState(_get(self.config, 'seed', 0) * 100003 + epoch).permutation(n)
+        return np.arange(n)
+
+    def _one_step(self, item, next_item):
+        eng = self.engine
+        if self.use_graph:
+            if not self._captured:
+                eng.enable_graph(self._capacities(self.train_loader.dataset), num_corr=int(item[4].shape[0]))
+                # capture() warms the step up by running it: put parameters, momentum and counters back afterwards
+                keep = (eng.flat.data.clone(), eng.opt.buf.clone(), eng.opt.state.clone())
+                eng.capture(item)
+                for dst, src in zip((eng.flat.data, eng.opt.buf, eng.opt.state), keep):
+                    dst.copy_(src)
+                self._captured = True
+            if eng.fits(item):
+                nxt = next_item if (next_item is not None and eng.fits(next_item)) else None
+                return eng.step_graph(item, nxt)
+        return eng.step(item)
+
+    def train(self):
+        self.model.train()
+        for epoch in range(self.start_epoch, self.max_epoch):
+            self.train_epoch(epoch + 1)
+            res = self.evaluate(epoch + 1)
+            if res['desc_loss'] < self.best_loss:
+                self.best_loss = res['desc_loss']
+                self._snapshot(epoch + 1, 'best_loss')
+            if res['accuracy'] > self.best_acc:
+                self.best_acc = res['accuracy']
+                self._snapshot(epoch + 1, 'best_acc')
+            for k, v in res.items():
+                self.writer.add_scalar('val/%s' % k, v, epoch + 1)
+            if (epoch + 1) % self.scheduler_interval == 0:
+                self.scheduler.step()
+            if (epoch + 1) % self.snapshot_interval == 0:
+                self._snapshot(epoch + 1)
+        if self.rank == 0:
+            print("Training finish!... save training results")
+
+    def train_epoch(self, epoch):
+        ds = self.train_loader.dataset
+        order = self._order(self.train_loader, epoch)
+        num_iter = min(self.training_max_iter, len(ds) // max(1, getattr(self.train_loader, 'batch_size', 1)) // self.world)
+        meters = _Meters(self.device)
+        item = ds[int(order[self.rank])] if num_iter else None
+        for it in range(num_iter):
+            nxt = ds[int(order[(it + 1) * self.world + self.rank])] if it + 1 < num_iter else None
+            _, desc, det, acc = self._one_step(item, nxt)
+            fp, an = self.engine.last_distances
+            meters.update(desc, det, acc, fp.mean(), an.mean())
+            item = nxt
+            if (it + 1) % self.log_interval == 0 and self.verbose:
+                avg = meters.averages()
+                self.engine.check_status()
+                if self.rank == 0:
+                    cur = num_iter * (epoch - 1) + it
+                    for tag, key in (('Desc_Loss', 'desc_loss'), ('Det_Loss', 'det_loss'), ('D_pos', 'd_pos'),
+                                     ('D_neg', 'd_neg'), ('Accuracy', 'accuracy')):
+                        self.writer.add_scalar('train/' + tag, avg[key], cur)
+                    print("Epoch: %d [%4d/%d] desc loss: %.2f det loss: %.2f acc:  %.2f d_pos: %.2f d_neg: %.2f "
+                          "lr: %.3g skipped steps: %d" % (epoch, it + 1, num_iter, avg['desc_loss'], avg['det_loss'],
+                                                          avg['accuracy'], avg['d_pos'], avg['d_neg'],
+                                                          self._get_lr(), int(self.optimizer.skipped)))
+        avg = meters.averages()
+        self.engine.check_status()
+        if self.rank == 0:
+            print("Epoch %d: Desc Loss: %.2f, Det Loss : %.2f, Accuracy: %.2f, D_pos: %.2f, D_neg: %.2f" % (
+                epoch, avg['desc_loss'], avg['det_loss'], avg['accuracy'], avg['d_pos'], avg['d_neg']))
+        return avg
+
+    def evaluate(self, epoch):
+        loader = self.val_loader if self.val_loader is not None else self.train_loader
+        ds = loader.dataset
+        num_iter = min(self.val_max_iter, len(ds) // max(1, getattr(loader, 'batch_size', 1)))
+        meters = _Meters(self.device)
+        for it in range(self.rank, num_iter, self.world):
+            _, desc, det, acc, d_pos, d_neg = self.engine.evaluate(ds[it])
+            meters.update(desc, det, acc, d_pos, d_neg)
+        if self.world > 1:
+            cnt = torch.tensor([float(meters.count)], dtype=torch.float64, device=self.device)
+            dist.all_reduce(meters.sum)
+            dist.all_reduce(cnt)
+            meters.count = int(cnt.item())
+        res = meters.averages()
+        if self.rank == 0:
+            print("Evaluation: Epoch %d: Desc Loss %s, Det Loss %s, Accuracy %s" % (
+                epoch, res['desc_loss'], res['det_loss'], res['accuracy']))
+        return res
+
+    # ---------------------------------------------------------------------------------------------------------
+    def _snapshot(self, epoch, name=None):
+        if self.rank != 0 or not self.save_dir:
+            return None
+        os.makedirs(self.save_dir, exist_ok=True)
+        state = {
+            'epoch': epoch,
+            # parameters are views into one flat buffer: clone so that each entry owns exactly its own storage
+            'state_dict': {k: v.detach().clone() for k, v in self.model.state_dict().items()},
+            'optimizer': self.optimizer.state_dict(),
+            'scheduler': self.scheduler.state_dict(),
+            'best_loss': self.best_loss,
+        }
+        filename = os.path.join(self.save_dir, 'model_%s.pth' % (epoch if name is None else name))
+        print("Save model to %s" % filename)
+        torch.save(state, filename)
+        return filename
+
+    def _load_pretrain(self, resume):
+        if not os.path.isfile(resume):
+            raise ValueError("=> no checkpoint found at '%s'" % resume)
+        print("=> loading checkpoint %s" % resume)
+        state = torch.load(resume, map_location=self.device, weights_only=True)
+        self.start_epoch = state['epoch']
+        self.model.load_state_dict(state['state_dict'])   # copies into the flat parameter buffer (views stay valid)
+        self.scheduler.load_state_dict(state['scheduler'])
+        self.optimizer.load_state_dict(state['optimizer'])
+        self.best_loss = state['best_loss']
+
+    def _get_lr(self, group=0):
+        return self.optimizer.param_groups[group]['lr']

@@ -274,9 +274,12 @@ int d3f_mutual_nn(const float* src_desc, int Ns, const float* tgt_desc, int Nt, 
  *   if every grad[i] is finite:  buf = momentum*buf + (grad + weight_decay*params);  params -= lr*buf
  *   else: nothing is modified and state[1] (skipped-step counter) is incremented.
  * state: int32[2] on the device; state[0] is scratch.
+ * hyper_device: NULL, or float[3] on the device = {lr, momentum, weight_decay}, read when the kernel executes in
+ * place of the scalar arguments -- the learning-rate schedule (ExponentialLR, training_3DMatch.py:78-81 stepped at
+ * trainer.py:59-60) then changes the step size of an already captured hipGraph.
  * ---------------------------------------------------------------------------------------------- */
 int d3f_sgd_guarded_step(const float* grad, float* params, float* momentum_buf, size_t n, float lr, float momentum,
-                         float weight_decay, int32_t* state, void* stream);
+                         float weight_decay, const float* hyper_device, int32_t* state, void* stream);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,149 @@
+"""CPU: epoch-loop host logic -- snapshot interchange with torch.optim.SGD / ExponentialLR (the reference's snapshot
+layout, trainer.py:193-218), the learning-rate recursion, the scalar log.  No kernel launches."""
+import json
+import os
+import types
+
+import numpy as np
+import torch
+
+from d3feat_pytorch_amd import config as cfgmod
+from d3feat_pytorch_amd.models.architectures import KPFCNN
+from d3feat_pytorch_amd.train import FlatParams, GuardedSGD
+from d3feat_pytorch_amd.trainer import ExponentialLR, ScalarLog, Trainer
+
+
+def _small_model(seed=0):
+    np.random.seed(seed)
+    torch.manual_seed(seed)
+    return KPFCNN(cfgmod.default_config(first_features_dim=16))
+
+
+def _fake_grads(model, seed):
+    g = torch.Generator().manual_seed(seed)
+    return [torch.randn(p.shape, generator=g) * 1e-2 if p.requires_grad else None for p in model.parameters()]
+
+
+def _reference_side(model, steps, gamma):
+    """What the reference's training script builds (training_3DMatch.py:62-81), stepped `steps` epochs."""
+    opt = torch.optim.SGD(model.parameters(), lr=0.01, momentum=0.98, weight_decay=1e-6)
+    sch = torch.optim.lr_scheduler.ExponentialLR(opt, gamma=gamma)
+    for s in range(steps):
+        for p, g in zip(model.parameters(), _fake_grads(model, s)):
+            p.grad = g
+        opt.step()
+        sch.step()
+    return opt, sch
+
+
+class _Loader:
+    def __init__(self):
+        self.dataset, self.batch_size, self.shuffle, self.limits = [], 1, False, [5, 5, 5, 5, 5]
+
+
+def _args(tmp, **kw):
+    cfg = cfgmod.default_config(first_features_dim=16)
+    cfg.max_epoch, cfg.save_dir, cfg.tboard_dir, cfg.device, cfg.graph = 2, str(tmp / 'snap'), str(tmp / 'tb'), 'cpu', False
+    cfg.train_loader = _Loader()
+    for k, v in kw.items():
+        setattr(cfg, k, v)
+    return cfg
+
+
+def test_reference_snapshot_loads_and_training_continues_identically(tmp_path):
+    gamma = 0.1 ** (1 / 80)
+    ref_model = _small_model()
+    ref_opt, ref_sch = _reference_side(ref_model, steps=3, gamma=gamma)
+    path = tmp_path / 'model_3.pth'
+    torch.save({'epoch': 3, 'state_dict': ref_model.state_dict(), 'optimizer': ref_opt.state_dict(),
+                'scheduler': ref_sch.state_dict(), 'best_loss': 1.25}, path)
+
+    tr = Trainer(_args(tmp_path, model=_small_model(seed=7), pretrain=str(path)))
+    assert tr.start_epoch == 3 and tr.best_loss == 1.25
+    assert tr._get_lr() == ref_opt.param_groups[0]['lr'] == ref_sch.get_last_lr()[0]
+    for (k, a), b in zip(tr.model.state_dict().items(), ref_model.state_dict().values()):
+        assert torch.equal(a, b), k
+    # parameters are still views of the flat buffer after load_state_dict
+    assert all(p.data_ptr() >= tr.engine.flat.data.data_ptr() for p in tr.engine.flat.params)
+    assert tr.engine.flat.params[0].untyped_storage().data_ptr() == tr.engine.flat.data.untyped_storage().data_ptr()
+
+    # one more epoch on both sides with the same gradients: same parameters, same momentum, same rate
+    grads = _fake_grads(ref_model, 99)
+    for p, g in zip(ref_model.parameters(), grads):
+        p.grad = g
+    ref_opt.step()
+    ref_sch.step()
+    flat = tr.engine.flat
+    off = 0
+    for p, g in zip(tr.model.parameters(), grads):
+        if p.requires_grad:
+            flat.grad[off:off + p.numel()] = g.reshape(-1)
+            off += p.numel()
+    assert bool(tr.optimizer.step())
+    tr.scheduler.step()
+    for (k, a), b in zip(tr.model.state_dict().items(), ref_model.state_dict().values()):
+        assert torch.allclose(a, b, rtol=0, atol=1e-7), k
+    assert tr._get_lr() == ref_opt.param_groups[0]['lr']
+
+    # ... and back: our snapshot loads into the reference's optimizer / scheduler objects
+    out = tr._snapshot(4)
+    state = torch.load(out, weights_only=True)
+    assert set(state) == {'epoch', 'state_dict', 'optimizer', 'scheduler', 'best_loss'}
+    m2 = _small_model(seed=11)
+    m2.load_state_dict(state['state_dict'])
+    o2 = torch.optim.SGD(m2.parameters(), lr=1.0, momentum=0.5)
+    s2 = torch.optim.lr_scheduler.ExponentialLR(o2, gamma=0.5)
+    s2.load_state_dict(state['scheduler'])
+    o2.load_state_dict(state['optimizer'])
+    assert o2.param_groups[0]['lr'] == ref_opt.param_groups[0]['lr'] and o2.param_groups[0]['momentum'] == 0.98
+    assert s2.last_epoch == ref_sch.last_epoch and s2.gamma == gamma
+    for i, p in enumerate(ref_model.parameters()):
+        if p.requires_grad:
+            a = o2.state[list(m2.parameters())[i]]['momentum_buffer']
+            assert torch.allclose(a, ref_opt.state[p]['momentum_buffer'], rtol=0, atol=1e-7)
+    # every saved tensor owns its storage (no 100 MB flat buffer behind a 16-element bias)
+    assert all(v.untyped_storage().nbytes() == v.numel() * v.element_size() for v in state['state_dict'].values())
+
+
+def test_exponential_lr_follows_torch_recursion_bit_for_bit():
+    lin = torch.nn.Linear(3, 2)
+    opt = GuardedSGD(FlatParams(lin), lr=0.01)
+    ours = ExponentialLR(opt, gamma=0.1 ** (1 / 80))
+    t_opt = torch.optim.SGD(torch.nn.Linear(3, 2).parameters(), lr=0.01, momentum=0.98)
+    theirs = torch.optim.lr_scheduler.ExponentialLR(t_opt, gamma=0.1 ** (1 / 80))
+    for _ in range(200):
+        t_opt.step()
+        theirs.step()
+        ours.step()
+        assert ours.get_last_lr() == theirs.get_last_lr()
+    assert float(opt.hyper[0]) == np.float32(ours.get_last_lr()[0])   # what the kernel will read
+    sd = ours.state_dict()
+    assert sd['last_epoch'] == theirs.state_dict()['last_epoch'] and sd['_step_count'] == theirs.state_dict()['_step_count']
+
+
+def test_optimizer_state_rejects_foreign_layouts():
+    lin = torch.nn.Linear(3, 2)
+    opt = GuardedSGD(FlatParams(lin))
+    sd = opt.state_dict()
+    assert set(sd['state']) == {0, 1} and sd['param_groups'][0]['params'] == [0, 1]
+    bad = {'state': {}, 'param_groups': [dict(sd['param_groups'][0], nesterov=True)]}
+    for broken in (bad, {'state': {}, 'param_groups': [dict(sd['param_groups'][0], params=[0])]},
+                   {'state': {0: {'momentum_buffer': torch.zeros(5)}}, 'param_groups': sd['param_groups']}):
+        try:
+            opt.load_state_dict(broken)
+        except ValueError:
+            continue
+        raise AssertionError("accepted %r" % (broken,))
+
+
+def test_scalar_log_and_missing_checkpoint(tmp_path):
+    log = ScalarLog(str(tmp_path / 'tb'))
+    log.add_scalar('val/accuracy', 12.5, 3)
+    rows = [json.loads(l) for l in open(os.path.join(str(tmp_path / 'tb'), 'scalars.jsonl'))]
+    assert rows == [{'tag': 'val/accuracy', 'value': 12.5, 'step': 3}]
+    try:
+        Trainer(_args(tmp_path, model=_small_model(), pretrain=str(tmp_path / 'nope.pth')))
+    except ValueError as e:
+        assert 'no checkpoint' in str(e)
+    else:
+        raise AssertionError
