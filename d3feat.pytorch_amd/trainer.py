@@ -130,7 +130,8 @@ class Trainer(object):
     # ---------------------------------------------------------------------------------------------------------
     def _capacities(self, dataset, samples=8, slack=1.06):
         """Static per-level row capacities for the captured graphs: level sizes of a few pairs, with head-room
-        (the device flags an overflow, D3F_ST_CAPACITY; such a pair is re-run on the eager path)."""
+        (a pair whose level 0 does not fit runs on the eager path; an overflow at a deeper level is flagged by the
+        device, D3F_ST_CAPACITY, and raised at the next check_status -- pass ``graph_capacities`` to size them)."""
         caps = _get(self.config, 'graph_capacities', None)
         if caps is not None:
             return [int(c) for c in caps]
