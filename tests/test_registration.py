@@ -1,0 +1,144 @@
+"""Registration protocol (reference test.py:20-128, geometric_registration/common.py): gt.log format and file naming on
+the CPU; matching + inlier statistics on the GPU against a NumPy restatement of the reference loop."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from d3feat_pytorch_amd import config as cfgmod
+from d3feat_pytorch_amd.geometric_registration import evaluate as ev
+
+# three blocks in the exact layout of the benchmark's gt.log files (leading blanks, trailing tab)
+GT_SAMPLE = (
+    "0\t 1\t 60\t\n"
+    " 9.96926560e-01\t  6.68735757e-02\t -4.06664421e-02\t -1.15576939e-01\t\n"
+    "-6.61289946e-02\t  9.97617877e-01\t  1.94008687e-02\t -3.87705398e-02\t\n"
+    " 4.18675510e-02\t -1.66517807e-02\t  9.98977765e-01\t  1.14874890e-01\t\n"
+    " 0.00000000e+00\t  0.00000000e+00\t  0.00000000e+00\t  1.00000000e+00\t\n"
+    "0\t 2\t 60\t\n"
+    " 9.54999224e-01\t  1.08859481e-01\t -2.75869135e-01\t -3.41060560e-01\t\n"
+    "-9.89491703e-02\t  9.93843326e-01\t  4.96360476e-02\t -1.78254668e-01\t\n"
+    " 2.79581388e-01\t -2.01060700e-02\t  9.59896612e-01\t  3.54627338e-01\t\n"
+    " 0.00000000e+00\t  0.00000000e+00\t  0.00000000e+00\t  1.00000000e+00\t\n")
+
+
+def _rigid(rng):
+    q, _ = np.linalg.qr(rng.normal(size=(3, 3)))
+    if np.linalg.det(q) < 0:
+        q[:, 0] = -q[:, 0]
+    T = np.eye(4)
+    T[:3, :3], T[:3, 3] = q, rng.normal(size=3)
+    return T
+
+
+def test_gt_log_round_trip_and_benchmark_layout(tmp_path):
+    (tmp_path / 'a').mkdir()
+    (tmp_path / 'a' / 'gt.log').write_text(GT_SAMPLE)
+    got = ev.loadlog(str(tmp_path / 'a'))
+    assert sorted(got) == ['0_1', '0_2'] and got['0_1'].shape == (4, 4)
+    assert got['0_1'][0, 3] == -1.15576939e-01 and got['0_2'][2, 0] == 2.79581388e-01 and got['0_2'][3, 3] == 1.0
+    rng = np.random.default_rng(0)
+    trs = {'0_1': _rigid(rng), '0_12': _rigid(rng), '3_4': _rigid(rng)}
+    ev.writelog(str(tmp_path / 'b'), trs, 13)
+    back = ev.loadlog(str(tmp_path / 'b'))
+    assert list(back) == ['0_1', '0_12', '3_4']
+    for k in trs:
+        assert np.allclose(back[k], trs[k], rtol=0, atol=1e-8)
+    (tmp_path / 'c').mkdir()
+    (tmp_path / 'c' / 'gt.log').write_text(GT_SAMPLE + "0\t 3\t 60\t\n")
+    with pytest.raises(ValueError):
+        ev.loadlog(str(tmp_path / 'c'))
+
+
+def _numpy_protocol(kp, desc, score, gt, num_frag, num_points, dthr, rthr):
+    """The reference loop (test.py:32-76, common.py:5-21) in NumPy float32/float64 as written there."""
+    pred = gtm = 0
+    nums, ratios = [], []
+    for i in range(num_frag):
+        for j in range(i + 1, num_frag):
+            if '%d_%d' % (i, j) not in gt:
+                continue
+            si = np.argsort(score[i].squeeze(), kind='stable')[-num_points:]
+            ti = np.argsort(score[j].squeeze(), kind='stable')[-num_points:]
+            sd, td = desc[i][si], desc[j][ti]
+            dist = np.sqrt(np.maximum(2 - 2 * (sd.astype(np.float64) @ td.astype(np.float64).T), 0))
+            a, b = dist.argmin(1), dist.argmin(0)
+            corr = np.array([[r, a[r]] for r in range(len(a)) if b[a[r]] == r]).reshape(-1, 2)
+            T = gt['%d_%d' % (i, j)]
+            f1 = kp[i][si][corr[:, 0]].astype(np.float64)
+            f2 = kp[j][ti][corr[:, 1]].astype(np.float64) @ T[:3, :3].T + T[:3, 3]
+            d = np.sqrt(((f1 - f2) ** 2).sum(1))
+            n_in = int((d < dthr).sum())
+            ratio = n_in / len(d) if len(d) else 0.0
+            pred += ratio > rthr
+            gtm += 1
+            nums.append(n_in)
+            ratios.append(ratio)
+    return pred * 100.0 / gtm, float(np.mean(nums)), float(np.mean(ratios))
+
+
+@pytest.mark.gpu
+def test_register_one_scene_matches_the_reference_protocol(tmp_path):
+    rng = np.random.default_rng(5)
+    world = rng.uniform(0, 2, size=(6000, 3))
+    wdesc = rng.normal(size=(6000, 32))
+    wdesc /= np.linalg.norm(wdesc, axis=1, keepdims=True)
+    wscore = rng.permutation(6000).astype(np.float32) / 6000     # saliency of a world point: distinct values
+    num_frag, scene, save = 4, 'synthetic-room', str(tmp_path / 'dump')
+    poses = [np.eye(4)] + [_rigid(rng) for _ in range(num_frag - 1)]      # fragment frame -> world frame
+    kp, desc, score = [], [], []
+    for f in range(num_frag):
+        ids = rng.permutation(6000)[:3000]
+        inv = np.linalg.inv(poses[f])
+        kp.append((world[ids] @ inv[:3, :3].T + inv[:3, 3] + rng.normal(scale=0.02, size=(3000, 3))).astype(np.float32))
+        d = wdesc[ids] + rng.normal(scale=0.08, size=(3000, 32))
+        desc.append((d / np.linalg.norm(d, axis=1, keepdims=True)).astype(np.float32))
+        score.append(wscore[ids][:, None])                   # fragments agree on what is salient
+    gt = {'%d_%d' % (i, j): np.linalg.inv(poses[i]) @ poses[j] for i in range(num_frag) for j in range(i + 1, num_frag)
+          if (i, j) != (1, 3)}                                                   # one pair is "below 30% overlap"
+    gt['0_2'] = _rigid(rng)                                                      # and one has a useless transform
+    dpath, kpath, spath = ev._paths(save, scene)
+    for p in (dpath, kpath, spath):
+        os.makedirs(p)
+    for f in range(num_frag):
+        np.save(os.path.join(dpath, 'cloud_bin_%d.D3Feat' % f), desc[f])
+        np.save(os.path.join(kpath, 'cloud_bin_%d' % f), kp[f])
+        np.save(os.path.join(spath, 'cloud_bin_%d' % f), score[f])
+    ev.writelog(str(tmp_path / 'gt'), gt, num_frag)
+    gt_read = ev.loadlog(str(tmp_path / 'gt'))
+    for k in (250, 1000):
+        want = _numpy_protocol(kp, desc, score, gt_read, num_frag, k, 0.10, 0.05)
+        got = ev.register_one_scene(0.05, 0.10, save, scene, str(tmp_path / 'gt'), num_points=k)
+        assert got[0] == want[0] == 80.0, (got, want)            # 4 of the 5 listed pairs register
+        assert abs(got[1] - want[1]) <= 1e-9 and abs(got[2] - want[2]) <= 1e-12, (got, want)
+    per_scene, avg = ev.evaluate_scenes(save, {scene: str(tmp_path / 'gt')}, num_points=250)
+    assert per_scene[scene][0] == avg['recall'] == 80.0
+    rnd = ev.register_one_scene(0.05, 0.10, save, scene, str(tmp_path / 'gt'), num_points=500, random_points=True)
+    assert rnd[0] == 80.0 and rnd[1] > 0
+
+
+@pytest.mark.gpu
+def test_generate_features_writes_the_reference_file_layout(golden_s0, tmp_path):
+    from d3feat_pytorch_amd.models.architectures import KPFCNN
+    g = golden_s0
+    cfg = cfgmod.default_config(first_features_dim=16)
+    np.random.seed(0)
+    torch.manual_seed(0)
+    model = KPFCNN(cfg).to('cuda:0')
+    limits = [int(x) for x in g['limits']]
+    frags = [g['pts0'], g['pts1']]
+    ev.generate_features(model, {'room': frags}, str(tmp_path), cfg, limits)
+    assert model.training        # mode restored
+    for i, pts in enumerate(frags):
+        d = ev.get_desc(str(tmp_path / 'descriptors' / 'room'), 'cloud_bin_%d' % i)
+        k = ev.get_keypts(str(tmp_path / 'keypoints' / 'room'), 'cloud_bin_%d' % i)
+        s = ev.get_scores(str(tmp_path / 'scores' / 'room'), 'cloud_bin_%d' % i)
+        n = pts.shape[0]
+        assert d.shape == (n, 32) and k.shape == (n, 3) and s.shape == (n, 1)
+        assert d.dtype == k.dtype == s.dtype == np.float32
+        assert np.array_equal(k, pts.astype(np.float32))
+        assert np.allclose(np.linalg.norm(d, axis=1), 1.0, atol=1e-5) and np.isfinite(s).all() and (s >= 0).all()
+        # same numbers as a direct eval-mode forward of the fragment stacked with itself
+        kk, dd, ss = ev.describe_fragment(model, pts, cfg, limits)
+        assert np.allclose(dd.cpu().numpy(), d, atol=1e-6) and np.allclose(ss.cpu().numpy(), s, atol=1e-6)
