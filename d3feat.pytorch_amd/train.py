@@ -22,6 +22,11 @@ from .models.architectures import KPFCNN
 from .utils.loss import CircleLoss
 
 
+# Other threads of the process (the RCCL watchdog of torch.distributed polls events) must not invalidate a capture
+# that is under way on this thread.
+_CAPTURE_MODE = "thread_local"
+
+
 class FlatParams:
     """All trainable parameters of a module as views into one flat fp32 buffer, plus a flat gradient buffer.
 
@@ -429,12 +434,13 @@ class TrainStep:
         self.check_status()
         # (stream priorities were tried: the range here is {0, -1}; replaying the network graphs on a priority -1 stream
         # made the step 3x slower, so both streams stay at the default priority)
-        self._side = torch.cuda.Stream(device=dev)
+        if getattr(self, '_side', None) is None:
+            self._side = torch.cuda.Stream(device=dev)
         self.g_net, self.g_net_b, self.g_pyr, self._graph_out, self._graph_dist = [], [], [], [], []
         for i in range(self.NSETS):
             # graphs of one kind never run concurrently and replay in capture order: they share a memory pool
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g, pool=self.g_net[0].pool() if self.g_net else None):
+            with torch.cuda.graph(g, pool=self.g_net[0].pool() if self.g_net else None, capture_error_mode=_CAPTURE_MODE):
                 if self.split_backward:
                     self._graph_out.append(self._backward_deep(self._set_batch(self.sets[i])))
                 else:
@@ -443,12 +449,12 @@ class TrainStep:
             self.g_net.append(g)
             if self.split_backward:  # stage 2 of the same step: continues in the same pool
                 g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g, pool=self.g_net[0].pool()):
+                with torch.cuda.graph(g, pool=self.g_net[0].pool(), capture_error_mode=_CAPTURE_MODE):
                     self._backward_shallow()
                 self.g_net_b.append(g)
         for i in range(self.NSETS):
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g, pool=self.g_pyr[0].pool() if self.g_pyr else None):
+            with torch.cuda.graph(g, pool=self.g_pyr[0].pool() if self.g_pyr else None, capture_error_mode=_CAPTURE_MODE):
                 self._build_set(self.sets[i])
             self.g_pyr.append(g)
         torch.cuda.synchronize(dev)

@@ -137,7 +137,7 @@ class Trainer(object):
             return [int(c) for c in caps]
         sizes = []
         for i in range(min(samples, len(dataset))):
-            b = self.engine.build_batch(dataset[i])
+            b = self.engine.build_batch(self._fetch(dataset, i))
             sizes.append([int(t.shape[0]) for t in b['points']])
         return TrainStep.capacities_for(sizes, slack=slack)
 
@@ -146,6 +146,32 @@ class Trainer(object):
         if getattr(loader, 'shuffle', False):
             return np.random.RandomState(_get(self.config, 'seed', 0) * 100003 + epoch).permutation(n)
         return np.arange(n)
+
+    def _fetch(self, dataset, i):
+        """Dataset item -> device tensors in the dtypes the step's static buffers use (host arrays from a dataset such
+        as ThreeDMatchDataset are float64 points / int corr; device tensors pass through)."""
+        item = dataset[int(i)]
+        if all(isinstance(t, torch.Tensor) and t.device == self.device for t in item):
+            return item
+        kinds = (torch.float32, torch.float32, torch.float32, torch.float32, torch.int64, torch.float64)
+        if self.device.type != 'cuda':
+            return tuple(torch.as_tensor(t).to(dtype=k) for t, k in zip(item, kinds))
+        # Upload on a stream of its own and wait for it on the host: the pipelined step reads the NEXT pair on its side
+        # stream, which does not wait for the training stream (TrainStep.step_graph), and a copy queued on the training
+        # stream would sit behind a whole network step.
+        if getattr(self, '_h2d', None) is None:
+            self._h2d = torch.cuda.Stream(device=self.device)
+        with torch.cuda.stream(self._h2d):
+            out = tuple(torch.as_tensor(np.ascontiguousarray(t) if isinstance(t, np.ndarray) else t).to(
+                device=self.device, dtype=k) for t, k in zip(item, kinds))
+        self._h2d.synchronize()
+        if getattr(self.engine, '_side', None) is None:
+            self.engine._side = torch.cuda.Stream(device=self.device)
+        users = [torch.cuda.current_stream(self.device), self.engine._side]
+        for t in out:   # consumed on other streams than the one that allocated them
+            for st in users:
+                t.record_stream(st)
+        return out
 
     def _one_step(self, item, next_item):
         eng = self.engine
@@ -188,9 +214,9 @@ class Trainer(object):
         order = self._order(self.train_loader, epoch)
         num_iter = min(self.training_max_iter, len(ds) // max(1, getattr(self.train_loader, 'batch_size', 1)) // self.world)
         meters = _Meters(self.device)
-        item = ds[int(order[self.rank])] if num_iter else None
+        item = self._fetch(ds, order[self.rank]) if num_iter else None
         for it in range(num_iter):
-            nxt = ds[int(order[(it + 1) * self.world + self.rank])] if it + 1 < num_iter else None
+            nxt = self._fetch(ds, order[(it + 1) * self.world + self.rank]) if it + 1 < num_iter else None
             _, desc, det, acc = self._one_step(item, nxt)
             fp, an = self.engine.last_distances
             meters.update(desc, det, acc, fp.mean(), an.mean())
@@ -220,7 +246,7 @@ class Trainer(object):
         num_iter = min(self.val_max_iter, len(ds) // max(1, getattr(loader, 'batch_size', 1)))
         meters = _Meters(self.device)
         for it in range(self.rank, num_iter, self.world):
-            _, desc, det, acc, d_pos, d_neg = self.engine.evaluate(ds[it])
+            _, desc, det, acc, d_pos, d_neg = self.engine.evaluate(self._fetch(ds, it))
             meters.update(desc, det, acc, d_pos, d_neg)
         if self.world > 1:
             cnt = torch.tensor([float(meters.count)], dtype=torch.float64, device=self.device)

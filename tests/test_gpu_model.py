@@ -398,3 +398,43 @@ def test_trainer_epochs_schedule_under_graph_and_snapshot_resume(golden_s0, tmp_
         worst = max(worst, float((v - final['state_dict'][k].to(DEV)).abs().max()))
     assert worst < 2e-4, worst
     assert 0.0 <= avg['accuracy'] <= 100.0 and avg['d_pos'] > 0 and avg['d_neg'] > 0
+
+
+def test_trainer_consumes_threedmatch_pickles(golden_s0, tmp_path):
+    """Host items of the dataset front-end (float64 points, fresh objects every draw) through the pipelined step."""
+    import pickle
+    import random
+    from d3feat_pytorch_amd.datasets.ThreeDMatch import ThreeDMatchDataset
+    from d3feat_pytorch_amd.train import TrainStep
+    from d3feat_pytorch_amd.trainer import Trainer
+    g = golden_s0
+    with open(tmp_path / '3DMatch_train_0.030_points.pkl', 'wb') as f:
+        pickle.dump({'room/a': g['pts0'].astype(np.float64), 'room/b': g['pts1'].astype(np.float64)}, f)
+    with open(tmp_path / '3DMatch_train_0.030_keypts.pkl', 'wb') as f:
+        pickle.dump({'room/a@room/b': g['sel_corr'].astype(np.int64)}, f)
+    ds = ThreeDMatchDataset(str(tmp_path), split='train', num_node=int(g['sel_corr'].shape[0]), downsample=0.03)
+
+    class _Many:   # one source fragment, visited several times per epoch with fresh augmentation draws
+        def __len__(self):
+            return 5
+
+        def __getitem__(self, i):
+            return ds[0]
+
+    class _Loader:
+        dataset, batch_size, shuffle = _Many(), 1, True
+        limits = [int(x) for x in g['limits']]
+    sizes = [int(g['batch.points.%d' % l].shape[0]) for l in range(5)]
+    cfg = cfgmod.default_config(first_features_dim=16, num_node=int(g['sel_corr'].shape[0]))
+    cfg.max_epoch, cfg.save_dir, cfg.tboard_dir, cfg.device, cfg.graph = 1, None, None, DEV, True
+    cfg.train_loader, cfg.val_max_iter = _Loader(), 1
+    cfg.graph_capacities = TrainStep.capacities_for([sizes], slack=1.3)
+    random.seed(0)
+    np.random.seed(0)
+    tr = Trainer(cfg)
+    before = tr.engine.flat.data.clone()
+    avg = tr.train_epoch(1)
+    res = tr.evaluate(1)
+    assert tr._captured and int(tr.optimizer.skipped) == 0
+    assert all(np.isfinite(v) for v in avg.values()) and all(np.isfinite(v) for v in res.values())
+    assert not torch.equal(before, tr.engine.flat.data)
