@@ -134,10 +134,19 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # Test hook (tests/test_gpu_model.py): D3F_BENCH_SHARE_GPU=1 puts every rank on cuda:0 and exchanges gradients over
+    # gloo, so the N > 1 control flow (broadcast, split backward, bucketed exchange, max-over-ranks timing) can be
+    # exercised on a one-GPU box.  RCCL refuses two ranks on one device; the timing of such a run means nothing.
+    share_gpu = os.environ.get("D3F_BENCH_SHARE_GPU") == "1"
+    if share_gpu:
+        local_rank = 0
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", rank=rank, world_size=world,
-                                device_id=torch.device("cuda", local_rank))
+        if share_gpu:
+            dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group(backend="nccl", rank=rank, world_size=world,
+                                    device_id=torch.device("cuda", local_rank))
     assert world == args.gpus or world == 1, "launch with torch.distributed.run for --gpus > 1"
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
@@ -221,6 +230,14 @@ def main():
     loss_val = float(out[0].item())
     if use_graph:
         ts.check_status()
+    # data-parallel sanity: after the timed steps every rank must hold bit-identical parameters
+    replica_spread = None
+    if world > 1:
+        chk = ts.flat.data.double().abs().sum().reshape(1)
+        hi, lo = chk.clone(), chk.clone()
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+        replica_spread = float((hi - lo).item())
     # Per-operator HIP-event timing (events on the launch stream around every C-ABI call).  Events cannot be recorded
     # inside a replayed graph, so the same steps are run eagerly right after the timed region, same process and data.
     ops.set_profiler(prof)
@@ -349,6 +366,8 @@ def main():
                                    "on-device radius search + grid subsample, SGD step)" % int(np.mean(n_pts)),
                        "points_per_pair": n_pts, "neighbor_limits": limits, "pairs_per_rank": len(items),
                        "parallelism": "dp%d" % world, "final_loss": round(loss_val, 5),
+                       "replica_param_checksum_spread": replica_spread,
+                       "skipped_steps": int(ts.opt.skipped),
                        "library_gemms": "TunableOp table tuned/tunableop_gfx950.csv" if tuned else "library default",
                        "launch": "hipGraph replay: network step on the training stream, next pair's pyramid graph on a side stream "
                                  "(static level capacities %s)" % ts.caps
