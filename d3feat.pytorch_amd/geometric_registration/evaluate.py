@@ -3,9 +3,10 @@
 Same on-disk contract as the reference, so either side can read the other's dumps:
 
 * ``generate_features``   (test.py:79-128): per fragment ``descriptors/<scene>/cloud_bin_<i>.D3Feat.npy`` [N,32] f32,
-  ``keypoints/<scene>/cloud_bin_<i>.npy`` [N,3] f32, ``scores/<scene>/cloud_bin_<i>.npy`` [N,1] f32.  A fragment is
-  pushed through the network stacked with itself (datasets/ThreeDMatch.py:203 returns ``(pts, pts, ...)``) and the
-  first half is kept (test.py:118-120), in eval mode (scores gated by the local-maximum mask).
+  ``keypoints/<scene>/cloud_bin_<i>.npy`` [N,3] f32, ``scores/<scene>/cloud_bin_<i>.npy`` [N,1] f32, eval mode
+  (scores gated by the local-maximum mask).  The reference pushes a fragment through the network stacked with itself
+  (datasets/ThreeDMatch.py:203 returns ``(pts, pts, ...)``) and keeps the first half (test.py:118-120); one copy gives
+  the same rows (see ``describe_fragment``), so that is what runs.
 * ``loadlog`` / ``writelog`` (geometric_registration/common.py:44-58): the ``gt.log`` trajectory format -- a
   ``id1 \\t id2 \\t n`` line followed by the 4x4 transform, tab separated.
 * ``register_one_scene``  (test.py:20-76): for every fragment pair listed in ``gt.log``: top-k keypoints by score (or a
@@ -73,22 +74,33 @@ def get_scores(scorepath, filename, desc_name=DESC_NAME):
 
 # ------------------------------------------------------------------------------------------ descriptor generation
 @torch.no_grad()
-def describe_fragment(model, points, config, neighborhood_limits, device=None):
-    """(keypoints [N,3], descriptors [N,32], scores [N,1]) of one fragment, device tensors (test.py:107-120)."""
+def describe_fragment(model, points, config, neighborhood_limits, device=None, stacked=False):
+    """(keypoints [N,3], descriptors [N,32], scores [N,1]) of one fragment, device tensors (test.py:107-120).
+
+    The reference feeds the fragment stacked with itself and keeps the first half.  Every operator of the network
+    works per cloud (neighbor tables never cross clouds) and the detector's global maximum over two copies equals the
+    maximum over one, so a single copy gives the same rows for half the work; ``stacked=True`` runs the literal
+    two-copy batch (used by the test that checks the equivalence)."""
     dev = torch.device(device) if device is not None else next(model.parameters()).device
     pts = torch.as_tensor(np.ascontiguousarray(points) if isinstance(points, np.ndarray) else points,
                           dtype=torch.float32, device=dev)
-    feat = torch.ones((pts.shape[0], 1), dtype=torch.float32, device=dev)
-    empty = torch.zeros((0, 2), dtype=torch.int64, device=dev)
-    batch = dl.collate_fn_descriptor([(pts, pts, feat, feat, empty, torch.zeros((0, 0), device=dev))], config,
-                                     neighborhood_limits, device=dev)
+    n = int(pts.shape[0])
+    feat = torch.ones((n, 1), dtype=torch.float32, device=dev)
+    if stacked:
+        empty = torch.zeros((0, 2), dtype=torch.int64, device=dev)
+        batch = dl.collate_fn_descriptor([(pts, pts, feat, feat, empty, torch.zeros((0, 0), device=dev))], config,
+                                         neighborhood_limits, device=dev)
+    else:
+        lengths = torch.tensor([n], dtype=torch.int32, device=dev)
+        batch = dl.build_pyramid(pts, lengths, config, neighborhood_limits, exact_width=True)
+        batch.pop('_status')
+        batch['features'] = feat
     was_training = model.training
     model.eval()
     try:
         features, scores = model(batch)
     finally:
         model.train(was_training)
-    n = int(pts.shape[0])
     return batch['points'][0][:n], features[:n], scores[:n]
 
 
