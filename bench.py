@@ -230,6 +230,28 @@ def main():
     loss_val = float(out[0].item())
     if use_graph:
         ts.check_status()
+    # The reference's boundary hands HOST arrays to the step (dataset item -> collate).  Same K steps again with every
+    # pair uploaded from pageable NumPy memory inside the timed region (TrainStep.upload); reported next to `value`,
+    # never as `value`.
+    pcie = None
+    if world == 1:
+        def run_host(k):
+            cur = run_host.cur if run_host.cur is not None else ts.upload(host_items[k % len(host_items)])
+            run_host.cur = ts.upload(host_items[(k + 1) % len(host_items)])
+            return ts.step_graph(cur, run_host.cur) if use_graph else ts.step(cur, next_item=run_host.cur)
+        run_host.cur = None
+        for k in range(2):
+            run_host(k)
+        torch.cuda.synchronize()
+        th0 = time.perf_counter()
+        for k in range(args.steps):
+            run_host(2 + k)
+        torch.cuda.synchronize()
+        th1 = time.perf_counter()
+        pcie = {"value": round(args.steps / (th1 - th0), 3), "unit": "fragment-pairs/s",
+                "ms_per_step": round((th1 - th0) / args.steps * 1e3, 3),
+                "note": "same step, every pair uploaded from pageable host arrays (points, correspondences, keypoint "
+                        "distances: ~0.6 MB) inside the timed region"}
     # data-parallel sanity: after the timed steps every rank must hold bit-identical parameters
     replica_spread = None
     if world > 1:
@@ -372,6 +394,7 @@ def main():
                        "launch": "hipGraph replay: network step on the training stream, next pair's pyramid graph on a side stream "
                                  "(static level capacities %s)" % ts.caps
                                  if use_graph else "eager launches, pyramid on a side stream"},
+            "pcie_inclusive": pcie,
             "roofline": roofline,
             "matching": matching,
             "evaluation": evaluation,

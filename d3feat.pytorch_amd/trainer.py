@@ -148,30 +148,7 @@ class Trainer(object):
         return np.arange(n)
 
     def _fetch(self, dataset, i):
-        """Dataset item -> device tensors in the dtypes the step's static buffers use (host arrays from a dataset such
-        as ThreeDMatchDataset are float64 points / int corr; device tensors pass through)."""
-        item = dataset[int(i)]
-        if all(isinstance(t, torch.Tensor) and t.device == self.device for t in item):
-            return item
-        kinds = (torch.float32, torch.float32, torch.float32, torch.float32, torch.int64, torch.float64)
-        if self.device.type != 'cuda':
-            return tuple(torch.as_tensor(t).to(dtype=k) for t, k in zip(item, kinds))
-        # Upload on a stream of its own and wait for it on the host: the pipelined step reads the NEXT pair on its side
-        # stream, which does not wait for the training stream (TrainStep.step_graph), and a copy queued on the training
-        # stream would sit behind a whole network step.
-        if getattr(self, '_h2d', None) is None:
-            self._h2d = torch.cuda.Stream(device=self.device)
-        with torch.cuda.stream(self._h2d):
-            out = tuple(torch.as_tensor(np.ascontiguousarray(t) if isinstance(t, np.ndarray) else t).to(
-                device=self.device, dtype=k) for t, k in zip(item, kinds))
-        self._h2d.synchronize()
-        if getattr(self.engine, '_side', None) is None:
-            self.engine._side = torch.cuda.Stream(device=self.device)
-        users = [torch.cuda.current_stream(self.device), self.engine._side]
-        for t in out:   # consumed on other streams than the one that allocated them
-            for st in users:
-                t.record_stream(st)
-        return out
+        return self.engine.upload(dataset[int(i)])
 
     def _one_step(self, item, next_item):
         eng = self.engine
