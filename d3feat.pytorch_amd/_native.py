@@ -38,6 +38,8 @@ SIGNATURES = {
                                  _vp, _vp, _vp, _sz, _vp]),
     "d3f_kpconv_grad_input_supported": (_i, [_i, _i, _i, _i]),
     "d3f_kpconv_aggregate": (_i, [_vp, _i, _vp, _i, _vp, _i, _vp, _i, _vp, _i, _f, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "d3f_kpconv_aggregate_modes": (_i, [_vp, _i, _vp, _i, _vp, _i, _vp, _i, _vp, _i, _f, _i, _vp, _vp, _vp]),
+    "d3f_kpconv_grad_input_modes": (_i, [_vp, _i, _vp, _i, _vp, _i, _i, _vp, _i, _f, _i, _vp, _vp, _vp]),
     "d3f_kpconv_grad_input": (_i, [_vp, _i, _vp, _i, _vp, _i, _vp, _i, _vp, _i, _f, _vp, _vp, _i, _vp, _vp, _sz, _vp]),
     "d3f_linear_grad_weight_supported": (_i, [_i, _i, _i]),
     "d3f_linear_fused_supported": (_i, [_i, _i, _i]),

@@ -15,6 +15,33 @@ namespace d3f {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+// Influence of kernel point `kk` (one per lane of a 16-lane group) on a neighbor at squared distance d2, for the
+// modes of blocks.py:327-352.  mode bits 0-1: 0 'linear' max(0, 1 - d/extent), 1 'constant' 1, 2 'gaussian'
+// exp(-d2 / gauss_denom) with gauss_denom = 2 (0.3 extent)^2 + 1e-9 (blocks.py:66-73,341-342); bit 2 ('closest'
+// aggregation, :348-350): only the kernel point nearest to the neighbor keeps its weight (first index on ties).
+__device__ __forceinline__ float influence_weight(float d2, bool klive, int kk, float extent, float gauss_denom,
+                                                  int mode) {
+  float w;
+  switch (mode & 3) {
+    case 1: w = 1.0f; break;
+    case 2: w = expf(-__fdiv_rn(d2, gauss_denom)); break;
+    default: w = fmaxf(0.0f, 1.0f - __fdiv_rn(__fsqrt_rn(d2), extent)); break;
+  }
+  if (!klive) w = 0.0f;
+  if (mode & 4) {
+    float bd = klive ? d2 : __builtin_huge_valf();
+    int bk = kk;
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) {
+      const float od = __shfl_xor(bd, o, 64);
+      const int ok = __shfl_xor(bk, o, 64);
+      if (od < bd || (od == bd && ok < bk)) { bd = od; bk = ok; }
+    }
+    if (kk != bk) w = 0.0f;
+  }
+  return w;
+}
+
 // ------------------------------------------------------------------------------------------------
 // Aggregation: one wave per query, lanes <-> input channels (CPL channels per lane).
 // The influence weight of kernel point k is computed by lane k and broadcast with v_readlane.
@@ -26,7 +53,8 @@ __global__ __launch_bounds__(256) void kpconv_wf_kernel(const float* __restrict_
                                                         const float* __restrict__ x,
                                                         const float* __restrict__ kp, int Nq, int Ns, int H, int Cin,
                                                         int K, float extent, float* __restrict__ wf,
-                                                        float* __restrict__ nn) {
+                                                        float* __restrict__ nn, float gauss_denom = 1.0f,
+                                                        int mode = 0) {
   const int lane = threadIdx.x & 63;
   const int q = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (q >= Nq) return;
@@ -48,7 +76,7 @@ __global__ __launch_bounds__(256) void kpconv_wf_kernel(const float* __restrict_
                 rz = s_pts[3 * (size_t)n + 2] - qz;
     const float dx = rx - kx, dy = ry - ky, dz = rz - kz;
     const float d2 = dx * dx + dy * dy + dz * dz;
-    float w = klive ? fmaxf(0.0f, 1.0f - __fdiv_rn(__fsqrt_rn(d2), extent)) : 0.0f;
+    const float w = influence_weight(d2, klive, kk, extent, gauss_denom, mode);
     float xs[CPL];
     float rs = 0.0f;
 #pragma unroll
@@ -91,7 +119,8 @@ __global__ __launch_bounds__(256) void kpconv_dx_kernel(const float* __restrict_
                                                         const int32_t* __restrict__ idx,
                                                         const float* __restrict__ kp, int Nq, int Ns, int H, int Cin,
                                                         int K, float extent, const float* __restrict__ gW,
-                                                        float* __restrict__ grad_x) {
+                                                        float* __restrict__ grad_x, float gauss_denom = 1.0f,
+                                                        int mode = 0) {
   const int lane = threadIdx.x & 63;
   const int q = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (q >= Nq) return;
@@ -116,7 +145,7 @@ __global__ __launch_bounds__(256) void kpconv_dx_kernel(const float* __restrict_
                 rz = s_pts[3 * (size_t)n + 2] - qz;
     const float dx = rx - kx, dy = ry - ky, dz = rz - kz;
     const float d2 = dx * dx + dy * dy + dz * dz;
-    const float w = klive ? fmaxf(0.0f, 1.0f - __fdiv_rn(__fsqrt_rn(d2), extent)) : 0.0f;
+    const float w = influence_weight(d2, klive, kk, extent, gauss_denom, mode);
     float e[CPL];
 #pragma unroll
     for (int j = 0; j < CPL; ++j) e[j] = 0.0f;
@@ -210,13 +239,20 @@ int launch_gemm(const float* A, long sai, long sak, const float* B, long sbk, lo
   return D3F_OK;
 }
 
+static float gauss_denominator(float extent) {
+  const double sigma = 0.3 * (double)extent;
+  return (float)(2.0 * sigma * sigma + 1e-9);
+}
+
 template <bool NN>
 int launch_wf(const float* q_pts, const float* s_pts, const int32_t* idx, const float* x, const float* kp, int Nq,
-              int Ns, int H, int Cin, int K, float extent, float* wf, float* nn, hipStream_t stream) {
+              int Ns, int H, int Cin, int K, float extent, float* wf, float* nn, hipStream_t stream, int mode = 0) {
   const int grid = cdiv(Nq, 4);
   const int cpl = cdiv(Cin, 64);
-#define D3F_WF(CPL) \
-  kpconv_wf_kernel<CPL, NN><<<grid, 256, 0, stream>>>(q_pts, s_pts, idx, x, kp, Nq, Ns, H, Cin, K, extent, wf, nn)
+  const float gd = gauss_denominator(extent);
+#define D3F_WF(CPL)                                                                                                  \
+  kpconv_wf_kernel<CPL, NN><<<grid, 256, 0, stream>>>(q_pts, s_pts, idx, x, kp, Nq, Ns, H, Cin, K, extent, wf, nn, gd, \
+                                                      mode)
   if (cpl <= 1) D3F_WF(1);
   else if (cpl <= 2) D3F_WF(2);
   else if (cpl <= 4) D3F_WF(4);
@@ -430,6 +466,47 @@ int d3f_kpconv_grad_input(const float* q_pts, int Nq, const float* s_pts, int Ns
   }
   return kpconv_grad_input_from_gw(q_pts, Nq, s_pts, Ns, idx, H, x, Cin, kernel_points, K, extent, gwf, spack_kept,
                                    grad_x_precleared, grad_x, ws, stream);
+}
+
+// ---- non-default influence / aggregation modes (blocks.py:327-352): general path only ---------------------------
+// mode = influence (0 'linear', 1 'constant', 2 'gaussian') | 4 when aggregation_mode == 'closest'.
+static bool mode_ok(int mode) { return mode >= 0 && mode < 8 && (mode & 3) != 3; }
+
+// wf [Nq, K*Cin] = sum_h w_mode[n,h,k] x[idx[n,h], :],  nn [Nq] = max(1, #neighbors with a positive feature sum)
+int d3f_kpconv_aggregate_modes(const float* q_pts, int Nq, const float* s_pts, int Ns, const int32_t* idx, int H,
+                               const float* x, int Cin, const float* kernel_points, int K, float extent, int mode,
+                               float* wf_out, float* nn_out, void* stream_) {
+  if (!q_pts || !s_pts || !idx || !x || !kernel_points || !wf_out || !nn_out || Nq < 0 || Ns < 1 || H < 1 ||
+      Cin < 1 || Cin > 512 || K < 1 || K > 16 || !(extent > 0.0f) || !mode_ok(mode))
+    return D3F_EINVAL;
+  if (Nq == 0) return D3F_OK;
+  return launch_wf<true>(q_pts, s_pts, idx, x, kernel_points, Nq, Ns, H, Cin, K, extent, wf_out, nn_out,
+                         (hipStream_t)stream_, mode);
+}
+
+// grad_x [Ns, Cin] (OVERWRITTEN) = scatter_h sum_k w_mode[n,h,k] gwf[n,k,:]   with gwf = (grad_out/nn) @ W^T
+int d3f_kpconv_grad_input_modes(const float* q_pts, int Nq, const float* s_pts, int Ns, const int32_t* idx, int H,
+                                int Cin, const float* kernel_points, int K, float extent, int mode, const float* gwf,
+                                float* grad_x, void* stream_) {
+  if (!q_pts || !s_pts || !idx || !kernel_points || !gwf || !grad_x || Nq < 0 || Ns < 1 || H < 1 || Cin < 1 ||
+      Cin > 512 || K < 1 || K > 16 || !(extent > 0.0f) || !mode_ok(mode))
+    return D3F_EINVAL;
+  hipStream_t stream = (hipStream_t)stream_;
+  if (d3f::zero_async(grad_x, sizeof(float) * (size_t)Ns * Cin, stream) != hipSuccess) return D3F_ELAUNCH;
+  if (Nq == 0) return D3F_OK;
+  const int grid = cdiv(Nq, 4);
+  const int cpl = cdiv(Cin, 64);
+  const float gd = gauss_denominator(extent);
+#define D3F_DX(CPL)                                                                                                 \
+  kpconv_dx_kernel<CPL><<<grid, 256, 0, stream>>>(q_pts, s_pts, idx, kernel_points, Nq, Ns, H, Cin, K, extent, gwf, \
+                                                  grad_x, gd, mode)
+  if (cpl <= 1) D3F_DX(1);
+  else if (cpl <= 2) D3F_DX(2);
+  else if (cpl <= 4) D3F_DX(4);
+  else D3F_DX(8);
+#undef D3F_DX
+  D3F_LAUNCH_CHECK();
+  return D3F_OK;
 }
 
 }  // extern "C"

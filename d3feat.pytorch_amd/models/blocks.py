@@ -8,8 +8,9 @@ SimpleBlock:544, ResnetBottleneckBlock:601, GlobalAverageBlock:689, NearestUpsam
 runs on top of it unchanged.  The operators themselves are the hand-written HIP kernels of
 ``libd3feat_hip.so`` -- there is no PyTorch implementation of the hot path in this file.
 
-Out of scope here (never enabled by D3Feat's config, config.py:39-46): deformable / modulated KPConv, the
-'constant' / 'gaussian' influences and 'closest' aggregation; they raise NotImplementedError.
+The 'constant' / 'gaussian' influences and the 'closest' aggregation (blocks.py:327-352; never enabled by D3Feat's
+config, config.py:39-41) run on the general-path kernels.  Out of scope: deformable / modulated KPConv
+(config.py:45-46), which raises NotImplementedError.
 """
 import math
 
@@ -89,8 +90,7 @@ class KPConv(nn.Module):
         self.offset_bias = None
         if deformable or modulated and deformable:
             raise NotImplementedError('deformable KPConv is outside the D3Feat hot path (config.py:45-46)')
-        if KP_influence != 'linear' or aggregation_mode != 'sum':
-            raise NotImplementedError("only KP_influence='linear', aggregation_mode='sum' (config.py:39,41)")
+        ops.kpconv_mode(KP_influence, aggregation_mode)   # unknown names raise like the reference (:344,:352)
         if p_dim != 3 or kernel_size > 16:
             raise NotImplementedError('HIP KPConv supports 3-D points and at most 16 kernel points')
         self.weights = Parameter(torch.zeros((self.K, in_channels, out_channels), dtype=torch.float32),
@@ -106,7 +106,8 @@ class KPConv(nn.Module):
         return Parameter(torch.tensor(kp, dtype=torch.float32), requires_grad=False)
 
     def forward(self, q_pts, s_pts, neighb_inds, x):
-        return ops.kpconv(q_pts, s_pts, neighb_inds, x, self.kernel_points, self.weights, self.KP_extent)
+        return ops.kpconv(q_pts, s_pts, neighb_inds, x, self.kernel_points, self.weights, self.KP_extent,
+                          self.KP_influence, self.aggregation_mode)
 
     def __repr__(self):
         return 'KPConv(radius: {:.2f}, extent: {:.2f}, in_feat: {:d}, out_feat: {:d})'.format(
@@ -249,7 +250,8 @@ class SimpleBlock(nn.Module):
         q_pts, s_pts, inds = _layer_inputs(self.block_name, self.layer_ind, batch)
         if not self.use_bn and x.is_cuda:
             return ops.kpconv_bias_act(q_pts, s_pts, inds, x, self.KPConv.kernel_points, self.KPConv.weights,
-                                       self.KPConv.KP_extent, self.batch_norm.bias, slope=0.1)
+                                       self.KPConv.KP_extent, self.batch_norm.bias, slope=0.1,
+                                       influence=self.KPConv.KP_influence, aggregation=self.KPConv.aggregation_mode)
         y = self.KPConv(q_pts, s_pts, inds, x)
         return self.leaky_relu(self.batch_norm(y))
 
@@ -281,7 +283,8 @@ class ResnetBottleneckBlock(nn.Module):
         x = self.unary1(features)
         if not self.use_bn and x.is_cuda:
             x = ops.kpconv_bias_act(q_pts, s_pts, inds, x, self.KPConv.kernel_points, self.KPConv.weights,
-                                    self.KPConv.KP_extent, self.batch_norm_conv.bias, slope=0.1)
+                                    self.KPConv.KP_extent, self.batch_norm_conv.bias, slope=0.1,
+                                    influence=self.KPConv.KP_influence, aggregation=self.KPConv.aggregation_mode)
         else:
             x = self.KPConv(q_pts, s_pts, inds, x)
         shortcut = max_pool(features, inds) if 'strided' in self.block_name else features

@@ -381,9 +381,13 @@ class _KPConvGemmBiasActFn(torch.autograd.Function):
                 (gb.view(-1) if gb is not None else None), None, None)
 
 
-def kpconv_bias_act(q_pts, s_pts, neighb_inds, x, kernel_points, weights, extent, bias, slope=0.1):
+def kpconv_bias_act(q_pts, s_pts, neighb_inds, x, kernel_points, weights, extent, bias, slope=0.1, influence='linear',
+                    aggregation='sum'):
     """LeakyReLU(KPConv(x) + bias): KPConv + the bias/activation that follows it in every block
     (reference blocks.py:594-598, 668-676)."""
+    if kpconv_mode(influence, aggregation) != 0:
+        return bias_act(kpconv(q_pts, s_pts, neighb_inds, x, kernel_points, weights, extent, influence, aggregation),
+                        bias, slope=slope)
     q_pts, s_pts, x = _f32(q_pts, "q_pts"), _f32(s_pts, "s_pts"), _f32(x, "x")
     Nq, H = int(q_pts.shape[0]), int(neighb_inds.shape[1])
     K, Cin = int(weights.shape[0]), int(weights.shape[1])
@@ -399,14 +403,76 @@ def kpconv_bias_act(q_pts, s_pts, neighb_inds, x, kernel_points, weights, extent
     return bias_act(kpconv(q_pts, s_pts, neighb_inds, x, kernel_points, weights, extent), bias, slope=slope)
 
 
-def kpconv(q_pts, s_pts, neighb_inds, x, kernel_points, weights, extent):
-    """Rigid KPConv, 'linear' influence, 'sum' aggregation.  Shapes as KPConv.forward (blocks.py:237)."""
+KP_INFLUENCES = {'linear': 0, 'constant': 1, 'gaussian': 2}
+KP_AGGREGATIONS = {'sum': 0, 'closest': 4}
+
+
+def kpconv_mode(influence='linear', aggregation='sum'):
+    """Mode word of the C ABI; the reference's error messages for unknown names (blocks.py:344,352)."""
+    if influence not in KP_INFLUENCES:
+        raise ValueError('Unknown influence function type (config.KP_influence)')
+    if aggregation not in KP_AGGREGATIONS:
+        raise ValueError("Unknown convolution mode. Should be 'closest' or 'sum'")
+    return KP_INFLUENCES[influence] | KP_AGGREGATIONS[aggregation]
+
+
+class _KPConvModesFn(torch.autograd.Function):
+    """KPConv with a non-default influence / aggregation mode (blocks.py:327-352): mode-aware aggregation and
+    grad-input kernels of the general path, contraction with the kernel weights by library GEMMs."""
+
+    @staticmethod
+    def forward(ctx, q_pts, s_pts, idx, x, kp, weights, extent, mode):
+        L = _native.lib()
+        Nq, Ns, H = int(q_pts.shape[0]), int(s_pts.shape[0]), int(idx.shape[1])
+        K, Cin, Cout = (int(v) for v in weights.shape)
+        wf = torch.empty((Nq, K * Cin), dtype=torch.float32, device=x.device)
+        nn_ = torch.empty((Nq,), dtype=torch.float32, device=x.device)
+        with _region("kpconv_modes_fwd[Nq=%d,Cin=%d,H=%d,mode=%d]" % (Nq, Cin, H, mode), 4 * Nq * H * (4 + Cin)):
+            _native.check(L.d3f_kpconv_aggregate_modes(_p(q_pts), Nq, _p(s_pts), Ns, _p(idx), H, _p(x), Cin, _p(kp), K,
+                                                       extent, mode, _p(wf), _p(nn_), _stream()),
+                          "d3f_kpconv_aggregate_modes")
+        out = torch.mm(wf, weights.reshape(K * Cin, Cout)) / nn_[:, None]
+        ctx.save_for_backward(q_pts, s_pts, idx, kp, weights, wf, nn_)
+        ctx.extent, ctx.mode, ctx.gw_slot = extent, mode, _grad_slot(weights)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        q_pts, s_pts, idx, kp, weights, wf, nn_ = ctx.saved_tensors
+        L = _native.lib()
+        Nq, Ns, H = int(q_pts.shape[0]), int(s_pts.shape[0]), int(idx.shape[1])
+        K, Cin, Cout = (int(v) for v in weights.shape)
+        g = grad_out.contiguous() / nn_[:, None]
+        gx = gw = None
+        if ctx.needs_input_grad[5]:
+            gw = torch.mm(wf.t(), g).reshape(K, Cin, Cout)
+            if ctx.gw_slot is not None:
+                ctx.gw_slot.copy_(gw)
+                gw = _adoptable(ctx.gw_slot)
+        if ctx.needs_input_grad[3]:
+            gwf = torch.mm(g, weights.reshape(K * Cin, Cout).t()).contiguous()
+            gx = torch.empty((Ns, Cin), dtype=torch.float32, device=g.device)
+            with _region("kpconv_modes_dx[Nq=%d,Cin=%d,H=%d,mode=%d]" % (Nq, Cin, H, ctx.mode), 8 * Nq * H * Cin):
+                _native.check(L.d3f_kpconv_grad_input_modes(_p(q_pts), Nq, _p(s_pts), Ns, _p(idx), H, Cin, _p(kp), K,
+                                                            ctx.extent, ctx.mode, _p(gwf), _p(gx), _stream()),
+                              "d3f_kpconv_grad_input_modes")
+        return None, None, None, gx, None, gw, None, None
+
+
+def kpconv(q_pts, s_pts, neighb_inds, x, kernel_points, weights, extent, influence='linear', aggregation='sum'):
+    """Rigid KPConv.  Shapes as KPConv.forward (blocks.py:237); 'linear' / 'sum' (the D3Feat configuration) runs on
+    the fused kernels, the other modes of blocks.py:327-352 on the general path."""
+    mode = kpconv_mode(influence, aggregation)
     q_pts, s_pts, x = _f32(q_pts, "q_pts"), _f32(s_pts, "s_pts"), _f32(x, "x")
     idx = _i32(neighb_inds, "neighb_inds")
     kp, w = _f32(kernel_points, "kernel_points"), _f32(weights, "weights")
     if x.shape[0] != s_pts.shape[0] or x.shape[1] != w.shape[1] or idx.shape[0] != q_pts.shape[0]:
         raise RuntimeError("KPConv: inconsistent shapes q%s s%s idx%s x%s W%s" % (
             tuple(q_pts.shape), tuple(s_pts.shape), tuple(idx.shape), tuple(x.shape), tuple(w.shape)))
+    if mode != 0:
+        if q_pts.shape[0] == 0 or s_pts.shape[0] == 0:
+            return x.new_zeros((q_pts.shape[0], w.shape[2])) + 0.0 * (x.sum() + w.sum())
+        return _KPConvModesFn.apply(q_pts, s_pts, idx, x, kp, w, float(extent), mode)
     return _KPConvFn.apply(q_pts, s_pts, idx, x, kp, w, float(extent))
 
 

@@ -268,6 +268,22 @@ int d3f_mutual_nn(const float* src_desc, int Ns, const float* tgt_desc, int Nt, 
                   int32_t* col_argmin, int32_t* mutual, void* ws, size_t ws_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * KPConv with the non-default influence / aggregation modes -- models/blocks.py:327-352 (KP_influence 'constant' /
+ * 'gaussian', aggregation_mode 'closest'; the D3Feat configuration uses 'linear' / 'sum', config.py:39,41, which the
+ * fused entry points above implement).  mode = influence (0 linear, 1 constant, 2 gaussian) | 4 for 'closest'.
+ * The caller contracts with the kernel weights by plain GEMMs:
+ *   forward : wf = aggregate_modes(...);  out = (wf @ W.view(K*Cin, Cout)) / nn
+ *   backward: gwf = (grad_out / nn) @ W^T;  grad_W = wf^T (grad_out / nn);  grad_x = grad_input_modes(gwf)
+ * wf_out [Nq, K*Cin], nn_out [Nq], gwf [Nq, K*Cin], grad_x [Ns, Cin] (overwritten).  Cin <= 512, K <= 16.
+ * ---------------------------------------------------------------------------------------------- */
+int d3f_kpconv_aggregate_modes(const float* q_pts, int Nq, const float* s_pts, int Ns, const int32_t* idx, int H,
+                               const float* x, int Cin, const float* kernel_points, int K, float extent, int mode,
+                               float* wf_out, float* nn_out, void* stream);
+int d3f_kpconv_grad_input_modes(const float* q_pts, int Nq, const float* s_pts, int Ns, const int32_t* idx, int H,
+                                int Cin, const float* kernel_points, int K, float extent, int mode, const float* gwf,
+                                float* grad_x, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Optimizer step with the reference's non-finite-gradient guard -- replaces trainer.py:104-111 (per-parameter
  * torch.isfinite(...).all() host checks, then optimizer.step()) + torch.optim.SGD(momentum, weight_decay) as
  * configured in training_3DMatch.py:62-76, on flat fp32 buffers of n elements (16-byte aligned):

@@ -12,14 +12,27 @@ import torch.nn.functional as F
 # ---------------------------------------------------------------------------------------------------------------
 # operators
 # ---------------------------------------------------------------------------------------------------------------
-def kpconv(q_pts, s_pts, neighb_inds, x, kernel_points, weights, extent):
-    """models/blocks.py:237-382, rigid / 'linear' / 'sum' path."""
+def kpconv(q_pts, s_pts, neighb_inds, x, kernel_points, weights, extent, influence='linear', aggregation='sum'):
+    """models/blocks.py:237-382, rigid path; influence / aggregation modes of :327-352."""
     idx = neighb_inds.long()
     s_pad = torch.cat([s_pts, torch.full_like(s_pts[:1], 1e6)], 0)          # :277 shadow point
     rel = s_pad[idx] - q_pts[:, None, :]                                     # :280-283  [n,H,3]
     diff = rel[:, :, None, :] - kernel_points[None, None, :, :]              # :293-294  [n,H,K,3]
     sq = (diff ** 2).sum(dim=3)                                              # :297
-    w = torch.clamp(1 - torch.sqrt(sq) / extent, min=0.0).transpose(1, 2)    # :336-337  [n,K,H]
+    if influence == 'constant':
+        w = torch.ones_like(sq).transpose(1, 2)                              # :329-331
+    elif influence == 'linear':
+        w = torch.clamp(1 - torch.sqrt(sq) / extent, min=0.0).transpose(1, 2)    # :336-337  [n,K,H]
+    elif influence == 'gaussian':
+        sigma = extent * 0.3                                                 # :341
+        w = torch.exp(-sq / (2 * sigma ** 2 + 1e-9)).transpose(1, 2)         # :342 -> radius_gaussian :66-73
+    else:
+        raise ValueError('Unknown influence function type (config.KP_influence)')
+    if aggregation == 'closest':
+        nearest = torch.argmin(sq, dim=2)                                    # :349
+        w = w * F.one_hot(nearest, kernel_points.shape[0]).transpose(1, 2)   # :350
+    elif aggregation != 'sum':
+        raise ValueError("Unknown convolution mode. Should be 'closest' or 'sum'")
     x_pad = torch.cat([x, torch.zeros_like(x[:1])], 0)                       # :356
     nx = x_pad[idx]                                                          # :359      [n,H,Cin]
     wf = torch.matmul(w, nx)                                                 # :362      [n,K,Cin]

@@ -491,3 +491,50 @@ def test_mutual_nn(ns, nt):
     assert (dot.max(axis=1) - dot[np.arange(ns), r] < 2e-6).all()
     c = col.cpu().numpy()
     assert (dot.max(axis=0) - dot[c, np.arange(nt)] < 2e-6).all()
+
+
+@pytest.mark.parametrize("influence", ["linear", "constant", "gaussian"])
+@pytest.mark.parametrize("aggregation", ["sum", "closest"])
+def test_kpconv_modes_match_reference_vectors(influence, aggregation):
+    """Influence / aggregation modes of blocks.py:327-352 through the module API, against vectors computed by the real
+    reference (tests/golden/kpconv_modes.npz) and against the oracle on a second, larger random problem."""
+    import os
+    from d3feat_pytorch_amd.models import blocks
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'kpconv_modes.npz'))
+    K, cin, cout = g['weights'].shape
+    conv = blocks.KPConv(K, 3, cin, cout, float(g['extent']), float(g['radius']), KP_influence=influence,
+                         aggregation_mode=aggregation).to(DEV)
+    with torch.no_grad():
+        conv.kernel_points.copy_(torch.from_numpy(g['kernel_points']))
+        conv.weights.copy_(torch.from_numpy(g['weights']))
+    x = torch.from_numpy(g['x']).to(DEV).requires_grad_(True)
+    out = conv(torch.from_numpy(g['q_pts']).to(DEV), torch.from_numpy(g['s_pts']).to(DEV),
+               torch.from_numpy(g['inds']).to(DEV), x)
+    out.backward(torch.from_numpy(g['gout']).to(DEV))
+    tag = '%s.%s.' % (influence, aggregation)
+    for got, key in ((out.detach(), 'out'), (x.grad, 'grad_x'), (conv.weights.grad, 'grad_w')):
+        want = g[tag + key]
+        err = np.abs(got.cpu().numpy() - want).max()
+        assert err <= 1e-4 * max(1.0, np.abs(want).max()), (key, err)      # tolerance: 1e-4 abs/rel fp32
+
+    # wider channels (two channel chunks per lane group), shadow-heavy table, vs the oracle
+    gen = torch.Generator().manual_seed(11)
+    ns, nq, H, ci, co = 900, 700, 33, 80, 24
+    s_pts = torch.rand((ns, 3), generator=gen)
+    q_pts = s_pts[torch.randperm(ns, generator=gen)[:nq]].contiguous()
+    d2 = ((q_pts[:, None] - s_pts[None]) ** 2).sum(-1)
+    dist, order = torch.sort(d2, dim=1)
+    inds = torch.where(dist[:, :H] < 0.2 ** 2, order[:, :H], torch.full_like(order[:, :H], ns))
+    kp = torch.from_numpy(g['kernel_points']) * 0.8
+    w = torch.randn((K, ci, co), generator=gen) * 0.1
+    xx = torch.randn((ns, ci), generator=gen)
+    go = torch.randn((nq, co), generator=gen)
+    a = [t.clone().requires_grad_(True) for t in (xx, w)]
+    ref = ops_ref.kpconv(q_pts, s_pts, inds, a[0], kp, a[1], 0.1, influence, aggregation)
+    ref.backward(go)
+    b = [t.clone().to(DEV).requires_grad_(True) for t in (xx, w)]
+    got = ops.kpconv(q_pts.to(DEV), s_pts.to(DEV), inds.to(DEV), b[0], kp.to(DEV), b[1], 0.1, influence, aggregation)
+    got.backward(go.to(DEV))
+    for name, u, v in (("out", got.detach(), ref.detach()), ("grad_x", b[0].grad, a[0].grad), ("grad_w", b[1].grad, a[1].grad)):
+        err = float((u.cpu() - v).abs().max())
+        assert err <= 1e-4 * max(1.0, float(v.abs().max())), (name, err)

@@ -108,8 +108,13 @@ def test_synthetic_is_deterministic_and_shaped(native):
 def test_unsupported_modes_raise():
     with pytest.raises(NotImplementedError):
         blocks.KPConv(15, 3, 8, 8, 0.06, 0.075, deformable=True)
-    with pytest.raises(NotImplementedError):
-        blocks.KPConv(15, 3, 8, 8, 0.06, 0.075, KP_influence='gaussian')
+    with pytest.raises(ValueError, match='Unknown influence'):
+        blocks.KPConv(15, 3, 8, 8, 0.06, 0.075, KP_influence='cubic')
+    with pytest.raises(ValueError, match='Unknown convolution mode'):
+        blocks.KPConv(15, 3, 8, 8, 0.06, 0.075, aggregation_mode='mean')
+    assert ops.kpconv_mode('gaussian', 'closest') == 6 and ops.kpconv_mode() == 0
+    conv = blocks.KPConv(15, 3, 8, 8, 0.06, 0.075, KP_influence='gaussian', aggregation_mode='closest')
+    assert conv.KP_influence == 'gaussian' and conv.aggregation_mode == 'closest'
     with pytest.raises(ValueError):
         blocks.block_decider('nonsense', 0.1, 8, 8, 0, cfgmod.default_config())
 

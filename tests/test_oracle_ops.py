@@ -1,6 +1,9 @@
 """CPU: the PyTorch-fp32 restatement (oracle/ops_ref.py) against golden vectors produced by the real reference
 (models/blocks.py, models/architectures.py, utils/loss.py, geometric_registration/common.py)."""
+import os
+
 import numpy as np
+import pytest
 import torch
 
 from d3feat_pytorch_amd import config as cfgmod
@@ -103,3 +106,22 @@ def test_collate_on_oracle_equals_reference_collate(golden_s0, native):
         assert_neighbors_equal_tie_aware(p, p, d['neighbors'][l].numpy(), g['batch.neighbors.%d' % l])
         assert d['pools'][l].shape == g['batch.pools.%d' % l].shape
         assert d['upsamples'][l].shape == g['batch.upsamples.%d' % l].shape
+
+
+@pytest.mark.parametrize("influence", ["linear", "constant", "gaussian"])
+@pytest.mark.parametrize("aggregation", ["sum", "closest"])
+def test_kpconv_modes_against_reference_vectors(influence, aggregation):
+    """Oracle restatement of the influence / aggregation modes (blocks.py:327-352) vs vectors from the real reference
+    (tests/golden/make_golden_modes.py)."""
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'kpconv_modes.npz'))
+    x = torch.from_numpy(g['x']).requires_grad_(True)
+    w = torch.from_numpy(g['weights']).requires_grad_(True)
+    out = ops_ref.kpconv(torch.from_numpy(g['q_pts']), torch.from_numpy(g['s_pts']), torch.from_numpy(g['inds']), x,
+                         torch.from_numpy(g['kernel_points']), w, float(g['extent']), influence, aggregation)
+    out.backward(torch.from_numpy(g['gout']))
+    tag = '%s.%s.' % (influence, aggregation)
+    for got, key in ((out.detach(), 'out'), (x.grad, 'grad_x'), (w.grad, 'grad_w')):
+        want = g[tag + key]
+        assert np.abs(got.numpy() - want).max() <= 1e-5 * max(1.0, np.abs(want).max()), key
+    if (influence, aggregation) != ('linear', 'sum'):
+        assert np.abs(g[tag + 'out'] - g['linear.sum.out']).max() > 1e-3    # the modes really differ on this input
