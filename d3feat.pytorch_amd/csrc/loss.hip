@@ -268,13 +268,14 @@ __global__ __launch_bounds__(256) void select_normalize_fwd_kernel(const float* 
                                                                    const int64_t* __restrict__ idx_p, int M,
                                                                    const int32_t* __restrict__ p_offset,
                                                                    float* __restrict__ out_a, float* __restrict__ out_p,
-                                                                   float* __restrict__ sa, float* __restrict__ sp) {
+                                                                   float* __restrict__ sa, float* __restrict__ sp,
+                                                                   int idx_stride) {
   const int lane = threadIdx.x & 63;
   const int m2 = blockIdx.x * 4 + (threadIdx.x >> 6);  // 0..2M-1: anchors then positives
   if (m2 >= 2 * M) return;
   const bool pos = m2 >= M;
   const int m = pos ? m2 - M : m2;
-  long row = pos ? idx_p[m] + (p_offset ? (long)*p_offset : 0) : idx_a[m];
+  long row = pos ? idx_p[(size_t)m * idx_stride] + (p_offset ? (long)*p_offset : 0) : idx_a[(size_t)m * idx_stride];
   row = row < 0 ? 0 : (row >= N ? N - 1 : row);
   float ss = 0.0f;
   for (int c = lane; c < C; c += 64) {
@@ -298,13 +299,13 @@ __global__ __launch_bounds__(256) void select_normalize_bwd_kernel(const float* 
                                                                    const float* __restrict__ g_sa,
                                                                    const float* __restrict__ g_sp,
                                                                    float* __restrict__ grad_x,
-                                                                   float* __restrict__ grad_s) {
+                                                                   float* __restrict__ grad_s, int idx_stride) {
   const int lane = threadIdx.x & 63;
   const int m2 = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (m2 >= 2 * M) return;
   const bool pos = m2 >= M;
   const int m = pos ? m2 - M : m2;
-  long row = pos ? idx_p[m] + (p_offset ? (long)*p_offset : 0) : idx_a[m];
+  long row = pos ? idx_p[(size_t)m * idx_stride] + (p_offset ? (long)*p_offset : 0) : idx_a[(size_t)m * idx_stride];
   row = row < 0 ? 0 : (row >= N ? N - 1 : row);
   const float* g = (pos ? g_p : g_a) + (size_t)m * C;
   float ss = 0.0f, dot = 0.0f;
@@ -381,31 +382,35 @@ int d3f_circle_det_loss_backward(const float* anchor, const float* positive, int
 
 /* Sampled-correspondence front end of the loss -- replaces F.normalize over all N descriptors
  * (models/architectures.py:318) followed by the four index selections of trainer.py:91-94.
- * idx_a / idx_p: int64 [M] row indices (idx_p is offset by *p_offset, a device int32 = points of the first cloud, or
- * NULL).  out_a/out_p [M,C] normalised descriptors, sa/sp [M] scores. */
+ * idx_a / idx_p: int64 row indices, element m at idx[m * idx_stride] (idx_stride = 2: the two columns of the [M,2]
+ * correspondence table read in place); idx_p is offset by *p_offset, a device int32 = points of the first cloud, or
+ * NULL.  out_a/out_p [M,C] normalised descriptors, sa/sp [M] scores. */
 int d3f_select_normalize_forward(const float* x, const float* scores, int N, int C, const int64_t* idx_a,
-                                 const int64_t* idx_p, int M, const int32_t* p_offset, float* out_a, float* out_p,
-                                 float* sa, float* sp, void* stream) {
-  if (!x || !scores || !idx_a || !idx_p || !out_a || !out_p || !sa || !sp || N < 1 || C < 1 || M < 1) return D3F_EINVAL;
+                                 const int64_t* idx_p, int idx_stride, int M, const int32_t* p_offset, float* out_a,
+                                 float* out_p, float* sa, float* sp, void* stream) {
+  if (!x || !scores || !idx_a || !idx_p || !out_a || !out_p || !sa || !sp || N < 1 || C < 1 || M < 1 || idx_stride < 1)
+    return D3F_EINVAL;
   select_normalize_fwd_kernel<<<d3f::cdiv(2 * M, 4), 256, 0, (hipStream_t)stream>>>(x, scores, N, C, idx_a, idx_p, M,
-                                                                                      p_offset, out_a, out_p, sa, sp);
+                                                                                      p_offset, out_a, out_p, sa, sp,
+                                                                                      idx_stride);
   D3F_LAUNCH_CHECK();
   return D3F_OK;
 }
 
 /* grad_x [N,C] and grad_scores [N] must be ONE allocation of N*(C+1) floats starting at grad_x (cleared here with a
  * single fill); g_* may be NULL for outputs that received no gradient. */
-int d3f_select_normalize_backward(const float* x, int N, int C, const int64_t* idx_a, const int64_t* idx_p, int M,
-                                  const int32_t* p_offset, const float* g_a, const float* g_p, const float* g_sa,
-                                  const float* g_sp, float* grad_x, float* grad_scores, void* stream) {
-  if (!x || !idx_a || !idx_p || !grad_x || !grad_scores || N < 1 || C < 1 || M < 1 ||
+int d3f_select_normalize_backward(const float* x, int N, int C, const int64_t* idx_a, const int64_t* idx_p,
+                                  int idx_stride, int M, const int32_t* p_offset, const float* g_a, const float* g_p,
+                                  const float* g_sa, const float* g_sp, float* grad_x, float* grad_scores,
+                                  void* stream) {
+  if (!x || !idx_a || !idx_p || !grad_x || !grad_scores || N < 1 || C < 1 || M < 1 || idx_stride < 1 ||
       grad_scores != grad_x + (size_t)N * C)
     return D3F_EINVAL;
   if (d3f::zero_async(grad_x, sizeof(float) * (size_t)N * (C + 1), (hipStream_t)stream) != hipSuccess)
     return D3F_ELAUNCH;
   select_normalize_bwd_kernel<<<d3f::cdiv(2 * M, 4), 256, 0, (hipStream_t)stream>>>(x, N, C, idx_a, idx_p, M, p_offset,
                                                                                       g_a, g_p, g_sa, g_sp, grad_x,
-                                                                                      grad_scores);
+                                                                                      grad_scores, idx_stride);
   D3F_LAUNCH_CHECK();
   return D3F_OK;
 }

@@ -976,49 +976,150 @@ def circle_det_loss(anchor, positive, dist_keypts, anc_score, pos_score, log_sca
     return _CircleDetFn.apply(anchor, positive, neg_mask, sa, sp, log_scale, safe_radius, pos_margin, neg_margin)
 
 
+def _corr_columns(idx_a, idx_p):
+    """(ptr_a, ptr_p, stride) of the two index vectors.  When they are the two columns of one contiguous [M,2] int64
+    table (``corr[:, 0]``, ``corr[:, 1]``) they are read in place with stride 2; otherwise compacted."""
+    if (idx_a.dtype == torch.int64 and idx_p.dtype == torch.int64 and idx_a.dim() == 1 and idx_p.dim() == 1
+            and idx_a.stride(0) == 2 and idx_p.stride(0) == 2 and idx_p.data_ptr() == idx_a.data_ptr() + 8
+            and idx_a.shape == idx_p.shape):
+        return idx_a, idx_p, 2
+    ia, ip = idx_a.contiguous(), idx_p.contiguous()
+    if ia.dtype != torch.int64 or ip.dtype != torch.int64:
+        ia, ip = ia.long(), ip.long()
+    return ia, ip, 1
+
+
+def _select_normalize_fwd(x, scores, ia, ip, stride, off):
+    N, C, M = int(x.shape[0]), int(x.shape[1]), int(ia.shape[0])
+    dev = x.device
+    oa = torch.empty((M, C), dtype=torch.float32, device=dev)
+    op = torch.empty((M, C), dtype=torch.float32, device=dev)
+    sa = torch.empty(M, dtype=torch.float32, device=dev)
+    sp = torch.empty(M, dtype=torch.float32, device=dev)
+    _native.check(_native.lib().d3f_select_normalize_forward(_p(x), _p(scores), N, C, _p(ia), _p(ip), stride, M,
+                                                             _p(off), _p(oa), _p(op), _p(sa), _p(sp), _stream()),
+                  "d3f_select_normalize_forward")
+    return oa, op, sa, sp
+
+
+def _select_normalize_bwd(x, ia, ip, stride, off, g_a, g_p, g_sa, g_sp):
+    N, C, M = int(x.shape[0]), int(x.shape[1]), int(ia.shape[0])
+    buf = torch.empty(N * (C + 1), dtype=torch.float32, device=x.device)
+    gx, gs = buf[:N * C].view(N, C), buf[N * C:].view(N, 1)
+    cont = [g.contiguous() if g is not None else None for g in (g_a, g_p, g_sa, g_sp)]
+    _native.check(_native.lib().d3f_select_normalize_backward(_p(x), N, C, _p(ia), _p(ip), stride, M, _p(off),
+                                                              _p(cont[0]), _p(cont[1]), _p(cont[2]), _p(cont[3]),
+                                                              _p(gx), _p(gs), _stream()), "d3f_select_normalize_backward")
+    return gx, gs
+
+
 class _SelectNormalizeFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, scores, idx_a, idx_p, p_offset):
-        N, C, M = int(x.shape[0]), int(x.shape[1]), int(idx_a.shape[0])
-        dev = x.device
-        oa = torch.empty((M, C), dtype=torch.float32, device=dev)
-        op = torch.empty((M, C), dtype=torch.float32, device=dev)
-        sa = torch.empty(M, dtype=torch.float32, device=dev)
-        sp = torch.empty(M, dtype=torch.float32, device=dev)
-        _native.check(_native.lib().d3f_select_normalize_forward(_p(x), _p(scores), N, C, _p(idx_a), _p(idx_p), M,
-                                                                 _p(p_offset), _p(oa), _p(op), _p(sa), _p(sp),
-                                                                 _stream()), "d3f_select_normalize_forward")
+    def forward(ctx, x, scores, idx_a, idx_p, p_offset, stride):
         ctx.save_for_backward(x, idx_a, idx_p, p_offset if p_offset is not None else idx_a.new_empty(0))
-        ctx.has_off = p_offset is not None
-        return oa, op, sa, sp
+        ctx.has_off, ctx.stride = p_offset is not None, stride
+        return _select_normalize_fwd(x, scores, idx_a, idx_p, stride, p_offset)
 
     @staticmethod
     def backward(ctx, g_a, g_p, g_sa, g_sp):
         x, idx_a, idx_p, p_off = ctx.saved_tensors
-        N, C, M = int(x.shape[0]), int(x.shape[1]), int(idx_a.shape[0])
-        buf = torch.empty(N * (C + 1), dtype=torch.float32, device=x.device)
-        gx, gs = buf[:N * C].view(N, C), buf[N * C:].view(N, 1)
-        cont = [g.contiguous() if g is not None else None for g in (g_a, g_p, g_sa, g_sp)]
-        _native.check(_native.lib().d3f_select_normalize_backward(_p(x), N, C, _p(idx_a), _p(idx_p), M,
-                                                                  _p(p_off) if ctx.has_off else None, _p(cont[0]),
-                                                                  _p(cont[1]), _p(cont[2]), _p(cont[3]), _p(gx),
-                                                                  _p(gs), _stream()), "d3f_select_normalize_backward")
-        return gx, gs, None, None, None
+        gx, gs = _select_normalize_bwd(x, idx_a, idx_p, ctx.stride, p_off if ctx.has_off else None, g_a, g_p, g_sa, g_sp)
+        return gx, gs, None, None, None, None
+
+
+def _p_offset(p_offset, device):
+    if p_offset is None:
+        return None
+    off = p_offset if isinstance(p_offset, torch.Tensor) else torch.tensor([int(p_offset)], device=device)
+    return off.reshape(-1)[:1].to(torch.int32).contiguous()
 
 
 def select_normalize(x, scores, idx_a, idx_p, p_offset=None):
     """(normalize(x)[idx_a], normalize(x)[idx_p + p_offset], scores[idx_a], scores[idx_p + p_offset]) without
-    normalising or differentiating through the other N - 2M rows.  idx_*: int64 [M]; p_offset: device int32 scalar."""
+    normalising or differentiating through the other N - 2M rows.  idx_*: int64 [M] (the two columns of a [M,2] table
+    are read in place); p_offset: device int32 scalar."""
     x = _f32(x, "x")
     sc = _f32(scores, "scores").reshape(-1, 1)
-    ia, ip = idx_a.contiguous(), idx_p.contiguous()
-    if ia.dtype != torch.int64 or ip.dtype != torch.int64:
-        ia, ip = ia.long(), ip.long()
-    off = None
-    if p_offset is not None:
-        off = p_offset if isinstance(p_offset, torch.Tensor) else torch.tensor([int(p_offset)], device=x.device)
-        off = off.reshape(-1)[:1].to(torch.int32).contiguous()
-    return _SelectNormalizeFn.apply(x, sc, ia, ip, off)
+    ia, ip, stride = _corr_columns(idx_a, idx_p)
+    return _SelectNormalizeFn.apply(x, sc, ia, ip, _p_offset(p_offset, x.device), stride)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# the whole loss of one training step (trainer.py:91-98) as ONE autograd node
+# ---------------------------------------------------------------------------------------------------------------
+class _TrainLossFn(torch.autograd.Function):
+    """x [N,C] raw descriptors, scores [N,1], corr [M,2] -> (total, scalars[6], dists, furthest_positive,
+    average_negative) with total = w_desc * desc + w_det * det.  Same three kernels as select_normalize +
+    circle_det_loss; what disappears is the autograd glue between them (index selects and their zero-filled
+    backward, the weighted sum and its backward: ~12 sub-5-us launches per step)."""
+
+    @staticmethod
+    def forward(ctx, x, scores, corr, p_offset, neg_mask, params, weights, gw):
+        L = _native.lib()
+        ia, ip, stride = _corr_columns(corr[:, 0], corr[:, 1])
+        oa, op, sa, sp = _select_normalize_fwd(x, scores, ia, ip, stride, p_offset)
+        M, C = int(oa.shape[0]), int(oa.shape[1])
+        dev = x.device
+        dists = torch.empty((M, M), dtype=torch.float32, device=dev)
+        fp = torch.empty(M, dtype=torch.float32, device=dev)
+        an = torch.empty(M, dtype=torch.float32, device=dev)
+        scalars = torch.empty(6, dtype=torch.float32, device=dev)
+        stats = torch.empty(L.d3f_circle_det_loss_stats_floats(M), dtype=torch.float32, device=dev)
+        s, sr, pm, nm = params
+        _native.check(L.d3f_circle_det_loss_forward(_p(oa), _p(op), M, C, _p(neg_mask), _p(sa), _p(sp), s, sr, pm, nm,
+                                                    _p(dists), _p(fp), _p(an), _p(scalars), _p(stats), _stream()),
+                      "d3f_circle_det_loss_forward")
+        if weights == (1.0, 1.0):
+            total = scalars[0] + scalars[1]
+        else:
+            total = torch.dot(scalars[:2], gw)
+        ctx.save_for_backward(x, ia, ip, p_offset if p_offset is not None else ia.new_empty(0), neg_mask, oa, op, sa,
+                              sp, dists, stats, gw)
+        ctx.meta = (stride, p_offset is not None, params)
+        ctx.mark_non_differentiable(scalars, dists, fp, an)
+        return total, scalars, dists, fp, an
+
+    @staticmethod
+    def backward(ctx, g_total, g_scalars, g_dists, g_fp, g_an):
+        x, ia, ip, p_off, neg_mask, oa, op, sa, sp, dists, stats, gw = ctx.saved_tensors
+        stride, has_off, (s, sr, pm, nm) = ctx.meta
+        L = _native.lib()
+        M, C = int(oa.shape[0]), int(oa.shape[1])
+        g = (gw * g_total).contiguous()          # d total / d (desc, det), on the device
+        ga, gp = torch.empty_like(oa), torch.empty_like(op)
+        gsa, gsp = torch.empty_like(sa), torch.empty_like(sp)
+        nbytes = L.d3f_circle_det_loss_ws_bytes(M)
+        ws = _ws(nbytes, x.device)
+        _native.check(L.d3f_circle_det_loss_backward(_p(oa), _p(op), M, C, _p(neg_mask), _p(sa), _p(sp), s, sr, pm, nm,
+                                                     _p(dists), _p(stats), g.data_ptr(), g.data_ptr() + 4, _p(ga),
+                                                     _p(gp), _p(gsa), _p(gsp), _p(ws), nbytes, _stream()),
+                      "d3f_circle_det_loss_backward")
+        gx, gs = _select_normalize_bwd(x, ia, ip, stride, p_off if has_off else None, ga, gp, gsa, gsp)
+        return gx, gs, None, None, None, None, None, None
+
+
+def train_loss(x, scores, corr, p_offset, dist_keypts, log_scale=10.0, safe_radius=0.1, pos_margin=0.1, neg_margin=1.4,
+               w_desc=1.0, w_det=1.0, _gw_cache={}):
+    """Loss of one training step on the un-normalised network output (trainer.py:91-98):
+    ``w_desc * CircleLoss(normalize(x)[corr[:,0]], normalize(x)[corr[:,1] + p_offset]) + w_det * DetLoss(...)``.
+    Returns (total, desc, det, accuracy, furthest_positive [M], average_negative [M]); only ``total`` carries
+    gradient."""
+    x = _f32(x, "x")
+    sc = _f32(scores, "scores").reshape(-1, 1)
+    if not (corr.is_cuda and corr.dtype == torch.int64 and corr.dim() == 2 and corr.shape[1] == 2):
+        raise ValueError("corr must be an int64 [M,2] device tensor")
+    corr = corr.contiguous()
+    if not dist_keypts.is_cuda:
+        raise RuntimeError("dist_keypts must be a CUDA/HIP tensor")
+    neg_mask = (dist_keypts > safe_radius).to(torch.uint8).contiguous()  # evaluated in the caller's dtype (f64)
+    key = (x.device, float(w_desc), float(w_det))
+    if key not in _gw_cache:
+        _gw_cache[key] = torch.tensor([float(w_desc), float(w_det)], dtype=torch.float32, device=x.device)
+    total, scalars, dists, fp, an = _TrainLossFn.apply(
+        x, sc, corr, _p_offset(p_offset, x.device), neg_mask,
+        (float(log_scale), float(safe_radius), float(pos_margin), float(neg_margin)), (float(w_desc), float(w_det)),
+        _gw_cache[key])
+    return total, scalars[0], scalars[1], scalars[2], fp, an
 
 
 # ---------------------------------------------------------------------------------------------------------------

@@ -250,16 +250,14 @@ class TrainStep:
     def _loss_from_raw(self, x, scores, batch):
         """Reference trainer.py:91-98 on the un-normalised descriptors: the 2M sampled rows are gathered and
         normalised by one launch (the other rows never enter the loss)."""
-        corr = batch['corr']
         n0 = batch['n0'] if 'n0' in batch else batch['stack_lengths'][0][:1]  # host int, or a device scalar (no sync)
-        ia, ip = corr[:, 0].contiguous(), corr[:, 1].contiguous()
-        fa, fp_, sa, sp = ops.select_normalize(x, scores, ia, ip, n0)
-        desc, acc, fp, an, _, dists = self.circle(fa, fp_, batch['dist_keypts'], sa, sp)
-        det = dists._d3f_det[0][1]
+        c = self.circle
+        loss, desc, det, acc, fp, an = ops.train_loss(x, scores, batch['corr'], n0, batch['dist_keypts'], c.log_scale,
+                                                      c.safe_radius, c.pos_margin, c.neg_margin, self.w_desc, self.w_det)
         # per-row furthest-positive / average-negative distances [M] (trainer.py:99-100 averages them on the host);
         # kept on the device for whoever wants the statistics -- no extra launches in the step itself
-        self.last_distances = (fp._t, an._t)
-        return desc * self.w_desc + det * self.w_det, desc, det, acc
+        self.last_distances = (fp, an)
+        return loss, desc, det, acc
 
     @torch.no_grad()
     def evaluate(self, item):

@@ -245,15 +245,17 @@ int d3f_circle_det_loss_backward(const float* anchor, const float* positive, int
 /* Sampled-correspondence front end of the loss -- replaces F.normalize over all N descriptors
  * (models/architectures.py:318) + the four index selections of trainer.py:91-94 and their backward:
  *   out[m,:] = x[idx[m],:] / max(||x[idx[m],:]||, 1e-12),  s[m] = scores[idx[m]].
- * idx_a / idx_p int64 [M]; idx_p is offset by *p_offset (device int32: rows of the first cloud) when given.
+ * idx_a / idx_p int64, element m at idx[m * idx_stride] (2 = the columns of the [M,2] correspondence table, read in
+ * place); idx_p is offset by *p_offset (device int32: rows of the first cloud) when given.
  * backward: grad_x [N,C] and grad_scores [N] are ONE allocation of N*(C+1) floats (grad_scores == grad_x + N*C),
  * overwritten; g_* may be NULL. */
 int d3f_select_normalize_forward(const float* x, const float* scores, int N, int C, const int64_t* idx_a,
-                                 const int64_t* idx_p, int M, const int32_t* p_offset, float* out_a, float* out_p,
-                                 float* sa, float* sp, void* stream);
-int d3f_select_normalize_backward(const float* x, int N, int C, const int64_t* idx_a, const int64_t* idx_p, int M,
-                                  const int32_t* p_offset, const float* g_a, const float* g_p, const float* g_sa,
-                                  const float* g_sp, float* grad_x, float* grad_scores, void* stream);
+                                 const int64_t* idx_p, int idx_stride, int M, const int32_t* p_offset, float* out_a,
+                                 float* out_p, float* sa, float* sp, void* stream);
+int d3f_select_normalize_backward(const float* x, int N, int C, const int64_t* idx_a, const int64_t* idx_p,
+                                  int idx_stride, int M, const int32_t* p_offset, const float* g_a, const float* g_p,
+                                  const float* g_sa, const float* g_sp, float* grad_x, float* grad_scores,
+                                  void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Dense matching -- replaces build_correspondence (geometric_registration/common.py:5-21): the

@@ -464,3 +464,38 @@ def test_two_rank_bench_control_flow_on_one_gpu():
     assert cfg["parallelism"] == "dp2" and cfg["launch"].startswith("hipGraph replay")
     assert cfg["replica_param_checksum_spread"] == 0.0 and cfg["skipped_steps"] == 0
     assert np.isfinite(cfg["final_loss"]) and "cpu_baseline" not in res
+
+
+@pytest.mark.parametrize("w_desc,w_det", [(1.0, 1.0), (0.7, 1.3)])
+def test_training_step_loss_node_equals_the_module_composition(golden_s0, w_desc, w_det):
+    """TrainStep's single loss node (select + normalise + circle + detector + weighted sum) == the reference's
+    composition normalize -> index -> CircleLoss -> DetLoss -> weighted sum (trainer.py:91-98): values vs the golden
+    losses, gradients vs the module path on the same weights."""
+    from d3feat_pytorch_amd.train import TrainStep
+    g = golden_s0
+    cfg = cfgmod.default_config(first_features_dim=16, desc_loss_weight=w_desc, det_loss_weight=w_det)
+    limits = [int(x) for x in g['limits']]
+    ts = TrainStep(cfg, limits, torch.device(DEV), model=_load_model(cfg, g, full_sd=True))
+    batch = ts.build_batch(_item(g))
+    ts.flat.zero_grad()
+    loss, desc, det, acc = ts.forward_loss(batch)
+    loss.backward()
+    fused = ts.flat.gather_grads().clone()
+    fp, an = ts.last_distances
+    assert abs(float(desc) - float(g['desc_loss'])) < 1e-4 and abs(float(det) - float(g['det_loss'])) < 1e-4
+    assert abs(float(loss) - (w_desc * float(g['desc_loss']) + w_det * float(g['det_loss']))) < 2e-4
+    assert abs(float(acc) - float(g['accuracy'])) < 1e-3
+    assert rel_err(fp.cpu().numpy(), g['furthest_positive']) < 1e-4
+
+    ts.flat.zero_grad()
+    feats, scores = ts.model(batch)
+    corr = batch['corr'].long()
+    n0 = int(batch['stack_lengths'][0][0])
+    circle = CircleLoss(dist_type='euclidean', log_scale=cfg.log_scale, safe_radius=cfg.safe_radius,
+                        pos_margin=cfg.pos_margin, neg_margin=cfg.neg_margin)
+    d2, _, _, _, _, dists = circle(feats[corr[:, 0]], feats[corr[:, 1] + n0], batch['dist_keypts'])
+    t2 = DetLoss('euclidean')(dists, scores[corr[:, 0]], scores[corr[:, 1] + n0])
+    (d2 * w_desc + t2 * w_det).backward()
+    modular = ts.flat.gather_grads()
+    assert float((fused - modular).abs().max()) <= 2e-4 * float(modular.abs().max())
+    assert float(modular.abs().max()) > 0
