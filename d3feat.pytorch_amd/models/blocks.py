@@ -176,12 +176,13 @@ class UnaryBlock(nn.Module):
         if not no_relu:
             self.leaky_relu = nn.LeakyReLU(0.1)
 
-    def forward(self, x, batch=None, residual=None):
+    def forward(self, x, batch=None, residual=None, grad_holder=None, grad_deposit=None):
         if not self.use_bn and x.is_cuda and x.dim() == 2:
             # Linear without its bias; both biases (+ residual) + LeakyReLU go into ONE epilogue launch whose backward
             # also yields the (shared) bias gradient -- no separate add / leaky / column-reduce kernels
             return ops.linear_bias_act(x, self.mlp.weight, self.mlp.bias, residual, self.batch_norm.bias,
-                                       slope=1.0 if (self.no_relu and residual is None) else 0.1)
+                                       slope=1.0 if (self.no_relu and residual is None) else 0.1,
+                                       grad_holder=grad_holder, grad_deposit=grad_deposit)
         x = self.batch_norm(self.mlp(x))
         if residual is not None:
             return self.leaky_relu_res(x + residual)
@@ -280,7 +281,22 @@ class ResnetBottleneckBlock(nn.Module):
 
     def forward(self, features, batch):
         q_pts, s_pts, inds = _layer_inputs(self.block_name, self.layer_ind, batch)
-        x = self.unary1(features)
+        # `features` feeds unary1 and the shortcut: the shortcut branch deposits its gradient, unary1's grad-input GEMM
+        # adds it (ops.GradHolder) -- no separate accumulation launch
+        fuse = (not self.use_bn) and features.is_cuda and isinstance(self.unary1, UnaryBlock) and features.requires_grad
+        holder = ops.GradHolder() if fuse else None
+        x = self.unary1(features, grad_holder=holder) if fuse else self.unary1(features)
+        if fuse:
+            strided = 'strided' in self.block_name
+            shortcut = ops.max_pool(features, inds, grad_deposit=holder) if strided else features
+            if isinstance(self.unary_shortcut, UnaryBlock):
+                shortcut = self.unary_shortcut(shortcut, grad_deposit=None if strided else holder)
+            elif not strided:
+                shortcut = ops.grad_tap(features, holder)
+            x = ops.kpconv_bias_act(q_pts, s_pts, inds, x, self.KPConv.kernel_points, self.KPConv.weights,
+                                    self.KPConv.KP_extent, self.batch_norm_conv.bias, slope=0.1,
+                                    influence=self.KPConv.KP_influence, aggregation=self.KPConv.aggregation_mode)
+            return self.unary2(x, residual=shortcut)
         if not self.use_bn and x.is_cuda:
             x = ops.kpconv_bias_act(q_pts, s_pts, inds, x, self.KPConv.kernel_points, self.KPConv.weights,
                                     self.KPConv.KP_extent, self.batch_norm_conv.bias, slope=0.1,

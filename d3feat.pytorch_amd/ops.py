@@ -477,21 +477,78 @@ def kpconv(q_pts, s_pts, neighb_inds, x, kernel_points, weights, extent, influen
 
 
 # ---------------------------------------------------------------------------------------------------------------
+# Two-branch gradient fusion.  The input of a bottleneck block feeds unary1 AND the shortcut (identity / max_pool /
+# linear, blocks.py:668-686); autograd would produce the two gradients separately and add them (one 5-us launch per
+# block, 13 per step).  The shortcut branch -- always the first to finish in backward, its nodes are younger than
+# unary1's -- DEPOSITS its input gradient in a GradHolder instead of returning it; unary1's grad-input GEMM picks it up
+# as the C operand (beta = 1, in place) and returns the sum.  If the order ever were the other way round the holder is
+# closed and the late branch returns its gradient the ordinary way, so the result is the same either way.
+# ---------------------------------------------------------------------------------------------------------------
+class GradHolder(object):
+    __slots__ = ("tensor", "closed")
+
+    def __init__(self):
+        self.tensor, self.closed = None, False
+
+    def deposit(self, g):
+        """True when `g` was taken (the caller then returns None as its gradient)."""
+        if self.closed or self.tensor is not None or g is None:
+            return False
+        self.tensor = g
+        return True
+
+    def collect(self):
+        self.closed = True
+        g, self.tensor = self.tensor, None
+        return g
+
+
+class _GradTapFn(torch.autograd.Function):
+    """Identity whose backward deposits the gradient (the identity shortcut of a bottleneck block)."""
+
+    @staticmethod
+    def forward(ctx, x, holder):
+        ctx.holder = holder
+        return x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        return (None if ctx.holder.deposit(g) else g), None
+
+
+def grad_tap(x, holder):
+    return _GradTapFn.apply(x, holder) if holder is not None else x
+
+
+def _add_deposited(holder, go, weight):
+    """grad_x = go @ weight (+ the sibling branch's deposited gradient, accumulated by the GEMM itself)."""
+    c = holder.collect() if holder is not None else None
+    if c is None:
+        return torch.mm(go, weight)
+    if c.is_contiguous() and c.dtype == go.dtype and c.shape == (go.shape[0], weight.shape[1]):
+        return c.addmm_(go, weight)      # beta = 1, in place: the deposited buffer has no other reader left
+    return torch.mm(go, weight).add_(c)
+
+
+# ---------------------------------------------------------------------------------------------------------------
 # 1x1 convolution of the unary blocks (models/blocks.py:481-515): library GEMMs for y = x W^T and grad_x, own
 # reduction-parallel kernel for grad_W (tall-skinny: the reduction runs over the points)
 # ---------------------------------------------------------------------------------------------------------------
 class _LinearFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, weight):
+    def forward(ctx, x, weight, holder=None, deposit=None):
         ctx.save_for_backward(x, weight)
         ctx.gw_slot = _grad_slot(weight)
+        ctx.holder, ctx.dep = holder, deposit
         return torch.mm(x, weight.t())
 
     @staticmethod
     def backward(ctx, grad_out):
         x, weight = ctx.saved_tensors
         go = grad_out.contiguous()
-        gx = torch.mm(go, weight) if ctx.needs_input_grad[0] else None
+        gx = _add_deposited(ctx.holder, go, weight) if ctx.needs_input_grad[0] else None
+        if gx is not None and ctx.dep is not None and ctx.dep.deposit(gx):
+            gx = None
         gw = None
         if ctx.needs_input_grad[1]:
             L = _native.lib()
@@ -508,7 +565,7 @@ class _LinearFn(torch.autograd.Function):
                 gw = torch.mm(go.t(), x, out=slot)
             else:
                 gw = torch.mm(go.t(), x)
-        return gx, (_adoptable(gw, ctx.gw_slot) if gw is not None else None)
+        return gx, (_adoptable(gw, ctx.gw_slot) if gw is not None else None), None, None
 
 
 class _LinearBiasActFn(torch.autograd.Function):
@@ -517,8 +574,9 @@ class _LinearBiasActFn(torch.autograd.Function):
     (reduction-parallel kernel)."""
 
     @staticmethod
-    def forward(ctx, x, weight, b1, add, b2, slope):
+    def forward(ctx, x, weight, b1, add, b2, slope, holder=None, deposit=None):
         L = _native.lib()
+        ctx.holder, ctx.dep = holder, deposit
         N, Cin, Cout = int(x.shape[0]), int(x.shape[1]), int(weight.shape[0])
         out = torch.empty((N, Cout), dtype=torch.float32, device=x.device)
         nb = int(b1 is not None and ctx.needs_input_grad[2]) + int(b2 is not None and ctx.needs_input_grad[4])
@@ -568,6 +626,11 @@ class _LinearBiasActFn(torch.autograd.Function):
             with _region("linear_dx[N=%d,Cin=%d,Cout=%d]" % (N, Cin, Cout), 4 * N * (Cin + Cout) + 4 * Cin * Cout):
                 _native.check(L.d3f_linear_grad_input(_p(gm), _p(weight), N, Cin, Cout, _p(gx), _stream()),
                               "d3f_linear_grad_input")
+            c = ctx.holder.collect() if ctx.holder is not None else None
+            if c is not None:
+                gx.add_(c)
+            if ctx.dep is not None and ctx.dep.deposit(gx):
+                gx = None
         if ctx.needs_input_grad[1]:
             slot = ctx.gw_slot
             if L.d3f_linear_grad_weight_supported(N, Cin, Cout):
@@ -580,7 +643,7 @@ class _LinearBiasActFn(torch.autograd.Function):
             else:
                 gw = torch.mm(gm.t(), x, out=slot) if slot is not None else torch.mm(gm.t(), x)
         return (gx, (_adoptable(gw, ctx.gw_slot) if gw is not None else None), g1,
-                gm if ctx.has[1] and ctx.needs_input_grad[3] else None, g2, None)
+                gm if ctx.has[1] and ctx.needs_input_grad[3] else None, g2, None, None, None)
 
 
 class _UpsampleLinearFn(torch.autograd.Function):
@@ -684,8 +747,10 @@ def upsample_linear_bias_act(x_coarse, inds, skip, weight, bias1=None, bias2=Non
 _FUSED_LINEAR_MIN_ROWS = 4096
 
 
-def linear_bias_act(x, weight, bias1=None, add=None, bias2=None, slope=0.1):
-    """act(x @ weight^T + bias1 + add + bias2) -- the whole unary block (reference blocks.py:481-541,686)."""
+def linear_bias_act(x, weight, bias1=None, add=None, bias2=None, slope=0.1, grad_holder=None, grad_deposit=None):
+    """act(x @ weight^T + bias1 + add + bias2) -- the whole unary block (reference blocks.py:481-541,686).
+    grad_holder: the gradient a sibling branch deposited for `x` is added by this op's grad-input GEMM;
+    grad_deposit: this op hands its own grad_x to the sibling instead of returning it (see GradHolder)."""
     x, weight = _f32(x, "x"), _f32(weight, "weight")
     N, Cin, Cout = int(x.shape[0]), int(x.shape[1]), int(weight.shape[0])
     # measured (profiles/unary_gemm_microbench.py): the fused kernel beats library GEMM + epilogue launch for
@@ -694,13 +759,13 @@ def linear_bias_act(x, weight, bias1=None, add=None, bias2=None, slope=0.1):
         b1 = _f32(bias1, "bias1") if bias1 is not None else None
         b2 = _f32(bias2, "bias2") if bias2 is not None else None
         a = _f32(add, "add") if add is not None else None
-        return _LinearBiasActFn.apply(x, weight, b1, a, b2, float(slope))
-    return bias_act(linear_nobias(x, weight), bias1, add, bias2, slope=slope)
+        return _LinearBiasActFn.apply(x, weight, b1, a, b2, float(slope), grad_holder, grad_deposit)
+    return bias_act(linear_nobias(x, weight, grad_holder, grad_deposit), bias1, add, bias2, slope=slope)
 
 
-def linear_nobias(x, weight):
+def linear_nobias(x, weight, grad_holder=None, grad_deposit=None):
     """x [N, Cin] @ weight[Cout, Cin]^T on the device (fp32)."""
-    return _LinearFn.apply(_f32(x, "x"), _f32(weight, "weight"))
+    return _LinearFn.apply(_f32(x, "x"), _f32(weight, "weight"), grad_holder, grad_deposit)
 
 
 # ---------------------------------------------------------------------------------------------------------------
@@ -708,7 +773,8 @@ def linear_nobias(x, weight):
 # ---------------------------------------------------------------------------------------------------------------
 class _MaxPoolFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, idx):
+    def forward(ctx, x, idx, deposit=None):
+        ctx.dep = deposit
         Ns, C = int(x.shape[0]), int(x.shape[1])
         Nq, H = int(idx.shape[0]), int(idx.shape[1])
         out = torch.empty((Nq, C), dtype=torch.float32, device=x.device)
@@ -733,11 +799,13 @@ class _MaxPoolFn(torch.autograd.Function):
             gx = torch.empty((Ns, C), dtype=torch.float32, device=go.device)
         _native.check(_native.lib().d3f_max_pool_backward(_p(go), _p(arg), int(arg.shape[0]), C, Ns, _p(gx), pre,
                                                           _stream()), "d3f_max_pool_backward")
-        return gx, None
+        if ctx.dep is not None and ctx.dep.deposit(gx):
+            gx = None
+        return gx, None, None
 
 
-def max_pool(x, inds):
-    return _MaxPoolFn.apply(_f32(x, "x"), _i32(inds, "inds"))
+def max_pool(x, inds, grad_deposit=None):
+    return _MaxPoolFn.apply(_f32(x, "x"), _i32(inds, "inds"), grad_deposit)
 
 
 class _ClosestPoolFn(torch.autograd.Function):

@@ -33,7 +33,8 @@ ts._build_set(st)
 for _ in range(2):
     ts._net_step(st)
 torch.cuda.synchronize()
-with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA]) as prof:
+STACKS = "--stacks" in sys.argv
+with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=STACKS) as prof:
     ts._net_step(st)
     torch.cuda.synchronize()
 rows = [(e.key, e.count, e.device_time_total if hasattr(e, "device_time_total") else e.cuda_time_total)
@@ -44,3 +45,17 @@ print("%-40s %6s %12s" % ("op", "calls", "device_us"))
 for k, c, t in rows[:40]:
     print("%-40s %6d %12.1f" % (k, c, t))
 print("total aten device time: %.1f us in %d op calls" % (sum(r[2] for r in rows), sum(r[1] for r in rows)))
+
+if STACKS:   # where do the small ATen launches come from?  (frames inside this repository only)
+    want = ("aten::add_", "aten::add", "aten::copy_", "aten::fill_", "aten::zero_", "aten::zeros", "aten::clone",
+            "aten::mul", "aten::select_backward", "aten::gt", "aten::_to_copy")
+    seen = {}
+    for e in prof.key_averages(group_by_stack_n=12):
+        dt = e.device_time_total if hasattr(e, "device_time_total") else e.cuda_time_total
+        if e.key in want and dt > 0:
+            frames = [f for f in e.stack if "d3feat" in f or "train.py" in f]
+            where = " <- ".join(f.split("/")[-1].strip() for f in frames[:3]) or "(autograd engine)"
+            k = (e.key, where)
+            seen[k] = (seen.get(k, (0, 0))[0] + e.count, seen.get(k, (0, 0))[1] + dt)
+    for (k, where), (c, t) in sorted(seen.items(), key=lambda kv: -kv[1][1]):
+        print("%-22s %3d %8.1f us  %s" % (k, c, t, where))
