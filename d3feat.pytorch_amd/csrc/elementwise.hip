@@ -21,9 +21,9 @@ __global__ __launch_bounds__(256) void bias_act_fwd_kernel(const float* __restri
                                                            const int32_t* __restrict__ add_idx, int idx_stride,
                                                            int add_rows) {
   // C % 4 == 0: one float4 per thread, columns of a float4 are c .. c+3
-  if (zinit && blockIdx.x == 0)
-    for (int t = threadIdx.x; t < zn; t += blockDim.x) zinit[t] = 0.0f;
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (zinit)  // side job: clear the caller's backward targets (a few bias rows up to a pooled-gradient matrix)
+    for (size_t t = i; t < (size_t)zn; t += (size_t)gridDim.x * blockDim.x) zinit[t] = 0.0f;
   if (i >= n4) return;
   const int c = (int)((i * 4) % (size_t)C);
   float4 v = ((const float4*)x)[i];
@@ -57,9 +57,9 @@ __global__ __launch_bounds__(256) void bias_act_fwd_scalar_kernel(const float* _
                                                                   const float* __restrict__ row_div,
                                                                   const int32_t* __restrict__ add_idx,
                                                                   int idx_stride, int add_rows) {
-  if (zinit && blockIdx.x == 0)
-    for (int t = threadIdx.x; t < zn; t += blockDim.x) zinit[t] = 0.0f;
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (zinit)
+    for (size_t t = i; t < (size_t)zn; t += (size_t)gridDim.x * blockDim.x) zinit[t] = 0.0f;
   if (i >= n) return;
   const int c = (int)(i % (size_t)C);
   float v = x[i];

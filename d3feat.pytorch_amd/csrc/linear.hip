@@ -285,10 +285,13 @@ int d3f_linear_bias_act_forward(const float* x, const float* weight, int N, int 
                                          (hipStream_t)stream);
 }
 
-/* grad_x [N,Cin] = grad_out [N,Cout] @ weight [Cout,Cin] */
-int d3f_linear_grad_input(const float* grad_out, const float* weight, int N, int Cin, int Cout, float* grad_x,
-                          void* stream) {
+/* grad_x [N,Cin] = grad_out [N,Cout] @ weight [Cout,Cin] (+ add [N,Cin], optional) */
+int d3f_linear_grad_input(const float* grad_out, const float* weight, int N, int Cin, int Cout, const float* add,
+                          float* grad_x, void* stream) {
   if (!grad_out || !weight || !grad_x || !d3f::rowgemm_supported(N, Cout, Cin)) return D3F_EINVAL;
+  if (add)  // epilogue with no bias and slope 1: acc + add
+    return d3f::rowgemm_launch<false, true>(grad_out, weight, N, Cout, Cin, nullptr, add, nullptr, 1.0f, grad_x,
+                                            nullptr, 0, (hipStream_t)stream);
   return d3f::rowgemm_launch<false, false>(grad_out, weight, N, Cout, Cin, nullptr, nullptr, nullptr, 1.0f, grad_x,
                                            nullptr, 0, (hipStream_t)stream);
 }

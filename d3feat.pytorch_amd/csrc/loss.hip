@@ -184,7 +184,7 @@ __global__ __launch_bounds__(kThreads) void loss_fwd_kernel(
     scalars[2] = ac * 100.0f / (float)M;
     scalars[3] = fps / (float)M;
     scalars[4] = ans / (float)M;
-    scalars[5] = 0.0f;
+    scalars[5] = l / (float)M + dt / (float)M;  // desc + det: the step's loss with unit weights (trainer.py:98)
   }
 }
 

@@ -12,7 +12,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from .. import ops
-from .blocks import KPConv, NearestUpsampleBlock, UnaryBlock, block_decider  # noqa: F401
+from .blocks import KPConv, NearestUpsampleBlock, ResnetBottleneckBlock, UnaryBlock, block_decider  # noqa: F401
 
 
 def _moves_level(block):
@@ -69,14 +69,24 @@ class KPFCNN(nn.Module):
     def forward_raw(self, batch):
         """(un-normalised descriptors [N,C], scores [N,1]) -- `forward` without the final F.normalize, for callers
         that only need a few normalised rows (the training step: ops.select_normalize)."""
-        x = batch['features'].clone().detach()
+        x = batch['features'].detach()   # (the reference clones, architectures.py:301; nothing writes into it here)
         skips = []
         for i, op in enumerate(self.encoder_blocks):
             if i in self.encoder_skips:
-                skips.append(x)
+                skips.append(self.mark_skip(x, op))
             x = op(x, batch)
         x = self._decode(x, skips, batch)
         return x, self.detection_scores(batch, x)
+
+    @staticmethod
+    def mark_skip(x, op):
+        """A skip tensor is consumed by the decoder (first in backward) and by the strided block `op` that follows it:
+        the decoder deposits its gradient, the block's pooling backward accumulates on top of it (ops.GradHolder)
+        instead of autograd adding the two."""
+        if x.is_cuda and x.requires_grad and isinstance(op, ResnetBottleneckBlock) and 'strided' in op.block_name \
+                and not op.use_bn:
+            x._d3f_grad_in = ops.GradHolder()
+        return x
 
     def _decode(self, x, skips, batch):
         """Decoder blocks with the skip concatenations of the reference (architectures.py:309-314)."""
@@ -89,8 +99,10 @@ class KPFCNN(nn.Module):
                     if isinstance(op, UnaryBlock) and not op.use_bn and (x.shape[1] * 4) % 16 == 0:
                         # unary block right after upsample + concat: the upsampled half of the product is computed
                         # on the coarse rows and upsampled in the epilogue (ops.upsample_linear_bias_act)
-                        x = ops.upsample_linear_bias_act(x, inds, skips.pop(), op.mlp.weight, op.mlp.bias,
-                                                         op.batch_norm.bias, slope=1.0 if op.no_relu else 0.1)
+                        skip = skips.pop()
+                        x = ops.upsample_linear_bias_act(x, inds, skip, op.mlp.weight, op.mlp.bias,
+                                                         op.batch_norm.bias, slope=1.0 if op.no_relu else 0.1,
+                                                         skip_grad_deposit=getattr(skip, '_d3f_grad_in', None))
                         continue
                     x = ops.closest_pool(x, inds, skip=skips.pop())
                 else:

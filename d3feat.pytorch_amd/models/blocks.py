@@ -288,7 +288,9 @@ class ResnetBottleneckBlock(nn.Module):
         x = self.unary1(features, grad_holder=holder) if fuse else self.unary1(features)
         if fuse:
             strided = 'strided' in self.block_name
-            shortcut = ops.max_pool(features, inds, grad_deposit=holder) if strided else features
+            # a skip tensor also feeds the decoder, whose gradient arrives first: the pooling backward scatters on top
+            incoming = getattr(features, '_d3f_grad_in', None) if strided else None
+            shortcut = ops.max_pool(features, inds, grad_deposit=holder, grad_incoming=incoming) if strided else features
             if isinstance(self.unary_shortcut, UnaryBlock):
                 shortcut = self.unary_shortcut(shortcut, grad_deposit=None if strided else holder)
             elif not strided:

@@ -623,12 +623,12 @@ class _LinearBiasActFn(torch.autograd.Function):
         gx = gw = None
         if ctx.needs_input_grad[0]:
             gx = torch.empty_like(x)
-            with _region("linear_dx[N=%d,Cin=%d,Cout=%d]" % (N, Cin, Cout), 4 * N * (Cin + Cout) + 4 * Cin * Cout):
-                _native.check(L.d3f_linear_grad_input(_p(gm), _p(weight), N, Cin, Cout, _p(gx), _stream()),
-                              "d3f_linear_grad_input")
             c = ctx.holder.collect() if ctx.holder is not None else None
-            if c is not None:
-                gx.add_(c)
+            if c is not None and not (c.is_contiguous() and c.shape == gx.shape and c.dtype == gx.dtype):
+                c = c.contiguous().float().reshape(gx.shape)
+            with _region("linear_dx[N=%d,Cin=%d,Cout=%d]" % (N, Cin, Cout), 4 * N * (Cin + Cout) + 4 * Cin * Cout):
+                _native.check(L.d3f_linear_grad_input(_p(gm), _p(weight), N, Cin, Cout, _p(c), _p(gx), _stream()),
+                              "d3f_linear_grad_input")
             if ctx.dep is not None and ctx.dep.deposit(gx):
                 gx = None
         if ctx.needs_input_grad[1]:
@@ -654,8 +654,9 @@ class _UpsampleLinearFn(torch.autograd.Function):
     backward pools the masked gradient back to the coarse rows before the two GEMMs that involve W1."""
 
     @staticmethod
-    def forward(ctx, xc, idx, skip, weight, b1, b2, slope):
+    def forward(ctx, xc, idx, skip, weight, b1, b2, slope, skip_deposit=None):
         L = _native.lib()
+        ctx.skip_dep = skip_deposit
         Nc, Cc = int(xc.shape[0]), int(xc.shape[1])
         N, Cs = int(skip.shape[0]), int(skip.shape[1])
         Cout, H = int(weight.shape[0]), int(idx.shape[1])
@@ -664,11 +665,12 @@ class _UpsampleLinearFn(torch.autograd.Function):
         y = torch.mm(skip, w2.t())                    # [N, Cout]
         out = torch.empty_like(y)
         nb = int(b1 is not None and ctx.needs_input_grad[4]) + int(b2 is not None and ctx.needs_input_grad[5])
-        gbuf = torch.empty((nb, Cout), dtype=torch.float32, device=xc.device) if nb else None
-        gt_buf = torch.empty((Nc, Cout), dtype=torch.float32, device=xc.device)  # pooled gradient, cleared below
-        _native.check(L.d3f_bias_act_forward(_p(y), _p(b1), _p(t), _p(b2), float(slope), N, Cout, _p(out), _p(gbuf),
-                                             nb * Cout, None, _p(idx), H, Nc, _stream()), "d3f_bias_act_forward")
-        gt_buf.zero_()
+        # backward targets, cleared by the forward launch on the side: bias-gradient rows + the pooled gradient [Nc, Cout]
+        zbuf = torch.empty((nb + Nc) * Cout, dtype=torch.float32, device=xc.device)
+        gbuf = zbuf[:nb * Cout].view(nb, Cout) if nb else None
+        gt_buf = zbuf[nb * Cout:].view(Nc, Cout)
+        _native.check(L.d3f_bias_act_forward(_p(y), _p(b1), _p(t), _p(b2), float(slope), N, Cout, _p(out), _p(zbuf),
+                                             int(zbuf.numel()), None, _p(idx), H, Nc, _stream()), "d3f_bias_act_forward")
         ctx.save_for_backward(xc, idx, skip, weight, out)
         ctx.gbuf, ctx.gt_buf, ctx.slope = gbuf, gt_buf, float(slope)
         ctx.has = (b1 is not None, b2 is not None)
@@ -711,25 +713,27 @@ class _UpsampleLinearFn(torch.autograd.Function):
         w1, w2 = weight[:, :Cc], weight[:, Cc:]
         gxc = torch.mm(gt, w1) if ctx.needs_input_grad[0] else None
         gskip = torch.mm(gm, w2) if ctx.needs_input_grad[2] else None
+        if gskip is not None and ctx.skip_dep is not None and ctx.skip_dep.deposit(gskip):
+            gskip = None    # handed to the encoder block that consumes the same skip tensor (GradHolder)
         gw = None
         if ctx.needs_input_grad[3]:
             slot = ctx.gw_slot
             gw = slot if slot is not None else torch.empty_like(weight)
-            gw[:, :Cc].copy_(torch.mm(gt.t(), xc))
+            torch.mm(gt.t(), xc, out=gw[:, :Cc])      # the GEMMs write their column block of W's gradient in place
             if N >= _SPLITK_MIN_ROWS and L.d3f_linear_grad_weight_supported(N, Cs, Cout):
                 tmp = torch.empty((Cout, Cs), dtype=torch.float32, device=go.device)
                 nbytes = L.d3f_linear_grad_weight_ws_bytes(N, Cs, Cout)
                 ws = _ws(nbytes, go.device)
                 _native.check(L.d3f_linear_grad_weight(_p(skip), _p(gm), N, Cs, Cout, _p(tmp), _p(ws), nbytes,
                                                        _stream()), "d3f_linear_grad_weight")
+                gw[:, Cc:].copy_(tmp)
             else:
-                tmp = torch.mm(gm.t(), skip)
-            gw[:, Cc:].copy_(tmp)
+                torch.mm(gm.t(), skip, out=gw[:, Cc:])
             gw = _adoptable(gw, slot)
-        return gxc, None, gskip, gw, g1, g2, None
+        return gxc, None, gskip, gw, g1, g2, None, None
 
 
-def upsample_linear_bias_act(x_coarse, inds, skip, weight, bias1=None, bias2=None, slope=0.1):
+def upsample_linear_bias_act(x_coarse, inds, skip, weight, bias1=None, bias2=None, slope=0.1, skip_grad_deposit=None):
     """act([x_coarse[inds[:,0]] | skip] @ weight^T + bias1 + bias2) without forming the upsampled matrix."""
     xc, sk, w = _f32(x_coarse, "x_coarse"), _f32(skip, "skip"), _f32(weight, "weight")
     idx = _i32(inds, "inds")
@@ -740,7 +744,7 @@ def upsample_linear_bias_act(x_coarse, inds, skip, weight, bias1=None, bias2=Non
             tuple(xc.shape), tuple(sk.shape), tuple(w.shape), tuple(idx.shape)))
     b1 = _f32(bias1, "bias1") if bias1 is not None else None
     b2 = _f32(bias2, "bias2") if bias2 is not None else None
-    return _UpsampleLinearFn.apply(xc, idx, sk, w, b1, b2, float(slope))
+    return _UpsampleLinearFn.apply(xc, idx, sk, w, b1, b2, float(slope), skip_grad_deposit)
 
 
 # rows from which the unary blocks use the fused row-streaming kernels instead of library GEMM + epilogue launch
@@ -773,8 +777,8 @@ def linear_nobias(x, weight, grad_holder=None, grad_deposit=None):
 # ---------------------------------------------------------------------------------------------------------------
 class _MaxPoolFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, idx, deposit=None):
-        ctx.dep = deposit
+    def forward(ctx, x, idx, deposit=None, incoming=None):
+        ctx.dep, ctx.incoming = deposit, incoming
         Ns, C = int(x.shape[0]), int(x.shape[1])
         Nq, H = int(idx.shape[0]), int(idx.shape[1])
         out = torch.empty((Nq, C), dtype=torch.float32, device=x.device)
@@ -795,17 +799,23 @@ class _MaxPoolFn(torch.autograd.Function):
         go = grad_out.contiguous().float()
         gx, ctx.gx_buf = ctx.gx_buf, None
         pre = 1 if gx is not None else 0
+        # a gradient an older consumer of x already produced (the decoder, for a skip tensor): scatter on top of it
+        c = ctx.incoming.collect() if ctx.incoming is not None else None
+        if c is not None and c.is_contiguous() and c.dtype == torch.float32 and tuple(c.shape) == (Ns, C):
+            gx, pre, c = c, 1, None
         if gx is None:
             gx = torch.empty((Ns, C), dtype=torch.float32, device=go.device)
         _native.check(_native.lib().d3f_max_pool_backward(_p(go), _p(arg), int(arg.shape[0]), C, Ns, _p(gx), pre,
                                                           _stream()), "d3f_max_pool_backward")
+        if c is not None:
+            gx.add_(c)
         if ctx.dep is not None and ctx.dep.deposit(gx):
             gx = None
-        return gx, None, None
+        return gx, None, None, None
 
 
-def max_pool(x, inds, grad_deposit=None):
-    return _MaxPoolFn.apply(_f32(x, "x"), _i32(inds, "inds"), grad_deposit)
+def max_pool(x, inds, grad_deposit=None, grad_incoming=None):
+    return _MaxPoolFn.apply(_f32(x, "x"), _i32(inds, "inds"), grad_deposit, grad_incoming)
 
 
 class _ClosestPoolFn(torch.autograd.Function):
@@ -1137,29 +1147,32 @@ class _TrainLossFn(torch.autograd.Function):
         _native.check(L.d3f_circle_det_loss_forward(_p(oa), _p(op), M, C, _p(neg_mask), _p(sa), _p(sp), s, sr, pm, nm,
                                                     _p(dists), _p(fp), _p(an), _p(scalars), _p(stats), _stream()),
                       "d3f_circle_det_loss_forward")
-        if weights == (1.0, 1.0):
-            total = scalars[0] + scalars[1]
-        else:
-            total = torch.dot(scalars[:2], gw)
+        # unit weights (config.py:58-59): the kernel's own desc + det (scalars[5]); no launch for the sum
+        total = scalars[5] if weights == (1.0, 1.0) else torch.dot(scalars[:2], gw)
         ctx.save_for_backward(x, ia, ip, p_offset if p_offset is not None else ia.new_empty(0), neg_mask, oa, op, sa,
                               sp, dists, stats, gw)
-        ctx.meta = (stride, p_offset is not None, params)
+        ctx.meta = (stride, p_offset is not None, params, weights == (1.0, 1.0))
         ctx.mark_non_differentiable(scalars, dists, fp, an)
         return total, scalars, dists, fp, an
 
     @staticmethod
     def backward(ctx, g_total, g_scalars, g_dists, g_fp, g_an):
         x, ia, ip, p_off, neg_mask, oa, op, sa, sp, dists, stats, gw = ctx.saved_tensors
-        stride, has_off, (s, sr, pm, nm) = ctx.meta
+        stride, has_off, (s, sr, pm, nm), unit = ctx.meta
         L = _native.lib()
         M, C = int(oa.shape[0]), int(oa.shape[1])
-        g = (gw * g_total).contiguous()          # d total / d (desc, det), on the device
+        if unit:   # d total / d desc = d total / d det = g_total: both pointers read the same scalar
+            g = g_total.contiguous().float().reshape(1)
+            p_desc = p_det = g.data_ptr()
+        else:
+            g = (gw * g_total).contiguous()
+            p_desc, p_det = g.data_ptr(), g.data_ptr() + 4
         ga, gp = torch.empty_like(oa), torch.empty_like(op)
         gsa, gsp = torch.empty_like(sa), torch.empty_like(sp)
         nbytes = L.d3f_circle_det_loss_ws_bytes(M)
         ws = _ws(nbytes, x.device)
         _native.check(L.d3f_circle_det_loss_backward(_p(oa), _p(op), M, C, _p(neg_mask), _p(sa), _p(sp), s, sr, pm, nm,
-                                                     _p(dists), _p(stats), g.data_ptr(), g.data_ptr() + 4, _p(ga),
+                                                     _p(dists), _p(stats), p_desc, p_det, _p(ga),
                                                      _p(gp), _p(gsa), _p(gsp), _p(ws), nbytes, _stream()),
                       "d3f_circle_det_loss_backward")
         gx, gs = _select_normalize_bwd(x, ia, ip, stride, p_off if has_off else None, ga, gp, gsa, gsp)
@@ -1167,19 +1180,24 @@ class _TrainLossFn(torch.autograd.Function):
 
 
 def train_loss(x, scores, corr, p_offset, dist_keypts, log_scale=10.0, safe_radius=0.1, pos_margin=0.1, neg_margin=1.4,
-               w_desc=1.0, w_det=1.0, _gw_cache={}):
+               w_desc=1.0, w_det=1.0, neg_mask=None, _gw_cache={}):
     """Loss of one training step on the un-normalised network output (trainer.py:91-98):
     ``w_desc * CircleLoss(normalize(x)[corr[:,0]], normalize(x)[corr[:,1] + p_offset]) + w_det * DetLoss(...)``.
     Returns (total, desc, det, accuracy, furthest_positive [M], average_negative [M]); only ``total`` carries
-    gradient."""
+    gradient.  ``neg_mask``: ``dist_keypts > safe_radius`` as uint8 when the caller already has it (the pipelined step
+    evaluates it with the pair's upload, off the training stream)."""
     x = _f32(x, "x")
     sc = _f32(scores, "scores").reshape(-1, 1)
     if not (corr.is_cuda and corr.dtype == torch.int64 and corr.dim() == 2 and corr.shape[1] == 2):
         raise ValueError("corr must be an int64 [M,2] device tensor")
     corr = corr.contiguous()
-    if not dist_keypts.is_cuda:
-        raise RuntimeError("dist_keypts must be a CUDA/HIP tensor")
-    neg_mask = (dist_keypts > safe_radius).to(torch.uint8).contiguous()  # evaluated in the caller's dtype (f64)
+    if neg_mask is None:
+        if not dist_keypts.is_cuda:
+            raise RuntimeError("dist_keypts must be a CUDA/HIP tensor")
+        neg_mask = (dist_keypts > safe_radius).to(torch.uint8).contiguous()  # evaluated in the caller's dtype (f64)
+    elif not (neg_mask.is_cuda and neg_mask.dtype == torch.uint8 and neg_mask.is_contiguous()
+              and tuple(neg_mask.shape) == (corr.shape[0], corr.shape[0])):
+        raise ValueError("neg_mask must be a contiguous uint8 [M,M] device tensor (dist_keypts > safe_radius)")
     key = (x.device, float(w_desc), float(w_det))
     if key not in _gw_cache:
         _gw_cache[key] = torch.tensor([float(w_desc), float(w_det)], dtype=torch.float32, device=x.device)

@@ -253,7 +253,8 @@ class TrainStep:
         n0 = batch['n0'] if 'n0' in batch else batch['stack_lengths'][0][:1]  # host int, or a device scalar (no sync)
         c = self.circle
         loss, desc, det, acc, fp, an = ops.train_loss(x, scores, batch['corr'], n0, batch['dist_keypts'], c.log_scale,
-                                                      c.safe_radius, c.pos_margin, c.neg_margin, self.w_desc, self.w_det)
+                                                      c.safe_radius, c.pos_margin, c.neg_margin, self.w_desc, self.w_det,
+                                                      neg_mask=batch.get('neg_mask'))
         # per-row furthest-positive / average-negative distances [M] (trainer.py:99-100 averages them on the host);
         # kept on the device for whoever wants the statistics -- no extra launches in the step itself
         self.last_distances = (fp, an)
@@ -274,6 +275,12 @@ class TrainStep:
         finally:
             self.model.train()
 
+    def _seed(self, loss):
+        """d loss / d loss = 1 as a cached device scalar (loss.backward() would fill a fresh one every step)."""
+        if getattr(self, '_one', None) is None or self._one.device != loss.device:
+            self._one = torch.ones((), dtype=loss.dtype, device=loss.device)
+        return self._one
+
     def forward_loss(self, batch):
         x, scores = self.model.forward_raw(batch)
         return self._loss_from_raw(x, scores, batch)
@@ -282,7 +289,7 @@ class TrainStep:
         """forward_loss with the autograd graph cut at the input of encoder block CUT: everything downstream (coarse
         encoder, decoder, loss) hangs off detached leaves.  Returns the loss tuple and [(tensor, leaf), ...]."""
         m = self.model
-        x = batch['features'].clone().detach()
+        x = batch['features'].detach()
         skips, cuts = [], []
         for i, op in enumerate(m.encoder_blocks):
             if i == self.CUT:
@@ -293,7 +300,7 @@ class TrainStep:
                 x = leaf_of(x)
                 skips = [leaf_of(t) for t in skips]
             if i in m.encoder_skips:
-                skips.append(x)
+                skips.append(m.mark_skip(x, op))
             x = op(x, batch)
         x = m._decode(x, skips, batch)
         scores = m.detection_scores(batch, x)
@@ -304,7 +311,7 @@ class TrainStep:
         self.flat.zero_grad()
         (loss, desc, det, acc), cuts = self._forward_loss_cut(batch)
         deep = self.flat.params[self.n_shallow:]
-        torch.autograd.backward(loss, inputs=deep + [leaf for _, leaf in cuts])
+        torch.autograd.backward(loss, self._seed(loss), inputs=deep + [leaf for _, leaf in cuts])
         self._cuts = cuts
         self.flat.gather_grads(self.n_shallow, None)
         return loss.detach(), desc.detach(), det.detach(), acc.detach()
@@ -365,6 +372,7 @@ class TrainStep:
             self.lens = torch.zeros(2, dtype=torch.int32, device=dev)
             self.corr = torch.zeros((num_corr, 2), dtype=torch.int64, device=dev)
             self.dk = torch.zeros((num_corr, num_corr), dtype=torch.float64, device=dev)
+            self.mask = torch.zeros((num_corr, num_corr), dtype=torch.uint8, device=dev)   # dk > safe_radius
             self.batch = None     # persistent pyramid tensors (filled by the side branch of the OTHER graph)
             self.status = None
             self.loaded = None    # the item whose pyramid `batch` holds
@@ -395,6 +403,7 @@ class TrainStep:
         st.lens[1] = n1
         st.corr.copy_(corr, non_blocking=True)
         st.dk.copy_(dk, non_blocking=True)
+        st.mask.copy_(st.dk > self.circle.safe_radius)   # with the upload, off the training stream (utils/loss.py:119)
 
     def _build_set(self, st):
         """Pyramid of the pair in ``st``'s input buffers -> ``st.batch`` (tensors adopted the first time, then
@@ -415,13 +424,14 @@ class TrainStep:
     def _set_batch(self, st):
         batch = dict(st.batch)
         batch['features'], batch['corr'], batch['dist_keypts'] = self.s_feat, st.corr, st.dk
+        batch['neg_mask'] = st.mask
         return batch
 
     def _net_step(self, st):
         batch = self._set_batch(st)
         self.flat.zero_grad()
         loss, desc, det, acc = self.forward_loss(batch)
-        loss.backward()
+        torch.autograd.backward(loss, self._seed(loss))
         self.flat.gather_grads()
         self.opt.step(want_ok=False)
         return loss.detach(), desc.detach(), det.detach(), acc.detach()
@@ -578,7 +588,7 @@ class TrainStep:
             return self._exchange_and_step(lambda: self._backward_deep(batch), self._backward_shallow)
         self.flat.zero_grad()
         loss, desc, det, acc = self.forward_loss(batch)
-        loss.backward()
+        torch.autograd.backward(loss, self._seed(loss))
         allreduce_mean_(self.flat.gather_grads(), self.world)
         self.opt.step(want_ok=False)
         return loss.detach(), desc.detach(), det.detach(), acc.detach()

@@ -146,8 +146,10 @@ int d3f_linear_fused_supported(int N, int Cin, int Cout);
 int d3f_linear_bias_act_forward(const float* x, const float* weight, int N, int Cin, int Cout, const float* bias1,
                                 const float* add, const float* bias2, float slope, float* out, float* zero_init,
                                 int zero_n, void* stream);
-int d3f_linear_grad_input(const float* grad_out, const float* weight, int N, int Cin, int Cout, float* grad_x,
-                          void* stream);
+/* grad_x [N,Cin] = grad_out [N,Cout] @ weight [Cout,Cin] (+ add [N,Cin] when given: the gradient another branch
+ * produced for the same tensor, accumulated in the epilogue instead of by a separate launch) */
+int d3f_linear_grad_input(const float* grad_out, const float* weight, int N, int Cin, int Cout, const float* add,
+                          float* grad_x, void* stream);
 size_t d3f_linear_grad_weight_ws_bytes(int N, int Cin, int Cout);
 int d3f_linear_grad_weight(const float* x, const float* grad_out, int N, int Cin, int Cout, float* grad_w, void* ws,
                            size_t ws_bytes, void* stream);
@@ -224,7 +226,8 @@ size_t d3f_detection_scores_ws_bytes(int N, int C);
  * anchor/positive [M,C]; neg_mask [M,M] uint8 = (dist_keypts > safe_radius), evaluated by the caller in the
  * dtype the dataset supplies (float64 in the reference, loss.py:116); anc_score/pos_score [M].
  * Outputs: dists [M,M], furthest_positive [M], average_negative [M],
- *   out_scalars[0..5] = desc_loss, det_loss, accuracy(%), mean furthest_positive, mean average_negative, 0;
+ *   out_scalars[0..5] = desc_loss, det_loss, accuracy(%), mean furthest_positive, mean average_negative,
+ *                      desc_loss + det_loss;
  *   stats [d3f_circle_det_loss_stats_floats(M)] = row/column log-sum-exps + closest negatives, kept for backward.
  * backward: gradients of  grad_desc*desc_loss + grad_det*det_loss  (device scalars; either may be NULL = 0)
  *   wrt anchor, positive [M,C] and the two score vectors [M] (optional).

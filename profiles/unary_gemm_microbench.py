@@ -51,5 +51,5 @@ for n, cin, cout in SHAPES:
     b = torch.randn(cout, device=dev); y = torch.empty(n, cout, device=dev); gx = torch.empty(n, cin, device=dev)
     st = torch.cuda.current_stream().cuda_stream
     f = timeit(lambda: L.d3f_linear_bias_act_forward(x.data_ptr(), w.data_ptr(), n, cin, cout, b.data_ptr(), None, b.data_ptr(), 0.1, y.data_ptr(), None, 0, st))
-    d = timeit(lambda: L.d3f_linear_grad_input(g.data_ptr(), w.data_ptr(), n, cin, cout, gx.data_ptr(), st))
+    d = timeit(lambda: L.d3f_linear_grad_input(g.data_ptr(), w.data_ptr(), n, cin, cout, None, gx.data_ptr(), st))
     print("%-20s %9.1f %9.1f" % ("%d,%d,%d" % (n, cin, cout), f, d))
