@@ -107,6 +107,9 @@ __global__ __launch_bounds__(256) void atb_reduce_kernel(const float* __restrict
   if (sub == 0 && e < MN) C[e] = ((s + sh[0][threadIdx.x]) + sh[1][threadIdx.x]) + sh[2][threadIdx.x];
 }
 
+#ifndef D3F_ATB_TARGET_WGS
+#define D3F_ATB_TARGET_WGS 512
+#endif
 static inline int tile_width(int n) { return n % 64 == 0 ? 4 : (n % 32 == 0 ? 2 : (n % 16 == 0 ? 1 : 0)); }
 
 bool atb_supported(int R, int M, int N) { return R >= 1 && tile_width(M) && tile_width(N); }
@@ -114,7 +117,7 @@ bool atb_supported(int R, int M, int N) { return R >= 1 && tile_width(M) && tile
 // number of row partitions = workgroups along the reduction
 static int atb_partitions(int R, int M, int N) {
   const long long nblocks = (long long)(M / (16 * tile_width(M))) * (N / (16 * tile_width(N)));
-  long long wgs = (1024 + nblocks - 1) / nblocks;         // ~4 workgroups per CU over the whole launch
+  long long wgs = (D3F_ATB_TARGET_WGS + nblocks - 1) / nblocks;  // workgroups over the whole launch (256 CUs)
   const long long max_by_rows = (R + 63) / 64;            // >= 16 rows (4 MFMA k-steps) per wave
   if (wgs > max_by_rows) wgs = max_by_rows;
   if (wgs > 512) wgs = 512;
