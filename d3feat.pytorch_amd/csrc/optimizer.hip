@@ -34,7 +34,8 @@ __global__ __launch_bounds__(256) void nonfinite_kernel(const float* __restrict_
   if (__any(bad) && (threadIdx.x & 63) == 0) atomicOr(state, 1);
 }
 
-__device__ __forceinline__ void sgd1(float g, float& p, float& b, float lr, float mom, float wd) {
+__device__ __forceinline__ void sgd1(float g, float& p, float& b, float lr, float mom, float wd, float gs) {
+  g = g * gs;
   const float d = g + wd * p;
   b = b * mom + d;
   p = p + (-lr) * b;
@@ -48,25 +49,27 @@ __global__ __launch_bounds__(256) void sgd_kernel(const float* __restrict__ g, f
     if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(state + 1, 1);
     return;
   }
-  if (hyper) {  // device-resident {lr, momentum, weight_decay}: a schedule can change them under a captured graph
+  float gs = 1.0f;
+  if (hyper) {  // device-resident {lr, momentum, weight_decay, grad_scale}: changeable under a captured graph
     lr = hyper[0];
     mom = hyper[1];
     wd = hyper[2];
+    gs = hyper[3];  // 1/world_size after a SUM all-reduce: the mean is taken here instead of by a pass of its own
   }
   const size_t n4 = n / 4;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
     const float4 gv = ((const float4*)g)[i];
     float4 pv = ((float4*)p)[i], bv = ((float4*)buf)[i];
-    sgd1(gv.x, pv.x, bv.x, lr, mom, wd);
-    sgd1(gv.y, pv.y, bv.y, lr, mom, wd);
-    sgd1(gv.z, pv.z, bv.z, lr, mom, wd);
-    sgd1(gv.w, pv.w, bv.w, lr, mom, wd);
+    sgd1(gv.x, pv.x, bv.x, lr, mom, wd, gs);
+    sgd1(gv.y, pv.y, bv.y, lr, mom, wd, gs);
+    sgd1(gv.z, pv.z, bv.z, lr, mom, wd, gs);
+    sgd1(gv.w, pv.w, bv.w, lr, mom, wd, gs);
     ((float4*)p)[i] = pv;
     ((float4*)buf)[i] = bv;
   }
   if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
     const size_t i = n4 * 4 + threadIdx.x;
-    sgd1(g[i], p[i], buf[i], lr, mom, wd);
+    sgd1(g[i], p[i], buf[i], lr, mom, wd, gs);
   }
 }
 
@@ -75,8 +78,9 @@ __global__ __launch_bounds__(256) void sgd_kernel(const float* __restrict__ g, f
 extern "C" {
 
 /* grad, params, momentum_buf: [n] fp32, 16-byte aligned.  state: int32[2] on the device = {scratch flag, number of
- * skipped steps so far}; state[0] is reset here, state[1] only ever incremented.  hyper_device: NULL, or float[3] on
- * the device = {lr, momentum, weight_decay} read at execution time instead of the three scalar arguments. */
+ * skipped steps so far}; state[0] is reset here, state[1] only ever incremented.  hyper_device: NULL, or float[4] on
+ * the device = {lr, momentum, weight_decay, grad_scale} read at execution time instead of the scalar arguments
+ * (grad_scale multiplies the gradient first: 1/world_size turns an all-reduced SUM into the mean). */
 int d3f_sgd_guarded_step(const float* grad, float* params, float* momentum_buf, size_t n, float lr, float momentum,
                          float weight_decay, const float* hyper_device, int32_t* state, void* stream) {
   if (!grad || !params || !momentum_buf || !state) return D3F_EINVAL;

@@ -1230,15 +1230,16 @@ def mutual_nn(source_desc, target_desc):
 # ---------------------------------------------------------------------------------------------------------------
 def sgd_guarded_step(grad, params, momentum_buf, lr, momentum, weight_decay, state, hyper=None):
     """In place: params/momentum_buf updated unless grad holds a non-finite value (then state[1] += 1).
-    ``hyper``: optional fp32[3] device tensor {lr, momentum, weight_decay} read by the kernel when it runs."""
+    ``hyper``: optional fp32[4] device tensor {lr, momentum, weight_decay, grad_scale} read by the kernel when it
+    runs."""
     for t, name in ((grad, "grad"), (params, "params"), (momentum_buf, "momentum_buf")):
         if not (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous() and t.numel() == grad.numel()):
             raise ValueError("%s must be a contiguous fp32 device tensor of %d elements" % (name, grad.numel()))
     if not (state.is_cuda and state.dtype == torch.int32 and state.numel() >= 2):
         raise ValueError("state must be an int32[2] device tensor")
-    if hyper is not None and not (hyper.is_cuda and hyper.dtype == torch.float32 and hyper.numel() == 3
+    if hyper is not None and not (hyper.is_cuda and hyper.dtype == torch.float32 and hyper.numel() == 4
                                   and hyper.is_contiguous()):
-        raise ValueError("hyper must be a contiguous fp32[3] device tensor")
+        raise ValueError("hyper must be a contiguous fp32[4] device tensor")
     with _region("sgd", 20 * grad.numel()):
         _native.check(_native.lib().d3f_sgd_guarded_step(_p(grad), _p(params), _p(momentum_buf), grad.numel(),
                                                          float(lr), float(momentum), float(weight_decay),

@@ -82,8 +82,8 @@ class FlatParams:
         return self.grad[a:a + sum(p.numel() for p in ps)]
 
 
-def allreduce_mean_(flat, world_size, n_buckets=4, group=None):
-    """Bucketed all-reduce(SUM) / world_size, in place.  xGMI rings are per-link bound, so a few large buckets
+def allreduce_mean_(flat, world_size, n_buckets=4, group=None, average=True):
+    """Bucketed all-reduce(SUM) (/ world_size unless ``average=False``), in place.  xGMI rings are per-link bound, so a few large buckets
     (>= 16 MB each at full width) keep every link busy while bounding the latency of the first bucket."""
     if world_size <= 1:
         return flat
@@ -96,7 +96,8 @@ def allreduce_mean_(flat, world_size, n_buckets=4, group=None):
             works.append(dist.all_reduce(chunk, op=dist.ReduceOp.SUM, group=group, async_op=True))
     for w in works:
         w.wait()
-    flat.mul_(1.0 / world_size)
+    if average:
+        flat.mul_(1.0 / world_size)
     return flat
 
 
@@ -112,8 +113,8 @@ class GuardedSGD:
         self.state = torch.zeros(2, dtype=torch.int32, device=flat.data.device)
         # {lr, momentum, weight_decay} live on the device: the kernel reads them when it runs, so a schedule changes the
         # step size of an already captured graph (a scalar argument would be frozen at capture)
-        self.hyper = torch.tensor([lr, momentum, weight_decay], dtype=torch.float32, device=flat.data.device)
-        self._hyper = [float(lr), float(momentum), float(weight_decay)]
+        self.hyper = torch.tensor([lr, momentum, weight_decay, 1.0], dtype=torch.float32, device=flat.data.device)
+        self._hyper = [float(lr), float(momentum), float(weight_decay), 1.0]
         self.initial_lr = float(lr)
 
     def _set(self, i, v):
@@ -123,6 +124,8 @@ class GuardedSGD:
     lr = property(lambda self: self._hyper[0], lambda self, v: self._set(0, v))
     momentum = property(lambda self: self._hyper[1], lambda self, v: self._set(1, v))
     weight_decay = property(lambda self: self._hyper[2], lambda self, v: self._set(2, v))
+    # the gradient is multiplied by this first: 1/world_size makes the mean out of an all-reduced SUM inside the step
+    grad_scale = property(lambda self: self._hyper[3], lambda self, v: self._set(3, v))
 
     @property
     def param_groups(self):
@@ -179,6 +182,8 @@ class GuardedSGD:
                                  hyper=self.hyper)
             return (self.state[1] == before) if want_ok else None
         ok = torch.isfinite(g).all()
+        if self.grad_scale != 1.0:
+            g = g * self.grad_scale
         d = torch.add(g, self.flat.data, alpha=self.weight_decay)       # g + wd * p
         new_buf = torch.add(d, self.buf, alpha=self.momentum)            # d + mom * buf
         self.buf.copy_(torch.where(ok, new_buf, self.buf))
@@ -203,6 +208,7 @@ class TrainStep:
                 dist.broadcast(t.data, src=0)
         self.flat = FlatParams(self.model)
         self.opt = GuardedSGD(self.flat, lr=config.lr, momentum=config.momentum, weight_decay=config.weight_decay)
+        self.opt.grad_scale = 1.0 / max(1, world_size)
         self.circle = CircleLoss(dist_type='euclidean', log_scale=config.log_scale, safe_radius=config.safe_radius,
                                  pos_margin=config.pos_margin, neg_margin=config.neg_margin)
         self.w_desc, self.w_det = float(config.desc_loss_weight), float(config.det_loss_weight)
@@ -341,8 +347,7 @@ class TrainStep:
         if self.world > 1:
             works.append(dist.all_reduce(g[:self.numel_shallow], op=dist.ReduceOp.SUM, async_op=True))
             for w in works:
-                w.wait()
-            g.mul_(1.0 / self.world)
+                w.wait()                 # SUM over ranks; the 1/world of the mean is opt.grad_scale
         self.opt.step(want_ok=False)
         return out
 
@@ -589,6 +594,6 @@ class TrainStep:
         self.flat.zero_grad()
         loss, desc, det, acc = self.forward_loss(batch)
         torch.autograd.backward(loss, self._seed(loss))
-        allreduce_mean_(self.flat.gather_grads(), self.world)
+        allreduce_mean_(self.flat.gather_grads(), self.world, average=False)   # the mean is opt.grad_scale
         self.opt.step(want_ok=False)
         return loss.detach(), desc.detach(), det.detach(), acc.detach()

@@ -295,8 +295,9 @@ int d3f_kpconv_grad_input_modes(const float* q_pts, int Nq, const float* s_pts, 
  *   if every grad[i] is finite:  buf = momentum*buf + (grad + weight_decay*params);  params -= lr*buf
  *   else: nothing is modified and state[1] (skipped-step counter) is incremented.
  * state: int32[2] on the device; state[0] is scratch.
- * hyper_device: NULL, or float[3] on the device = {lr, momentum, weight_decay}, read when the kernel executes in
- * place of the scalar arguments -- the learning-rate schedule (ExponentialLR, training_3DMatch.py:78-81 stepped at
+ * hyper_device: NULL, or float[4] on the device = {lr, momentum, weight_decay, grad_scale}, read when the kernel
+ * executes in place of the scalar arguments (grad_scale multiplies the gradient first: 1/world_size turns an
+ * all-reduced SUM into the mean without a pass of its own) -- the learning-rate schedule (ExponentialLR, training_3DMatch.py:78-81 stepped at
  * trainer.py:59-60) then changes the step size of an already captured hipGraph.
  * ---------------------------------------------------------------------------------------------- */
 int d3f_sgd_guarded_step(const float* grad, float* params, float* momentum_buf, size_t n, float lr, float momentum,

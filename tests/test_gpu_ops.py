@@ -538,3 +538,43 @@ def test_kpconv_modes_match_reference_vectors(influence, aggregation):
     for name, u, v in (("out", got.detach(), ref.detach()), ("grad_x", b[0].grad, a[0].grad), ("grad_w", b[1].grad, a[1].grad)):
         err = float((u.cpu() - v).abs().max())
         assert err <= 1e-4 * max(1.0, float(v.abs().max())), (name, err)
+
+
+def test_guarded_sgd_step_matches_torch_sgd_and_skips_on_nonfinite():
+    """d3f_sgd_guarded_step vs torch.optim.SGD(momentum, weight_decay) (training_3DMatch.py:62-76) + the guard of
+    trainer.py:104-111; device-resident hyper-parameters incl. the gradient scale of the data-parallel mean."""
+    from d3feat_pytorch_amd.train import FlatParams, GuardedSGD
+    torch.manual_seed(0)
+    model = torch.nn.Sequential(torch.nn.Linear(37, 53), torch.nn.Linear(53, 7)).to(DEV)
+    ref = torch.nn.Sequential(torch.nn.Linear(37, 53), torch.nn.Linear(53, 7)).to(DEV)
+    ref.load_state_dict(model.state_dict())
+    flat = FlatParams(model)
+    opt = GuardedSGD(flat, lr=0.01, momentum=0.98, weight_decay=1e-6)
+    ropt = torch.optim.SGD(ref.parameters(), lr=0.01, momentum=0.98, weight_decay=1e-6)
+    gen = torch.Generator(device=DEV).manual_seed(1)
+    for step in range(6):
+        g = torch.randn(flat.numel, generator=gen, device=DEV)
+        scale = 0.125 if step >= 3 else 1.0           # as if 8 ranks had summed their gradients
+        if step == 3:
+            opt.grad_scale = 0.125
+            opt.lr = 0.004
+            for grp in ropt.param_groups:
+                grp['lr'] = 0.004
+        poisoned = step == 4
+        flat.grad.copy_(g)
+        if poisoned:
+            flat.grad[flat.numel // 2] = float('inf')
+        off = 0
+        for p in ref.parameters():
+            p.grad = (g[off:off + p.numel()] * scale).view_as(p).clone()
+            off += p.numel()
+        before = flat.data.clone()
+        ok = opt.step()
+        if poisoned:
+            assert not bool(ok) and torch.equal(before, flat.data)
+            continue
+        assert bool(ok)
+        ropt.step()
+        want = torch.cat([p.detach().reshape(-1) for p in ref.parameters()])
+        assert float((flat.data - want).abs().max()) <= 1e-7 * max(1.0, float(want.abs().max())), step
+    assert int(opt.skipped) == 1

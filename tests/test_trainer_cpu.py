@@ -147,3 +147,17 @@ def test_scalar_log_and_missing_checkpoint(tmp_path):
         assert 'no checkpoint' in str(e)
     else:
         raise AssertionError
+
+
+def test_gradient_scale_is_the_data_parallel_mean():
+    a, b = torch.nn.Linear(5, 3), torch.nn.Linear(5, 3)
+    b.load_state_dict(a.state_dict())
+    fa, fb = FlatParams(a), FlatParams(b)
+    oa, ob = GuardedSGD(fa, lr=0.1, momentum=0.9, weight_decay=1e-3), GuardedSGD(fb, lr=0.1, momentum=0.9, weight_decay=1e-3)
+    oa.grad_scale = 0.25
+    for s in range(3):
+        g = torch.randn(fa.numel, generator=torch.Generator().manual_seed(s))
+        fa.grad.copy_(g)            # the SUM over 4 ranks
+        fb.grad.copy_(g * 0.25)     # the mean, scaled beforehand
+        assert bool(oa.step()) and bool(ob.step())
+        assert torch.equal(fa.data, fb.data)
