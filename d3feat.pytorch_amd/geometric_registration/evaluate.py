@@ -74,13 +74,15 @@ def get_scores(scorepath, filename, desc_name=DESC_NAME):
 
 # ------------------------------------------------------------------------------------------ descriptor generation
 @torch.no_grad()
-def describe_fragment(model, points, config, neighborhood_limits, device=None, stacked=False):
+def describe_fragment(model, points, config, neighborhood_limits, device=None, stacked=False, exact_width=True):
     """(keypoints [N,3], descriptors [N,32], scores [N,1]) of one fragment, device tensors (test.py:107-120).
 
     The reference feeds the fragment stacked with itself and keeps the first half.  Every operator of the network
     works per cloud (neighbor tables never cross clouds) and the detector's global maximum over two copies equals the
     maximum over one, so a single copy gives the same rows for half the work; ``stacked=True`` runs the literal
-    two-copy batch (used by the test that checks the equivalence)."""
+    two-copy batch (used by the test that checks the equivalence).  ``exact_width=False`` keeps every neighbor table at
+    the full calibrated width instead of the reference's min(limit, max_count) -- what the static-shape graph engine
+    (``infer.InferStep``) does; see the note on table widths in DESIGN.md section 3."""
     dev = torch.device(device) if device is not None else next(model.parameters()).device
     pts = torch.as_tensor(np.ascontiguousarray(points) if isinstance(points, np.ndarray) else points,
                           dtype=torch.float32, device=dev)
@@ -92,7 +94,7 @@ def describe_fragment(model, points, config, neighborhood_limits, device=None, s
                                          neighborhood_limits, device=dev)
     else:
         lengths = torch.tensor([n], dtype=torch.int32, device=dev)
-        batch = dl.build_pyramid(pts, lengths, config, neighborhood_limits, exact_width=True)
+        batch = dl.build_pyramid(pts, lengths, config, neighborhood_limits, exact_width=exact_width)
         batch.pop('_status')
         batch['features'] = feat
     was_training = model.training
@@ -104,20 +106,34 @@ def describe_fragment(model, points, config, neighborhood_limits, device=None, s
     return batch['points'][0][:n], features[:n], scores[:n]
 
 
-def generate_features(model, scenes, save_path, config, neighborhood_limits, device=None, verbose=False):
+def generate_features(model, scenes, save_path, config, neighborhood_limits, device=None, verbose=False, engine=None):
     """``scenes``: {scene name: sequence of fragment point arrays [N,3]} (already voxel-subsampled at
-    ``config.downsample`` like ThreeDMatchTestset does).  Writes the three .npy files per fragment."""
+    ``config.downsample`` like ThreeDMatchTestset does).  Writes the three .npy files per fragment.
+
+    ``engine``: an ``infer.InferStep(model, ..., clouds=1)`` with graphs enabled -- fragments that fit its capacities
+    go through the pipelined graph replay (the next fragment's pyramid is built under the current one's network),
+    the others through the eager ``describe_fragment``."""
     for scene, fragments in scenes.items():
         dpath, kpath, spath = _paths(save_path, scene)
         for p in (dpath, kpath, spath):
             os.makedirs(p, exist_ok=True)
-        for ids, points in enumerate(fragments):
-            pts, features, scores = describe_fragment(model, points, config, neighborhood_limits, device)
+        frags = [np.ascontiguousarray(f, dtype=np.float32) for f in fragments]
+        dev = torch.device(device) if device is not None else next(model.parameters()).device
+        on_dev = [torch.from_numpy(f).to(dev) for f in frags] if engine is not None else None
+        for ids, points in enumerate(frags):
+            if engine is not None and engine.fits((on_dev[ids],)):
+                nxt = (on_dev[ids + 1],) if ids + 1 < len(frags) and engine.fits((on_dev[ids + 1],)) else None
+                features, scores = engine.describe((on_dev[ids],), nxt)
+                pts = on_dev[ids]
+            else:
+                pts, features, scores = describe_fragment(model, points, config, neighborhood_limits, device)
             np.save(os.path.join(dpath, 'cloud_bin_%d.%s' % (ids, DESC_NAME)), features.cpu().numpy().astype(np.float32))
             np.save(os.path.join(kpath, 'cloud_bin_%d' % ids), pts.cpu().numpy().astype(np.float32))
             np.save(os.path.join(spath, 'cloud_bin_%d' % ids), scores.cpu().numpy().astype(np.float32))
             if verbose:
                 print("Generate cloud_bin_%d for %s" % (ids, scene))
+        if engine is not None:
+            engine.check_status()
 
 
 # ----------------------------------------------------------------------------------------------------- registration

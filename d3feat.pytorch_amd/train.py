@@ -206,6 +206,9 @@ class TrainStep:
         if world_size > 1:  # identical start on every rank (kernel points are RNG-initialised per process)
             for t in list(self.model.parameters()) + list(self.model.buffers()):
                 dist.broadcast(t.data, src=0)
+        self._init_training_state(config, world_size)
+
+    def _init_training_state(self, config, world_size):
         self.flat = FlatParams(self.model)
         self.opt = GuardedSGD(self.flat, lr=config.lr, momentum=config.momentum, weight_decay=config.weight_decay)
         self.opt.grad_scale = 1.0 / max(1, world_size)

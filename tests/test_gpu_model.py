@@ -499,3 +499,69 @@ def test_training_step_loss_node_equals_the_module_composition(golden_s0, w_desc
     modular = ts.flat.gather_grads()
     assert float((fused - modular).abs().max()) <= 2e-4 * float(modular.abs().max())
     assert float(modular.abs().max()) > 0
+
+
+def test_inference_pipeline_matches_eager_eval_forward(golden_s0, tmp_path):
+    """InferStep (forward-only hipGraph replay, pyramid of the next input on the side stream) == the eager eval-mode
+    forward, for stacked pairs and for single fragments, incl. an input the pipeline has not prefetched."""
+    from d3feat_pytorch_amd.geometric_registration import evaluate as ev
+    from d3feat_pytorch_amd.infer import InferStep
+    from d3feat_pytorch_amd.train import TrainStep
+    g = golden_s0
+    cfg = cfgmod.default_config(first_features_dim=16)
+    limits = [int(x) for x in g['limits']]
+    model = _load_model(cfg, g, full_sd=True)
+    p0, p1 = (torch.from_numpy(np.ascontiguousarray(g[k])).to(DEV) for k in ('pts0', 'pts1'))
+    sizes = [int(g['batch.points.%d' % l].shape[0]) for l in range(5)]
+    caps = TrainStep.capacities_for([sizes], slack=1.3)
+
+    def eager(clouds):
+        pts = torch.cat(clouds, 0)
+        lens = torch.tensor([c.shape[0] for c in clouds], dtype=torch.int32, device=DEV)
+        batch = dl.build_pyramid(pts, lens, cfg, limits, exact_width=True)
+        batch.pop('_status')
+        batch['features'] = torch.ones((pts.shape[0], 1), device=DEV)
+        model.eval()
+        with torch.no_grad():
+            return model(batch)
+
+    pair = InferStep(model, cfg, limits, torch.device(DEV), clouds=2)
+    pair.enable_graph(caps)
+    seq = [(p0, p1), (p1, p0), (p0, p1)]
+    for k, item in enumerate(seq):
+        f, s = pair.describe(item, seq[k + 1] if k + 1 < len(seq) else None)
+        fe, se = eager(list(item))
+        assert f.shape == fe.shape and float((f - fe).abs().max()) < 1e-5 and float((s - se).abs().max()) < 1e-5, k
+    other = (p1.clone(), p0.clone())          # not prefetched: built on demand
+    f, s = pair.describe(other)
+    fe, se = eager(list(other))
+    assert float((f - fe).abs().max()) < 1e-5 and float((s - se).abs().max()) < 1e-5
+    pair.check_status()
+    with pytest.raises(RuntimeError):
+        pair.describe((p0,))
+
+    # single fragments through generate_features.  The graph engine keeps every neighbor table at the calibrated width;
+    # the eager reference path trims to min(limit, max_count).  The two differ only where NO query of a table reaches
+    # the limit (pts1's coarse levels here: max_pool then sees an extra zero shadow entry on full rows), so: identical
+    # files against the full-width eager pass for both fragments, and against the reference-width pass for pts0.
+    one = InferStep(model, cfg, limits, torch.device(DEV), clouds=1)
+    lv = []
+    for p in (p0, p1):
+        b1 = dl.build_pyramid(p, torch.tensor([p.shape[0]], dtype=torch.int32, device=DEV), cfg, limits)
+        lv.append([int(t.shape[0]) for t in b1['points']])
+    one.enable_graph(TrainStep.capacities_for(lv, slack=1.0))
+    frags = [g['pts0'], g['pts1'], g['pts0']]
+    ev.generate_features(model, {'room': frags}, str(tmp_path / 'a'), cfg, limits, engine=one)
+    ev.generate_features(model, {'room': frags}, str(tmp_path / 'b'), cfg, limits)
+    for i, pts in enumerate(frags):
+        a_d = np.load(tmp_path / 'a' / 'descriptors' / 'room' / ('cloud_bin_%d.D3Feat.npy' % i))
+        a_s = np.load(tmp_path / 'a' / 'scores' / 'room' / ('cloud_bin_%d.npy' % i))
+        a_k = np.load(tmp_path / 'a' / 'keypoints' / 'room' / ('cloud_bin_%d.npy' % i))
+        _, fd, fs = ev.describe_fragment(model, pts, cfg, limits, exact_width=False)
+        assert np.array_equal(a_k, pts.astype(np.float32))
+        assert np.abs(a_d - fd.cpu().numpy()).max() < 1e-5 and np.abs(a_s - fs.cpu().numpy()).max() < 1e-5, i
+        if i != 1:
+            b_d = np.load(tmp_path / 'b' / 'descriptors' / 'room' / ('cloud_bin_%d.D3Feat.npy' % i))
+            b_s = np.load(tmp_path / 'b' / 'scores' / 'room' / ('cloud_bin_%d.npy' % i))
+            assert np.abs(a_d - b_d).max() < 1e-5 and np.abs(a_s - b_s).max() < 1e-5, i
+    assert not model.training
