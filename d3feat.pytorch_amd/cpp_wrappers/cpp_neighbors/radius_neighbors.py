@@ -1,5 +1,4 @@
 """``radius_neighbors`` module mirror (reference cpp_wrappers/cpp_neighbors/wrapper.cpp:25-52): ``batch_query``."""
-import numpy as np
 import torch
 
 from ... import ops

@@ -2,7 +2,6 @@
 layout, trainer.py:193-218), the learning-rate recursion, the scalar log.  No kernel launches."""
 import json
 import os
-import types
 
 import numpy as np
 import torch
