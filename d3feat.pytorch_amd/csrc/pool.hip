@@ -13,7 +13,7 @@ namespace {
 // backward needs no fill launch of its own.
 __global__ void max_pool_fwd_kernel(const float* __restrict__ x, int Ns, int C, const int32_t* __restrict__ idx,
                                     int Nq, int H, float* __restrict__ out, int32_t* __restrict__ argmax,
-                                    float* __restrict__ clear) {
+                                    float* __restrict__ clear, const int32_t* __restrict__ width) {
   const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (clear)
     for (size_t i = t; i < (size_t)Ns * C; i += (size_t)gridDim.x * blockDim.x) clear[i] = 0.0f;
@@ -22,7 +22,10 @@ __global__ void max_pool_fwd_kernel(const float* __restrict__ x, int Ns, int C, 
   const int32_t* row = idx + (size_t)n * H;
   float best = -INFINITY;
   int arg = Ns;
-  for (int h = 0; h < H; ++h) {
+  // the reference's table has min(limit, max_count) columns (dataloader.py:64-66): with a wider, static-shape table the
+  // device-resident max_count says how many leading columns it would have kept
+  const int Hw = width ? min(H, max(1, __builtin_amdgcn_readfirstlane(*width))) : H;  // wave-uniform loop bound
+  for (int h = 0; h < Hw; ++h) {
     const int m = row[h];
     const bool real = m >= 0 && m < Ns;
     const float v = real ? x[(size_t)m * C + c] : 0.0f;  // shadow row is zeros (blocks.py:103)
@@ -77,15 +80,15 @@ __global__ void closest_pool_bwd_kernel(const float* __restrict__ go, int ld, co
 extern "C" {
 
 int d3f_max_pool_forward(const float* x, int Ns, int C, const int32_t* idx, int Nq, int H, float* out,
-                         int32_t* argmax_out, float* grad_x_clear, void* stream) {
+                         int32_t* argmax_out, float* grad_x_clear, const int32_t* width_dev, void* stream) {
   if (!x || !idx || !out || Ns < 0 || C < 1 || Nq < 0 || H < 1) return D3F_EINVAL;
   if (Nq == 0) {
     if (grad_x_clear && d3f::zero_async(grad_x_clear, sizeof(float) * (size_t)Ns * C, (hipStream_t)stream) != hipSuccess)
       return D3F_ELAUNCH;
     return D3F_OK;
   }
-  max_pool_fwd_kernel<<<d3f::cdiv((long long)Nq * C, 256), 256, 0, (hipStream_t)stream>>>(x, Ns, C, idx, Nq, H, out,
-                                                                                          argmax_out, grad_x_clear);
+  max_pool_fwd_kernel<<<d3f::cdiv((long long)Nq * C, 256), 256, 0, (hipStream_t)stream>>>(
+      x, Ns, C, idx, Nq, H, out, argmax_out, grad_x_clear, width_dev);
   D3F_LAUNCH_CHECK();
   return D3F_OK;
 }

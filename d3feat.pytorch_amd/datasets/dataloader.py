@@ -137,23 +137,28 @@ def build_pyramid_static(points, lengths, config, neighborhood_limits, capacitie
         return grids[key]
 
     empty_idx = torch.zeros((0, 1), dtype=torch.int32, device=dev)
-    neighbors, pools, upsamples = [], [], []
+    neighbors, pools, pools_width, upsamples = [], [], [], []
     level = 0
     for li, e in enumerate(walk.layers):
         lim = int(neighborhood_limits[li])
         neighbors.append(grid_for(level, e['conv_r']).query(pts[level], lens[level], lim)
                          if e['conv_r'] is not None else empty_idx)
         if e['pool']:
-            pools.append(grid_for(level, e['pool_r']).query(pts[level + 1], lens[level + 1], lim))
+            # static width = the limit; the reference trims to min(limit, max_count) (dataloader.py:64-66).  Only max_pool
+            # can tell the difference (a full row gains zero-valued shadow candidates): it gets max_count, on the device
+            tab, mx = grid_for(level, e['pool_r']).query(pts[level + 1], lens[level + 1], lim, want_max=True)
+            pools.append(tab)
+            pools_width.append(mx)
             upsamples.append(grid_for(level + 1, e['up_r']).query(pts[level], lens[level], lim))
             level += 1
         else:
             pools.append(empty_idx)
+            pools_width.append(None)
             upsamples.append(empty_idx)
     n_levels = len(neighbors)
     return {'points': [pts[min(i, len(pts) - 1)] for i in range(n_levels)], 'neighbors': neighbors, 'pools': pools,
-            'upsamples': upsamples, 'stack_lengths': [lens[min(i, len(lens) - 1)] for i in range(n_levels)],
-            '_status': status, '_static': True}
+            'pools_width': pools_width, 'upsamples': upsamples,
+            'stack_lengths': [lens[min(i, len(lens) - 1)] for i in range(n_levels)], '_status': status, '_static': True}
 
 
 def build_pyramid(points, lengths, config, neighborhood_limits, index_dtype=torch.int32, exact_width=False,
@@ -192,7 +197,7 @@ def build_pyramid(points, lengths, config, neighborhood_limits, index_dtype=torc
         return grids[key]
 
     empty_idx = torch.zeros((0, 1), dtype=index_dtype, device=dev)
-    neighbors, pools, upsamples, maxima = [], [], [], []
+    neighbors, pools, pools_width, upsamples, maxima = [], [], [], [], []
     level = 0
     for li, e in enumerate(walk.layers):
         lim = int(neighborhood_limits[li])
@@ -204,13 +209,21 @@ def build_pyramid(points, lengths, config, neighborhood_limits, index_dtype=torc
                 return res[0]
             return res
 
+        def run_pool(qlevel, slevel, radius):
+            if exact_width:
+                return run(qlevel, slevel, radius), None
+            return grid_for(slevel, radius).query(pts[qlevel], lens[qlevel], lim, want_max=True)
+
         neighbors.append(run(level, level, e['conv_r']) if e['conv_r'] is not None else empty_idx)
         if e['pool']:
-            pools.append(run(level + 1, level, e['pool_r']))
+            tab, tab_width = run_pool(level + 1, level, e['pool_r'])
+            pools.append(tab)
+            pools_width.append(tab_width)
             upsamples.append(run(level, level + 1, e['up_r']))
             level += 1
         else:
             pools.append(empty_idx)
+            pools_width.append(None)
             upsamples.append(empty_idx)
     if exact_width and maxima:
         mx = torch.cat(maxima).tolist()  # second read-back; walk in the order the maxima were appended
@@ -233,8 +246,11 @@ def build_pyramid(points, lengths, config, neighborhood_limits, index_dtype=torc
     n_levels = len(neighbors)
     out_pts = [pts[min(i, len(pts) - 1)] for i in range(n_levels)]
     out_lens = [lens[min(i, len(lens) - 1)] for i in range(n_levels)]
-    return {'points': out_pts, 'neighbors': neighbors, 'pools': pools, 'upsamples': upsamples,
-            'stack_lengths': out_lens, '_status': status}
+    out = {'points': out_pts, 'neighbors': neighbors, 'pools': pools, 'upsamples': upsamples,
+           'stack_lengths': out_lens, '_status': status}
+    if not exact_width:   # full-width tables: max_pool gets each table's max neighbor count (device int32[1])
+        out['pools_width'] = pools_width
+    return out
 
 
 def collate_fn_descriptor(list_data, config, neighborhood_limits, device=None, index_dtype=torch.int32,

@@ -224,6 +224,13 @@ def _layer_inputs(block_name, layer_ind, batch):
     return batch['points'][layer_ind], batch['points'][layer_ind], batch['neighbors'][layer_ind]
 
 
+def _pool_width(layer_ind, batch):
+    """Device int32[1] max neighbor count of the pooling table when the batch keeps its tables wider than the
+    reference would (static shapes): ops.max_pool then reads the columns the reference's table has."""
+    w = batch.get('pools_width') if isinstance(batch, dict) else None
+    return w[layer_ind] if w is not None else None
+
+
 def _make_kpconv(block_name, in_dim, out_dim, radius, config):
     extent = radius * config.KP_extent / config.conv_radius
     return KPConv(config.num_kernel_points, config.in_points_dim, in_dim, out_dim, extent, radius,
@@ -290,7 +297,8 @@ class ResnetBottleneckBlock(nn.Module):
             strided = 'strided' in self.block_name
             # a skip tensor also feeds the decoder, whose gradient arrives first: the pooling backward scatters on top
             incoming = getattr(features, '_d3f_grad_in', None) if strided else None
-            shortcut = ops.max_pool(features, inds, grad_deposit=holder, grad_incoming=incoming) if strided else features
+            shortcut = ops.max_pool(features, inds, grad_deposit=holder, grad_incoming=incoming,
+                                    width=_pool_width(self.layer_ind, batch)) if strided else features
             if isinstance(self.unary_shortcut, UnaryBlock):
                 shortcut = self.unary_shortcut(shortcut, grad_deposit=None if strided else holder)
             elif not strided:
@@ -305,7 +313,8 @@ class ResnetBottleneckBlock(nn.Module):
                                     influence=self.KPConv.KP_influence, aggregation=self.KPConv.aggregation_mode)
         else:
             x = self.KPConv(q_pts, s_pts, inds, x)
-        shortcut = max_pool(features, inds) if 'strided' in self.block_name else features
+        shortcut = ops.max_pool(features, inds, width=_pool_width(self.layer_ind, batch)) \
+            if 'strided' in self.block_name else features
         shortcut = self.unary_shortcut(shortcut)
         if not self.use_bn:
             return self.unary2(x, residual=shortcut)  # leaky(unary2(x) + shortcut) in the epilogue of unary2
@@ -341,4 +350,4 @@ class MaxPoolBlock(nn.Module):
         self.layer_ind = layer_ind
 
     def forward(self, x, batch):
-        return max_pool(x, batch['pools'][self.layer_ind + 1])
+        return ops.max_pool(x, batch['pools'][self.layer_ind + 1], width=_pool_width(self.layer_ind + 1, batch))

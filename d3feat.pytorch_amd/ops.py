@@ -777,7 +777,7 @@ def linear_nobias(x, weight, grad_holder=None, grad_deposit=None):
 # ---------------------------------------------------------------------------------------------------------------
 class _MaxPoolFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, idx, deposit=None, incoming=None):
+    def forward(ctx, x, idx, deposit=None, incoming=None, width=None):
         ctx.dep, ctx.incoming = deposit, incoming
         Ns, C = int(x.shape[0]), int(x.shape[1])
         Nq, H = int(idx.shape[0]), int(idx.shape[1])
@@ -786,7 +786,7 @@ class _MaxPoolFn(torch.autograd.Function):
         gx_buf = torch.empty_like(x) if ctx.needs_input_grad[0] else None  # cleared by the forward launch
         with _region("max_pool_fwd[Nq=%d,C=%d]" % (Nq, C), 4 * Nq * H + 4 * Nq * H * C + 4 * Nq * C):
             _native.check(_native.lib().d3f_max_pool_forward(_p(x), Ns, C, _p(idx), Nq, H, _p(out), _p(arg),
-                                                             _p(gx_buf), _stream()), "d3f_max_pool_forward")
+                                                             _p(gx_buf), _p(width), _stream()), "d3f_max_pool_forward")
         ctx.save_for_backward(arg)
         ctx.shape = (Ns, C)
         ctx.gx_buf = gx_buf
@@ -811,11 +811,16 @@ class _MaxPoolFn(torch.autograd.Function):
             gx.add_(c)
         if ctx.dep is not None and ctx.dep.deposit(gx):
             gx = None
-        return gx, None, None, None
+        return gx, None, None, None, None
 
 
-def max_pool(x, inds, grad_deposit=None, grad_incoming=None):
-    return _MaxPoolFn.apply(_f32(x, "x"), _i32(inds, "inds"), grad_deposit, grad_incoming)
+def max_pool(x, inds, grad_deposit=None, grad_incoming=None, width=None):
+    """max over the neighbors of every query row, zero shadow row included (blocks.py:94-110).  ``width``: device
+    int32[1] = the table's max neighbor count; only the first min(H, width) columns count -- the table the reference
+    would have built (dataloader.py:64-66) when ``inds`` is kept at a wider, static width."""
+    if width is not None and not (width.is_cuda and width.dtype == torch.int32 and width.numel() == 1):
+        raise ValueError("width must be a device int32[1] tensor")
+    return _MaxPoolFn.apply(_f32(x, "x"), _i32(inds, "inds"), grad_deposit, grad_incoming, width)
 
 
 class _ClosestPoolFn(torch.autograd.Function):

@@ -423,9 +423,9 @@ class TrainStep:
             return
         st.status.word.copy_(status.word)
         done = set()
-        for key in ('points', 'neighbors', 'pools', 'upsamples', 'stack_lengths'):
+        for key in ('points', 'neighbors', 'pools', 'pools_width', 'upsamples', 'stack_lengths'):
             for dst, src in zip(st.batch[key], batch[key]):
-                if dst.data_ptr() not in done and dst.numel():
+                if dst is not None and dst.data_ptr() not in done and dst.numel():
                     dst.copy_(src)
                     done.add(dst.data_ptr())
 

@@ -161,8 +161,11 @@ int d3f_linear_grad_weight(const float* x, const float* grad_out, int N, int Cin
  * (Ns if the shadow won), saved for backward.
  * grad_x_clear (optional, [Ns,C]): the backward's scatter target, zeroed by the forward launch on the side; the backward
  * is then called with grad_x_precleared = 1 and launches no fill. */
+/* width_dev (optional, device int32[1]): the table's max neighbor count as d3f_radius_query reports it; only the
+ * first min(H, *width_dev) columns take part, which is the table the reference would have built
+ * (dataloader.py:64-66 trims to the max count) when idx is kept at a wider, static width. */
 int d3f_max_pool_forward(const float* x, int Ns, int C, const int32_t* idx, int Nq, int H, float* out,
-                         int32_t* argmax_out, float* grad_x_clear, void* stream);
+                         int32_t* argmax_out, float* grad_x_clear, const int32_t* width_dev, void* stream);
 int d3f_max_pool_backward(const float* grad_out, const int32_t* argmax, int Nq, int C, int Ns, float* grad_x,
                           int grad_x_precleared, void* stream);
 /* out[n,:] = x'[idx[n,0],:]  (idx has row stride H); backward: grad_out has row stride ld >= C (a column slice of
