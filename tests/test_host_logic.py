@@ -152,3 +152,27 @@ def test_reference_architectures_runs_on_our_blocks_unchanged():
         for k, v in saved.items():
             if v is not None:
                 sys.modules[k] = v
+
+
+def test_grad_holder_protocol():
+    """ops.GradHolder: first deposit wins, collect closes, a late deposit is refused (its owner then returns the
+    gradient the ordinary way) -- pure host logic of the two-branch gradient fusion."""
+    h = ops.GradHolder()
+    a, b = torch.ones(2), torch.zeros(2)
+    assert not h.deposit(None)
+    assert h.deposit(a) and not h.deposit(b)          # one slot
+    assert h.collect() is a and h.closed
+    assert h.collect() is None                         # emptied
+    assert not h.deposit(b)                            # closed: late branch keeps its gradient
+    # the identity tap defers to the holder only while it is open
+    x = torch.randn(3, requires_grad=True)
+    h2 = ops.GradHolder()
+    y = ops.grad_tap(x, h2)
+    (y * 2).sum().backward()
+    assert x.grad is None and torch.equal(h2.collect(), torch.full((3,), 2.0))
+    h3 = ops.GradHolder()
+    h3.collect()                                       # consumer ran first
+    y = ops.grad_tap(x, h3)
+    (y * 3).sum().backward()
+    assert torch.equal(x.grad, torch.full((3,), 3.0))
+    assert ops.grad_tap(x, None) is x
