@@ -6,7 +6,8 @@ Layout mirrors the reference's module paths so its callers keep working:
   datasets.dataloader      batch_neighbors_kpconv, batch_grid_subsampling_kpconv, collate_fn_descriptor, calibrate_neighbors
   utils.loss               cdist, CircleLoss, DetLoss, ContrastiveLoss
   cpp_wrappers.cpp_neighbors.radius_neighbors.batch_query / cpp_wrappers.cpp_subsampling.grid_subsampling.subsample_batch
-  geometric_registration.common.build_correspondence
+  geometric_registration.common.build_correspondence          geometric_registration.evaluate (test.py's protocol)
+  datasets.ThreeDMatch     ThreeDMatchDataset / ThreeDMatchTestset          trainer.Trainer (trainer.py's epoch loop)
 ``install_reference_aliases()`` registers those names in ``sys.modules`` so the reference's own
 ``models/architectures.py`` (``from models.blocks import *``) runs on top of this package unchanged.
 """
@@ -18,7 +19,7 @@ _ALIASES = ["models", "models.blocks", "models.architectures", "datasets", "data
             "utils.loss", "kernels", "kernels.kernel_points", "cpp_wrappers", "cpp_wrappers.cpp_neighbors",
             "cpp_wrappers.cpp_neighbors.radius_neighbors", "cpp_wrappers.cpp_subsampling",
             "cpp_wrappers.cpp_subsampling.grid_subsampling", "geometric_registration",
-            "geometric_registration.common"]
+            "geometric_registration.common", "datasets.ThreeDMatch", "trainer"]
 
 
 def install_reference_aliases(names=None, overwrite=False):
