@@ -12,7 +12,7 @@ _REPO = os.path.dirname(_PKG_DIR)
 LIB_PATH = os.path.join(_PKG_DIR, "libd3feat_hip.so")
 CSRC = os.path.join(_PKG_DIR, "csrc")
 SOURCES = ["radius_neighbors.hip", "grid_subsample.hip", "kpconv.hip", "kpconv_fused.hip", "kpconv_small.hip", "pool.hip", "detection.hip", "loss.hip",
-           "matching.hip", "elementwise.hip", "linear.hip", "optimizer.hip", "misc.hip"]
+           "matching.hip", "elementwise.hip", "linear.hip", "gemm.hip", "optimizer.hip", "misc.hip"]
 
 _vp, _i, _f, _sz = C.c_void_p, C.c_int, C.c_float, C.c_size_t
 
@@ -47,6 +47,9 @@ SIGNATURES = {
     "d3f_linear_grad_input": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp]),
     "d3f_linear_grad_weight_ws_bytes": (_sz, [_i, _i, _i]),
     "d3f_linear_grad_weight": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _sz, _vp]),
+    "d3f_gemm_ws_bytes": (_sz, [_i, _i, _i, _i]),
+    "d3f_gemm_debug_set_flags": (None, [_i]),
+    "d3f_gemm": (_i, [_vp, _vp, _sz, _vp]),
     "d3f_max_pool_forward": (_i, [_vp, _i, _i, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     "d3f_max_pool_backward": (_i, [_vp, _vp, _i, _i, _i, _vp, _i, _vp]),
     "d3f_closest_pool_forward": (_i, [_vp, _i, _i, _vp, _i, _i, _vp, _i, _vp, _vp, _vp]),
@@ -80,14 +83,52 @@ STATUS_BITS = {1: "a query has more in-radius candidates than the kernel can ran
                8: "a pyramid level needs more rows than its capacity (raise the capacities)"}
 
 
-def build(verbose=False):
-    """Compile every HIP source for gfx950 into the in-tree shared library (cross-compiles without a GPU)."""
+class GemmArgs(C.Structure):
+    """``d3f_gemm_args`` of include/d3feat_hip.h, field for field."""
+    _fields_ = [("A", _vp), ("B", _vp), ("C", _vp),
+                ("M", C.c_int32), ("N", C.c_int32), ("K", C.c_int32),
+                ("lda", C.c_int32), ("ldb", C.c_int32), ("ldc", C.c_int32),
+                ("a_layout", C.c_int32), ("b_layout", C.c_int32),
+                ("a_mask", _vp), ("mask_slope", _f),
+                ("rowsum", _vp), ("rowsum2", _vp),
+                ("row_div", _vp), ("bias1", _vp), ("bias2", _vp),
+                ("add", _vp), ("ldadd", C.c_int32), ("add_idx", _vp), ("idx_stride", C.c_int32),
+                ("add_rows", C.c_int32), ("slope", _f), ("zero_init", _vp), ("zero_n", C.c_int32)]
+
+
+GEMM_KC, GEMM_KS = 0, 1
+
+
+def build(verbose=False, jobs=None):
+    """Compile every HIP source for gfx950 into the in-tree shared library (cross-compiles without a GPU).
+    One object per source under ``build/`` (recompiled only when the source or a header changed), then one link."""
     # -ffp-contract=off: HIP's __fmul_rn/__fadd_rn are plain operators on AMD, so with the default contract=fast
     # the compiler fuses the "exact" d2 = (dx*dx + dy*dy) + dz*dz into FMAs and the strict d2 < r2 test / the
     # distance order stop matching the reference's x86 arithmetic bit for bit.  Fusion is requested explicitly
     # (fmaf / MFMA) where it is wanted.
-    cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-Wno-pass-failed", "-fPIC", "-shared",
-           "-I" + os.path.join(_REPO, "include"), "-o", LIB_PATH] + [os.path.join(CSRC, s) for s in SOURCES]
+    from concurrent.futures import ThreadPoolExecutor
+    flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-Wno-pass-failed", "-fPIC",
+             "-I" + os.path.join(_REPO, "include")]
+    objdir = os.path.join(_PKG_DIR, "build")
+    os.makedirs(objdir, exist_ok=True)
+    headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hpp", ".h"))]
+    headers.append(os.path.join(_REPO, "include", "d3feat_hip.h"))
+    hdr_time = max(os.path.getmtime(h) for h in headers)
+
+    def compile_one(src):
+        obj = os.path.join(objdir, src.replace(".hip", ".o"))
+        path = os.path.join(CSRC, src)
+        if os.path.exists(obj) and os.path.getmtime(obj) > max(os.path.getmtime(path), hdr_time):
+            return obj
+        cmd = ["hipcc"] + flags + ["-c", path, "-o", obj]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd)
+        return obj
+
+    with ThreadPoolExecutor(max_workers=jobs or min(8, os.cpu_count() or 1)) as pool:
+        objs = list(pool.map(compile_one, SOURCES))
+    cmd = ["hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB_PATH] + objs
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)
