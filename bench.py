@@ -43,27 +43,46 @@ def fwd_kernel_cost(Nq, Ns, H, Cin, Cout, K):
     return kpconv_fwd_bytes(Nq, Ns, H, K, Cin, Cout), 2 * Nq * H * K * Cin + 2 * Nq * K * Cin * Cout
 
 
-def timed_kernel(lib, which, run_steps, cost):
-    """HIP events on the launch stream around every launch of one library kernel (d3f_debug_kernel_timing_*)."""
+def gather_kernel_cost(edges):
+    """Cost model of the gather-form grad-input kernel; ``edges[(Nq, Ns)]`` = valid entries of the table it runs on."""
+    def cost(Nq, Ns, H, Cin, Cout, K):
+        E = edges.get((Nq, Ns), Nq * 42)
+        b = Ns * (12 + 8 + 4 * Cin) + E * (4 + 12 + 4 + 4 * Cout) + 4 * K * Cin * Cout   # rows, CSR entries + gathers, W
+        return b, 2 * E * K * Cout + 2 * Ns * K * Cout * Cin
+    return cost
+
+
+KERNEL_NAMES = {1: "kpconv_fwd_fused_kernel (KPConv forward: gather + influence + aggregation + contraction on f32 MFMA)",
+                2: "kpconv_bwd_dx_kernel (KPConv grad-input, scatter form: gW tile on f32 MFMA + float atomics)",
+                3: "kpconv_dx_gather_kernel (KPConv grad-input, gather form over the reverse neighbor table: "
+                   "aggregation + W^T contraction on f32 MFMA, no atomics)"}
+
+
+def timed_kernels(lib, run_steps, costs, n_steps):
+    """HIP events on the launch stream around every launch of the hand-written KPConv kernels
+    (d3f_debug_kernel_timing_*), grouped by kernel: {which: stats}."""
     import ctypes
-    cap = 1024
-    if lib.d3f_debug_kernel_timing_begin(which, cap) != 0:
-        return None
+    cap = 2048
+    if lib.d3f_debug_kernel_timing_begin(-7, cap) != 0:
+        return {}
     run_steps()
     torch.cuda.synchronize()
     ms = (ctypes.c_float * cap)()
     sh = (ctypes.c_int32 * (6 * cap))()
     n = min(lib.d3f_debug_kernel_timing_end(ms, sh, cap), cap)
-    if n <= 0:
-        return None
-    tot_ms = tot_b = tot_f = 0.0
-    for i in range(n):
-        b, f = cost(*[int(sh[6 * i + j]) for j in range(6)])
-        tot_ms += ms[i]
-        tot_b += b
-        tot_f += f
-    return {"launches": n, "avg_us": tot_ms / n * 1e3, "bytes_per_launch": tot_b / n, "flops_per_launch": tot_f / n,
-            "gbs": tot_b / (tot_ms * 1e-3) / 1e9, "tflops": tot_f / (tot_ms * 1e-3) / 1e12}
+    groups = {}
+    for i in range(max(n, 0)):
+        shape = [int(sh[6 * i + j]) for j in range(6)]
+        which, shape[5] = shape[5] >> 8, shape[5] & 255
+        b, f = costs[which](*shape)
+        g = groups.setdefault(which, [0, 0.0, 0.0, 0.0])
+        g[0] += 1
+        g[1] += ms[i]
+        g[2] += b
+        g[3] += f
+    return {w: {"launches": g[0], "avg_us": g[1] / g[0] * 1e3, "us_per_step": g[1] / n_steps * 1e3,
+                "bytes_per_launch": g[2] / g[0], "flops_per_launch": g[3] / g[0],
+                "gbs": g[2] / (g[1] * 1e-3) / 1e9, "tflops": g[3] / (g[1] * 1e-3) / 1e12} for w, g in groups.items()}
 
 
 def kpconv_fwd_bytes(Nq, Ns, H, K, Cin, Cout):
@@ -274,15 +293,25 @@ def main():
         dist.all_reduce(elapsed, op=dist.ReduceOp.MAX)
     elapsed = float(elapsed.item())
 
-    # Roofline leg: the dominant kernel of the training stream (profiles/r01*_kernel_stats*.txt) is the KPConv
-    # grad-input kernel; every launch of it in 3 eager steps is bracketed by HIP events inside the library, on the
-    # stream it is launched on.  The fused forward kernel is timed the same way for reference.
+    # Roofline leg: the hand-written KPConv kernels are the largest kernels of the training stream (profiles/r02*);
+    # every launch of them in 3 eager steps is bracketed by HIP events inside the library, on the stream it is launched
+    # on, and the one with the most time per step is reported as `roofline`.
     def _three_steps():
         ts._pending = None
         for k in range(3):
             ts.step(items[k % len(items)])
-    dx_t = timed_kernel(_native.lib(), 2, _three_steps, dx_kernel_cost)
-    fw_t = timed_kernel(_native.lib(), 1, _three_steps, fwd_kernel_cost)
+    edges = {}
+    for k in range(min(3, len(items))):   # valid entries of the transposed tables (cost model of the gather kernel)
+        b_k = ts.build_batch(items[k])
+        for tabs in (b_k['neighbors'], b_k['pools']):
+            for t in tabs:
+                r = getattr(t, '_d3f_rev', None)
+                if r is not None:
+                    edges[(r.Nq, r.Ns)] = r.edges()
+    kt = timed_kernels(_native.lib(), _three_steps,
+                       {1: fwd_kernel_cost, 2: dx_kernel_cost, 3: gather_kernel_cost(edges)}, 3)
+    dom = max(kt, key=lambda w: kt[w]["us_per_step"]) if kt else None
+    dx_t = kt.get(dom)
 
     # dense mutual-NN matching of the pair's descriptors (19k x 19k x 32, the distance matrix is
     # never materialised) -- the one MFMA-bound kernel of the path; timed with HIP events on the current stream.
@@ -378,31 +407,34 @@ def main():
             tpath = os.path.join(REPO, "profiles", "pmc_traffic.json")
             if os.path.exists(tpath):
                 with open(tpath) as f:
-                    traffic = json.load(f).get("kpconv_bwd_dx_kernel", {}).get("hbm_bytes_per_launch")
+                    traffic = json.load(f).get(KERNEL_NAMES[dom].split(" ")[0], {}).get("hbm_bytes_per_launch")
             f_hbm = dx_t["gbs"] / HBM_PEAK_GBS
             f_mfma = dx_t["tflops"] / F32_MFMA_PEAK_TFLOPS
             mfma_bound = f_mfma > f_hbm
             roofline = {
                 "bound": "mfma" if mfma_bound else "hbm",
-                "kernel": "kpconv_bwd_dx_kernel (KPConv grad-input: gW tile on f32 MFMA + influence-weighted scatter; "
-                          "all channel-width instantiations, every layer)",
+                "kernel": KERNEL_NAMES[dom] + "; all channel-width instantiations, every layer it runs on",
                 "achieved": round(dx_t["tflops"] if mfma_bound else dx_t["gbs"], 2),
                 "peak": F32_MFMA_PEAK_TFLOPS if mfma_bound else HBM_PEAK_GBS,
                 "unit": "TFLOP/s" if mfma_bound else "GB/s",
                 "frac": round(max(f_mfma, f_hbm), 4),
                 "traffic": traffic,
                 "avg_us": round(dx_t["avg_us"], 2), "launches_timed": dx_t["launches"],
+                "us_per_step": round(dx_t["us_per_step"], 1),
                 "algorithmic_bytes_per_launch": int(dx_t["bytes_per_launch"]),
                 "algorithmic_flops_per_launch": int(dx_t["flops_per_launch"]),
                 "hbm": {"achieved_GBs": round(dx_t["gbs"], 1), "frac": round(f_hbm, 4)},
                 "mfma_f32": {"achieved_TFLOPs": round(dx_t["tflops"], 2), "frac": round(f_mfma, 4)},
-                "also_timed": None if fw_t is None else {
-                    "kernel": "kpconv_fwd_fused_kernel", "avg_us": round(fw_t["avg_us"], 2),
-                    "launches_timed": fw_t["launches"], "achieved_GBs": round(fw_t["gbs"], 1),
-                    "achieved_TFLOPs": round(fw_t["tflops"], 2)},
+                "also_timed": [{"kernel": KERNEL_NAMES[w].split(" ")[0], "avg_us": round(v["avg_us"], 2),
+                                "launches_timed": v["launches"], "us_per_step": round(v["us_per_step"], 1),
+                                "achieved_GBs": round(v["gbs"], 1), "hbm_frac": round(v["gbs"] / HBM_PEAK_GBS, 4),
+                                "achieved_TFLOPs": round(v["tflops"], 2),
+                                "mfma_frac": round(v["tflops"] / F32_MFMA_PEAK_TFLOPS, 4)}
+                               for w, v in sorted(kt.items()) if w != dom],
                 "measured": "hipEventRecord on the launch stream immediately before/after each launch of the kernel "
                             "(d3f_debug_kernel_timing_*), 3 eager steps after the timed region; averages are "
-                            "time-weighted over all launches (13 KPConv layers per step)"}
+                            "time-weighted over all launches; the kernel reported is the hand-written kernel with the "
+                            "most time per training step"}
         res = {
             "metric": "fragment-pairs/sec (fwd+bwd) on 3DMatch-shaped pairs",
             "value": round(args.steps * world / elapsed, 3),

@@ -12,7 +12,7 @@ _REPO = os.path.dirname(_PKG_DIR)
 LIB_PATH = os.path.join(_PKG_DIR, "libd3feat_hip.so")
 CSRC = os.path.join(_PKG_DIR, "csrc")
 SOURCES = ["radius_neighbors.hip", "grid_subsample.hip", "kpconv.hip", "kpconv_fused.hip", "kpconv_small.hip", "pool.hip", "detection.hip", "loss.hip",
-           "matching.hip", "elementwise.hip", "linear.hip", "gemm.hip", "optimizer.hip", "misc.hip"]
+           "reverse_table.hip", "kpconv_dx_gather.hip", "matching.hip", "elementwise.hip", "linear.hip", "gemm.hip", "optimizer.hip", "misc.hip"]
 
 _vp, _i, _f, _sz = C.c_void_p, C.c_int, C.c_float, C.c_size_t
 
@@ -27,6 +27,7 @@ SIGNATURES = {
     "d3f_radius_grid_ws_bytes": (_sz, [_i]),
     "d3f_radius_grid_build": (_i, [_vp, _i, _vp, _i, _f, _vp, _sz, _vp, _vp]),
     "d3f_radius_query": (_i, [_vp, _vp, _i, _vp, _vp, _i, _vp, _i, _f, _i, _vp, _vp, _vp, _vp, _vp]),
+    "d3f_radius_query_ex": (_i, [_vp, _vp, _i, _vp, _i, _vp, _i, _f, _f, _i, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp]),
     "d3f_grid_subsample_ws_bytes": (_sz, [_i, _i]),
     "d3f_grid_subsample": (_i, [_vp, _i, _vp, _i, _f, _i, _i, _vp, _i, _vp, _vp, _vp, _sz, _vp, _vp]),
     "d3f_kpconv_ws_bytes": (_sz, [_i, _i, _i, _i, _i, _i]),
@@ -41,6 +42,10 @@ SIGNATURES = {
     "d3f_kpconv_aggregate_modes": (_i, [_vp, _i, _vp, _i, _vp, _i, _vp, _i, _vp, _i, _f, _i, _vp, _vp, _vp]),
     "d3f_kpconv_grad_input_modes": (_i, [_vp, _i, _vp, _i, _vp, _i, _i, _vp, _i, _f, _i, _vp, _vp, _vp]),
     "d3f_kpconv_grad_input": (_i, [_vp, _i, _vp, _i, _vp, _i, _vp, _i, _vp, _i, _f, _vp, _vp, _i, _vp, _vp, _sz, _vp]),
+    "d3f_reverse_table_ws_bytes": (_sz, [_i, _i, _i]),
+    "d3f_reverse_table_build": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _sz, _vp]),
+    "d3f_kpconv_grad_input_gather_supported": (_i, [_i, _i, _i]),
+    "d3f_kpconv_grad_input_gather": (_i, [_vp, _i, _vp, _i, _vp, _vp, _vp, _i, _vp, _i, _vp, _i, _i, _f, _vp, _vp, _vp, _vp]),
     "d3f_linear_grad_weight_supported": (_i, [_i, _i, _i]),
     "d3f_linear_fused_supported": (_i, [_i, _i, _i]),
     "d3f_linear_bias_act_forward": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp, _f, _vp, _vp, _i, _vp]),
@@ -80,7 +85,8 @@ ERRORS = {-1: "invalid argument", -2: "workspace too small", -3: "HIP launch fai
 STATUS_BITS = {1: "a query has more in-radius candidates than the kernel can rank (512)",
                2: "a point lies outside the addressable cell grid",
                4: "voxel hash table full",
-               8: "a pyramid level needs more rows than its capacity (raise the capacities)"}
+               8: "a pyramid level needs more rows than its capacity (raise the capacities)",
+               16: "a point has more in-radius neighbors than the reverse (wide) table holds"}
 
 
 class GemmArgs(C.Structure):

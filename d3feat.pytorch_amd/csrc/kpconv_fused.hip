@@ -44,29 +44,40 @@ void kpconv_set_debug_flags(int f) { g_debug_flags = f; }
 // this file (1 = fused forward, 2 = grad input), one event pair per launch, read back after a synchronisation.
 struct TimedLaunch { hipEvent_t e0, e1; int shape[6]; };
 static TimedLaunch* g_timed = nullptr;
-static int g_timed_which = 0, g_timed_cap = 0, g_timed_n = 0;
+static int g_timed_mask = 0, g_timed_cap = 0, g_timed_n = 0;
+
+// which: 1 fused forward, 2 scatter-form grad input, 3 gather-form grad input (kpconv_dx_gather.hip).  The kernel id
+// is kept in the record as shape[5] = K | which << 8.
+void* kpconv_timing_open(int which, hipStream_t stream, int Nq, int Ns, int H, int Cin, int Cout, int K) {
+  if (!g_timed || !(g_timed_mask & (1 << (which - 1))) || g_timed_n >= g_timed_cap) return nullptr;
+  TimedLaunch* t = &g_timed[g_timed_n++];
+  const int sh[6] = {Nq, Ns, H, Cin, Cout, K | (which << 8)};
+  for (int i = 0; i < 6; ++i) t->shape[i] = sh[i];
+  (void)hipEventRecord(t->e0, stream);
+  return t;
+}
+void kpconv_timing_close(void* rec, hipStream_t stream) {
+  if (rec) (void)hipEventRecord(((TimedLaunch*)rec)->e1, stream);
+}
 
 struct TimingScope {
   hipStream_t st;
-  TimedLaunch* t;
-  TimingScope(int which, hipStream_t stream, int Nq, int Ns, int H, int Cin, int Cout, int K) : st(stream), t(nullptr) {
-    if (which != g_timed_which || g_timed_n >= g_timed_cap) return;
-    t = &g_timed[g_timed_n++];
-    const int sh[6] = {Nq, Ns, H, Cin, Cout, K};
-    for (int i = 0; i < 6; ++i) t->shape[i] = sh[i];
-    (void)hipEventRecord(t->e0, st);
-  }
-  ~TimingScope() { if (t) (void)hipEventRecord(t->e1, st); }
+  void* t;
+  TimingScope(int which, hipStream_t stream, int Nq, int Ns, int H, int Cin, int Cout, int K)
+      : st(stream), t(kpconv_timing_open(which, stream, Nq, Ns, H, Cin, Cout, K)) {}
+  ~TimingScope() { kpconv_timing_close(t, st); }
 };
 
+// which: one kernel id (1..3) or, negative, a mask of ids: -(bit0 | bit1 | bit2)
 int kpconv_timing_begin(int which, int max_launches) {
-  if (g_timed || which < 1 || which > 2 || max_launches < 1) return D3F_EINVAL;
+  const int mask = which < 0 ? -which : (which >= 1 && which <= 3 ? 1 << (which - 1) : 0);
+  if (g_timed || mask == 0 || mask > 7 || max_launches < 1) return D3F_EINVAL;
   g_timed = new TimedLaunch[max_launches];
   for (int i = 0; i < max_launches; ++i)
     if (hipEventCreate(&g_timed[i].e0) != hipSuccess || hipEventCreate(&g_timed[i].e1) != hipSuccess) return D3F_ELAUNCH;
   g_timed_cap = max_launches;
   g_timed_n = 0;
-  g_timed_which = which;
+  g_timed_mask = mask;
   return D3F_OK;
 }
 
@@ -83,7 +94,7 @@ int kpconv_timing_end(float* ms_out, int* shapes_out, int cap) {
   for (int i = 0; i < g_timed_cap; ++i) { (void)hipEventDestroy(g_timed[i].e0); (void)hipEventDestroy(g_timed[i].e1); }
   delete[] g_timed;
   g_timed = nullptr;
-  g_timed_which = g_timed_cap = g_timed_n = 0;
+  g_timed_mask = g_timed_cap = g_timed_n = 0;
   return n;
 }
 

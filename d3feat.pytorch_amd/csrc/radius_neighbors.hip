@@ -130,7 +130,7 @@ __global__ __launch_bounds__(kQueryWaves * 64) void radius_query_kernel(
     int Ns, double inv_cell, float r2, uint32_t mask, const int32_t* __restrict__ start,
     const int32_t* __restrict__ end, const float4* __restrict__ pts, const uint64_t* __restrict__ key, int width,
     int32_t* __restrict__ out_idx, int32_t* __restrict__ out_counts, int32_t* __restrict__ max_count,
-    int32_t* __restrict__ status) {
+    int32_t* __restrict__ status, int32_t* __restrict__ out_wide, int wide_width, uint64_t* __restrict__ out_last_key) {
   __shared__ WaveScratch scratch[kQueryWaves];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int qi = blockIdx.x * kQueryWaves + wave;
@@ -138,8 +138,12 @@ __global__ __launch_bounds__(kQueryWaves * 64) void radius_query_kernel(
   WaveScratch& ws = scratch[wave];
   volatile uint64_t* cand = ws.cand;
   if (qi >= d3f::batch_offset(q_len, B)) {  // Nq is a row capacity: rows past sum(q_len) get an all-shadow row
-    for (int c = lane; c < width; c += 64) out_idx[(size_t)qi * width + c] = Ns;
+    if (out_idx)
+      for (int c = lane; c < width; c += 64) out_idx[(size_t)qi * width + c] = Ns;
+    if (out_wide)
+      for (int c = lane; c < wide_width; c += 64) out_wide[(size_t)qi * wide_width + c] = Ns;
     if (lane == 0 && out_counts) out_counts[qi] = 0;
+    if (lane == 0 && out_last_key) out_last_key[qi] = ~0ull;
     return;
   }
 
@@ -202,9 +206,10 @@ __global__ __launch_bounds__(kQueryWaves * 64) void radius_query_kernel(
     if (out_counts) out_counts[qi] = T;
     if (max_count && T > *max_count) atomicMax(max_count, T);
     if (T > kCand) atomicOr(status, D3F_ST_CAND_OVERFLOW);
+    if (out_wide && T > wide_width) atomicOr(status, D3F_ST_WIDE_OVERFLOW);
   }
   const int Tc = T < kCand ? T : kCand;
-  int32_t* row = out_idx + (size_t)qi * width;
+  int32_t* row = out_idx ? out_idx + (size_t)qi * width : nullptr;
 
   if (Tc <= 64) {
     // rank in registers: 64-key bitonic network over the wave
@@ -219,8 +224,20 @@ __global__ __launch_bounds__(kQueryWaves * 64) void radius_query_kernel(
         v = (lower == up) ? mn : mx;
       }
     }
-    if (lane < width) row[lane] = lane < Tc ? (int32_t)(uint32_t)v : Ns;
-    for (int c = 64 + lane; c < width; c += 64) row[c] = Ns;
+    if (row) {
+      if (lane < width) row[lane] = lane < Tc ? (int32_t)(uint32_t)v : Ns;
+      for (int c = 64 + lane; c < width; c += 64) row[c] = Ns;
+    }
+    if (out_wide) {  // the whole ranked list (the reverse-table form of a same-cloud search, see d3feat_hip.h)
+      int32_t* wrow = out_wide + (size_t)qi * wide_width;
+      if (lane < wide_width) wrow[lane] = lane < Tc ? (int32_t)(uint32_t)v : Ns;
+      for (int c = 64 + lane; c < wide_width; c += 64) wrow[c] = Ns;
+    }
+    if (out_last_key) {  // rank key of the last entry the capped row keeps; ~0 when the row keeps everything
+      const uint64_t lk = __shfl((uint32_t)v, width <= 64 ? width - 1 : 63, 64) |
+                          ((uint64_t)__shfl((uint32_t)(v >> 32), width <= 64 ? width - 1 : 63, 64) << 32);
+      if (lane == 0) out_last_key[qi] = (Tc > width && width <= 64) ? lk : ~0ull;
+    }
     return;
   }
 
@@ -241,7 +258,12 @@ __global__ __launch_bounds__(kQueryWaves * 64) void radius_query_kernel(
       }
     }
   }
-  for (int c = lane; c < width; c += 64) row[c] = c < Tc ? (int32_t)(uint32_t)cand[c] : Ns;
+  if (row)
+    for (int c = lane; c < width; c += 64) row[c] = c < Tc ? (int32_t)(uint32_t)cand[c] : Ns;
+  if (out_wide)
+    for (int c = lane; c < wide_width; c += 64)
+      out_wide[(size_t)qi * wide_width + c] = c < Tc ? (int32_t)(uint32_t)cand[c] : Ns;
+  if (out_last_key && lane == 0) out_last_key[qi] = Tc > width ? cand[width - 1] : ~0ull;
 }
 
 }  // namespace
@@ -274,23 +296,32 @@ int d3f_radius_grid_build(const float* supports, int Ns, const int32_t* s_len, i
   return D3F_OK;
 }
 
-int d3f_radius_query(const void* grid_ws, const float* queries, int Nq, const int32_t* q_len, const float* supports,
-                     int Ns, const int32_t* s_len, int B, float radius, int width, int32_t* out_idx,
-                     int32_t* out_counts, int32_t* max_count, int32_t* status, void* stream_) {
-  (void)supports;
-  if (!grid_ws || !queries || !q_len || !s_len || !out_idx || !status || Nq < 0 || Ns < 0 || B < 1 ||
-      B > D3F_MAX_BATCH || width < 1 || width > kCand || !(radius > 0.0f))
+int d3f_radius_query_ex(const void* grid_ws, const float* queries, int Nq, const int32_t* q_len, int Ns,
+                        const int32_t* s_len, int B, float grid_radius, float radius, int width, int32_t* out_idx,
+                        int32_t* out_counts, int32_t* max_count, int32_t* out_wide, int wide_width,
+                        uint64_t* out_last_key, int32_t* status, void* stream_) {
+  if (!grid_ws || !queries || !q_len || !s_len || (!out_idx && !out_wide) || !status || Nq < 0 || Ns < 0 || B < 1 ||
+      B > D3F_MAX_BATCH || width < 1 || width > kCand || !(radius > 0.0f) || !(grid_radius >= radius) ||
+      (out_wide && (wide_width < 1 || wide_width > kCand)))
     return D3F_EINVAL;
   if (Nq == 0) return D3F_OK;
   hipStream_t stream = (hipStream_t)stream_;
   GridLayout g = grid_layout(const_cast<void*>(grid_ws), Ns);
-  const double inv_cell = 1.0 / ((double)radius * kCellSlack);
+  const double inv_cell = 1.0 / ((double)grid_radius * kCellSlack);  // cells of the list the grid was built with
   const float r2 = radius * radius;  // float32 product, like neighbors.cpp:226
   radius_query_kernel<<<d3f::cdiv(Nq, kQueryWaves), kQueryWaves * 64, 0, stream>>>(
       queries, Nq, q_len, s_len, B, Ns, inv_cell, r2, g.M - 1, g.start, g.end, g.pts, g.key, width, out_idx,
-      out_counts, max_count, status);
+      out_counts, max_count, status, out_wide, wide_width, out_last_key);
   D3F_LAUNCH_CHECK();
   return D3F_OK;
+}
+
+int d3f_radius_query(const void* grid_ws, const float* queries, int Nq, const int32_t* q_len, const float* supports,
+                     int Ns, const int32_t* s_len, int B, float radius, int width, int32_t* out_idx,
+                     int32_t* out_counts, int32_t* max_count, int32_t* status, void* stream_) {
+  (void)supports;
+  return d3f_radius_query_ex(grid_ws, queries, Nq, q_len, Ns, s_len, B, radius, radius, width, out_idx, out_counts,
+                             max_count, nullptr, 0, nullptr, status, stream_);
 }
 
 }  // extern "C"

@@ -111,7 +111,37 @@ class _Walk:
             layer_blocks = []
 
 
-def build_pyramid_static(points, lengths, config, neighborhood_limits, capacities, order=ops.ORDER_REFERENCE):
+def _conv_table(grid_for, pts, lens, level, e, lim, reverse_tables):
+    """neighbors[l] (dataloader.py:122-128).  With ``reverse_tables`` the same search also leaves the table's transpose
+    in search form (its whole ranked list + the key of the last kept entry): the in-radius relation of a cloud with
+    itself is symmetric, so the list of s IS the candidate set of rev(s) -- no transposition pass."""
+    if e['conv_r'] is None:
+        return torch.zeros((0, 1), dtype=torch.int32, device=pts[level].device)
+    grid = grid_for(level, e['conv_r'])
+    n = pts[level].shape[0]
+    if not (reverse_tables and ops.wants_reverse_table(n)):
+        return grid.query(pts[level], lens[level], lim)
+    tab, wide, lkey = grid.query(pts[level], lens[level], lim, wide=ops.REV_WIDTH_CONV, want_last_key=True)
+    ops.attach_reverse_table(tab, ops.ReverseTable(wide, n, lim, n, last_key=lkey))
+    return tab
+
+
+def _pool_table(grid_for, pts, lens, level, e, lim, reverse_tables):
+    """(pools[l], device max count) (dataloader.py:141-147); the transpose (coarse points around every fine point) is one
+    more search of the fine points over the coarse cloud's cell list (built for the upsampling radius 2r anyway)."""
+    grid = grid_for(level, e['pool_r'])
+    ns = pts[level].shape[0]
+    if not (reverse_tables and ops.wants_reverse_table(ns)):
+        return grid.query(pts[level + 1], lens[level + 1], lim, want_max=True)
+    tab, mx, lkey = grid.query(pts[level + 1], lens[level + 1], lim, want_max=True, want_last_key=True)
+    wide = grid_for(level + 1, e['up_r']).query(pts[level], lens[level], 1, radius=e['pool_r'],
+                                                wide=ops.REV_WIDTH_POOL, table=False)
+    ops.attach_reverse_table(tab, ops.ReverseTable(wide, pts[level + 1].shape[0], lim, ns, last_key=lkey))
+    return tab, mx
+
+
+def build_pyramid_static(points, lengths, config, neighborhood_limits, capacities, order=ops.ORDER_REFERENCE,
+                         reverse_tables=False):
     """Capacity-shaped pyramid: every level l has ``capacities[l]`` rows, the live row counts stay on the device.
 
     No host synchronisation at all (hipGraph-capturable): voxel levels write into fixed-capacity buffers (rows past
@@ -141,12 +171,11 @@ def build_pyramid_static(points, lengths, config, neighborhood_limits, capacitie
     level = 0
     for li, e in enumerate(walk.layers):
         lim = int(neighborhood_limits[li])
-        neighbors.append(grid_for(level, e['conv_r']).query(pts[level], lens[level], lim)
-                         if e['conv_r'] is not None else empty_idx)
+        neighbors.append(_conv_table(grid_for, pts, lens, level, e, lim, reverse_tables))
         if e['pool']:
             # static width = the limit; the reference trims to min(limit, max_count) (dataloader.py:64-66).  Only max_pool
             # can tell the difference (a full row gains zero-valued shadow candidates): it gets max_count, on the device
-            tab, mx = grid_for(level, e['pool_r']).query(pts[level + 1], lens[level + 1], lim, want_max=True)
+            tab, mx = _pool_table(grid_for, pts, lens, level, e, lim, reverse_tables)
             pools.append(tab)
             pools_width.append(mx)
             upsamples.append(grid_for(level + 1, e['up_r']).query(pts[level], lens[level], lim))
@@ -162,7 +191,7 @@ def build_pyramid_static(points, lengths, config, neighborhood_limits, capacitie
 
 
 def build_pyramid(points, lengths, config, neighborhood_limits, index_dtype=torch.int32, exact_width=False,
-                  order=ops.ORDER_REFERENCE):
+                  order=ops.ORDER_REFERENCE, reverse_tables=False):
     """points [N0,3] + stack lengths [B] -> dict(points, neighbors, pools, upsamples, stack_lengths) on the device.
 
     One host synchronisation (level sizes) per call; with ``exact_width`` a second one trims every neighbor table
@@ -239,6 +268,17 @@ def build_pyramid(points, lengths, config, neighborhood_limits, index_dtype=torc
                     raise RuntimeError("Error")
                 if w < lst[li].shape[1]:
                     lst[li] = lst[li][:, :w].contiguous()
+    if reverse_tables and index_dtype == torch.int32:
+        # transposes of the tables KPConv runs on (conv + pooling), for the gather-form grad-input; attached to the
+        # tables themselves (ops.build_reverse_table), so the batch dict keeps the reference's keys
+        level = 0
+        for li, e in enumerate(walk.layers):
+            if e['conv_r'] is not None and ops.wants_reverse_table(pts[level].shape[0]):
+                ops.build_reverse_table(neighbors[li], pts[level].shape[0])
+            if e['pool']:
+                if ops.wants_reverse_table(pts[level].shape[0]):
+                    ops.build_reverse_table(pools[li], pts[level].shape[0])
+                level += 1
     if index_dtype != torch.int32:
         neighbors = [t.to(index_dtype) for t in neighbors]
         pools = [t.to(index_dtype) for t in pools]
@@ -254,7 +294,7 @@ def build_pyramid(points, lengths, config, neighborhood_limits, index_dtype=torc
 
 
 def collate_fn_descriptor(list_data, config, neighborhood_limits, device=None, index_dtype=torch.int32,
-                          exact_width=True):
+                          exact_width=True, reverse_tables=False):
     """One fragment pair -> the multi-scale batch dict of the reference (dataloader.py:69-189), built on the GPU."""
     assert len(list_data) == 1
     dev = _device(device)
@@ -263,7 +303,8 @@ def collate_fn_descriptor(list_data, config, neighborhood_limits, device=None, i
     points = torch.cat([p0, p1], dim=0)
     feats = torch.cat([_to_dev(feat0, torch.float32, dev), _to_dev(feat1, torch.float32, dev)], dim=0)
     lengths = torch.tensor([p0.shape[0], p1.shape[0]], dtype=torch.int32, device=dev)
-    d = build_pyramid(points, lengths, config, neighborhood_limits, index_dtype=index_dtype, exact_width=exact_width)
+    d = build_pyramid(points, lengths, config, neighborhood_limits, index_dtype=index_dtype, exact_width=exact_width,
+                      reverse_tables=reverse_tables)
     d.pop('_status')
     d['features'] = feats
     d['corr'] = sel_corr.to(dev) if isinstance(sel_corr, torch.Tensor) else torch.from_numpy(np.asarray(sel_corr)).to(dev)

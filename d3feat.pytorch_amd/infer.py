@@ -14,6 +14,8 @@ from .train import TrainStep
 
 
 class InferStep(TrainStep):
+    reverse_tables = False   # forward only
+
     def __init__(self, model, config, neighborhood_limits, device, clouds=1):
         self.clouds = int(clouds)
         super().__init__(config, neighborhood_limits, device, world_size=1, model=model)

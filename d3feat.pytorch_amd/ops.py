@@ -141,8 +141,14 @@ class RadiusGrid:
                                                   int(self.s_len.numel()), self.radius, _p(self.ws), nbytes,
                                                   _p(self.status.word), _stream()), "d3f_radius_grid_build")
 
-    def query(self, queries, q_len, width, want_counts=False, want_max=False):
-        """int32 [Nq, width] neighbor table (+ per-query uncapped counts, + device max count)."""
+    def query(self, queries, q_len, width, want_counts=False, want_max=False, radius=None, wide=0, want_last_key=False,
+              table=True):
+        """int32 [Nq, width] neighbor table (+ per-query uncapped counts, + device max count).
+
+        ``radius`` (<= the grid's): search radius when it differs from the one the cell list was built for.
+        ``wide`` > 0: additionally the whole ranked list of every query as an int32 [Nq, wide] table; ``want_last_key``:
+        uint64 [Nq] rank key of the last entry each capped row keeps -- together the transposed form of a table for the
+        gather-form KPConv grad-input (d3f_radius_query_ex).  ``table=False`` skips the capped table itself."""
         q = _f32(queries, "queries")
         if q.dim() != 2 or q.shape[1] != 3:
             raise RuntimeError("Wrong dimensions : query.shape is not (N, 3)")
@@ -150,20 +156,24 @@ class RadiusGrid:
         if q_len.numel() != self.s_len.numel():
             raise RuntimeError("Wrong number of batch elements: different for queries and supports ")
         Nq = int(q.shape[0])
-        out = torch.empty((Nq, int(width)), dtype=torch.int32, device=q.device)
+        r = self.radius if radius is None else float(radius)
+        if r > self.radius:
+            raise RuntimeError("search radius %g exceeds the cell list's %g" % (r, self.radius))
+        out = torch.empty((Nq, int(width)), dtype=torch.int32, device=q.device) if table else None
         counts = torch.empty(Nq, dtype=torch.int32, device=q.device) if want_counts else None
         mx = torch.zeros(1, dtype=torch.int32, device=q.device) if want_max else None
-        with _region("radius_query[Nq=%d,Ns=%d]" % (Nq, self.Ns), 12 * Nq + 12 * self.Ns + 4 * Nq * int(width)):
-            _native.check(_native.lib().d3f_radius_query(_p(self.ws), _p(q), Nq, _p(q_len), _p(self.supports), self.Ns,
-                                                         _p(self.s_len), int(q_len.numel()), self.radius, int(width),
-                                                         _p(out), _p(counts), _p(mx), _p(self.status.word),
-                                                         _stream()), "d3f_radius_query")
-        res = (out,)
-        if want_counts:
-            res += (counts,)
-        if want_max:
-            res += (mx,)
-        return res if len(res) > 1 else out
+        wtab = torch.empty((Nq, int(wide)), dtype=torch.int32, device=q.device) if wide else None
+        lkey = torch.empty(Nq, dtype=torch.int64, device=q.device) if want_last_key else None
+        with _region("radius_query[Nq=%d,Ns=%d]" % (Nq, self.Ns), 12 * Nq + 12 * self.Ns + 4 * Nq * (int(width) + int(wide))):
+            _native.check(_native.lib().d3f_radius_query_ex(_p(self.ws), _p(q), Nq, _p(q_len), self.Ns, _p(self.s_len),
+                                                            int(q_len.numel()), self.radius, r, int(width), _p(out),
+                                                            _p(counts), _p(mx), _p(wtab), int(wide), _p(lkey),
+                                                            _p(self.status.word), _stream()), "d3f_radius_query_ex")
+        res = (out,) if table else ()
+        for flag, t in ((want_counts, counts), (want_max, mx), (wide, wtab), (want_last_key, lkey)):
+            if flag:
+                res += (t,)
+        return res if len(res) != 1 else res[0]
 
 
 # ---------------------------------------------------------------------------------------------------------------
@@ -196,6 +206,92 @@ def grid_subsample_raw(points, lens, sampleDl, max_p=0, order=ORDER_REFERENCE, s
 
 
 # ---------------------------------------------------------------------------------------------------------------
+# reverse neighbor tables (csrc/reverse_table.hip): CSR transpose of a table, for the gather-form KPConv grad-input
+# ---------------------------------------------------------------------------------------------------------------
+class ReverseTable(object):
+    """The transpose of a neighbor table [Nq, H] over Ns supports, in one of two forms (int32 / int64 device tensors):
+      CSR    ``ent[ptr[s] : ptr[s+1]]`` = the queries that list support s, ascending (build_reverse_table);
+      search ``ent`` [Ns, width] = every query point within the radius of s, ranked, and ``last_key`` [Nq] = rank key of
+             the last entry each table row kept: q lists s iff key(q, s) <= last_key[q] (RadiusGrid.query outputs)."""
+    __slots__ = ("ptr", "ent", "last_key", "width", "Nq", "H", "Ns")
+
+    def __init__(self, ent, Nq, H, Ns, ptr=None, last_key=None):
+        if (ptr is None) == (last_key is None):
+            raise ValueError("a reverse table is either CSR (ptr) or search-form (last_key)")
+        self.ptr, self.ent, self.last_key = ptr, ent, last_key
+        self.width = int(ent.shape[1]) if ptr is None else 0
+        self.Nq, self.H, self.Ns = int(Nq), int(H), int(Ns)
+
+    def matches(self, Nq, H, Ns):
+        return (self.Nq, self.H, self.Ns) == (int(Nq), int(H), int(Ns))
+
+    def tensors(self):
+        return [t for t in (self.ptr, self.ent, self.last_key) if t is not None]
+
+    def edges(self):
+        """Number of (query, support) pairs (one host read-back; measurement only)."""
+        if self.ptr is not None:
+            return int(self.ptr[-1])
+        return int((self.ent < self.Nq).sum())
+
+
+def attach_reverse_table(neighb_inds, rev):
+    """Hand a table its transpose, so that operators given only the table (reference signatures) find it."""
+    try:
+        neighb_inds._d3f_rev = rev
+    except AttributeError:  # pragma: no cover
+        pass
+    return rev
+
+
+def build_reverse_table(neighb_inds, Ns):
+    """CSR transpose of ``neighb_inds`` [Nq, H] (int32 device table, shadow entries >= Ns) over ``Ns`` supports, for
+    tables that did not come with a search-form transpose.  Also attached to the table (``_d3f_rev``)."""
+    idx = _i32(neighb_inds, "neighb_inds")
+    Nq, H = int(idx.shape[0]), int(idx.shape[1])
+    dev = idx.device
+    ptr = torch.empty(int(Ns) + 1, dtype=torch.int32, device=dev)
+    ent = torch.empty(max(Nq * H, 1), dtype=torch.int32, device=dev)
+    L = _native.lib()
+    nbytes = L.d3f_reverse_table_ws_bytes(Nq, H, int(Ns))
+    ws = _ws(nbytes, dev)
+    with _region("reverse_table[Nq=%d,H=%d,Ns=%d]" % (Nq, H, Ns), 12 * Nq * H + 8 * Ns):
+        _native.check(L.d3f_reverse_table_build(_p(idx), Nq, H, int(Ns), _p(ptr), _p(ent), _p(ws), nbytes, _stream()),
+                      "d3f_reverse_table_build")
+    return attach_reverse_table(neighb_inds, ReverseTable(ent, Nq, H, Ns, ptr=ptr))
+
+
+def reverse_table_of(neighb_inds, Nq, H, Ns, rev=None):
+    """The reverse table to use for a table: the explicit one, else the one its builder attached; None otherwise."""
+    if rev is None:
+        rev = getattr(neighb_inds, "_d3f_rev", None)
+    if rev is not None and not rev.matches(Nq, H, Ns):
+        raise RuntimeError("reverse table of a [%d,%d] table over %d supports used with a [%d,%d] table over %d" % (
+            rev.Nq, rev.H, rev.Ns, Nq, H, Ns))
+    return rev
+
+
+# KPConv layers whose grad-input runs as a gather over the reverse table: those with at least this many SUPPORT rows.
+# Measured per layer of the S1 pair (profiles/r02b_timeline.txt vs r02a): 38k rows 177 -> 67 us, 8k rows x 64 ch
+# 84 -> 36 us, the 8k -> 2k strided layer 43 -> 29 us; at 2k rows a tie, below that the scatter (few edges, the chip
+# is filled by splitting channels, which the gather form would pay for with repeated aggregation) stays ahead.
+DX_GATHER_MIN_ROWS = 4096
+
+
+# widths of the search-form transposes (whole in-radius lists).  Conv tables: a point's uncapped neighbor count (S1:
+# mean 41, max 68 at the 80 % limit of 42); pooling tables: coarse points within the fine point's radius (mean 7, max
+# 18).  More than that sets D3F_ST_WIDE_OVERFLOW.
+REV_WIDTH_CONV = 96
+REV_WIDTH_POOL = 32
+
+
+def wants_reverse_table(Ns):
+    """Whether a table over ``Ns`` supports is worth transposing (what the pyramid builders ask)."""
+    return int(Ns) >= DX_GATHER_MIN_ROWS
+
+
+
+# ---------------------------------------------------------------------------------------------------------------
 # KPConv (models/blocks.py:237-382)
 # ---------------------------------------------------------------------------------------------------------------
 def _adoptable(t, slot):
@@ -221,10 +317,13 @@ _GEMM_DX_MAX_ROWS = 4096
 
 class _KPConvFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, q_pts, s_pts, idx, x, kernel_points, weights, extent):
+    def forward(ctx, q_pts, s_pts, idx, x, kernel_points, weights, extent, rev=None):
         L = _native.lib()
         Nq, Ns, H = int(q_pts.shape[0]), int(s_pts.shape[0]), int(idx.shape[1])
         K, Cin, Cout = int(weights.shape[0]), int(weights.shape[1]), int(weights.shape[2])
+        if rev is not None and not (Ns >= DX_GATHER_MIN_ROWS and L.d3f_kpconv_grad_input_gather_supported(Cin, Cout, K)):
+            rev = None
+        ctx.rev = rev
         out = torch.empty((Nq, Cout), dtype=torch.float32, device=x.device)
         nn = torch.empty(Nq, dtype=torch.float32, device=x.device)
         nbytes = L.d3f_kpconv_ws_bytes(Nq, Ns, H, K, Cin, Cout)
@@ -239,7 +338,7 @@ class _KPConvFn(torch.autograd.Function):
         if (ctx.needs_input_grad[3] or ctx.needs_input_grad[5]) and Nq > 0 and Ns > 0 and \
                 L.d3f_kpconv_packs_supports(Cin, Cout, K, H, Ns):
             keep = torch.empty(16 * Ns, dtype=torch.uint8, device=x.device)
-            if ctx.needs_input_grad[3]:
+            if ctx.needs_input_grad[3] and rev is None:   # (the gather form writes every row: nothing to clear)
                 gx_buf = torch.empty_like(x)
         with _region("kpconv_fwd[Nq=%d,Cin=%d,Cout=%d,H=%d]" % (Nq, Cin, Cout, H),
                      kpconv_fwd_bytes(Nq, Ns, H, K, Cin, Cout)):
@@ -273,6 +372,17 @@ class _KPConvFn(torch.autograd.Function):
         go = grad_out.contiguous().float() if (need_x or need_w) else None
         gw_native, gx_native = gw, gx
         gon = None
+        if need_x and ctx.rev is not None and Nq > 0:
+            # gather over the reverse table: aggregate grad_out/nn around every support, then contract with W^T
+            rev = ctx.rev
+            with _region("kpconv_dx_gather[Ns=%d,Cin=%d,Cout=%d]" % (Ns, Cin, Cout),
+                         kpconv_bwd_bytes(Nq, Ns, H, K, Cin, Cout)):
+                _native.check(L.d3f_kpconv_grad_input_gather(_p(q_pts), Nq, _p(s_pts), Ns, _p(rev.ptr), _p(rev.ent),
+                                                             _p(rev.last_key), rev.width, _p(kernel_points), K,
+                                                             _p(weights), Cin, Cout, ctx.extent, _p(nn), _p(go),
+                                                             _p(gx), _stream()),
+                              "d3f_kpconv_grad_input_gather")
+            gx_native = None
         if need_w and wf is not None and Nq < _SPLITK_MIN_ROWS:
             # few points, wide layers (bottom of the U-Net): grad_W = wf^T (g/nn) is an ordinary GEMM with a short
             # reduction -- a library call; the reduction-parallel kernel is for the tall-skinny upper levels
@@ -280,7 +390,7 @@ class _KPConvFn(torch.autograd.Function):
             with _region("kpconv_dw_gemm[Nq=%d,Cin=%d,Cout=%d]" % (Nq, Cin, Cout), 4 * Nq * (K * Cin + Cout)):
                 torch.mm(wf.t(), gon, out=gw.view(K * Cin, Cout))
             gw_native = None
-        if need_x and 0 < Nq < _GEMM_DX_MAX_ROWS and L.d3f_kpconv_grad_input_supported(Cin, K, H, Ns):
+        if gx_native is not None and 0 < Nq < _GEMM_DX_MAX_ROWS and L.d3f_kpconv_grad_input_supported(Cin, K, H, Ns):
             # same layers: gW = (g/nn) W^T over all queries is one library GEMM; the kernel only scatters
             if gon is None:
                 gon = go / nn.unsqueeze(1)
@@ -302,7 +412,7 @@ class _KPConvFn(torch.autograd.Function):
                                                     _p(go), _p(wf), _p(keep), pre, _p(gx_native), _p(gw_native),
                                                     _p(ws), nbytes, _stream()),
                               "d3f_kpconv_backward")
-        return None, None, None, gx, None, (_adoptable(gw, ctx.gw_slot) if gw is not None else None), None
+        return None, None, None, gx, None, (_adoptable(gw, ctx.gw_slot) if gw is not None else None), None, None
 
 
 class _KPConvGemmBiasActFn(torch.autograd.Function):
@@ -314,17 +424,20 @@ class _KPConvGemmBiasActFn(torch.autograd.Function):
     backward saves the separate g/nn pass."""
 
     @staticmethod
-    def forward(ctx, q_pts, s_pts, idx, x, kernel_points, weights, bias, extent, slope):
+    def forward(ctx, q_pts, s_pts, idx, x, kernel_points, weights, bias, extent, slope, rev=None):
         L = _native.lib()
         Nq, Ns, H = int(q_pts.shape[0]), int(s_pts.shape[0]), int(idx.shape[1])
         K, Cin, Cout = int(weights.shape[0]), int(weights.shape[1]), int(weights.shape[2])
+        if rev is not None and not (Ns >= DX_GATHER_MIN_ROWS and L.d3f_kpconv_grad_input_gather_supported(Cin, Cout, K)):
+            rev = None
+        ctx.rev = rev
         dev = x.device
         wf = torch.empty((Nq, K * Cin), dtype=torch.float32, device=dev)
         nn = torch.empty(Nq, dtype=torch.float32, device=dev)
         nbytes = L.d3f_kpconv_ws_bytes(Nq, Ns, H, K, Cin, 64)
         ws = _ws(nbytes, dev)
         keep = gx_buf = None
-        if ctx.needs_input_grad[3]:
+        if ctx.needs_input_grad[3] and rev is None:
             keep = torch.empty(16 * Ns, dtype=torch.uint8, device=dev)
             gx_buf = torch.empty_like(x)
         with _region("kpconv_aggregate[Nq=%d,Cin=%d,H=%d]" % (Nq, Cin, H), 4 * Nq * H * (4 + Cin) + 4 * Nq * K * Cin):
@@ -365,7 +478,17 @@ class _KPConvGemmBiasActFn(torch.autograd.Function):
         if ctx.needs_input_grad[5]:
             gw = ctx.gw_slot if ctx.gw_slot is not None else torch.empty_like(weights)
             torch.mm(wf.t(), gon, out=gw.view(K * Cin, Cout))
-        if ctx.needs_input_grad[3]:
+        if ctx.needs_input_grad[3] and ctx.rev is not None:
+            rev = ctx.rev   # gather form: one launch instead of the gW GEMM + atomic scatter (gon is already / nn)
+            gx = torch.empty_like(x)
+            with _region("kpconv_dx_gather[Ns=%d,Cin=%d,Cout=%d]" % (Ns, Cin, Cout),
+                         kpconv_bwd_bytes(Nq, Ns, H, K, Cin, Cout)):
+                _native.check(L.d3f_kpconv_grad_input_gather(_p(q_pts), Nq, _p(s_pts), Ns, _p(rev.ptr), _p(rev.ent),
+                                                             _p(rev.last_key), rev.width, _p(kernel_points), K,
+                                                             _p(weights), Cin, Cout, ctx.extent, None, _p(gon),
+                                                             _p(gx), _stream()),
+                              "d3f_kpconv_grad_input_gather")
+        elif ctx.needs_input_grad[3]:
             gx, ctx.gx_buf = ctx.gx_buf, None
             pre = 1 if gx is not None else 0
             if gx is None:
@@ -378,11 +501,11 @@ class _KPConvGemmBiasActFn(torch.autograd.Function):
                                                       _p(kernel_points), K, ctx.extent, _p(gwf), _p(ctx.keep), pre,
                                                       _p(gx), _p(ws), nbytes, _stream()), "d3f_kpconv_grad_input")
         return (None, None, None, gx, None, (_adoptable(gw, ctx.gw_slot) if gw is not None else None),
-                (gb.view(-1) if gb is not None else None), None, None)
+                (gb.view(-1) if gb is not None else None), None, None, None)
 
 
 def kpconv_bias_act(q_pts, s_pts, neighb_inds, x, kernel_points, weights, extent, bias, slope=0.1, influence='linear',
-                    aggregation='sum'):
+                    aggregation='sum', rev=None):
     """LeakyReLU(KPConv(x) + bias): KPConv + the bias/activation that follows it in every block
     (reference blocks.py:594-598, 668-676)."""
     if kpconv_mode(influence, aggregation) != 0:
@@ -399,8 +522,9 @@ def kpconv_bias_act(q_pts, s_pts, neighb_inds, x, kernel_points, weights, extent
             raise RuntimeError("KPConv: inconsistent shapes q%s s%s idx%s x%s W%s" % (
                 tuple(q_pts.shape), tuple(s_pts.shape), tuple(idx.shape), tuple(x.shape), tuple(w.shape)))
         b = _f32(bias, "bias") if bias is not None else None
-        return _KPConvGemmBiasActFn.apply(q_pts, s_pts, idx, x, kp, w, b, float(extent), float(slope))
-    return bias_act(kpconv(q_pts, s_pts, neighb_inds, x, kernel_points, weights, extent), bias, slope=slope)
+        rev = reverse_table_of(neighb_inds, Nq, H, int(s_pts.shape[0]), rev) if x.requires_grad else None
+        return _KPConvGemmBiasActFn.apply(q_pts, s_pts, idx, x, kp, w, b, float(extent), float(slope), rev)
+    return bias_act(kpconv(q_pts, s_pts, neighb_inds, x, kernel_points, weights, extent, rev=rev), bias, slope=slope)
 
 
 KP_INFLUENCES = {'linear': 0, 'constant': 1, 'gaussian': 2}
@@ -459,9 +583,11 @@ class _KPConvModesFn(torch.autograd.Function):
         return None, None, None, gx, None, gw, None, None
 
 
-def kpconv(q_pts, s_pts, neighb_inds, x, kernel_points, weights, extent, influence='linear', aggregation='sum'):
+def kpconv(q_pts, s_pts, neighb_inds, x, kernel_points, weights, extent, influence='linear', aggregation='sum',
+           rev=None):
     """Rigid KPConv.  Shapes as KPConv.forward (blocks.py:237); 'linear' / 'sum' (the D3Feat configuration) runs on
-    the fused kernels, the other modes of blocks.py:327-352 on the general path."""
+    the fused kernels, the other modes of blocks.py:327-352 on the general path.  ``rev``: the table's ReverseTable
+    (build_reverse_table; found on the table itself when its builder attached it): grad_x is then a gather."""
     mode = kpconv_mode(influence, aggregation)
     q_pts, s_pts, x = _f32(q_pts, "q_pts"), _f32(s_pts, "s_pts"), _f32(x, "x")
     idx = _i32(neighb_inds, "neighb_inds")
@@ -473,7 +599,11 @@ def kpconv(q_pts, s_pts, neighb_inds, x, kernel_points, weights, extent, influen
         if q_pts.shape[0] == 0 or s_pts.shape[0] == 0:
             return x.new_zeros((q_pts.shape[0], w.shape[2])) + 0.0 * (x.sum() + w.sum())
         return _KPConvModesFn.apply(q_pts, s_pts, idx, x, kp, w, float(extent), mode)
-    return _KPConvFn.apply(q_pts, s_pts, idx, x, kp, w, float(extent))
+    if x.requires_grad:
+        rev = reverse_table_of(neighb_inds, int(q_pts.shape[0]), int(idx.shape[1]), int(s_pts.shape[0]), rev)
+    else:
+        rev = None
+    return _KPConvFn.apply(q_pts, s_pts, idx, x, kp, w, float(extent), rev)
 
 
 # ---------------------------------------------------------------------------------------------------------------

@@ -253,8 +253,12 @@ class TrainStep:
             t.record_stream(self._side)
         return out
 
+    # training builds the transposes of the KPConv tables with the pyramid (gather-form grad-input); inference does not
+    reverse_tables = True
+
     def build_batch(self, item):
-        return dl.collate_fn_descriptor([item], self.config, self.limits, device=self.device, exact_width=False)
+        return dl.collate_fn_descriptor([item], self.config, self.limits, device=self.device, exact_width=False,
+                                        reverse_tables=self.reverse_tables)
 
     def _loss_from_raw(self, x, scores, batch):
         """Reference trainer.py:91-98 on the un-normalised descriptors: the 2M sampled rows are gathered and
@@ -416,18 +420,23 @@ class TrainStep:
     def _build_set(self, st):
         """Pyramid of the pair in ``st``'s input buffers -> ``st.batch`` (tensors adopted the first time, then
         overwritten in place so every graph sees the same addresses)."""
-        batch = dl.build_pyramid_static(st.pts, st.lens, self.config, self.limits, self.caps)
+        batch = dl.build_pyramid_static(st.pts, st.lens, self.config, self.limits, self.caps,
+                                        reverse_tables=self.reverse_tables)
         status = batch.pop('_status')
         if st.batch is None:
             st.batch, st.status = batch, status
             return
-        st.status.word.copy_(status.word)
+        st.status.word.bitwise_or_(status.word)   # sticky: only check_status() clears a flag (it raises)
         done = set()
         for key in ('points', 'neighbors', 'pools', 'pools_width', 'upsamples', 'stack_lengths'):
             for dst, src in zip(st.batch[key], batch[key]):
                 if dst is not None and dst.data_ptr() not in done and dst.numel():
                     dst.copy_(src)
                     done.add(dst.data_ptr())
+                    rd, rs = getattr(dst, '_d3f_rev', None), getattr(src, '_d3f_rev', None)
+                    if rd is not None and rs is not None:   # the table's transpose lives at static addresses as well
+                        for td, tsrc in zip(rd.tensors(), rs.tensors()):
+                            td.copy_(tsrc)
 
     def _set_batch(self, st):
         batch = dict(st.batch)

@@ -36,15 +36,17 @@ extern "C" {
 #define D3F_ST_CELL_RANGE 2     /* a point fell outside the +-32767-cell addressable grid */
 #define D3F_ST_TABLE_FULL 4     /* voxel hash table full (workspace sized for fewer points) */
 #define D3F_ST_CAPACITY 8       /* an output needed more rows than the caller's capacity */
+#define D3F_ST_WIDE_OVERFLOW 16 /* a point has more in-radius neighbors than the wide (reverse) table holds */
 
 const char* d3f_version(void);
 int d3f_device_arch_ok(void); /* 1 if the current HIP device is gfx950, 0 otherwise, <0 = -(hipError_t) */
 int d3f_device_arch_name(char* out, int n); /* gcnArchName of the current device */
 void d3f_debug_set_flags(int flags);      /* profiling aid: ablation switches of the fused KPConv kernels (0 = off) */
 /* measurement aid (bench.py roofline leg): HIP events on the launch stream around every launch of ONE kernel
- * (which = 1 fused KPConv forward kernel, 2 KPConv grad-input kernel) between begin and end.  end -- after the caller
- * synchronised the device -- returns the number of launches seen and fills ms_out[i] and shapes_out[6*i .. 6*i+5] =
- * {Nq, Ns, H, Cin, Cout, K} for the first `cap` of them. */
+ * (which = 1 fused KPConv forward kernel, 2 scatter-form grad-input kernel, 3 gather-form grad-input kernel; or,
+ * negative, minus a bit mask of several: -(1 | 2 | 4)) between begin and end.  end -- after the caller synchronised
+ * the device -- returns the number of launches seen and fills ms_out[i] and shapes_out[6*i .. 6*i+5] =
+ * {Nq, Ns, H, Cin, Cout, K | which << 8} for the first `cap` of them. */
 int d3f_debug_kernel_timing_begin(int which, int max_launches);
 int d3f_debug_kernel_timing_end(float* ms_out, int32_t* shapes_out, int cap);
 
@@ -66,6 +68,20 @@ int d3f_radius_grid_build(const float* supports, int Ns, const int32_t* s_len, i
 int d3f_radius_query(const void* grid_ws, const float* queries, int Nq, const int32_t* q_len,
                      const float* supports, int Ns, const int32_t* s_len, int B, float radius, int width,
                      int32_t* out_idx, int32_t* out_counts, int32_t* max_count, int32_t* status, void* stream);
+
+/* Extended query.  radius <= grid_radius: a search with a smaller radius on a cell list built for grid_radius (the
+ * 27-cell scan is a superset).  Optional extra outputs, for the gather-form KPConv grad-input (no reference
+ * counterpart -- autograd scatters):
+ *   out_wide [Nq, wide_width]: the WHOLE ranked list of every query, padded with Ns (more than wide_width entries
+ *     sets D3F_ST_WIDE_OVERFLOW);
+ *   out_last_key [Nq] uint64: rank key (d2 bits << 32 | index) of the last entry the capped row (width) keeps, ~0 when
+ *     the row keeps every candidate.  s is listed by query q  <=>  d2(q,s) < r2 and key(q,s) <= last_key[q], which
+ *     makes the wide list of a point s over the QUERY cloud, filtered by that test, the transpose of the capped
+ *     table (the in-radius relation is symmetric and d2 is bit-identical both ways). */
+int d3f_radius_query_ex(const void* grid_ws, const float* queries, int Nq, const int32_t* q_len, int Ns,
+                        const int32_t* s_len, int B, float grid_radius, float radius, int width, int32_t* out_idx,
+                        int32_t* out_counts, int32_t* max_count, int32_t* out_wide, int wide_width,
+                        uint64_t* out_last_key, int32_t* status, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Grid subsampling -- replaces grid_subsampling.subsample_batch, points-only branch
@@ -114,6 +130,27 @@ int d3f_kpconv_backward(const float* q_pts, int Nq, const float* s_pts, int Ns, 
                         float extent, const float* nn, const float* grad_out, const float* wf_saved,
                         const void* spack_kept, int grad_x_precleared, float* grad_x, float* grad_w, void* ws,
                         size_t ws_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Reverse neighbor table + gather-form grad-input of KPConv -- replaces the scatter-add (index_add_) autograd runs
+ *   for the gathers of models/blocks.py:277-280,356-359 in backward.
+ * d3f_reverse_table_build: CSR transpose of idx [Nq,H] over Ns supports (entries outside [0,Ns) are shadow):
+ *   rev_ent[rev_ptr[s] .. rev_ptr[s+1]) = the queries that list support s, ascending; rev_ptr [Ns+1], rev_ent [Nq*H].
+ *   Deterministic.  Built once per table (next to the radius search) and reused by every layer on that table.
+ * d3f_kpconv_grad_input_gather: grad_x [Ns,Cin] = sum_k (sum_{q in rev(s)} w(q,s,k) grad_out[q,:]/nn[q]) @ W[k]^T
+ *   (OVERWRITTEN; no atomics, bit-reproducible).  nn may be NULL (grad_out already divided).  rev(s) comes in one of
+ *   two forms: CSR (rev_ptr + rev_ent, rev_last_key NULL) or the search's own output (rev_ptr NULL): rev_ent =
+ *   out_wide [Ns, rev_width] of a d3f_radius_query_ex of the SUPPORT points over the QUERY cloud with the table's
+ *   radius, rev_last_key = out_last_key [Nq] of the query that produced the table -- no transposition pass at all.
+ * ---------------------------------------------------------------------------------------------- */
+size_t d3f_reverse_table_ws_bytes(int Nq, int H, int Ns);
+int d3f_reverse_table_build(const int32_t* idx, int Nq, int H, int Ns, int32_t* rev_ptr, int32_t* rev_ent, void* ws,
+                            size_t ws_bytes, void* stream);
+int d3f_kpconv_grad_input_gather_supported(int Cin, int Cout, int K);
+int d3f_kpconv_grad_input_gather(const float* q_pts, int Nq, const float* s_pts, int Ns, const int32_t* rev_ptr,
+                                 const int32_t* rev_ent, const uint64_t* rev_last_key, int rev_width,
+                                 const float* kernel_points, int K, const float* weights, int Cin, int Cout,
+                                 float extent, const float* nn, const float* grad_out, float* grad_x, void* stream);
 
 /* grad_x alone, from gwf = (grad_out / nn) @ W^T  [Nq, K*Cin] computed by the caller (an ordinary GEMM: the right
  * tool for the few-point / 256..512-channel layers at the bottom of the U-Net, where the fused kernel's own gW tile

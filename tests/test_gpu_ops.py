@@ -150,6 +150,125 @@ def test_kpconv_forward_backward(nq, ns, h, cin, cout, gemm_dx_rows, monkeypatch
     assert rel_err(out32.cpu().numpy(), out.detach().cpu().numpy()) < 1e-6  # atomically combined partial sums
 
 
+@pytest.mark.parametrize("nq,h,ns", [(1000, 42, 900), (37, 5, 4000), (3000, 64, 70), (1, 1, 1), (500, 42, 500)])
+def test_reverse_table_is_the_sorted_transpose(nq, h, ns):
+    """rev.ent[rev.ptr[s]:rev.ptr[s+1]] = ascending list of the queries whose row holds s (shadow entries skipped)."""
+    rng = np.random.default_rng(nq + h)
+    idx = np.stack([rng.permutation(max(ns, h) + 3)[:h] for _ in range(nq)]).astype(np.int32)  # no repeats within a row
+    idx[idx >= ns] = ns                                                                       # -> shadow entries
+    if ns == 70:
+        idx[:, 0] = 7   # one support listed by every query: a 3000-entry row (the > 64 path of the sort kernel)
+    tab = cu(idx)
+    rev = ops.build_reverse_table(tab, ns)
+    assert getattr(tab, "_d3f_rev") is rev and rev.edges() == int((idx < ns).sum())
+    ptr, ent = rev.ptr.cpu().numpy(), rev.ent.cpu().numpy()
+    qs, hs = np.nonzero(idx < ns)
+    order = np.lexsort((qs, idx[qs, hs]))
+    counts = np.bincount(idx[qs, hs], minlength=ns)
+    assert np.array_equal(ptr, np.concatenate([[0], np.cumsum(counts)]))
+    assert np.array_equal(ent[:ptr[-1]], qs[order])
+    again = ops.build_reverse_table(cu(idx), ns)
+    assert torch.equal(again.ent[:int(ptr[-1])], rev.ent[:int(ptr[-1])])
+
+
+def _rev_sets_csr(rev):
+    ptr, ent = rev.ptr.cpu().numpy(), rev.ent.cpu().numpy()
+    return [set(ent[ptr[s]:ptr[s + 1]].tolist()) for s in range(rev.Ns)]
+
+
+def _rev_sets_search(rev, q, s, r):
+    """Decode a search-form transpose on the host: entries of row s that pass key(q,s) <= last_key[q]."""
+    ent, lk = rev.ent.cpu().numpy(), rev.last_key.cpu().numpy().view(np.uint64)
+    out = []
+    for si in range(rev.Ns):
+        row = ent[si][ent[si] < rev.Nq]
+        d = (q[row] - s[si]).astype(np.float32)
+        d2 = ((d[:, 0] * d[:, 0] + d[:, 1] * d[:, 1]).astype(np.float32) + d[:, 2] * d[:, 2]).astype(np.float32)
+        key = (d2.view(np.uint32).astype(np.uint64) << np.uint64(32)) | np.uint64(si)
+        out.append(set(row[key <= lk[row]].tolist()))
+    return out
+
+
+@pytest.mark.parametrize("n0,n1,r,lim", [(2500, 1800, 0.11, 20), (1500, 1, 0.2, 42), (3000, 2000, 0.07, 8)])
+def test_search_form_transpose_equals_the_csr_transpose(n0, n1, r, lim):
+    """The whole ranked list of s, filtered by key(q,s) <= last_key[q], is exactly the set of queries whose CAPPED row
+    lists s -- for a cloud searched against itself (conv tables) and for coarse-over-fine tables (pooling)."""
+    rng = np.random.default_rng(n0)
+    lens = np.array([n0, n1], np.int32)
+    fine = _cloud(rng, n0 + n1)
+    coarse, clen = dl.batch_grid_subsampling_kpconv(cu(fine), cu(lens), sampleDl=r * 0.8)
+    coarse_np = coarse.cpu().numpy()
+    g_fine = ops.RadiusGrid(cu(fine), cu(lens), r)
+    # conv: same cloud both ways
+    tab, wide, lk = g_fine.query(cu(fine), cu(lens), lim, wide=ops.REV_WIDTH_CONV * 2, want_last_key=True)
+    rev = ops.ReverseTable(wide, n0 + n1, lim, n0 + n1, last_key=lk)
+    csr = ops.build_reverse_table(tab, n0 + n1)
+    assert _rev_sets_search(rev, fine, fine, r) == _rev_sets_csr(csr)
+    assert int((tab < n0 + n1).sum()) == rev.edges() or lim < int((wide < n0 + n1).sum(1).max())   # truncation happened
+    # pooling: queries = coarse points, supports = fine points; transpose = fine points searched over the coarse cloud
+    tabp, lkp = g_fine.query(coarse, clen, lim, want_last_key=True)
+    g_coarse = ops.RadiusGrid(coarse, clen, 2 * r)
+    widep = g_coarse.query(cu(fine), cu(lens), 1, radius=r, wide=64, table=False)
+    revp = ops.ReverseTable(widep, coarse.shape[0], lim, n0 + n1, last_key=lkp)
+    csrp = ops.build_reverse_table(tabp, n0 + n1)
+    assert _rev_sets_search(revp, coarse_np, fine, r) == _rev_sets_csr(csrp)
+    g_fine.status.raise_if_set()
+    g_coarse.status.raise_if_set()
+    # and the two forms give the same gradient, bit for bit up to summation order inside a row
+    x = cu(rng.normal(size=(n0 + n1, 32)).astype(np.float32))
+    w = cu((rng.normal(size=(15, 32, 32)) / 20).astype(np.float32))
+    kp = cu((rng.normal(size=(15, 3)) * r / 3).astype(np.float32))
+    go = cu(rng.normal(size=(n0 + n1, 32)).astype(np.float32))
+    grads = []
+    for rv in (rev, csr):
+        gx = x.clone().requires_grad_(True)
+        ops.kpconv(cu(fine), cu(fine), tab, gx, kp, w, r * 0.8, rev=rv).backward(go)
+        grads.append(gx.grad)
+    assert rel_err(grads[0].cpu().numpy(), grads[1].cpu().numpy()) < 1e-5
+
+
+@pytest.mark.parametrize("nq,ns,h,cin,cout", [(1000, 1000, 42, 32, 32), (333, 1000, 37, 64, 64), (4500, 4500, 42, 64, 64),
+                                              (257, 300, 45, 128, 128), (97, 154, 23, 512, 512), (300, 400, 42, 16, 16),
+                                              (300, 400, 40, 32, 64), (150, 160, 42, 256, 128), (2100, 2100, 42, 64, 32),
+                                              (571, 2053, 42, 128, 128), (5000, 900, 64, 32, 32)])
+def test_kpconv_grad_input_as_a_gather_over_the_reverse_table(nq, ns, h, cin, cout, monkeypatch):
+    """grad_x = sum_k (sum_{q in rev(s)} w gn[q]) W[k]^T  ==  the oracle's autograd gradient; bit-identical run to run
+    (no atomics), on the fused path and on the aggregate + GEMM path of the few-point layers."""
+    monkeypatch.setattr(ops, "DX_GATHER_MIN_ROWS", 0)   # (the training step uses it from 4096 support rows)
+    rng = np.random.default_rng(nq + cin)
+    q, s, idx, x, kp, w = _kpconv_case(rng, nq, ns, h, cin, cout)
+    ext = 0.05
+    tx = torch.from_numpy(x).requires_grad_(True)
+    ref = ops_ref.kpconv(torch.from_numpy(q), torch.from_numpy(s), torch.from_numpy(idx), tx, torch.from_numpy(kp),
+                         torch.from_numpy(w), ext)
+    go = torch.from_numpy(rng.normal(size=ref.shape).astype(np.float32))
+    ref.backward(go)
+    tab = cu(idx, torch.int32)
+    rev = ops.build_reverse_table(tab, ns)
+    grads = []
+    for _ in range(2):
+        gx, gw = cu(x).requires_grad_(True), cu(w).requires_grad_(True)
+        out = ops.kpconv(cu(q), cu(s), tab, gx, cu(kp), gw, ext)          # finds the table's transpose on the table
+        out.backward(cu(go))
+        grads.append(gx.grad.clone())
+    assert rel_err(out.detach().cpu().numpy(), ref.detach().numpy()) < FWD_TOL
+    assert rel_err(grads[0].cpu().numpy(), tx.grad.numpy()) < BWD_TOL
+    assert torch.equal(grads[0], grads[1])
+    # block form (KPConv + bias + LeakyReLU), explicit rev argument, int64 table as the reference hands it
+    bias = cu(rng.normal(size=cout).astype(np.float32))
+    gx = cu(x).requires_grad_(True)
+    y = ops.kpconv_bias_act(cu(q), cu(s), cu(idx), gx, cu(kp), cu(w), ext, bias, slope=0.1, rev=rev)
+    y.backward(cu(go))
+    tx2 = torch.from_numpy(x).requires_grad_(True)
+    r2 = torch.nn.functional.leaky_relu(ops_ref.kpconv(torch.from_numpy(q), torch.from_numpy(s), torch.from_numpy(idx), tx2,
+                                                        torch.from_numpy(kp), torch.from_numpy(w), ext) + bias.cpu(), 0.1)
+    r2.backward(go)
+    assert rel_err(y.detach().cpu().numpy(), r2.detach().numpy()) < FWD_TOL
+    assert rel_err(gx.grad.cpu().numpy(), tx2.grad.numpy()) < BWD_TOL
+    with pytest.raises(RuntimeError):   # a transpose of another table is refused
+        ops.kpconv(cu(q)[:-1], cu(s), tab[:-1], cu(x).requires_grad_(True), cu(kp), cu(w), ext, rev=rev)
+
+
 @pytest.mark.parametrize("nq,ns,h,cin,cout", [(1000, 1000, 42, 32, 32), (97, 154, 23, 512, 512), (300, 400, 42, 16, 16),
                                               (150, 160, 42, 256, 128), (200, 260, 42, 24, 40)])
 @pytest.mark.parametrize("min_rows", [1, 1 << 30])  # reduction-parallel kernel / library GEMM for grad_W
