@@ -45,7 +45,7 @@ SIGNATURES = {
     "d3f_reverse_table_ws_bytes": (_sz, [_i, _i, _i]),
     "d3f_reverse_table_build": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _sz, _vp]),
     "d3f_kpconv_grad_input_gather_supported": (_i, [_i, _i, _i]),
-    "d3f_kpconv_grad_input_gather": (_i, [_vp, _i, _vp, _i, _vp, _vp, _vp, _i, _vp, _i, _vp, _i, _i, _f, _vp, _vp, _vp, _vp]),
+    "d3f_kpconv_grad_input_gather": (_i, [_vp, _i, _vp, _i, _vp, _vp, _vp, _i, _f, _vp, _i, _vp, _i, _i, _f, _vp, _vp, _vp, _vp, _vp]),
     "d3f_linear_grad_weight_supported": (_i, [_i, _i, _i]),
     "d3f_linear_fused_supported": (_i, [_i, _i, _i]),
     "d3f_linear_bias_act_forward": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp, _f, _vp, _vp, _i, _vp]),

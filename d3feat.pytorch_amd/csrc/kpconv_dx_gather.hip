@@ -32,6 +32,8 @@ struct RevTest {
   const uint64_t* last_key;  // null: CSR form, every entry counts
   float sx, sy, sz;
   unsigned s;
+  float r2;                  // > 0: the row comes from a search with a LARGER radius (the upsampling table of a pooling
+                             // layer, radius 2r): only its entries with d2 < r2 belong to the transposed table
 };
 
 template <int CV, int NSTEPS>
@@ -54,7 +56,7 @@ __device__ __forceinline__ void dxg_chunk(int n_lane, bool lane_live, __amdgpu_b
   if (rt.last_key && lane_live) {
     const float d2 = sqdist_exact(qx, qy, qz, rt.sx, rt.sy, rt.sz);
     const uint64_t key = ((uint64_t)__float_as_uint(d2) << 32) | rt.s;
-    lane_live = key <= rt.last_key[n_lane];
+    lane_live = key <= rt.last_key[n_lane] && (rt.r2 <= 0.0f || d2 < rt.r2);
   }
   const float inn = lane_live ? (has_nn ? 1.0f / nnv : 1.0f) : 0.0f;
 #pragma unroll
@@ -76,7 +78,8 @@ __global__ __launch_bounds__(256) void kpconv_dx_gather_kernel(
     const float* __restrict__ s_pts, const float* __restrict__ q_pts, const int32_t* __restrict__ rev_ptr,
     const int32_t* __restrict__ rev_ent, const float* __restrict__ gout, const float* __restrict__ nn,
     const float* __restrict__ kp, const float* __restrict__ W, int Ns, int Nq, int Cin, int Cout, int K, float extent,
-    float* __restrict__ gx, const uint64_t* __restrict__ last_key, int rev_width) {
+    float* __restrict__ gx, const uint64_t* __restrict__ last_key, int rev_width, float rev_r2,
+    int32_t* __restrict__ status) {
   constexpr int CC = 16 * CV;
   constexpr int WN = 4 / WK;
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -127,13 +130,22 @@ __global__ __launch_bounds__(256) void kpconv_dx_gather_kernel(
         const int end = rev_ptr ? __builtin_amdgcn_readfirstlane(rev_ptr[s + 1]) : beg + rev_width;
         const float sx = s_pts[3 * (size_t)s + 0], sy = s_pts[3 * (size_t)s + 1], sz = s_pts[3 * (size_t)s + 2];
         const float cx = sx - kx, cy = sy - ky, cz = sz - kz;
-        const RevTest rt = {last_key, sx, sy, sz, (unsigned)s};
+        const RevTest rt = {last_key, sx, sy, sz, (unsigned)s, rev_r2};
         for (int c0 = beg; c0 < end; c0 += 64) {
           int rem = end - c0;
           int n = lane < rem ? min(max(rev_ent[(size_t)c0 + lane], 0), Nq) : Nq;
           if (!rev_ptr) {  // table form: the live prefix of this chunk
             rem = __popcll(__ballot(n < Nq));
             if (rem == 0) break;
+            if (rev_r2 > 0.0f && status && ch == 0 && c0 + 64 >= end) {
+              // a full row of the wider search whose last entry is still within r: members may have been cut off
+              const int last = __shfl(n, (end - c0 - 1) & 63, 64);
+              if (last < Nq && lane == 0) {
+                const float d2 = sqdist_exact(q_pts[3 * (size_t)last], q_pts[3 * (size_t)last + 1],
+                                              q_pts[3 * (size_t)last + 2], sx, sy, sz);
+                if (d2 < rev_r2) atomicOr(status, D3F_ST_WIDE_OVERFLOW);
+              }
+            }
           }
           const bool live = lane < rem && n < Nq;
           const int steps = (min(rem, 64) + 15) >> 4;
@@ -230,8 +242,8 @@ bool kpconv_dx_gather_supported(int Cin, int Cout, int K) {
 template <int CV>
 static int launch_dxg(const float* s_pts, const float* q_pts, const int32_t* rev_ptr, const int32_t* rev_ent,
                       const float* gout, const float* nn, const float* kp, const float* W, int Ns, int Nq, int Cin,
-                      int Cout, int K, float extent, float* gx, const uint64_t* last_key, int rev_width,
-                      hipStream_t stream) {
+                      int Cout, int K, float extent, float* gx, const uint64_t* last_key, int rev_width, float rev_r2,
+                      int32_t* status, hipStream_t stream) {
   const int tiles = cdiv(Ns, 16);
   constexpr int CC = 16 * CV;
   const size_t lds_base = sizeof(float) * (size_t)(16 * (16 * CC + 4));
@@ -243,7 +255,7 @@ static int launch_dxg(const float* s_pts, const float* q_pts, const int32_t* rev
     dim3 grid(tiles, Cin / slab);                                                                                   \
     kpconv_dx_gather_kernel<CV, NBW, WK><<<grid, 256, lds, stream>>>(s_pts, q_pts, rev_ptr, rev_ent, gout, nn, kp, W, \
                                                                       Ns, Nq, Cin, Cout, K, extent, gx, last_key,    \
-                                                                      rev_width);                                    \
+                                                                      rev_width, rev_r2, status);                    \
   }
   void* timing = kpconv_timing_open(3, stream, Nq, Ns, 0, Cin, Cout, K);
   switch (slab) {
@@ -270,9 +282,10 @@ int d3f_kpconv_grad_input_gather_supported(int Cin, int Cout, int K) {
 }
 
 int d3f_kpconv_grad_input_gather(const float* q_pts, int Nq, const float* s_pts, int Ns, const int32_t* rev_ptr,
-                                 const int32_t* rev_ent, const uint64_t* rev_last_key, int rev_width,
+                                 const int32_t* rev_ent, const uint64_t* rev_last_key, int rev_width, float rev_radius,
                                  const float* kernel_points, int K, const float* weights, int Cin, int Cout,
-                                 float extent, const float* nn, const float* grad_out, float* grad_x, void* stream) {
+                                 float extent, const float* nn, const float* grad_out, float* grad_x, int32_t* status,
+                                 void* stream) {
   if (!q_pts || !s_pts || !rev_ent || !kernel_points || !weights || !grad_out || !grad_x || Nq < 0 || Ns < 0 ||
       !d3f::kpconv_dx_gather_supported(Cin, Cout, K) || !(extent > 0.0f))
     return D3F_EINVAL;
@@ -281,11 +294,12 @@ int d3f_kpconv_grad_input_gather(const float* q_pts, int Nq, const float* s_pts,
   if ((double)Nq * Cout * 4.0 >= 4294967295.0 || (!rev_ptr && (double)Ns * rev_width >= 2147483647.0)) return D3F_EINVAL;
   if (Ns == 0) return D3F_OK;
   hipStream_t st = (hipStream_t)stream;
+  const float rev_r2 = rev_radius > 0.0f ? rev_radius * rev_radius : 0.0f;  // float32 product, like the search
   if (Cout == 16)
-    return d3f::launch_dxg<1>(s_pts, q_pts, rev_ptr, rev_ent, grad_out, nn, kernel_points, weights, Ns, Nq, Cin, Cout, K, extent, grad_x, rev_last_key, rev_width, st);
+    return d3f::launch_dxg<1>(s_pts, q_pts, rev_ptr, rev_ent, grad_out, nn, kernel_points, weights, Ns, Nq, Cin, Cout, K, extent, grad_x, rev_last_key, rev_width, rev_r2, status, st);
   if (Cout == 32)
-    return d3f::launch_dxg<2>(s_pts, q_pts, rev_ptr, rev_ent, grad_out, nn, kernel_points, weights, Ns, Nq, Cin, Cout, K, extent, grad_x, rev_last_key, rev_width, st);
-  return d3f::launch_dxg<4>(s_pts, q_pts, rev_ptr, rev_ent, grad_out, nn, kernel_points, weights, Ns, Nq, Cin, Cout, K, extent, grad_x, rev_last_key, rev_width, st);
+    return d3f::launch_dxg<2>(s_pts, q_pts, rev_ptr, rev_ent, grad_out, nn, kernel_points, weights, Ns, Nq, Cin, Cout, K, extent, grad_x, rev_last_key, rev_width, rev_r2, status, st);
+  return d3f::launch_dxg<4>(s_pts, q_pts, rev_ptr, rev_ent, grad_out, nn, kernel_points, weights, Ns, Nq, Cin, Cout, K, extent, grad_x, rev_last_key, rev_width, rev_r2, status, st);
 }
 
 }  // extern "C"

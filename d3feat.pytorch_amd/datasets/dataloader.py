@@ -126,22 +126,24 @@ def _conv_table(grid_for, pts, lens, level, e, lim, reverse_tables):
     return tab
 
 
-def _pool_table(grid_for, pts, lens, level, e, lim, reverse_tables):
-    """(pools[l], device max count) (dataloader.py:141-147); the transpose (coarse points around every fine point) is one
-    more search of the fine points over the coarse cloud's cell list (built for the upsampling radius 2r anyway)."""
+def _pool_tables(grid_for, pts, lens, level, e, lim, reverse_tables, status):
+    """(pools[l], device max count, upsamples[l]) (dataloader.py:141-152).  The transpose of the pooling table (coarse
+    points around every fine point, radius r) is the leading part of the rows of the upsampling table (same point
+    pairs, radius 2r, nearest first): nothing extra is searched, the pooling query only adds its last-kept keys."""
     grid = grid_for(level, e['pool_r'])
     ns = pts[level].shape[0]
+    up = grid_for(level + 1, e['up_r']).query(pts[level], lens[level], lim)
     if not (reverse_tables and ops.wants_reverse_table(ns)):
-        return grid.query(pts[level + 1], lens[level + 1], lim, want_max=True)
+        tab, mx = grid.query(pts[level + 1], lens[level + 1], lim, want_max=True)
+        return tab, mx, up
     tab, mx, lkey = grid.query(pts[level + 1], lens[level + 1], lim, want_max=True, want_last_key=True)
-    wide = grid_for(level + 1, e['up_r']).query(pts[level], lens[level], 1, radius=e['pool_r'],
-                                                wide=ops.REV_WIDTH_POOL, table=False)
-    ops.attach_reverse_table(tab, ops.ReverseTable(wide, pts[level + 1].shape[0], lim, ns, last_key=lkey))
-    return tab, mx
+    ops.attach_reverse_table(tab, ops.ReverseTable(up, pts[level + 1].shape[0], lim, ns, last_key=lkey,
+                                                   radius=e['pool_r'], status=status))
+    return tab, mx, up
 
 
 def build_pyramid_static(points, lengths, config, neighborhood_limits, capacities, order=ops.ORDER_REFERENCE,
-                         reverse_tables=False):
+                         reverse_tables=False, status=None):
     """Capacity-shaped pyramid: every level l has ``capacities[l]`` rows, the live row counts stay on the device.
 
     No host synchronisation at all (hipGraph-capturable): voxel levels write into fixed-capacity buffers (rows past
@@ -150,7 +152,7 @@ def build_pyramid_static(points, lengths, config, neighborhood_limits, capacitie
     live row.  A level outgrowing its capacity sets D3F_ST_CAPACITY in the returned status word."""
     dev = points.device
     walk = _Walk(config)
-    status = ops.DeviceStatus(dev)
+    status = status if status is not None else ops.DeviceStatus(dev)   # (a caller's word collects flags across builds)
     pts, lens = [points], [ops._lens(lengths, dev, "lengths")]
     for e in walk.layers:
         if e['pool']:
@@ -175,10 +177,10 @@ def build_pyramid_static(points, lengths, config, neighborhood_limits, capacitie
         if e['pool']:
             # static width = the limit; the reference trims to min(limit, max_count) (dataloader.py:64-66).  Only max_pool
             # can tell the difference (a full row gains zero-valued shadow candidates): it gets max_count, on the device
-            tab, mx = _pool_table(grid_for, pts, lens, level, e, lim, reverse_tables)
+            tab, mx, up = _pool_tables(grid_for, pts, lens, level, e, lim, reverse_tables, status)
             pools.append(tab)
             pools_width.append(mx)
-            upsamples.append(grid_for(level + 1, e['up_r']).query(pts[level], lens[level], lim))
+            upsamples.append(up)
             level += 1
         else:
             pools.append(empty_idx)
@@ -227,6 +229,7 @@ def build_pyramid(points, lengths, config, neighborhood_limits, index_dtype=torc
 
     empty_idx = torch.zeros((0, 1), dtype=index_dtype, device=dev)
     neighbors, pools, pools_width, upsamples, maxima = [], [], [], [], []
+    search_form = reverse_tables and not exact_width and index_dtype == torch.int32
     level = 0
     for li, e in enumerate(walk.layers):
         lim = int(neighborhood_limits[li])
@@ -243,6 +246,19 @@ def build_pyramid(points, lengths, config, neighborhood_limits, index_dtype=torc
                 return run(qlevel, slevel, radius), None
             return grid_for(slevel, radius).query(pts[qlevel], lens[qlevel], lim, want_max=True)
 
+        if search_form:   # the training path: tables at the limit's width + their transposes straight from the searches
+            neighbors.append(_conv_table(grid_for, pts, lens, level, e, lim, True))
+            if e['pool']:
+                tab, tab_width, up = _pool_tables(grid_for, pts, lens, level, e, lim, True, status)
+                pools.append(tab)
+                pools_width.append(tab_width)
+                upsamples.append(up)
+                level += 1
+            else:
+                pools.append(empty_idx)
+                pools_width.append(None)
+                upsamples.append(empty_idx)
+            continue
         neighbors.append(run(level, level, e['conv_r']) if e['conv_r'] is not None else empty_idx)
         if e['pool']:
             tab, tab_width = run_pool(level + 1, level, e['pool_r'])
@@ -268,8 +284,8 @@ def build_pyramid(points, lengths, config, neighborhood_limits, index_dtype=torc
                     raise RuntimeError("Error")
                 if w < lst[li].shape[1]:
                     lst[li] = lst[li][:, :w].contiguous()
-    if reverse_tables and index_dtype == torch.int32:
-        # transposes of the tables KPConv runs on (conv + pooling), for the gather-form grad-input; attached to the
+    if reverse_tables and not search_form and index_dtype == torch.int32:
+        # reference-width (trimmed) tables: CSR transposes of the tables KPConv runs on (conv + pooling), attached to the
         # tables themselves (ops.build_reverse_table), so the batch dict keeps the reference's keys
         level = 0
         for li, e in enumerate(walk.layers):

@@ -213,12 +213,15 @@ class ReverseTable(object):
       CSR    ``ent[ptr[s] : ptr[s+1]]`` = the queries that list support s, ascending (build_reverse_table);
       search ``ent`` [Ns, width] = every query point within the radius of s, ranked, and ``last_key`` [Nq] = rank key of
              the last entry each table row kept: q lists s iff key(q, s) <= last_key[q] (RadiusGrid.query outputs)."""
-    __slots__ = ("ptr", "ent", "last_key", "width", "Nq", "H", "Ns")
+    __slots__ = ("ptr", "ent", "last_key", "width", "Nq", "H", "Ns", "radius", "status")
 
-    def __init__(self, ent, Nq, H, Ns, ptr=None, last_key=None):
+    def __init__(self, ent, Nq, H, Ns, ptr=None, last_key=None, radius=0.0, status=None):
         if (ptr is None) == (last_key is None):
             raise ValueError("a reverse table is either CSR (ptr) or search-form (last_key)")
         self.ptr, self.ent, self.last_key = ptr, ent, last_key
+        # radius > 0: `ent` comes from a search with a larger radius (an upsampling table); only its entries within
+        # `radius` count.  status: DeviceStatus that receives D3F_ST_WIDE_OVERFLOW if such a row was cut short.
+        self.radius, self.status = float(radius), status
         self.width = int(ent.shape[1]) if ptr is None else 0
         self.Nq, self.H, self.Ns = int(Nq), int(H), int(Ns)
 
@@ -232,7 +235,7 @@ class ReverseTable(object):
         """Number of (query, support) pairs (one host read-back; measurement only)."""
         if self.ptr is not None:
             return int(self.ptr[-1])
-        return int((self.ent < self.Nq).sum())
+        return int((self.ent < self.Nq).sum())   # (an upper bound when radius > 0)
 
 
 def attach_reverse_table(neighb_inds, rev):
@@ -278,11 +281,10 @@ def reverse_table_of(neighb_inds, Nq, H, Ns, rev=None):
 DX_GATHER_MIN_ROWS = 4096
 
 
-# widths of the search-form transposes (whole in-radius lists).  Conv tables: a point's uncapped neighbor count (S1:
-# mean 41, max 68 at the 80 % limit of 42); pooling tables: coarse points within the fine point's radius (mean 7, max
-# 18).  More than that sets D3F_ST_WIDE_OVERFLOW.
+# width of the search-form transpose of a conv table (the whole in-radius list of a point; S1: mean 41, max 68 at the
+# 80 % limit of 42).  More than that sets D3F_ST_WIDE_OVERFLOW.  A pooling table's transpose is read off the
+# upsampling table (coarse points within 2r of a fine point, nearest first: those within r -- mean 7, max 18 -- lead).
 REV_WIDTH_CONV = 96
-REV_WIDTH_POOL = 32
 
 
 def wants_reverse_table(Ns):
@@ -378,9 +380,11 @@ class _KPConvFn(torch.autograd.Function):
             with _region("kpconv_dx_gather[Ns=%d,Cin=%d,Cout=%d]" % (Ns, Cin, Cout),
                          kpconv_bwd_bytes(Nq, Ns, H, K, Cin, Cout)):
                 _native.check(L.d3f_kpconv_grad_input_gather(_p(q_pts), Nq, _p(s_pts), Ns, _p(rev.ptr), _p(rev.ent),
-                                                             _p(rev.last_key), rev.width, _p(kernel_points), K,
-                                                             _p(weights), Cin, Cout, ctx.extent, _p(nn), _p(go),
-                                                             _p(gx), _stream()),
+                                                             _p(rev.last_key), rev.width, rev.radius,
+                                                             _p(kernel_points), K, _p(weights), Cin, Cout, ctx.extent,
+                                                             _p(nn), _p(go), _p(gx),
+                                                             _p(rev.status.word) if rev.status is not None else None,
+                                                             _stream()),
                               "d3f_kpconv_grad_input_gather")
             gx_native = None
         if need_w and wf is not None and Nq < _SPLITK_MIN_ROWS:
@@ -484,9 +488,11 @@ class _KPConvGemmBiasActFn(torch.autograd.Function):
             with _region("kpconv_dx_gather[Ns=%d,Cin=%d,Cout=%d]" % (Ns, Cin, Cout),
                          kpconv_bwd_bytes(Nq, Ns, H, K, Cin, Cout)):
                 _native.check(L.d3f_kpconv_grad_input_gather(_p(q_pts), Nq, _p(s_pts), Ns, _p(rev.ptr), _p(rev.ent),
-                                                             _p(rev.last_key), rev.width, _p(kernel_points), K,
-                                                             _p(weights), Cin, Cout, ctx.extent, None, _p(gon),
-                                                             _p(gx), _stream()),
+                                                             _p(rev.last_key), rev.width, rev.radius,
+                                                             _p(kernel_points), K, _p(weights), Cin, Cout, ctx.extent,
+                                                             None, _p(gon), _p(gx),
+                                                             _p(rev.status.word) if rev.status is not None else None,
+                                                             _stream()),
                               "d3f_kpconv_grad_input_gather")
         elif ctx.needs_input_grad[3]:
             gx, ctx.gx_buf = ctx.gx_buf, None

@@ -417,16 +417,19 @@ class TrainStep:
         st.dk.copy_(dk, non_blocking=True)
         st.mask.copy_(st.dk > self.circle.safe_radius)   # with the upload, off the training stream (utils/loss.py:119)
 
-    def _build_set(self, st):
-        """Pyramid of the pair in ``st``'s input buffers -> ``st.batch`` (tensors adopted the first time, then
-        overwritten in place so every graph sees the same addresses)."""
+    def _build_set(self, st, adopt=False):
+        """Pyramid of the pair in ``st``'s input buffers -> ``st.batch``.  Every kernel of the build ORs its flags into
+        the set's own status word, which only ``check_status`` reads (sticky).  ``adopt`` (the first build, and the
+        captured one: a graph's outputs have static addresses) makes the new tensors the set's batch; otherwise they
+        are copied into the existing ones so that an already captured network graph keeps seeing its addresses."""
+        if st.status is None:
+            st.status = ops.DeviceStatus(self.device)
         batch = dl.build_pyramid_static(st.pts, st.lens, self.config, self.limits, self.caps,
-                                        reverse_tables=self.reverse_tables)
-        status = batch.pop('_status')
-        if st.batch is None:
-            st.batch, st.status = batch, status
+                                        reverse_tables=self.reverse_tables, status=st.status)
+        batch.pop('_status')
+        if st.batch is None or adopt:
+            st.batch = batch
             return
-        st.status.word.bitwise_or_(status.word)   # sticky: only check_status() clears a flag (it raises)
         done = set()
         for key in ('points', 'neighbors', 'pools', 'pools_width', 'upsamples', 'stack_lengths'):
             for dst, src in zip(st.batch[key], batch[key]):
@@ -436,7 +439,9 @@ class TrainStep:
                     rd, rs = getattr(dst, '_d3f_rev', None), getattr(src, '_d3f_rev', None)
                     if rd is not None and rs is not None:   # the table's transpose lives at static addresses as well
                         for td, tsrc in zip(rd.tensors(), rs.tensors()):
-                            td.copy_(tsrc)
+                            if td.data_ptr() not in done:
+                                td.copy_(tsrc)
+                                done.add(td.data_ptr())
 
     def _set_batch(self, st):
         batch = dict(st.batch)
@@ -488,8 +493,20 @@ class TrainStep:
         if getattr(self, '_side', None) is None:
             self._side = torch.cuda.Stream(device=dev)
         self.g_net, self.g_net_b, self.g_pyr, self._graph_out, self._graph_dist = [], [], [], [], []
+        # pyramid graphs first: the tensors a captured build produces have static addresses, so they BECOME the set's
+        # batch (no copies into separately held buffers: 34 launches per pyramid), and the network graphs are then
+        # recorded against them.  Each pyramid graph owns its memory pool: in a shared pool the scratch of one build
+        # would be laid over the adopted outputs of another set, which a network graph may be reading at that moment.
+        # (The network graphs never run concurrently and replay in capture order: they do share a pool.)
         for i in range(self.NSETS):
-            # graphs of one kind never run concurrently and replay in capture order: they share a memory pool
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, capture_error_mode=_CAPTURE_MODE):
+                self._build_set(self.sets[i], adopt=True)
+            self.g_pyr.append(g)
+        for g in self.g_pyr:    # a capture records, it does not run: fill the adopted tensors (inputs are loaded)
+            g.replay()
+        torch.cuda.synchronize(dev)
+        for i in range(self.NSETS):
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g, pool=self.g_net[0].pool() if self.g_net else None, capture_error_mode=_CAPTURE_MODE):
                 if self.split_backward:
@@ -503,11 +520,6 @@ class TrainStep:
                 with torch.cuda.graph(g, pool=self.g_net[0].pool(), capture_error_mode=_CAPTURE_MODE):
                     self._backward_shallow()
                 self.g_net_b.append(g)
-        for i in range(self.NSETS):
-            g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g, pool=self.g_pyr[0].pool() if self.g_pyr else None, capture_error_mode=_CAPTURE_MODE):
-                self._build_set(self.sets[i])
-            self.g_pyr.append(g)
         torch.cuda.synchronize(dev)
         self.ev_net = [torch.cuda.Event() for _ in range(self.NSETS)]
         self.ev_pyr = [torch.cuda.Event() for _ in range(self.NSETS)]

@@ -142,15 +142,19 @@ int d3f_kpconv_backward(const float* q_pts, int Nq, const float* s_pts, int Ns, 
  *   two forms: CSR (rev_ptr + rev_ent, rev_last_key NULL) or the search's own output (rev_ptr NULL): rev_ent =
  *   out_wide [Ns, rev_width] of a d3f_radius_query_ex of the SUPPORT points over the QUERY cloud with the table's
  *   radius, rev_last_key = out_last_key [Nq] of the query that produced the table -- no transposition pass at all.
+ *   rev_radius > 0: rev_ent comes from a search with a LARGER radius (a pooling table's transpose is the prefix, within
+ *   the pooling radius rev_radius, of the rows of the upsampling table the pyramid holds anyway: radius 2r, ranked by
+ *   distance); a full row whose last entry is still within rev_radius sets D3F_ST_WIDE_OVERFLOW in status (optional).
  * ---------------------------------------------------------------------------------------------- */
 size_t d3f_reverse_table_ws_bytes(int Nq, int H, int Ns);
 int d3f_reverse_table_build(const int32_t* idx, int Nq, int H, int Ns, int32_t* rev_ptr, int32_t* rev_ent, void* ws,
                             size_t ws_bytes, void* stream);
 int d3f_kpconv_grad_input_gather_supported(int Cin, int Cout, int K);
 int d3f_kpconv_grad_input_gather(const float* q_pts, int Nq, const float* s_pts, int Ns, const int32_t* rev_ptr,
-                                 const int32_t* rev_ent, const uint64_t* rev_last_key, int rev_width,
+                                 const int32_t* rev_ent, const uint64_t* rev_last_key, int rev_width, float rev_radius,
                                  const float* kernel_points, int K, const float* weights, int Cin, int Cout,
-                                 float extent, const float* nn, const float* grad_out, float* grad_x, void* stream);
+                                 float extent, const float* nn, const float* grad_out, float* grad_x, int32_t* status,
+                                 void* stream);
 
 /* grad_x alone, from gwf = (grad_out / nn) @ W^T  [Nq, K*Cin] computed by the caller (an ordinary GEMM: the right
  * tool for the few-point / 256..512-channel layers at the bottom of the U-Net, where the fused kernel's own gW tile

@@ -177,7 +177,8 @@ def _rev_sets_csr(rev):
 
 
 def _rev_sets_search(rev, q, s, r):
-    """Decode a search-form transpose on the host: entries of row s that pass key(q,s) <= last_key[q]."""
+    """Decode a search-form transpose on the host: entries of row s that pass key(q,s) <= last_key[q] (and d2 < r2
+    when the rows come from a wider search)."""
     ent, lk = rev.ent.cpu().numpy(), rev.last_key.cpu().numpy().view(np.uint64)
     out = []
     for si in range(rev.Ns):
@@ -185,7 +186,10 @@ def _rev_sets_search(rev, q, s, r):
         d = (q[row] - s[si]).astype(np.float32)
         d2 = ((d[:, 0] * d[:, 0] + d[:, 1] * d[:, 1]).astype(np.float32) + d[:, 2] * d[:, 2]).astype(np.float32)
         key = (d2.view(np.uint32).astype(np.uint64) << np.uint64(32)) | np.uint64(si)
-        out.append(set(row[key <= lk[row]].tolist()))
+        ok = key <= lk[row]
+        if rev.radius > 0:
+            ok &= d2 < np.float32(rev.radius) * np.float32(rev.radius)
+        out.append(set(row[ok].tolist()))
     return out
 
 
@@ -212,6 +216,20 @@ def test_search_form_transpose_equals_the_csr_transpose(n0, n1, r, lim):
     revp = ops.ReverseTable(widep, coarse.shape[0], lim, n0 + n1, last_key=lkp)
     csrp = ops.build_reverse_table(tabp, n0 + n1)
     assert _rev_sets_search(revp, coarse_np, fine, r) == _rev_sets_csr(csrp)
+    # ... or, as the pyramid does it, the leading part (d2 < r2) of the upsampling table's rows (radius 2r)
+    up = g_coarse.query(cu(fine), cu(lens), 42)
+    revu = ops.ReverseTable(up, coarse.shape[0], lim, n0 + n1, last_key=lkp, radius=r, status=g_coarse.status)
+    assert _rev_sets_search(revu, coarse_np, fine, r) == _rev_sets_csr(csrp)
+    xf = cu(rng.normal(size=(n0 + n1, 32)).astype(np.float32))
+    wp = cu((rng.normal(size=(15, 32, 32)) / 20).astype(np.float32))
+    kpp = cu((rng.normal(size=(15, 3)) * r / 3).astype(np.float32))
+    gop = cu(rng.normal(size=(coarse.shape[0], 32)).astype(np.float32))
+    gp = []
+    for rv in (revu, revp, csrp):
+        gx = xf.clone().requires_grad_(True)
+        ops.kpconv(coarse, cu(fine), tabp, gx, kpp, wp, r * 0.8, rev=rv).backward(gop)
+        gp.append(gx.grad)
+    assert rel_err(gp[0].cpu().numpy(), gp[2].cpu().numpy()) < 1e-5 and rel_err(gp[1].cpu().numpy(), gp[2].cpu().numpy()) < 1e-5
     g_fine.status.raise_if_set()
     g_coarse.status.raise_if_set()
     # and the two forms give the same gradient, bit for bit up to summation order inside a row
