@@ -53,7 +53,6 @@ SIGNATURES = {
     "d3f_linear_grad_weight_ws_bytes": (_sz, [_i, _i, _i]),
     "d3f_linear_grad_weight": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _sz, _vp]),
     "d3f_gemm_ws_bytes": (_sz, [_i, _i, _i, _i]),
-    "d3f_gemm_debug_set_flags": (None, [_i]),
     "d3f_gemm": (_i, [_vp, _vp, _sz, _vp]),
     "d3f_max_pool_forward": (_i, [_vp, _i, _i, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     "d3f_max_pool_backward": (_i, [_vp, _vp, _i, _i, _i, _vp, _i, _vp]),

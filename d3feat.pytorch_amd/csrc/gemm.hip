@@ -31,7 +31,10 @@ namespace d3f {
 
 constexpr int G_BK = 64;                // reduction indices per staged tile
 constexpr int G_KQ = G_BK / 4;          // float4 per row of a KC tile
-constexpr int G_KC_LD = G_BK + 4;   // floats per row of a KC tile
+constexpr int G_KC_LD = G_BK + 2;   // floats per row of a KC tile: row stride 2 mod 32 banks -> the 16 rows of a fragment
+                                    // read (8 B per lane) fall on 16 distinct bank pairs, conflict-free also when hipcc
+                                    // merges two reads into ds_read2_b64 (banks mod 32); rows are only 8-B aligned,
+                                    // so a staged float4 goes in as two 8-byte writes
 
 // ROWS = 64 or 32 output rows/columns of the operand tile; a KS tile row (one reduction index) holds ROWS + 8 floats
 template <int ROWS>
@@ -51,7 +54,6 @@ struct GemmP {
   float slope;
   float* zero_init; int zero_n;
   float* slab;                                 // split-K: [S][M*N (+ M)] partial results
-  int dbg;                                     // profiling ablations (profiles/gemm_ablate.py): 1 no global loads, 2 no staging, 4 no fragment reads, 8 no MFMA
 };
 
 // Operand tiles are fetched with raw buffer loads: an offset past the operand's extent returns zeros, which is the
@@ -102,7 +104,11 @@ __device__ __forceinline__ void g_store(float* __restrict__ T, int tid, const fl
   for (int j = 0; j < GTile<ROWS>::NV; ++j) {
     const int f = tid + 256 * j;
     constexpr int Q = ROWS / 4;
-    if (!KS) *(float4*)(T + (f / G_KQ) * G_KC_LD + 4 * (f % G_KQ)) = v[j];
+    if (!KS) {
+      float* dst = T + (f / G_KQ) * G_KC_LD + 4 * (f % G_KQ);
+      *(float2*)dst = make_float2(v[j].x, v[j].y);
+      *(float2*)(dst + 2) = make_float2(v[j].z, v[j].w);
+    }
     else *(float4*)(T + (f / Q) * GTile<ROWS>::KS_LD + 4 * (f % Q)) = v[j];
   }
 }
@@ -205,46 +211,58 @@ __global__ __launch_bounds__(256) void gemm_tile_kernel(const GemmP p) {
       for (int j = 0; j < TA::NV; ++j) { asum.x += va[j].x; asum.y += va[j].y; asum.z += va[j].z; asum.w += va[j].w; }
     }
   };
-  auto compute = [&](int buf) {
+  // Fragments are double-buffered in registers: the LDS reads of step ps+1 are issued BEFORE the MFMAs of step ps
+  // (pinned with sched_barrier: hipcc otherwise sinks them behind the MFMAs), so their latency runs under 8*FM matrix
+  // instructions.  `mid` runs after the first step's MFMAs are issued: the staging stores of the NEXT tile go there,
+  // into the other LDS buffer, and execute in the LDS pipe while the matrix pipe works.
+  auto compute = [&](int buf, auto&& mid) {
     const float* As = lds[buf];
     const float* Bs = lds[buf] + TA::FLOATS;
+    constexpr int NP = G_BK / 16;         // pipeline steps of two sub-steps (16 reduction indices) each
+    float a[2][2][FM][2], b[2][2][2][2];  // [register set][sub-step][fragment][k-step]
+    auto read = [&](int pstep, int slot) {
 #pragma unroll
-    for (int kk = 0; kk < G_BK / 8; ++kk) {
-      float a[FM][2], b[2][2];
-      if (p.dbg & 4) {
+      for (int h = 0; h < 2; ++h) {
 #pragma unroll
-        for (int f = 0; f < 2; ++f) { a[f % FM][0] = a[f % FM][1] = (float)lane; b[f][0] = b[f][1] = (float)kk; }
-      } else {
+        for (int f = 0; f < FM; ++f) g_frag<AKS, BM>(As, wr * 16 * FM + f * 16, 2 * pstep + h, li, lg, a[slot][h][f]);
 #pragma unroll
-        for (int f = 0; f < FM; ++f) g_frag<AKS, BM>(As, wr * 16 * FM + f * 16, kk, li, lg, a[f]);
-#pragma unroll
-        for (int f = 0; f < 2; ++f) g_frag<BKS, 64>(Bs, wc * 32 + f * 16, kk, li, lg, b[f]);
+        for (int f = 0; f < 2; ++f) g_frag<BKS, 64>(Bs, wc * 32 + f * 16, 2 * pstep + h, li, lg, b[slot][h][f]);
       }
-      if (p.dbg & 8) {
+    };
+    read(0, 0);
 #pragma unroll
-        for (int fa = 0; fa < FM; ++fa)
+    for (int ps = 0; ps < NP; ++ps) {
+      const int cur = ps & 1;
+      if (ps + 1 < NP) read(ps + 1, cur ^ 1);
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-          for (int fb = 0; fb < 2; ++fb) acc[fa][fb][0] += a[fa][0] * b[fb][1] + a[fa][1] * b[fb][0];
-        continue;
-      }
+      for (int h = 0; h < 2; ++h)
 #pragma unroll
-      for (int s = 0; s < 2; ++s)
+        for (int s = 0; s < 2; ++s)
 #pragma unroll
-        for (int fa = 0; fa < FM; ++fa)
+          for (int fa = 0; fa < FM; ++fa)
 #pragma unroll
-          for (int fb = 0; fb < 2; ++fb)
-            acc[fa][fb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[fa][s], b[fb][s], acc[fa][fb], 0, 0, 0);
+            for (int fb = 0; fb < 2; ++fb)
+              acc[fa][fb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[cur][h][fa][s], b[cur][h][fb][s], acc[fa][fb], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      if (ps == 0) mid();
     }
   };
-  if (T > 0 && !(p.dbg & 32)) {
+  // Schedule (one barrier per tile; tile t is computed from LDS buffer t & 1):
+  //   the registers hold tile t+1, loaded during the previous iteration (a whole compute phase of latency cover);
+  //   they are staged into the buffer tile t-1 has left, behind the first MFMAs of tile t, and refilled with the
+  //   loads of tile t+2.
+  if (T > 0) {
     fetch(0, va0, vb0, vm0);
     stage(0, va0, vb0, vm0);
+    if (T > 1) fetch(1, va0, vb0, vm0);
   }
   __syncthreads();
-  for (int t = 0; t < T; ++t) {  // tile t lives in LDS buffer t & 1
-    if (t + 1 < T && !(p.dbg & 1)) fetch(t + 1, va0, vb0, vm0);
-    compute(t & 1);
-    if (t + 1 < T && !(p.dbg & 2)) stage(t + 1, va0, vb0, vm0);
+  for (int t = 0; t < T; ++t) {
+    compute(t & 1, [&]() {
+      if (t + 1 < T) stage(t + 1, va0, vb0, vm0);
+      if (t + 2 < T) fetch(t + 2, va0, vb0, vm0);
+    });
     __syncthreads();
   }
 
@@ -284,7 +302,6 @@ __global__ __launch_bounds__(256) void gemm_tile_kernel(const GemmP p) {
       }
     return;
   }
-  if (p.dbg & 16) { if (acc[0][0][0] == 123.456f) p.C[0] = 1.0f; return; }
   float bia1[2], bia2[2], dv[FM][4], ad[FM][2][4];
   int arow[FM][4];
 #pragma unroll
@@ -387,9 +404,6 @@ size_t gemm_ws_bytes(int M, int N, int K, bool rowsum) {
   return align_up(sizeof(float) * (size_t)S * ((size_t)M * N + (rowsum ? M : 0)), 256);
 }
 
-static int g_gemm_debug = 0;
-void gemm_set_debug(int f) { g_gemm_debug = f; }
-
 static bool aligned16(const void* p) { return ((uintptr_t)p & 15u) == 0; }
 
 int gemm_launch(GemmP p, bool a_ks, bool b_ks, void* ws, size_t ws_bytes, hipStream_t stream) {
@@ -439,8 +453,6 @@ int gemm_launch(GemmP p, bool a_ks, bool b_ks, void* ws, size_t ws_bytes, hipStr
 
 extern "C" {
 
-void d3f_gemm_debug_set_flags(int flags) { d3f::gemm_set_debug(flags); }
-
 size_t d3f_gemm_ws_bytes(int M, int N, int K, int with_rowsum) { return d3f::gemm_ws_bytes(M, N, K, with_rowsum != 0); }
 
 int d3f_gemm(const d3f_gemm_args* a, void* ws, size_t ws_bytes, void* stream) {
@@ -455,7 +467,6 @@ int d3f_gemm(const d3f_gemm_args* a, void* ws, size_t ws_bytes, void* stream) {
   p.slope = a->slope;
   p.zero_init = a->zero_init; p.zero_n = a->zero_n;
   p.slab = nullptr;
-  p.dbg = d3f::g_gemm_debug;
   if (p.add_idx && (p.idx_stride < 1 || p.add_rows < 0)) return D3F_EINVAL;
   return d3f::gemm_launch(p, a->a_layout == D3F_GEMM_KS, a->b_layout == D3F_GEMM_KS, ws, ws_bytes, (hipStream_t)stream);
 }

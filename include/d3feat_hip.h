@@ -253,7 +253,6 @@ typedef struct d3f_gemm_args {
   float* zero_init; int32_t zero_n;
 } d3f_gemm_args;
 size_t d3f_gemm_ws_bytes(int M, int N, int K, int with_rowsum);
-void d3f_gemm_debug_set_flags(int flags); /* profiling aid: phase ablations of the GEMM kernel (0 = off; results are wrong otherwise) */
 int d3f_gemm(const d3f_gemm_args* args, void* ws, size_t ws_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
