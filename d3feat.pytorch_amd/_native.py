@@ -64,7 +64,7 @@ SIGNATURES = {
     "d3f_global_max": (_i, [_vp, _sz, _vp, _vp, _sz, _vp]),
     "d3f_global_max_rows": (_i, [_vp, _i, _i, _vp, _i, _vp, _vp, _sz, _vp]),
     "d3f_detection_scores_aux_floats": (_i, [_i]),
-    "d3f_detection_scores_forward": (_i, [_vp, _i, _i, _vp, _i, _vp, _i, _vp, _vp, _vp]),
+    "d3f_detection_scores_forward": (_i, [_vp, _i, _i, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp]),
     "d3f_detection_scores_ws_bytes": (_sz, [_i, _i]),
     "d3f_detection_scores_backward": (_i, [_vp, _i, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "d3f_circle_det_loss_stats_floats": (_sz, [_i]),

@@ -67,13 +67,16 @@ template <int CP>
 __global__ __launch_bounds__(256) void det_fwd_kernel(const float* __restrict__ feat, int N, int C,
                                                       const int32_t* __restrict__ idx, int H,
                                                       const float* __restrict__ fmax, int training,
-                                                      float* __restrict__ scores) {
+                                                      float* __restrict__ scores, const int32_t* __restrict__ width) {
   const int lane = threadIdx.x & 63;
   const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (n >= N) return;
   const int c = lane % CP, g = lane / CP;
   const float denom = fmaxf(*fmax, 0.0f) + 1e-6f;  // the reference's max includes its zero shadow row (:336-342)
-  PointStats s = point_stats<CP>(feat, N, C, idx + (size_t)n * H, H, denom, c, g);
+  // columns of the table the reference would have built: min(H, max neighbor count) (dataloader.py:64-66); the columns
+  // past it are all shadow and only matter to the local-maximum gate (a zero candidate the reference does not have)
+  const int Hw = width ? min(H, max(1, __builtin_amdgcn_readfirstlane(*width))) : H;
+  PointStats s = point_stats<CP>(feat, N, C, idx + (size_t)n * H, Hw, denom, c, g);
   const float fself = c < C ? feat[(size_t)n * C + c] / denom : -INFINITY;
   const float dmax = group_max<CP>(fself);
   const float alpha = softplus_t(fself - s.mean);
@@ -137,7 +140,8 @@ template <int LP>
 __global__ __launch_bounds__(256) void det_fwd_v4_kernel(const float* __restrict__ feat, int N,
                                                          const int32_t* __restrict__ idx, int H,
                                                          const float* __restrict__ fmax, int training,
-                                                         float* __restrict__ scores, float* __restrict__ aux) {
+                                                         float* __restrict__ scores, float* __restrict__ aux,
+                                                         const int32_t* __restrict__ width) {
   constexpr int C = 4 * LP, G = 64 / LP;
   const int lane = threadIdx.x & 63;
   const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -150,15 +154,16 @@ __global__ __launch_bounds__(256) void det_fwd_v4_kernel(const float* __restrict
   // the whole index row in one coalesced load (H <= 64), then all gathers of a batch of steps issued back to back:
   // one memory latency per batch instead of two dependent ones per step
   const int mrow = lane < H ? row[lane] : N;
+  const int Hw = width ? min(H, max(1, __builtin_amdgcn_readfirstlane(*width))) : H;  // see det_fwd_kernel
   constexpr int SB = 4;  // steps per batch
-  for (int h0 = 0; h0 < H; h0 += G * SB) {
+  for (int h0 = 0; h0 < Hw; h0 += G * SB) {
     float4 raw[SB];
     bool live[SB];
 #pragma unroll
     for (int s = 0; s < SB; ++s) {
       const int h = h0 + s * G + g;
       const int m = __shfl(mrow, h & 63, 64);
-      live[s] = h < H && m >= 0 && m < N;
+      live[s] = h < Hw && m >= 0 && m < N;
       raw[s] = live[s] ? *(const float4*)(feat + (size_t)m * C + 4 * c4) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
 #pragma unroll
@@ -167,7 +172,7 @@ __global__ __launch_bounds__(256) void det_fwd_v4_kernel(const float* __restrict
       const float4 v = live[s] ? make_float4(raw[s].x / denom, raw[s].y / denom, raw[s].z / denom, raw[s].w / denom)
                                : make_float4(0.f, 0.f, 0.f, 0.f);
       const float rs = group_sum<LP>((v.x + v.y) + (v.z + v.w));
-      if (h < H) {
+      if (h < Hw) {
         cnt += rs != 0.0f;
         msum.x += v.x; msum.y += v.y; msum.z += v.z; msum.w += v.w;
         lmax.x = fmaxf(lmax.x, v.x); lmax.y = fmaxf(lmax.y, v.y); lmax.z = fmaxf(lmax.z, v.z); lmax.w = fmaxf(lmax.w, v.w);
@@ -360,22 +365,22 @@ int d3f_global_max_rows(const float* x, int cap_rows, int C, const int32_t* len,
 int d3f_detection_scores_aux_floats(int C) { return (C == 16 || C == 32 || C == 64) ? 8 : 0; }  /* and H <= 64 */
 
 int d3f_detection_scores_forward(const float* feat, int N, int C, const int32_t* idx, int H, const float* feat_max,
-                                 int training, float* scores, float* aux, void* stream_) {
+                                 int training, float* scores, float* aux, const int32_t* width, void* stream_) {
   if (!feat || !idx || !feat_max || !scores || N < 0 || C < 1 || C > 64 || H < 1) return D3F_EINVAL;
   if (aux && (!training || !d3f_detection_scores_aux_floats(C) || H > 64)) return D3F_EINVAL;
   if (N == 0) return D3F_OK;
   hipStream_t stream = (hipStream_t)stream_;
   const int grid = d3f::cdiv(N, 4);
   if ((C == 16 || C == 32 || C == 64) && H <= 64) {
-    if (C == 16) det_fwd_v4_kernel<4><<<grid, 256, 0, stream>>>(feat, N, idx, H, feat_max, training, scores, aux);
-    else if (C == 32) det_fwd_v4_kernel<8><<<grid, 256, 0, stream>>>(feat, N, idx, H, feat_max, training, scores, aux);
-    else det_fwd_v4_kernel<16><<<grid, 256, 0, stream>>>(feat, N, idx, H, feat_max, training, scores, aux);
+    if (C == 16) det_fwd_v4_kernel<4><<<grid, 256, 0, stream>>>(feat, N, idx, H, feat_max, training, scores, aux, width);
+    else if (C == 32) det_fwd_v4_kernel<8><<<grid, 256, 0, stream>>>(feat, N, idx, H, feat_max, training, scores, aux, width);
+    else det_fwd_v4_kernel<16><<<grid, 256, 0, stream>>>(feat, N, idx, H, feat_max, training, scores, aux, width);
     D3F_LAUNCH_CHECK();
     return D3F_OK;
   }
-  if (C <= 16) det_fwd_kernel<16><<<grid, 256, 0, stream>>>(feat, N, C, idx, H, feat_max, training, scores);
-  else if (C <= 32) det_fwd_kernel<32><<<grid, 256, 0, stream>>>(feat, N, C, idx, H, feat_max, training, scores);
-  else det_fwd_kernel<64><<<grid, 256, 0, stream>>>(feat, N, C, idx, H, feat_max, training, scores);
+  if (C <= 16) det_fwd_kernel<16><<<grid, 256, 0, stream>>>(feat, N, C, idx, H, feat_max, training, scores, width);
+  else if (C <= 32) det_fwd_kernel<32><<<grid, 256, 0, stream>>>(feat, N, C, idx, H, feat_max, training, scores, width);
+  else det_fwd_kernel<64><<<grid, 256, 0, stream>>>(feat, N, C, idx, H, feat_max, training, scores, width);
   D3F_LAUNCH_CHECK();
   return D3F_OK;
 }

@@ -111,19 +111,21 @@ class _Walk:
             layer_blocks = []
 
 
-def _conv_table(grid_for, pts, lens, level, e, lim, reverse_tables):
-    """neighbors[l] (dataloader.py:122-128).  With ``reverse_tables`` the same search also leaves the table's transpose
+def _conv_table(grid_for, pts, lens, level, e, lim, reverse_tables, want_max=False):
+    """neighbors[l] (dataloader.py:122-128); with ``want_max`` a pair (table, device max neighbor count).  With ``reverse_tables`` the same search also leaves the table's transpose
     in search form (its whole ranked list + the key of the last kept entry): the in-radius relation of a cloud with
     itself is symmetric, so the list of s IS the candidate set of rev(s) -- no transposition pass."""
     if e['conv_r'] is None:
-        return torch.zeros((0, 1), dtype=torch.int32, device=pts[level].device)
+        empty = torch.zeros((0, 1), dtype=torch.int32, device=pts[level].device)
+        return (empty, None) if want_max else empty
     grid = grid_for(level, e['conv_r'])
     n = pts[level].shape[0]
     if not (reverse_tables and ops.wants_reverse_table(n)):
-        return grid.query(pts[level], lens[level], lim)
-    tab, wide, lkey = grid.query(pts[level], lens[level], lim, wide=ops.REV_WIDTH_CONV, want_last_key=True)
+        return grid.query(pts[level], lens[level], lim, want_max=want_max)
+    res = grid.query(pts[level], lens[level], lim, want_max=want_max, wide=ops.REV_WIDTH_CONV, want_last_key=True)
+    tab, wide, lkey = res[0], res[-2], res[-1]
     ops.attach_reverse_table(tab, ops.ReverseTable(wide, n, lim, n, last_key=lkey))
-    return tab
+    return (tab, res[1]) if want_max else tab
 
 
 def _pool_tables(grid_for, pts, lens, level, e, lim, reverse_tables, status):
@@ -169,11 +171,13 @@ def build_pyramid_static(points, lengths, config, neighborhood_limits, capacitie
         return grids[key]
 
     empty_idx = torch.zeros((0, 1), dtype=torch.int32, device=dev)
-    neighbors, pools, pools_width, upsamples = [], [], [], []
+    neighbors, neighbors_width, pools, pools_width, upsamples = [], [], [], [], []
     level = 0
     for li, e in enumerate(walk.layers):
         lim = int(neighborhood_limits[li])
-        neighbors.append(_conv_table(grid_for, pts, lens, level, e, lim, reverse_tables))
+        tab, tab_max = _conv_table(grid_for, pts, lens, level, e, lim, reverse_tables, want_max=True)
+        neighbors.append(tab)
+        neighbors_width.append(tab_max)
         if e['pool']:
             # static width = the limit; the reference trims to min(limit, max_count) (dataloader.py:64-66).  Only max_pool
             # can tell the difference (a full row gains zero-valued shadow candidates): it gets max_count, on the device
@@ -188,7 +192,7 @@ def build_pyramid_static(points, lengths, config, neighborhood_limits, capacitie
             upsamples.append(empty_idx)
     n_levels = len(neighbors)
     return {'points': [pts[min(i, len(pts) - 1)] for i in range(n_levels)], 'neighbors': neighbors, 'pools': pools,
-            'pools_width': pools_width, 'upsamples': upsamples,
+            'pools_width': pools_width, 'neighbors_width': neighbors_width, 'upsamples': upsamples,
             'stack_lengths': [lens[min(i, len(lens) - 1)] for i in range(n_levels)], '_status': status, '_static': True}
 
 
@@ -228,16 +232,20 @@ def build_pyramid(points, lengths, config, neighborhood_limits, index_dtype=torc
         return grids[key]
 
     empty_idx = torch.zeros((0, 1), dtype=index_dtype, device=dev)
-    neighbors, pools, pools_width, upsamples, maxima = [], [], [], [], []
+    neighbors, neighbors_width, pools, pools_width, upsamples, maxima = [], [], [], [], [], []
     search_form = reverse_tables and not exact_width and index_dtype == torch.int32
     level = 0
     for li, e in enumerate(walk.layers):
         lim = int(neighborhood_limits[li])
 
-        def run(qlevel, slevel, radius):
-            res = grid_for(slevel, radius).query(pts[qlevel], lens[qlevel], lim, want_max=exact_width)
+        def run(qlevel, slevel, radius, keep_max=None):
+            res = grid_for(slevel, radius).query(pts[qlevel], lens[qlevel], lim,
+                                                 want_max=exact_width or keep_max is not None)
             if exact_width:
                 maxima.append(res[1])
+                return res[0]
+            if keep_max is not None:
+                keep_max.append(res[1])
                 return res[0]
             return res
 
@@ -247,7 +255,9 @@ def build_pyramid(points, lengths, config, neighborhood_limits, index_dtype=torc
             return grid_for(slevel, radius).query(pts[qlevel], lens[qlevel], lim, want_max=True)
 
         if search_form:   # the training path: tables at the limit's width + their transposes straight from the searches
-            neighbors.append(_conv_table(grid_for, pts, lens, level, e, lim, True))
+            tab, tab_max = _conv_table(grid_for, pts, lens, level, e, lim, True, want_max=True)
+            neighbors.append(tab)
+            neighbors_width.append(tab_max)
             if e['pool']:
                 tab, tab_width, up = _pool_tables(grid_for, pts, lens, level, e, lim, True, status)
                 pools.append(tab)
@@ -259,7 +269,12 @@ def build_pyramid(points, lengths, config, neighborhood_limits, index_dtype=torc
                 pools_width.append(None)
                 upsamples.append(empty_idx)
             continue
-        neighbors.append(run(level, level, e['conv_r']) if e['conv_r'] is not None else empty_idx)
+        if e['conv_r'] is not None:
+            neighbors.append(run(level, level, e['conv_r'], keep_max=None if exact_width else neighbors_width))
+        else:
+            neighbors.append(empty_idx)
+            if not exact_width:
+                neighbors_width.append(None)
         if e['pool']:
             tab, tab_width = run_pool(level + 1, level, e['pool_r'])
             pools.append(tab)
@@ -304,8 +319,9 @@ def build_pyramid(points, lengths, config, neighborhood_limits, index_dtype=torc
     out_lens = [lens[min(i, len(lens) - 1)] for i in range(n_levels)]
     out = {'points': out_pts, 'neighbors': neighbors, 'pools': pools, 'upsamples': upsamples,
            'stack_lengths': out_lens, '_status': status}
-    if not exact_width:   # full-width tables: max_pool gets each table's max neighbor count (device int32[1])
+    if not exact_width:   # full-width tables: max_pool / the detector get each table's max neighbor count (device int32[1])
         out['pools_width'] = pools_width
+        out['neighbors_width'] = neighbors_width
     return out
 
 

@@ -121,4 +121,6 @@ class KPFCNN(nn.Module):
         """Saliency score of every point [N,1] (reference architectures.py:322-368); eval mode adds the
         local-maximum gate."""
         lens = inputs['stack_lengths'][0] if inputs.get('_static', False) else None  # capacity-shaped batch
-        return ops.detection_scores(features, inputs['neighbors'][0], training=self.training, lens=lens)
+        widths = inputs.get('neighbors_width')   # full-limit tables: the level-0 table's max count, on the device
+        return ops.detection_scores(features, inputs['neighbors'][0], training=self.training, lens=lens,
+                                    width=widths[0] if widths else None)

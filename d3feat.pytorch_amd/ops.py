@@ -1166,7 +1166,7 @@ def global_max(x, lens=None):
 
 class _DetScoreFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, feat, idx, training, lens=None):
+    def forward(ctx, feat, idx, training, lens=None, width=None):
         N, C, H = int(feat.shape[0]), int(feat.shape[1]), int(idx.shape[1])
         fmax = global_max(feat, lens)
         scores = torch.empty((N, 1), dtype=torch.float32, device=feat.device)
@@ -1175,7 +1175,7 @@ class _DetScoreFn(torch.autograd.Function):
         with _region("detection_fwd[N=%d]" % N, 4 * N * H + 4 * N * H * C + 4 * N * C + 4 * N):
             _native.check(_native.lib().d3f_detection_scores_forward(_p(feat), N, C, _p(idx), H, _p(fmax),
                                                                      1 if training else 0, _p(scores), _p(aux),
-                                                                     _stream()), "d3f_detection_scores_forward")
+                                                                     _p(width), _stream()), "d3f_detection_scores_forward")
         ctx.aux = aux
         ctx.save_for_backward(feat, idx, fmax)
         ctx.training = bool(training)
@@ -1194,13 +1194,17 @@ class _DetScoreFn(torch.autograd.Function):
             _native.check(_native.lib().d3f_detection_scores_backward(_p(feat), N, C, _p(idx), H, _p(fmax), _p(gs),
                                                                       _p(ctx.aux), _p(gf), _p(ws), 256, _stream()),
                           "d3f_detection_scores_backward")
-        return gf, None, None, None
+        return gf, None, None, None, None
 
 
-def detection_scores(features, neighbors, training=True, lens=None):
+def detection_scores(features, neighbors, training=True, lens=None, width=None):
     """scores [N,1] from un-normalised descriptors [N,C] and the layer-0 neighbor table.  ``lens`` (device int32
-    stack lengths) restricts the global-max normaliser to the live rows of a capacity-shaped batch."""
-    return _DetScoreFn.apply(_f32(features, "features"), _i32(neighbors, "neighbors"), bool(training), lens)
+    stack lengths) restricts the global-max normaliser to the live rows of a capacity-shaped batch; ``width`` (device
+    int32[1], the table's max neighbor count) makes a table kept at the full limit behave like the reference's
+    min(limit, max_count)-column table in the eval-mode local-maximum gate (as for max_pool)."""
+    if width is not None and not (width.is_cuda and width.dtype == torch.int32 and width.numel() == 1):
+        raise ValueError("width must be a device int32[1] tensor")
+    return _DetScoreFn.apply(_f32(features, "features"), _i32(neighbors, "neighbors"), bool(training), lens, width)
 
 
 # ---------------------------------------------------------------------------------------------------------------

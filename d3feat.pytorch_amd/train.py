@@ -431,7 +431,7 @@ class TrainStep:
             st.batch = batch
             return
         done = set()
-        for key in ('points', 'neighbors', 'pools', 'pools_width', 'upsamples', 'stack_lengths'):
+        for key in ('points', 'neighbors', 'pools', 'pools_width', 'neighbors_width', 'upsamples', 'stack_lengths'):
             for dst, src in zip(st.batch[key], batch[key]):
                 if dst is not None and dst.data_ptr() not in done and dst.numel():
                     dst.copy_(src)

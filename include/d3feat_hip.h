@@ -292,8 +292,11 @@ int d3f_global_max_rows(const float* x, int cap_rows, int C, const int32_t* len,
 /* aux (optional, training only, [N, d3f_detection_scores_aux_floats(C)]): per-point scalars of the winning channel,
  * left behind so that the backward pass does not gather features again. */
 int d3f_detection_scores_aux_floats(int C); /* 8 for C in {16, 32, 64}, 0 (aux unsupported) otherwise */
+/* width (optional, device int32[1]): max neighbor count of the table when idx is kept wider than the reference would
+ * build it (min(limit, max_count) columns, dataloader.py:64-66): the extra all-shadow columns are then ignored -- they
+ * would give the eval-mode local-maximum gate a zero candidate the reference does not have. */
 int d3f_detection_scores_forward(const float* feat, int N, int C, const int32_t* idx, int H, const float* feat_max,
-                                 int training, float* scores, float* aux, void* stream);
+                                 int training, float* scores, float* aux, const int32_t* width, void* stream);
 /* grad_feat [N,C] is OVERWRITTEN.  Includes the gradient through the global max normaliser.  aux: the forward's
  * (optional; without it the neighborhood statistics are recomputed). */
 int d3f_detection_scores_backward(const float* feat, int N, int C, const int32_t* idx, int H, const float* feat_max,

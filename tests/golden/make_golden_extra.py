@@ -1,0 +1,176 @@
+#!/usr/bin/env python
+"""More golden vectors from the REAL reference (build container only; /root/reference never travels).
+
+    python tests/golden/make_golden_extra.py
+
+Reuses make_golden.py's harness (reference Python imported unmodified, its native modules served by the in-place
+compiled reference C++), and adds what round 1 left unpinned:
+
+  tests/golden/s1_match.npz      the S1 benchmark pair in EVAL mode, full size: descriptors [N,32] and detector scores
+                                 [N] of both fragments, the reference's ``build_correspondence``
+                                 (geometric_registration/common.py:5-21) for top-250 / top-5000 keypoints by score
+                                 (test.py:56-57) and for ALL points (19k x 19k, BASELINE configs[3]), plus the row /
+                                 column argmins the reference loop computes on the way.
+  tests/golden/registration.npz  the reference's ``register_one_scene`` (test.py:20-76) and ``loadlog``
+                                 (common.py:43-58) run on a synthetic 4-fragment scene: inputs (keypoints, descriptors,
+                                 scores, gt.log text) and outputs (recall, mean inlier count, mean inlier ratio) for
+                                 several (num_points, thresholds).  ``open3d`` is not installed: the three calls
+                                 test.py makes on it (PointCloud(), Vector3dVector, PointCloud.transform) are served by
+                                 a 10-line stand-in that applies the 4x4 matrix in float64 like Open3D does.
+"""
+import os
+import sys
+import tempfile
+import types
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+import make_golden as mg  # noqa: E402  (installs the reference import environment, cwd = /root/reference)
+
+import torch  # noqa: E402
+
+
+def s1_match():
+    cfg1 = mg.cfgmod.default_config()
+    item1 = mg.synthetic.make_pair(1, 2, mg.ref_subsample)
+    limits1 = mg.calibrate_neighbors(mg.OnePair(item1, cfg1), cfg1, collate_fn=mg.collate_fn_descriptor,
+                                     samples_threshold=10 ** 9)
+    batch = mg.collate_fn_descriptor([item1], cfg1, limits1)
+    np.random.seed(0)
+    torch.manual_seed(0)
+    model = mg.KPFCNN(cfg1)
+    model.eval()
+    with torch.no_grad():
+        feats, scores = model(batch)
+    fe, se = feats.numpy().astype(np.float32), scores.numpy().reshape(-1).astype(np.float32)
+    n0 = int(batch['stack_lengths'][0][0])
+    g = {'n0': np.int64(n0), 'features_eval': fe, 'scores_eval': se, 'limits': np.asarray(limits1, np.int64)}
+    for k in (250, 5000):
+        si = np.argsort(se[:n0])[-k:]
+        ti = np.argsort(se[n0:])[-k:]
+        g['src_idx%d' % k], g['tgt_idx%d' % k] = si, ti
+        g['corr%d' % k] = mg.build_correspondence(fe[:n0][si], fe[n0:][ti])
+    S, T = fe[:n0], fe[n0:]
+    g['corr_all'] = mg.build_correspondence(S, T)
+    # the intermediate argmins of common.py:11-15, blockwise (the 19k x 19k matrix is 1.4 GB)
+    row_arg = np.empty(S.shape[0], np.int64)
+    col_best = np.full(T.shape[0], np.inf, np.float32)
+    col_arg = np.zeros(T.shape[0], np.int64)
+    for b0 in range(0, S.shape[0], 2048):
+        d = np.sqrt(2 - 2 * (S[b0:b0 + 2048] @ T.T))
+        row_arg[b0:b0 + 2048] = np.argmin(d, axis=1)
+        cb, ca = np.min(d, axis=0), np.argmin(d, axis=0)
+        upd = cb < col_best          # strict: argmin keeps the first minimum
+        col_best[upd], col_arg[upd] = cb[upd], ca[upd] + b0
+    g['row_argmin'], g['col_argmin'] = row_arg, col_arg
+    np.savez_compressed(os.path.join(HERE, 's1_match.npz'), **g)
+    print('wrote s1_match.npz', os.path.getsize(os.path.join(HERE, 's1_match.npz')) / 1e6, 'MB;',
+          {k: (v.shape if hasattr(v, 'shape') else v) for k, v in g.items() if k.startswith('corr')})
+
+
+class _FakePointCloud:
+    """The three Open3D calls of test.py:63-66 (float64 homogeneous transform, like open3d.geometry.PointCloud)."""
+
+    def __init__(self):
+        self.points = np.zeros((0, 3))
+
+    def transform(self, T):
+        p = np.asarray(self.points, dtype=np.float64)
+        self.points = p @ np.asarray(T, np.float64)[:3, :3].T + np.asarray(T, np.float64)[:3, 3]
+        return self
+
+
+def registration():
+    o3d = sys.modules['open3d']
+    o3d.geometry = types.SimpleNamespace(PointCloud=_FakePointCloud)
+    o3d.utility = types.SimpleNamespace(Vector3dVector=lambda a: np.asarray(a, dtype=np.float64))
+    o3d.io = types.SimpleNamespace()
+    for name in ('easydict', 'tensorboardX'):
+        sys.modules.setdefault(name, types.ModuleType(name))
+    sys.modules['easydict'].EasyDict = dict
+    sys.modules['tensorboardX'].SummaryWriter = object
+    import importlib.util
+    spec = importlib.util.spec_from_file_location('ref_test', os.path.join(mg.REF, 'test.py'))
+    ref_test = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ref_test)                     # the `if __name__ == '__main__'` part does not run
+    from geometric_registration.common import loadlog     # reference
+
+    rng = np.random.default_rng(7)
+    scene, num_frag = 'synth-scene', 4
+    base = rng.normal(size=(1500, 3)).astype(np.float32)
+    base_desc = rng.normal(size=(1500, 32)).astype(np.float32)
+    frags, gt_text, trans = [], '', {}
+    poses = []
+    for i in range(num_frag):
+        q, _ = np.linalg.qr(rng.normal(size=(3, 3)))
+        if np.linalg.det(q) < 0:
+            q[:, 0] = -q[:, 0]
+        poses.append((q, rng.normal(size=3)))
+    for i in range(num_frag):
+        sel = np.sort(rng.choice(1500, 900, replace=False))      # overlapping subsets of one world cloud
+        q, t = poses[i]
+        kp = ((base[sel] - t) @ q).astype(np.float32)              # world -> fragment frame
+        kp += rng.normal(scale=0.02, size=kp.shape).astype(np.float32)
+        desc = base_desc[sel] + rng.normal(scale=0.35, size=(900, 32)).astype(np.float32)
+        desc /= np.linalg.norm(desc, axis=1, keepdims=True)
+        score = rng.random((900, 1)).astype(np.float32)
+        frags.append((kp, desc.astype(np.float32), score))
+    for i in range(num_frag):
+        for j in range(i + 1, num_frag):
+            if (i, j) == (1, 3):
+                continue                                           # a pair below 30 % overlap: absent from gt.log
+            qi, ti = poses[i]
+            qj, tj = poses[j]
+            T = np.eye(4)                                          # fragment j -> fragment i
+            T[:3, :3] = qi.T @ qj
+            T[:3, 3] = qi.T @ (tj - ti)
+            trans['%d_%d' % (i, j)] = T
+            gt_text += '%d\t %d\t %d\t\n' % (i, j, num_frag)
+            for row in T:
+                gt_text += ''.join(' % .8e\t ' % v for v in row).rstrip(' ') + '\n'
+    out = {'gt_log': np.frombuffer(gt_text.encode(), dtype=np.uint8), 'num_frag': np.int64(num_frag)}
+    for i, (kp, desc, score) in enumerate(frags):
+        out['kp%d' % i], out['desc%d' % i], out['score%d' % i] = kp, desc, score
+    cwd = os.getcwd()
+    with tempfile.TemporaryDirectory() as tmp:
+        os.makedirs(os.path.join(tmp, 'geometric_registration', 'gt_result', scene + '-evaluation'))
+        with open(os.path.join(tmp, 'geometric_registration', 'gt_result', scene + '-evaluation', 'gt.log'), 'w') as f:
+            f.write(gt_text)
+        os.makedirs(os.path.join(tmp, 'data', 'fragments', scene))
+        save = os.path.join(tmp, 'save')
+        for sub in ('keypoints', 'descriptors', 'scores'):
+            os.makedirs(os.path.join(save, sub, scene))
+        for i, (kp, desc, score) in enumerate(frags):
+            open(os.path.join(tmp, 'data', 'fragments', scene, 'cloud_bin_%d.ply' % i), 'w').close()
+            np.save(os.path.join(save, 'keypoints', scene, 'cloud_bin_%d' % i), kp)
+            np.save(os.path.join(save, 'descriptors', scene, 'cloud_bin_%d.D3Feat' % i), desc)
+            np.save(os.path.join(save, 'scores', scene, 'cloud_bin_%d' % i), score)
+        os.chdir(tmp)
+        try:
+            parsed = loadlog(os.path.join('geometric_registration', 'gt_result', scene + '-evaluation'))
+            for k, T in parsed.items():
+                out['loadlog.' + k] = T
+            ref_test.config = types.SimpleNamespace(root=os.path.join(tmp, 'data'))
+            cases = [(250, 0.05, 0.10), (100, 0.20, 0.05), (900, 0.05, 0.10), (250, 0.50, 0.03)]
+            res = []
+            for num_points, rthr, dthr in cases:
+                ref_test.args = types.SimpleNamespace(random_points=False, num_points=num_points)
+                ret = {}
+                r = ref_test.register_one_scene(rthr, dthr, save, ret, scene)
+                res.append([num_points, rthr, dthr, r[0], r[1], r[2]])
+            out['cases'] = np.asarray(res, dtype=np.float64)
+        finally:
+            os.chdir(cwd)
+    np.savez_compressed(os.path.join(HERE, 'registration.npz'), **out)
+    print('wrote registration.npz; reference results (num_points, ratio thr, dist thr, recall, inliers, ratio):')
+    print(out['cases'])
+
+
+if __name__ == '__main__':
+    which = sys.argv[1:] or ['s1', 'reg']
+    if 'reg' in which:
+        registration()
+    if 's1' in which:
+        s1_match()

@@ -33,23 +33,26 @@ def test_pyramid_matches_reference_collate_s0(golden_s0):
     cfg = cfgmod.default_config(first_features_dim=16)
     batch = dl.collate_fn_descriptor([_item(g)], cfg, g['limits'], index_dtype=torch.int64, exact_width=True)
     ties = 0
+    stats = {}
     for l in range(5):
         pts = batch['points'][l].cpu().numpy()
         assert np.array_equal(pts.view(np.uint32), g['batch.points.%d' % l].view(np.uint32)), "points level %d" % l
         assert np.array_equal(batch['stack_lengths'][l].cpu().numpy(), g['batch.stack_lengths.%d' % l])
         t, _ = assert_neighbors_equal_tie_aware(pts, pts, batch['neighbors'][l].cpu().numpy(),
-                                                g['batch.neighbors.%d' % l], 'neighbors %d' % l)
+                                                g['batch.neighbors.%d' % l], 'neighbors %d' % l, stats)
         ties += t
         if l < 4:
             nxt = g['batch.points.%d' % (l + 1)]
             assert_neighbors_equal_tie_aware(nxt, pts, batch['pools'][l].cpu().numpy(), g['batch.pools.%d' % l],
-                                             'pools %d' % l)
+                                             'pools %d' % l, stats)
             assert_neighbors_equal_tie_aware(pts, nxt, batch['upsamples'][l].cpu().numpy(),
-                                             g['batch.upsamples.%d' % l], 'upsamples %d' % l)
+                                             g['batch.upsamples.%d' % l], 'upsamples %d' % l, stats)
         else:
             assert batch['pools'][l].shape == (0, 1) and batch['upsamples'][l].shape == (0, 1)
         assert batch['neighbors'][l].dtype == torch.int64
     assert batch['features'].shape == (g['batch.points.0'].shape[0], 1)
+    # the tie-aware comparison has ONE freedom left, a tie group cut by the column limit: it never occurs on this pair
+    assert stats.get('cut', 0) == 0, stats
 
 
 def test_pyramid_s1_hashes_and_sampled_rows(golden_s1):
@@ -61,6 +64,7 @@ def test_pyramid_s1_hashes_and_sampled_rows(golden_s1):
     assert sha(item[0]) == str(g['pts0.sha']) and sha(item[1]) == str(g['pts1.sha'])
     assert np.array_equal(item[4], g['sel_corr'])
     batch = dl.collate_fn_descriptor([item], cfg, g['limits'], exact_width=True)
+    stats = {}
     for l in range(5):
         pts = batch['points'][l].cpu().numpy()
         assert sha(pts) == str(g['batch.points.%d.sha' % l]), "level %d" % l
@@ -73,7 +77,31 @@ def test_pyramid_s1_hashes_and_sampled_rows(golden_s1):
             assert list(table.shape) == g[key + '.shape'].tolist(), key
             qp = batch['points'][q].cpu().numpy()[rows]
             sp = batch['points'][s].cpu().numpy()
-            assert_neighbors_equal_tie_aware(qp, sp, table[rows], g[key + '.sample'], key)
+            assert_neighbors_equal_tie_aware(qp, sp, table[rows], g[key + '.sample'], key, stats)
+    assert stats.get('cut', 0) == 0, stats   # no tie group is cut by the limit column on the benchmark pair either
+
+
+class _Pair:
+    def __init__(self, item, config):
+        self.item, self.config = item, config
+
+    def __len__(self):
+        return 1
+
+    def __getitem__(self, i):
+        return self.item
+
+
+def test_calibrate_neighbors_equals_the_reference_limits(golden_s0, golden_s1):
+    """The count-only device pass (datasets/dataloader.py:191-223 in the reference: uncapped searches + histogram + 80 %
+    rule) must give the limits the reference computed for the same pair."""
+    cfg0 = cfgmod.default_config(first_features_dim=16)
+    got0 = dl.calibrate_neighbors(_Pair(_item(golden_s0), cfg0), cfg0, samples_threshold=10 ** 9)
+    assert [int(x) for x in got0] == [int(x) for x in golden_s0['limits']], (got0, golden_s0['limits'])
+    cfg1 = cfgmod.default_config()
+    item1 = synthetic.make_pair(1, 2, _gpu_subsample)
+    got1 = dl.calibrate_neighbors(_Pair(item1, cfg1), cfg1, samples_threshold=10 ** 9)
+    assert [int(x) for x in got1] == [int(x) for x in golden_s1['limits']], (got1, golden_s1['limits'])
 
 
 def _load_model(cfg, g, full_sd):
@@ -176,6 +204,77 @@ def test_model_forward_backward_s1_full_width(golden_s1):
     with torch.no_grad():
         fe, se = model(batch)
     assert np.abs(fe.cpu().numpy()[g['features_eval.rows']] - g['features_eval.sample']).max() < 1e-4
+
+
+def test_encoder_blocks_s1_match_the_reference_block_outputs(golden_s1):
+    """BASELINE configs[1]: the KPConv encoder on the 20k-point fragments -- the output rows of encoder blocks
+    0, 1, 2 (strided), 3 and 12 that the reference run recorded (forward hooks on KPConv, make_golden.py:196-200)."""
+    from d3feat_pytorch_amd.models.blocks import KPConv
+    g = golden_s1
+    cfg = cfgmod.default_config()
+    model = _load_model(cfg, g, full_sd=False).train()
+    item = synthetic.make_pair(1, 2, _gpu_subsample)
+    batch = dl.collate_fn_descriptor([item], cfg, g['limits'])
+    seen = {}
+    hooks = []
+    for n, m in model.named_modules():
+        if isinstance(m, KPConv) and ('kpconv.%s.out' % n) in g.files:
+            hooks.append(m.register_forward_hook(lambda mod, inp, outp, n=n: seen.__setitem__(n, outp.detach())))
+    # the fused block path calls ops.kpconv_bias_act (KPConv + bias + LeakyReLU in one node): tap the raw KPConv too
+    from d3feat_pytorch_amd import ops
+    real = ops.kpconv_bias_act
+
+    def tapped(q, s_, idx, x, kp, w, ext, bias, slope=0.1, **kw):
+        raw = ops.kpconv(q, s_, idx, x.detach(), kp, w.detach(), ext)
+        for n, m in model.named_modules():
+            if isinstance(m, KPConv) and m.weights is w:
+                seen[n] = raw
+        return real(q, s_, idx, x, kp, w, ext, bias, slope=slope, **kw)
+    ops.kpconv_bias_act = tapped
+    try:
+        with torch.no_grad():
+            model(batch)
+    finally:
+        ops.kpconv_bias_act = real
+        for h in hooks:
+            h.remove()
+    names = [k[len('kpconv.'):-len('.out')] for k in g.files if k.startswith('kpconv.') and k.endswith('.out')]
+    assert len(names) == 5 and all(n in seen for n in names), (names, list(seen))
+    for n in names:
+        rows, want = g['kpconv.%s.rows' % n], g['kpconv.%s.out' % n]
+        got = seen[n].cpu().numpy()[rows]
+        assert rel_err(got, want) < 1e-4, n
+
+
+def test_single_fragment_encoder_and_descriptors_match_the_oracle():
+    """B = 1 (one ~5k-point fragment, the inference shape of test.py:107-120): pyramid, per-block encoder features and
+    descriptors against the CPU oracle run on the same cloud and weights."""
+    from oracle import native as onative, ops_ref
+    cfg = cfgmod.default_config(first_features_dim=32)
+    frag = synthetic.make_fragment(31, _gpu_subsample, n_raw=60000, scale=0.3)
+    limits = [38, 36, 36, 38, 36]
+    np.random.seed(0)
+    torch.manual_seed(0)
+    model = KPFCNN(cfg).to(DEV).eval()
+    pts = torch.from_numpy(frag).to(DEV)
+    lengths = torch.tensor([frag.shape[0]], dtype=torch.int32, device=DEV)
+    batch = dl.build_pyramid(pts, lengths, cfg, limits, exact_width=True)
+    batch.pop('_status')
+    batch['features'] = torch.ones((frag.shape[0], 1), device=DEV)
+    with torch.no_grad():
+        feats, scores = model(batch)
+    sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+    cpu_batch = ops_ref.collate(frag, frag[:0], cfg, limits, onative)
+    for l in range(5):
+        assert torch.equal(batch['points'][l].cpu(), cpu_batch['points'][l]), l
+        assert batch['neighbors'][l].shape == cpu_batch['neighbors'][l].shape
+        assert torch.equal(batch['neighbors'][l].cpu().long(), cpu_batch['neighbors'][l]), l
+    cpu_batch['features'] = torch.ones((frag.shape[0], 1))
+    rf, rs = ops_ref.kpfcnn_forward(sd, cpu_batch, cfg, training=False)
+    assert float((feats.cpu() - rf).abs().max()) < 1e-4
+    live = (scores.cpu() != 0) & (rs != 0)
+    assert float(((scores.cpu() != 0) == (rs != 0)).float().mean()) > 0.999
+    assert float((scores.cpu() - rs)[live].abs().max()) < 1e-4
 
 
 def test_graph_mode_matches_eager_step(golden_s0):

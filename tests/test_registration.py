@@ -51,6 +51,48 @@ def test_gt_log_round_trip_and_benchmark_layout(tmp_path):
         ev.loadlog(str(tmp_path / 'c'))
 
 
+@pytest.fixture(scope="module")
+def golden_reg():
+    here = os.path.dirname(os.path.abspath(__file__))
+    return np.load(os.path.join(here, 'golden', 'registration.npz'), allow_pickle=False)
+
+
+def test_loadlog_equals_the_reference_parser(golden_reg, tmp_path):
+    """gt.log text -> transforms, against what the reference's own loadlog (common.py:43-58) returned for it."""
+    g = golden_reg
+    (tmp_path / 'gt').mkdir()
+    (tmp_path / 'gt' / 'gt.log').write_bytes(g['gt_log'].tobytes())
+    got = ev.loadlog(str(tmp_path / 'gt'))
+    want = {k[len('loadlog.'):]: g[k] for k in g.files if k.startswith('loadlog.')}
+    assert sorted(got) == sorted(want) and len(want) == 5
+    for k in want:
+        assert np.array_equal(got[k], want[k]), k
+
+
+@pytest.mark.gpu
+def test_register_one_scene_equals_the_reference_run(golden_reg, tmp_path):
+    """Recall / mean inlier count / mean inlier ratio of a synthetic 4-fragment scene == the numbers the REFERENCE's
+    register_one_scene (test.py:20-76) produced on the same dumps (tests/golden/make_golden_extra.py), for four
+    (num_points, inlier-ratio threshold, distance threshold) settings."""
+    g = golden_reg
+    scene, save = 'synth-scene', str(tmp_path / 'dump')
+    dpath, kpath, spath = ev._paths(save, scene)
+    for p_ in (dpath, kpath, spath):
+        os.makedirs(p_)
+    for f in range(int(g['num_frag'])):
+        np.save(os.path.join(dpath, 'cloud_bin_%d.D3Feat' % f), g['desc%d' % f])
+        np.save(os.path.join(kpath, 'cloud_bin_%d' % f), g['kp%d' % f])
+        np.save(os.path.join(spath, 'cloud_bin_%d' % f), g['score%d' % f])
+    (tmp_path / 'gt').mkdir()
+    (tmp_path / 'gt' / 'gt.log').write_bytes(g['gt_log'].tobytes())
+    for num_points, rthr, dthr, recall, n_in, ratio in g['cases']:
+        got = ev.register_one_scene(rthr, dthr, save, scene, str(tmp_path / 'gt'), num_points=int(num_points))
+        assert got[0] == recall, (num_points, got, recall)
+        # the reference matches in float32 (np.sqrt(2 - 2 S T^T)); a near-tie between two candidates may resolve the
+        # other way here: allow one match of difference per pair on the means
+        assert abs(got[1] - n_in) <= 1.0 and abs(got[2] - ratio) <= 1.0 / max(1.0, n_in), (num_points, got, n_in, ratio)
+
+
 def _numpy_protocol(kp, desc, score, gt, num_frag, num_points, dthr, rthr):
     """The reference loop (test.py:32-76, common.py:5-21) in NumPy float32/float64 as written there."""
     pred = gtm = 0

@@ -26,9 +26,11 @@ def neighbor_d2(queries, supports, table):
     return d2
 
 
-def assert_neighbors_equal_tie_aware(queries, supports, ours, ref, what=""):
+def assert_neighbors_equal_tie_aware(queries, supports, ours, ref, what="", stats=None):
     """Neighbor tables must agree exactly except for the ORDER inside groups of equal d2, which the reference leaves
-    unspecified (std::sort on distance only, nanoflann.hpp:208-214).  Returns (#tie rows, #rows)."""
+    unspecified (std::sort on distance only, nanoflann.hpp:208-214).  Returns (#tie rows, #rows).  A tie group that
+    reaches the last column may have been cut by the column limit and keep different members; such rows are counted in
+    ``stats['cut']`` (a dict the caller passes) so that a test can insist that none occurred."""
     ours = np.asarray(ours).astype(np.int64)
     ref = np.asarray(ref).astype(np.int64)
     assert ours.shape == ref.shape, "%s shape %s vs %s" % (what, ours.shape, ref.shape)
@@ -47,6 +49,8 @@ def assert_neighbors_equal_tie_aware(queries, supports, ours, ref, what=""):
             last_group_cut = end == width - 1  # a tie group cut by the column limit may keep different members
             if not last_group_cut:
                 assert sorted(a[start:end + 1]) == sorted(b[start:end + 1]), "%s row %d: tie group differs" % (what, r)
+            elif sorted(a[start:end + 1]) != sorted(b[start:end + 1]) and stats is not None:
+                stats['cut'] = stats.get('cut', 0) + 1
             start = end + 1
     return len(bad), ours.shape[0]
 
