@@ -77,7 +77,8 @@ SIGNATURES = {
     "d3f_select_normalize_backward": (_i, [_vp, _i, _i, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "d3f_mutual_nn_ws_bytes": (_sz, [_i, _i]),
     "d3f_mutual_nn": (_i, [_vp, _i, _vp, _i, _i, _vp, _vp, _vp, _vp, _sz, _vp]),
-    "d3f_sgd_guarded_step": (_i, [_vp, _vp, _vp, _sz, _f, _f, _f, _vp, _vp, _vp]),
+    "d3f_sgd_guarded_step": (_i, [_vp, _vp, _vp, _sz, _f, _f, _f, _vp, _vp, _vp, _vp]),
+    "d3f_poison_gradient_if_status": (_i, [_vp, _vp, _vp, _vp]),
 }
 
 ERRORS = {-1: "invalid argument", -2: "workspace too small", -3: "HIP launch failure"}

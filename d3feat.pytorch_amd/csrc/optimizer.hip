@@ -3,7 +3,8 @@
 // Replaces the reference's optimizer step and its host-side NaN/Inf guard (trainer.py:104-111: loop over parameters,
 // `torch.isfinite(p.grad).all()` -> one device->host sync each, then torch.optim.SGD(momentum 0.98, weight decay
 // 1e-6), training_3DMatch.py:62-76).  Two launches over the flat buffers and no host sync:
-//   1. nonfinite_kernel : state[0] |= any(!isfinite(g))
+//   1. nonfinite_kernel : state[0] |= any(!isfinite(g))  (or the pair's device status word is set: a pyramid that
+//                         overflowed a capacity must not reach the parameters -- state[2] |= flags, ++state[3])
 //   2. sgd_kernel       : if (!state[0]) { buf = momentum*buf + (g + wd*p); p -= lr*buf; } else ++state[1]
 // The operation order is torch.optim.SGD's (d = g + wd*p; buf = buf*momentum + d; p = p + (-lr)*buf), unfused.
 // HBM-bound: 4 B/param read in (1), 12 B read + 8 B written in (2).
@@ -13,7 +14,16 @@ namespace {
 
 __device__ __forceinline__ bool nonfinite(float v) { return (__float_as_uint(v) & 0x7f800000u) == 0x7f800000u; }
 
-__global__ __launch_bounds__(256) void nonfinite_kernel(const float* __restrict__ g, size_t n, int* __restrict__ state) {
+__global__ __launch_bounds__(256) void nonfinite_kernel(const float* __restrict__ g, size_t n, int* __restrict__ state,
+                                                        const int32_t* __restrict__ pair_status) {
+  if (pair_status && blockIdx.x == 0 && threadIdx.x == 0) {
+    const int f = *pair_status;
+    if (f) {
+      atomicOr(state, 1);
+      atomicOr(state + 2, f);
+      atomicAdd(state + 3, 1);
+    }
+  }
   const size_t n4 = n / 4;
   const size_t stride = (size_t)gridDim.x * blockDim.x;
   // exponent bits all ones <=> Inf/NaN: OR the words of four independent 16-byte loads per round, test once
@@ -73,25 +83,48 @@ __global__ __launch_bounds__(256) void sgd_kernel(const float* __restrict__ g, f
   }
 }
 
+__global__ void poison_kernel(float* __restrict__ g, const int32_t* __restrict__ pair_status, int* __restrict__ state) {
+  if (threadIdx.x != 0) return;
+  const int f = *pair_status;
+  if (f) {
+    g[0] = __uint_as_float(0x7fc00000u);
+    atomicOr(state + 2, f);
+    atomicAdd(state + 3, 1);
+  }
+}
+
 }  // namespace
 
 extern "C" {
 
-/* grad, params, momentum_buf: [n] fp32, 16-byte aligned.  state: int32[2] on the device = {scratch flag, number of
- * skipped steps so far}; state[0] is reset here, state[1] only ever incremented.  hyper_device: NULL, or float[4] on
+/* grad, params, momentum_buf: [n] fp32, 16-byte aligned.  state: int32[4] on the device = {scratch flag, number of
+ * skipped steps so far, OR of the pair-status flags that caused a skip, number of such skips}; state[0] is reset here,
+ * the others only ever grow.  pair_status (optional, device int32[1]): the device status word of the pair this
+ * gradient came from; non-zero skips the update like a non-finite gradient does.  hyper_device: NULL, or float[4] on
  * the device = {lr, momentum, weight_decay, grad_scale} read at execution time instead of the scalar arguments
  * (grad_scale multiplies the gradient first: 1/world_size turns an all-reduced SUM into the mean). */
 int d3f_sgd_guarded_step(const float* grad, float* params, float* momentum_buf, size_t n, float lr, float momentum,
-                         float weight_decay, const float* hyper_device, int32_t* state, void* stream) {
+                         float weight_decay, const float* hyper_device, int32_t* state, const int32_t* pair_status,
+                         void* stream) {
   if (!grad || !params || !momentum_buf || !state) return D3F_EINVAL;
   if ((((uintptr_t)grad | (uintptr_t)params | (uintptr_t)momentum_buf) & 15) != 0) return D3F_EINVAL;
   hipStream_t st = (hipStream_t)stream;
   if (d3f::zero_async(state, sizeof(int32_t), st) != hipSuccess) return D3F_ELAUNCH;
   if (n == 0) return D3F_OK;
   const int blocks = (int)std::min<size_t>(2048, (size_t)d3f::cdiv((long long)(n / 4 + 1), 256));
-  nonfinite_kernel<<<blocks, 256, 0, st>>>(grad, n, state);
+  nonfinite_kernel<<<blocks, 256, 0, st>>>(grad, n, state, pair_status);
   D3F_LAUNCH_CHECK();
   sgd_kernel<<<blocks, 256, 0, st>>>(grad, params, momentum_buf, n, lr, momentum, weight_decay, hyper_device, state);
+  D3F_LAUNCH_CHECK();
+  return D3F_OK;
+}
+
+/* Data-parallel form of the same gate: BEFORE the gradient exchange, a rank whose pair raised a status flag turns
+ * grad[0] into NaN, so that the guard evaluated on the REDUCED gradient skips the step on every rank alike.
+ * state as above (state[2] |= flags, ++state[3] on this rank). */
+int d3f_poison_gradient_if_status(float* grad, const int32_t* pair_status, int32_t* state, void* stream) {
+  if (!grad || !pair_status || !state) return D3F_EINVAL;
+  poison_kernel<<<1, 64, 0, (hipStream_t)stream>>>(grad, pair_status, state);
   D3F_LAUNCH_CHECK();
   return D3F_OK;
 }

@@ -145,7 +145,7 @@ def _pool_tables(grid_for, pts, lens, level, e, lim, reverse_tables, status):
 
 
 def build_pyramid_static(points, lengths, config, neighborhood_limits, capacities, order=ops.ORDER_REFERENCE,
-                         reverse_tables=False, status=None):
+                         reverse_tables=False, status=None, conv_widths=True):
     """Capacity-shaped pyramid: every level l has ``capacities[l]`` rows, the live row counts stay on the device.
 
     No host synchronisation at all (hipGraph-capturable): voxel levels write into fixed-capacity buffers (rows past
@@ -175,7 +175,12 @@ def build_pyramid_static(points, lengths, config, neighborhood_limits, capacitie
     level = 0
     for li, e in enumerate(walk.layers):
         lim = int(neighborhood_limits[li])
-        tab, tab_max = _conv_table(grid_for, pts, lens, level, e, lim, reverse_tables, want_max=True)
+        # the level-0 table's max count is what the detector's eval-mode gate needs (conv_widths=False: training only --
+        # 38k waves reducing into one word cost the level-0 search 25 us)
+        if li == 0 and conv_widths:
+            tab, tab_max = _conv_table(grid_for, pts, lens, level, e, lim, reverse_tables, want_max=True)
+        else:
+            tab, tab_max = _conv_table(grid_for, pts, lens, level, e, lim, reverse_tables), None
         neighbors.append(tab)
         neighbors_width.append(tab_max)
         if e['pool']:
@@ -255,7 +260,10 @@ def build_pyramid(points, lengths, config, neighborhood_limits, index_dtype=torc
             return grid_for(slevel, radius).query(pts[qlevel], lens[qlevel], lim, want_max=True)
 
         if search_form:   # the training path: tables at the limit's width + their transposes straight from the searches
-            tab, tab_max = _conv_table(grid_for, pts, lens, level, e, lim, True, want_max=True)
+            if li == 0:
+                tab, tab_max = _conv_table(grid_for, pts, lens, level, e, lim, True, want_max=True)
+            else:
+                tab, tab_max = _conv_table(grid_for, pts, lens, level, e, lim, True), None
             neighbors.append(tab)
             neighbors_width.append(tab_max)
             if e['pool']:
@@ -269,7 +277,10 @@ def build_pyramid(points, lengths, config, neighborhood_limits, index_dtype=torc
                 pools_width.append(None)
                 upsamples.append(empty_idx)
             continue
-        if e['conv_r'] is not None:
+        if e['conv_r'] is not None and li > 0 and not exact_width:
+            neighbors.append(run(level, level, e['conv_r']))
+            neighbors_width.append(None)
+        elif e['conv_r'] is not None:
             neighbors.append(run(level, level, e['conv_r'], keep_max=None if exact_width else neighbors_width))
         else:
             neighbors.append(empty_idx)
@@ -326,7 +337,7 @@ def build_pyramid(points, lengths, config, neighborhood_limits, index_dtype=torc
 
 
 def collate_fn_descriptor(list_data, config, neighborhood_limits, device=None, index_dtype=torch.int32,
-                          exact_width=True, reverse_tables=False):
+                          exact_width=True, reverse_tables=False, keep_status=False):
     """One fragment pair -> the multi-scale batch dict of the reference (dataloader.py:69-189), built on the GPU."""
     assert len(list_data) == 1
     dev = _device(device)
@@ -337,7 +348,8 @@ def collate_fn_descriptor(list_data, config, neighborhood_limits, device=None, i
     lengths = torch.tensor([p0.shape[0], p1.shape[0]], dtype=torch.int32, device=dev)
     d = build_pyramid(points, lengths, config, neighborhood_limits, index_dtype=index_dtype, exact_width=exact_width,
                       reverse_tables=reverse_tables)
-    d.pop('_status')
+    if not keep_status:   # (the voxel levels were checked at the size read-back; search flags need a caller that syncs)
+        d.pop('_status')
     d['features'] = feats
     d['corr'] = sel_corr.to(dev) if isinstance(sel_corr, torch.Tensor) else torch.from_numpy(np.asarray(sel_corr)).to(dev)
     d['dist_keypts'] = dist_keypts.to(dev) if isinstance(dist_keypts, torch.Tensor) \

@@ -24,6 +24,14 @@ class InferStep(TrainStep):
     def _init_training_state(self, config, world_size):   # no flat parameter buffer, optimizer or loss
         self.split_backward = False
         self.last_distances = None
+        self.opt = None
+
+    def _build_set(self, st, adopt=False):
+        # forward only: nothing consumes the set's flags between builds, so they stay sticky until check_status()
+        keep = st.status.word.clone() if st.status is not None else None
+        super()._build_set(st, adopt)
+        if keep is not None:
+            st.status.word.bitwise_or_(keep)
 
     # ---- static inputs: `clouds` point arrays per item ------------------------------------------------------------
     def enable_graph(self, capacities, num_corr=1):

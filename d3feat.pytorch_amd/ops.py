@@ -1437,15 +1437,16 @@ def mutual_nn(source_desc, target_desc):
 # ---------------------------------------------------------------------------------------------------------------
 # guarded SGD step on flat buffers (trainer.py:104-111 + training_3DMatch.py:62-76)
 # ---------------------------------------------------------------------------------------------------------------
-def sgd_guarded_step(grad, params, momentum_buf, lr, momentum, weight_decay, state, hyper=None):
+def sgd_guarded_step(grad, params, momentum_buf, lr, momentum, weight_decay, state, hyper=None, pair_status=None):
     """In place: params/momentum_buf updated unless grad holds a non-finite value (then state[1] += 1).
     ``hyper``: optional fp32[4] device tensor {lr, momentum, weight_decay, grad_scale} read by the kernel when it
-    runs."""
+    runs.  ``pair_status``: optional device int32[1], the status word of the pair the gradient came from: non-zero
+    skips the update too (state[2] |= flags, state[3] += 1)."""
     for t, name in ((grad, "grad"), (params, "params"), (momentum_buf, "momentum_buf")):
         if not (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous() and t.numel() == grad.numel()):
             raise ValueError("%s must be a contiguous fp32 device tensor of %d elements" % (name, grad.numel()))
-    if not (state.is_cuda and state.dtype == torch.int32 and state.numel() >= 2):
-        raise ValueError("state must be an int32[2] device tensor")
+    if not (state.is_cuda and state.dtype == torch.int32 and state.numel() >= 4):
+        raise ValueError("state must be an int32[4] device tensor")
     if hyper is not None and not (hyper.is_cuda and hyper.dtype == torch.float32 and hyper.numel() == 4
                                   and hyper.is_contiguous()):
         raise ValueError("hyper must be a contiguous fp32[4] device tensor")
@@ -1453,4 +1454,10 @@ def sgd_guarded_step(grad, params, momentum_buf, lr, momentum, weight_decay, sta
         _native.check(_native.lib().d3f_sgd_guarded_step(_p(grad), _p(params), _p(momentum_buf), grad.numel(),
                                                          float(lr), float(momentum), float(weight_decay),
                                                          _p(hyper) if hyper is not None else None, _p(state),
-                                                         _stream()), "d3f_sgd_guarded_step")
+                                                         _p(pair_status), _stream()), "d3f_sgd_guarded_step")
+
+
+def poison_gradient_if_status(grad, pair_status, state):
+    """Data-parallel form of the pair-status gate (before the gradient exchange): see d3f_poison_gradient_if_status."""
+    _native.check(_native.lib().d3f_poison_gradient_if_status(_p(grad), _p(pair_status), _p(state), _stream()),
+                  "d3f_poison_gradient_if_status")

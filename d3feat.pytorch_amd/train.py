@@ -110,7 +110,8 @@ class GuardedSGD:
     def __init__(self, flat, lr=0.01, momentum=0.98, weight_decay=1e-6):
         self.flat = flat
         self.buf = torch.zeros_like(flat.data)
-        self.state = torch.zeros(2, dtype=torch.int32, device=flat.data.device)
+        # {scratch, skipped steps, OR of pair-status flags that caused a skip, number of those skips}
+        self.state = torch.zeros(4, dtype=torch.int32, device=flat.data.device)
         # {lr, momentum, weight_decay} live on the device: the kernel reads them when it runs, so a schedule changes the
         # step size of an already captured graph (a scalar argument would be frozen at capture)
         self.hyper = torch.tensor([lr, momentum, weight_decay, 1.0], dtype=torch.float32, device=flat.data.device)
@@ -172,16 +173,23 @@ class GuardedSGD:
         return self.state[1]
 
     @torch.no_grad()
-    def step(self, want_ok=True):
+    def step(self, want_ok=True, pair_status=None):
         """Returns a 0-dim bool tensor: True when the update was applied (None with want_ok=False: the training
-        step only consults the skipped-step counter)."""
+        step only consults the skipped-step counter).  ``pair_status``: device status word (int32[1]) of the pair the
+        gradient came from; when it is set the update is skipped like for a non-finite gradient (a pyramid that
+        outgrew a graph capacity, say, never reaches the parameters) and the flags are kept in ``state[2:4]``."""
         g = self.flat.grad
         if g.is_cuda:
             before = self.state[1].clone() if want_ok else None
             ops.sgd_guarded_step(g, self.flat.data, self.buf, self.lr, self.momentum, self.weight_decay, self.state,
-                                 hyper=self.hyper)
+                                 hyper=self.hyper, pair_status=pair_status)
             return (self.state[1] == before) if want_ok else None
         ok = torch.isfinite(g).all()
+        if pair_status is not None:
+            bad = pair_status.reshape(-1)[0] != 0
+            self.state[2] |= pair_status.reshape(-1)[0].to(self.state.dtype)
+            self.state[3] += bad.to(self.state.dtype)
+            ok = ok & ~bad
         if self.grad_scale != 1.0:
             g = g * self.grad_scale
         d = torch.add(g, self.flat.data, alpha=self.weight_decay)       # g + wd * p
@@ -257,8 +265,16 @@ class TrainStep:
     reverse_tables = True
 
     def build_batch(self, item):
-        return dl.collate_fn_descriptor([item], self.config, self.limits, device=self.device, exact_width=False,
-                                        reverse_tables=self.reverse_tables)
+        batch = dl.collate_fn_descriptor([item], self.config, self.limits, device=self.device, exact_width=False,
+                                         reverse_tables=self.reverse_tables, keep_status=True)
+        # flags the searches raised after the level-size read-back (candidate overflow, ...): checked at the caller's
+        # next check_status() instead of being dropped
+        pend = getattr(self, '_eager_status', None)
+        if pend is None:
+            pend = self._eager_status = []
+        pend.append(batch.pop('_status'))
+        del pend[:-64]
+        return batch
 
     def _loss_from_raw(self, x, scores, batch):
         """Reference trainer.py:91-98 on the un-normalised descriptors: the 2M sampled rows are gathered and
@@ -336,12 +352,16 @@ class TrainStep:
                                 inputs=self.flat.params[:self.n_shallow])
         self.flat.gather_grads(0, self.n_shallow)
 
-    def _exchange_and_step(self, after_deep, after_shallow):
+    def _exchange_and_step(self, after_deep, after_shallow, pair_status=None):
         """after_deep(): runs/launches stage 1; after_shallow(): stage 2.  The deep bucket's all-reduce is in flight
-        while stage 2 executes."""
+        while stage 2 executes.  ``pair_status``: this rank's pair status word -- with several ranks a flagged pair
+        poisons its gradient BEFORE the exchange, so the guard on the reduced gradient skips the step on every rank."""
         out = after_deep()
         g = self.flat.grad
         works = []
+        if self.world > 1 and pair_status is not None and g.is_cuda:
+            ops.poison_gradient_if_status(g[self.numel_shallow:], pair_status, self.opt.state)
+            pair_status = None
         if self.world > 1:
             deep = g[self.numel_shallow:]
             nb = 3
@@ -355,7 +375,7 @@ class TrainStep:
             works.append(dist.all_reduce(g[:self.numel_shallow], op=dist.ReduceOp.SUM, async_op=True))
             for w in works:
                 w.wait()                 # SUM over ranks; the 1/world of the mean is opt.grad_scale
-        self.opt.step(want_ok=False)
+        self.opt.step(want_ok=False, pair_status=pair_status)
         return out
 
     # -- static shapes + hipGraph ---------------------------------------------------------------------------
@@ -381,6 +401,7 @@ class TrainStep:
 
         def __init__(self, caps, num_corr, dev):
             self.pts = torch.zeros((caps[0], 3), dtype=torch.float32, device=dev)
+            self.feat = None      # [caps[0], in_features_dim]: the pair's input features (set by enable_graph)
             self.lens = torch.zeros(2, dtype=torch.int32, device=dev)
             self.corr = torch.zeros((num_corr, 2), dtype=torch.int64, device=dev)
             self.dk = torch.zeros((num_corr, num_corr), dtype=torch.float64, device=dev)
@@ -393,7 +414,9 @@ class TrainStep:
         dev = self.device
         self.caps = [int(c) for c in capacities]
         self.sets = [TrainStep._Set(self.caps, num_corr, dev) for _ in range(self.NSETS)]
-        self.s_feat = torch.ones((self.caps[0], 1), dtype=torch.float32, device=dev)
+        fdim = int(getattr(self.config, 'in_features_dim', 1))
+        for st in self.sets:    # input features at static addresses (the reference feeds ones, or zeros under
+            st.feat = torch.ones((self.caps[0], fdim), dtype=torch.float32, device=dev)   # self_augment)
         self.graphs = None
         self.cur = 0
 
@@ -411,6 +434,9 @@ class TrainStep:
                 n0, n1, self.caps[0], tuple(corr.shape)))
         st.pts[:n0].copy_(p0, non_blocking=True)
         st.pts[n0:n0 + n1].copy_(p1, non_blocking=True)
+        if len(item) >= 6 and item[2] is not None and item[3] is not None:   # (feat0, feat1) of the dataset item
+            st.feat[:n0].copy_(item[2].reshape(n0, -1), non_blocking=True)
+            st.feat[n0:n0 + n1].copy_(item[3].reshape(n1, -1), non_blocking=True)
         st.lens[0] = n0
         st.lens[1] = n1
         st.corr.copy_(corr, non_blocking=True)
@@ -418,14 +444,18 @@ class TrainStep:
         st.mask.copy_(st.dk > self.circle.safe_radius)   # with the upload, off the training stream (utils/loss.py:119)
 
     def _build_set(self, st, adopt=False):
-        """Pyramid of the pair in ``st``'s input buffers -> ``st.batch``.  Every kernel of the build ORs its flags into
-        the set's own status word, which only ``check_status`` reads (sticky).  ``adopt`` (the first build, and the
+        """Pyramid of the pair in ``st``'s input buffers -> ``st.batch``.  Every kernel of the build (and of the
+        network step on that pair) ORs its flags into the set's own status word; the optimizer skips the update of a
+        flagged pair and keeps the flags (GuardedSGD.step), ``check_status`` reports them.  ``adopt`` (the first build, and the
         captured one: a graph's outputs have static addresses) makes the new tensors the set's batch; otherwise they
         are copied into the existing ones so that an already captured network graph keeps seeing its addresses."""
         if st.status is None:
             st.status = ops.DeviceStatus(self.device)
+        else:
+            st.status.word.zero_()   # the word describes THIS pair; what it caused is kept by the optimizer (state[2:4])
         batch = dl.build_pyramid_static(st.pts, st.lens, self.config, self.limits, self.caps,
-                                        reverse_tables=self.reverse_tables, status=st.status)
+                                        reverse_tables=self.reverse_tables, status=st.status,
+                                        conv_widths=not self.reverse_tables)   # (the eval-mode gate's input: inference)
         batch.pop('_status')
         if st.batch is None or adopt:
             st.batch = batch
@@ -445,7 +475,7 @@ class TrainStep:
 
     def _set_batch(self, st):
         batch = dict(st.batch)
-        batch['features'], batch['corr'], batch['dist_keypts'] = self.s_feat, st.corr, st.dk
+        batch['features'], batch['corr'], batch['dist_keypts'] = st.feat, st.corr, st.dk
         batch['neg_mask'] = st.mask
         return batch
 
@@ -455,7 +485,7 @@ class TrainStep:
         loss, desc, det, acc = self.forward_loss(batch)
         torch.autograd.backward(loss, self._seed(loss))
         self.flat.gather_grads()
-        self.opt.step(want_ok=False)
+        self.opt.step(want_ok=False, pair_status=st.status.word)
         return loss.detach(), desc.detach(), det.detach(), acc.detach()
 
     def _static_step(self, item):
@@ -482,7 +512,8 @@ class TrainStep:
                 self._build_set(self.sets[(k + 1) % self.NSETS])
                 if self.split_backward:
                     batch = self._set_batch(self.sets[k % self.NSETS])
-                    out = self._exchange_and_step(lambda: self._backward_deep(batch), self._backward_shallow)
+                    out = self._exchange_and_step(lambda: self._backward_deep(batch), self._backward_shallow,
+                                                  pair_status=self.sets[k % self.NSETS].status.word)
                 else:
                     out = self._net_step(self.sets[k % self.NSETS])
         main.wait_stream(warm)
@@ -568,7 +599,7 @@ class TrainStep:
             def stage2():
                 self.g_net_b[i].replay()
                 self.ev_net[i].record(main)
-            self._exchange_and_step(stage1, stage2)
+            self._exchange_and_step(stage1, stage2, pair_status=st.status.word)
         else:
             self.g_net[i].replay()
             self.ev_net[i].record(main)
@@ -576,11 +607,32 @@ class TrainStep:
         self.last_distances = self._graph_dist[i]
         return self._graph_out[i]
 
-    def check_status(self):
-        """Raise if a device-side condition (capacity overflow, candidate overflow, ...) was flagged (one sync)."""
-        for st in getattr(self, 'sets', []):
-            if st.status is not None:
-                st.status.raise_if_set()
+    def check_status(self, raise_on_skip=True):
+        """One synchronisation: what the device flagged since the last call.
+
+        Graph mode: a pair whose pyramid overflowed a capacity (D3F_ST_CAPACITY, ...) has had its update SKIPPED by the
+        optimizer (GuardedSGD.step, ``pair_status``) -- the parameters never saw it; the flags and the number of such
+        pairs are returned as ``(flags, count)`` and, with ``raise_on_skip``, raised as the RuntimeError the reference's
+        native modules would have thrown.  Eager pyramids (``step``) raise at build time already; the status words they
+        left behind (searches) are checked here as well."""
+        flags = count = 0
+        opt = getattr(self, 'opt', None)
+        if opt is not None and opt.state.is_cuda:
+            s = opt.state.tolist()
+            flags, count = int(s[2]), int(s[3])
+            opt.state[2:4] = 0
+        for st in getattr(self, 'sets', None) or []:
+            if st.status is not None and opt is None:    # forward-only engines have no optimizer to park the flags in
+                flags |= int(st.status.word.item())
+                st.status.word.zero_()
+        for status in getattr(self, '_eager_status', []):
+            flags |= int(status.word.item())
+        self._eager_status = []
+        if flags and raise_on_skip:
+            from . import _native
+            raise RuntimeError("%s (%d training pair(s) skipped)" % (_native.status_message(flags) or
+                                                                     ("device status %d" % flags), count))
+        return flags, count
 
     # -- pyramid construction on a side stream ---------------------------------------------------------------
     # build_pyramid reads the level sizes back once; done on the training stream that read-back would wait for the

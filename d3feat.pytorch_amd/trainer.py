@@ -128,24 +128,43 @@ class Trainer(object):
             self._load_pretrain(args.pretrain)
 
     # ---------------------------------------------------------------------------------------------------------
-    def _capacities(self, dataset, samples=8, slack=1.06):
-        """Static per-level row capacities for the captured graphs: level sizes of a few pairs, with head-room
-        (a pair whose level 0 does not fit runs on the eager path; an overflow at a deeper level is flagged by the
-        device, D3F_ST_CAPACITY, and raised at the next check_status -- pass ``graph_capacities`` to size them)."""
+    def _capacities(self, dataset, samples=32, slack=1.10):
+        """Static per-level row capacities for the captured graphs: level sizes of up to ``samples`` pairs spread over
+        the dataset, with head-room.  A pair whose level 0 does not fit runs on the eager path; an overflow at a deeper
+        level is flagged on the device (D3F_ST_CAPACITY), the optimizer skips that pair's update and the epoch report
+        counts it -- pass ``graph_capacities`` to size the levels by hand."""
         caps = _get(self.config, 'graph_capacities', None)
         if caps is not None:
             return [int(c) for c in caps]
         sizes = []
-        for i in range(min(samples, len(dataset))):
+        n = len(dataset)
+        for i in sorted(set(int(round(k * (n - 1) / max(1, min(samples, n) - 1))) for k in range(min(samples, n)))):
             b = self.engine.build_batch(self._fetch(dataset, i))
             sizes.append([int(t.shape[0]) for t in b['points']])
         return TrainStep.capacities_for(sizes, slack=slack)
 
+    def _shuffles(self, loader):
+        """Whether the loader asks for a random order: our ``_PairLoader.shuffle``, or a ``torch.utils.data.DataLoader``
+        built with ``shuffle=True`` (it then carries a RandomSampler).  Only ``loader.dataset`` is used: the pairs are
+        collated on the device by the engine, the loader's own collate_fn / workers are not involved."""
+        if hasattr(loader, 'shuffle'):
+            return bool(loader.shuffle)
+        sampler = getattr(loader, 'sampler', None)
+        return sampler is not None and type(sampler).__name__ in ('RandomSampler', 'DistributedSampler')
+
     def _order(self, loader, epoch):
         n = len(loader.dataset)
-        if getattr(loader, 'shuffle', False):
+        if _get(self.config, 'shuffle', None) if _get(self.config, 'shuffle', None) is not None else self._shuffles(loader):
             return np.random.RandomState(_get(self.config, 'seed', 0) * 100003 + epoch).permutation(n)
         return np.arange(n)
+
+    def _report_skipped(self):
+        flags, count = self.engine.check_status(raise_on_skip=False)
+        if count and self.rank == 0:
+            from . import _native
+            print("warning: %d pair(s) skipped -- %s" % (count, _native.status_message(flags) or ("status %d" % flags)))
+        self.skipped_pairs = getattr(self, 'skipped_pairs', 0) + count
+        return count
 
     def _fetch(self, dataset, i):
         return self.engine.upload(dataset[int(i)])
@@ -200,7 +219,7 @@ class Trainer(object):
             item = nxt
             if (it + 1) % self.log_interval == 0 and self.verbose:
                 avg = meters.averages()
-                self.engine.check_status()
+                self._report_skipped()
                 if self.rank == 0:
                     cur = num_iter * (epoch - 1) + it
                     for tag, key in (('Desc_Loss', 'desc_loss'), ('Det_Loss', 'det_loss'), ('D_pos', 'd_pos'),
@@ -211,7 +230,7 @@ class Trainer(object):
                                                           avg['accuracy'], avg['d_pos'], avg['d_neg'],
                                                           self._get_lr(), int(self.optimizer.skipped)))
         avg = meters.averages()
-        self.engine.check_status()
+        self._report_skipped()
         if self.rank == 0:
             print("Epoch %d: Desc Loss: %.2f, Det Loss : %.2f, Accuracy: %.2f, D_pos: %.2f, D_neg: %.2f" % (
                 epoch, avg['desc_loss'], avg['det_loss'], avg['accuracy'], avg['d_pos'], avg['d_neg']))

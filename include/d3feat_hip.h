@@ -378,14 +378,19 @@ int d3f_kpconv_grad_input_modes(const float* q_pts, int Nq, const float* s_pts, 
  * configured in training_3DMatch.py:62-76, on flat fp32 buffers of n elements (16-byte aligned):
  *   if every grad[i] is finite:  buf = momentum*buf + (grad + weight_decay*params);  params -= lr*buf
  *   else: nothing is modified and state[1] (skipped-step counter) is incremented.
- * state: int32[2] on the device; state[0] is scratch.
+ * state: int32[4] on the device; state[0] is scratch, state[2] / state[3] collect the flags / the number of steps
+ * skipped because pair_status (optional, device int32[1]: the status word of the pair the gradient came from --
+ * capacity or candidate overflow of its pyramid) was set: such a gradient is treated like a non-finite one.
  * hyper_device: NULL, or float[4] on the device = {lr, momentum, weight_decay, grad_scale}, read when the kernel
  * executes in place of the scalar arguments (grad_scale multiplies the gradient first: 1/world_size turns an
  * all-reduced SUM into the mean without a pass of its own) -- the learning-rate schedule (ExponentialLR, training_3DMatch.py:78-81 stepped at
  * trainer.py:59-60) then changes the step size of an already captured hipGraph.
  * ---------------------------------------------------------------------------------------------- */
 int d3f_sgd_guarded_step(const float* grad, float* params, float* momentum_buf, size_t n, float lr, float momentum,
-                         float weight_decay, const float* hyper_device, int32_t* state, void* stream);
+                         float weight_decay, const float* hyper_device, int32_t* state, const int32_t* pair_status,
+                         void* stream);
+/* data-parallel form of the pair-status gate: poisons grad[0] with NaN before the exchange when the flag is set */
+int d3f_poison_gradient_if_status(float* grad, const int32_t* pair_status, int32_t* state, void* stream);
 
 #ifdef __cplusplus
 }

@@ -329,9 +329,20 @@ def test_graph_mode_matches_eager_step(golden_s0):
     # a too-small capacity is reported, not silently truncated
     small = fresh()
     small.enable_graph([sizes[0][0] + 64, 64, 64, 64, 64], num_corr=item[4].shape[0])
+    before = small.flat.data.clone()
     small._static_step(item)
-    with pytest.raises(RuntimeError):
+    # ... and the truncated pyramid never reaches the parameters: the optimizer skipped that pair's update
+    assert torch.equal(small.flat.data, before) and int(small.opt.state[3]) == 1 and int(small.opt.skipped) == 1
+    with pytest.raises(RuntimeError, match="capacity"):
         small.check_status()
+    assert small.check_status(raise_on_skip=False) == (0, 0)      # reported once, then cleared
+    # the pair's input features travel with it (self_augment zeroes them, ThreeDMatch.py:141-143): graph == eager
+    aug = (item[0], item[1], torch.zeros_like(item[2]), item[3], item[4], item[5])
+    ga, ea = fresh(), fresh()
+    ga.enable_graph(graph.caps, num_corr=item[4].shape[0])
+    la = float(ga._static_step(aug)[0])
+    le = float(ea.step(aug)[0])
+    assert abs(la - le) < 1e-4 * max(1.0, abs(le)) and abs(le - losses_e[0]) > 1e-3
 
 
 def test_every_graph_replay_reproduces_the_eager_gradient(golden_s0):

@@ -160,3 +160,16 @@ def test_gradient_scale_is_the_data_parallel_mean():
         fb.grad.copy_(g * 0.25)     # the mean, scaled beforehand
         assert bool(oa.step()) and bool(ob.step())
         assert torch.equal(fa.data, fb.data)
+
+
+def test_trainer_reads_the_loaders_shuffle_request():
+    """A torch DataLoader built with shuffle=True carries a RandomSampler; our pair loader has a .shuffle attribute."""
+    import torch.utils.data as tud
+    from d3feat_pytorch_amd.trainer import Trainer
+    ds = list(range(7))
+    assert Trainer._shuffles(None, tud.DataLoader(ds, shuffle=True)) is True
+    assert Trainer._shuffles(None, tud.DataLoader(ds, shuffle=False)) is False
+
+    class L:
+        shuffle = True
+    assert Trainer._shuffles(None, L()) is True
