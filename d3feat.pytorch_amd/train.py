@@ -359,8 +359,14 @@ class TrainStep:
         out = after_deep()
         g = self.flat.grad
         works = []
-        if self.world > 1 and pair_status is not None and g.is_cuda:
-            ops.poison_gradient_if_status(g[self.numel_shallow:], pair_status, self.opt.state)
+        if self.world > 1 and pair_status is not None:
+            if g.is_cuda:
+                ops.poison_gradient_if_status(g[self.numel_shallow:], pair_status, self.opt.state)
+            else:   # host tensors (gloo tests of the exchange logic): the same arithmetic in torch
+                bad = pair_status.reshape(-1)[0] != 0
+                g[self.numel_shallow] = torch.where(bad, torch.full((), float('nan')), g[self.numel_shallow])
+                self.opt.state[2] |= pair_status.reshape(-1)[0].to(self.opt.state.dtype)
+                self.opt.state[3] += bad.to(self.opt.state.dtype)
             pair_status = None
         if self.world > 1:
             deep = g[self.numel_shallow:]

@@ -66,6 +66,62 @@ def _worker(rank, world, port, ret):
     dist.destroy_process_group()
 
 
+def _split_worker(rank, world, port, ret):
+    """TrainStep._exchange_and_step (the split-backward path of the multi-GPU step): deep bucket in 3 chunks + shallow
+    bucket, mean folded into the optimizer's gradient scale, pair-status poison -- against one plain all-reduce."""
+    sys.path.insert(0, REPO)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from d3feat_pytorch_amd.train import FlatParams, GuardedSGD, TrainStep
+    torch.manual_seed(0)
+    model = torch.nn.Sequential(torch.nn.Linear(7, 13), torch.nn.LeakyReLU(0.1), torch.nn.Linear(13, 11),
+                                torch.nn.LeakyReLU(0.1), torch.nn.Linear(11, 5))
+    ref = torch.nn.Sequential(torch.nn.Linear(7, 13), torch.nn.LeakyReLU(0.1), torch.nn.Linear(13, 11),
+                              torch.nn.LeakyReLU(0.1), torch.nn.Linear(11, 5))
+    ref.load_state_dict(model.state_dict())
+    eng = TrainStep.__new__(TrainStep)
+    eng.world = world
+    eng.flat = FlatParams(model)
+    eng.opt = GuardedSGD(eng.flat, lr=0.1, momentum=0.9, weight_decay=1e-3)
+    eng.opt.grad_scale = 1.0 / world
+    eng.numel_shallow = sum(p.numel() for p in model[0].parameters())      # "fine levels" = the first layer
+    ref_opt = torch.optim.SGD(ref.parameters(), lr=0.1, momentum=0.9, weight_decay=1e-3)
+    ok = True
+    for step in range(4):
+        g = torch.Generator().manual_seed(7 * step)
+        xs = [torch.randn(6, 7, generator=g) for _ in range(world)]
+        ys = [torch.randn(6, 5, generator=g) for _ in range(world)]
+        eng.flat.zero_grad()
+        ((model(xs[rank]) - ys[rank]) ** 2).mean().backward()
+        eng.flat.gather_grads()
+        status = torch.tensor([8 if (step == 1 and rank == 1) else 0], dtype=torch.int32)   # rank 1's pair overflowed
+        eng._exchange_and_step(lambda: None, lambda: None, pair_status=status)
+        ref_opt.zero_grad()
+        (sum(((ref(xs[r]) - ys[r]) ** 2).mean() for r in range(world)) / world).backward()
+        if step != 1:
+            ref_opt.step()
+        for p, q in zip(model.parameters(), ref.parameters()):
+            ok &= torch.allclose(p, q, atol=1e-6)
+    ok &= int(eng.opt.skipped.item()) == 1                       # every rank skipped the same step
+    ok &= int(eng.opt.state[3]) == (1 if rank == 1 else 0) and int(eng.opt.state[2]) == (8 if rank == 1 else 0)
+    mine = eng.flat.data.clone()
+    other = [torch.zeros_like(mine) for _ in range(world)]
+    dist.all_gather(other, mine)
+    ok &= all(torch.equal(o, other[0]) for o in other)
+    ret[rank] = bool(ok)
+    dist.destroy_process_group()
+
+
+def test_split_bucket_exchange_equals_one_allreduce_and_status_poison_is_collective():
+    world = 2
+    port = _free_port()
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_split_worker, args=(world, port, ret), nprocs=world, join=True)
+    assert dict(ret) == {0: True, 1: True}
+
+
 def test_two_rank_gradient_exchange_and_guard():
     world = 2
     port = _free_port()

@@ -574,6 +574,8 @@ def test_two_rank_bench_control_flow_on_one_gpu():
     assert cfg["parallelism"] == "dp2" and cfg["launch"].startswith("hipGraph replay")
     assert cfg["replica_param_checksum_spread"] == 0.0 and cfg["skipped_steps"] == 0
     assert np.isfinite(cfg["final_loss"]) and "cpu_baseline" not in res
+    ex = res["exchange"]     # the overlap leg: step with / without the exchange, the exchange alone
+    assert ex["rccl_ranks"] == 2 and "error" not in ex and ex["bytes_per_step"] > 9e7 and ex["exchange_alone_ms"] > 0
 
 
 @pytest.mark.parametrize("w_desc,w_det", [(1.0, 1.0), (0.7, 1.3)])
