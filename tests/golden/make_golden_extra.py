@@ -168,8 +168,57 @@ def registration():
     print(out['cases'])
 
 
+def dataset():
+    """tests/golden/dataset_items.npz: items of the REFERENCE ThreeDMatchDataset (datasets/ThreeDMatch.py:36-151) on a
+    synthetic pair of pickles, seeded -- fragment choice, augmentation draws, correspondence sampling, self_augment."""
+    import pickle
+    import random
+    o3d = sys.modules['open3d']
+    o3d.geometry = types.SimpleNamespace(PointCloud=_FakePointCloud)
+    o3d.utility = types.SimpleNamespace(Vector3dVector=lambda a: np.array(a, dtype=np.float64))
+    from datasets.ThreeDMatch import ThreeDMatchDataset   # reference
+    rng = np.random.default_rng(21)
+    sizes = {'sceneA/cloud_bin_0': 700, 'sceneA/cloud_bin_1': 650, 'sceneA/cloud_bin_2': 820, 'sceneB/cloud_bin_0': 500,
+             'sceneB/cloud_bin_5': 540}
+    pts = {k: rng.uniform(-1.5, 1.5, size=(n, 3)) for k, n in sizes.items()}
+    pairs = [('sceneA/cloud_bin_0', 'sceneA/cloud_bin_1'), ('sceneA/cloud_bin_0', 'sceneA/cloud_bin_2'),
+             ('sceneA/cloud_bin_1', 'sceneA/cloud_bin_2'), ('sceneB/cloud_bin_0', 'sceneB/cloud_bin_5')]
+    corr = {}
+    for a, b in pairs:
+        m = int(min(sizes[a], sizes[b]) * 0.4)
+        corr['%s@%s' % (a, b)] = np.stack([rng.permutation(sizes[a])[:m], rng.permutation(sizes[b])[:m]], axis=1)
+    out = {'ids': np.array(list(sizes.keys())), 'pair_keys': np.array(list(corr.keys()))}
+    for i, k in enumerate(sizes):
+        out['points%d' % i] = pts[k]
+    for i, k in enumerate(corr):
+        out['corr%d' % i] = corr[k]
+    with tempfile.TemporaryDirectory() as tmp:
+        with open(os.path.join(tmp, '3DMatch_train_0.030_points.pkl'), 'wb') as f:
+            pickle.dump(pts, f)
+        with open(os.path.join(tmp, '3DMatch_train_0.030_keypts.pkl'), 'wb') as f:
+            pickle.dump(corr, f)
+        runs = [(False, 64, 1, [0, 1, 2, 0]), (True, 32, 3, [1, 0])]
+        out['runs'] = np.asarray([[int(sa), nn_, ax, len(idx)] for sa, nn_, ax, idx in runs])
+        for r, (self_aug, num_node, axis, indices) in enumerate(runs):
+            ds = ThreeDMatchDataset(root=tmp, split='train', num_node=num_node, downsample=0.03, self_augment=self_aug,
+                                    augment_noise=0.005, augment_axis=axis, augment_rotation=1.0,
+                                    augment_translation=0.5)
+            random.seed(100 + r)
+            np.random.seed(100 + r)
+            out['run%d.indices' % r] = np.asarray(indices)
+            for j, index in enumerate(indices):
+                item = ds[index]
+                for name, v in zip(('pts0', 'pts1', 'feat0', 'feat1', 'sel_corr', 'dist_keypts'), item):
+                    out['run%d.item%d.%s' % (r, j, name)] = np.asarray(v)
+            out['run%d.len' % r] = np.int64(len(ds))
+    np.savez_compressed(os.path.join(HERE, 'dataset_items.npz'), **out)
+    print('wrote dataset_items.npz', os.path.getsize(os.path.join(HERE, 'dataset_items.npz')) / 1e6, 'MB')
+
+
 if __name__ == '__main__':
-    which = sys.argv[1:] or ['s1', 'reg']
+    which = sys.argv[1:] or ['s1', 'reg', 'dataset']
+    if 'dataset' in which:
+        dataset()
     if 'reg' in which:
         registration()
     if 's1' in which:

@@ -117,3 +117,34 @@ def test_ply_reader_and_testset_order(tmp_path):
     assert p.dtype == np.float32 and np.array_equal(p, clouds[10][::2]) and p is not q or np.array_equal(p, q)
     assert f.shape == (p.shape[0], 1) and c.size == 0 and d.size == 0
     assert [len(v) for v in ts.fragments_by_scene().values()] == [3]
+
+
+def test_training_items_equal_the_reference_datasets_items(tmp_path):
+    """Item for item against what the REFERENCE ThreeDMatchDataset returned (tests/golden/make_golden_extra.py) for the
+    same pickles and the same seeds of `random` / `numpy.random`: fragment choice, rotation axis and angle,
+    translation, noise, correspondence sampling, keypoint distances, self_augment feature masking."""
+    import os
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'dataset_items.npz'),
+                allow_pickle=False)
+    pts = {str(k): g['points%d' % i] for i, k in enumerate(g['ids'])}
+    corr = {str(k): g['corr%d' % i] for i, k in enumerate(g['pair_keys'])}
+    with open(tmp_path / '3DMatch_train_0.030_points.pkl', 'wb') as f:
+        pickle.dump(pts, f)
+    with open(tmp_path / '3DMatch_train_0.030_keypts.pkl', 'wb') as f:
+        pickle.dump(corr, f)
+    for r, (self_aug, num_node, axis, n_items) in enumerate(g['runs'].tolist()):
+        ds = tdm.ThreeDMatchDataset(str(tmp_path), split='train', num_node=num_node, downsample=0.03,
+                                    self_augment=bool(self_aug), augment_noise=0.005, augment_axis=axis,
+                                    augment_rotation=1.0, augment_translation=0.5)
+        assert len(ds) == int(g['run%d.len' % r])
+        random.seed(100 + r)
+        np.random.seed(100 + r)
+        for j, index in enumerate(g['run%d.indices' % r].tolist()):
+            item = ds[index]
+            for name, v in zip(('pts0', 'pts1', 'feat0', 'feat1', 'sel_corr', 'dist_keypts'), item):
+                want = g['run%d.item%d.%s' % (r, j, name)]
+                assert v.shape == want.shape and v.dtype == want.dtype, (r, j, name, v.dtype, want.dtype)
+                if name == 'pts1':     # the rigid transform: Open3D's float64 product vs ours, last-bit differences
+                    assert np.allclose(v, want, rtol=0, atol=1e-12), (r, j, name)
+                else:
+                    assert np.array_equal(v, want), (r, j, name)
