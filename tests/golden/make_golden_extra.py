@@ -215,8 +215,33 @@ def dataset():
     print('wrote dataset_items.npz', os.path.getsize(os.path.join(HERE, 'dataset_items.npz')) / 1e6, 'MB')
 
 
+def kernels():
+    """tests/golden/kernel_points.npz: the reference's kernel-point generators (kernels/kernel_points.py) run under
+    fixed global NumPy seeds -- the repulsion optimiser (:258-396) for (K, dim, fixed) = (7,3,center), (6,2,none),
+    (9,3,verticals) with 8 candidate kernels, the Monte-Carlo Lloyd relaxation (:78-254) for 32 cells with 60
+    iterations, and load_kernels (:400-482) for the shipped K=15 disposition at two radii."""
+    from kernels import kernel_points as ref
+    g = {}
+    for tag, (k, dim, fixed) in {'a': (7, 3, 'center'), 'b': (6, 2, 'none'), 'c': (9, 3, 'verticals')}.items():
+        np.random.seed(11)
+        pts, hist = ref.kernel_point_optimization_debug(1.0, k, num_kernels=8, dimension=dim, fixed=fixed, verbose=0)
+        g['opt.%s.args' % tag] = np.array([k, dim, {'center': 0, 'none': 1, 'verticals': 2}[fixed]])
+        g['opt.%s.points' % tag] = pts
+        g['opt.%s.last' % tag] = hist[-1]
+        g['opt.%s.iters' % tag] = np.int64((hist.max(axis=1) > 0).sum())
+    np.random.seed(12)
+    g['lloyd.points'] = ref.spherical_Lloyd(1.0, 32, dimension=3, fixed='center', max_iter=60, verbose=0)
+    np.random.seed(13)
+    g['load.15.a'] = ref.load_kernels(0.075, 15, 3, 'center')
+    g['load.15.b'] = ref.load_kernels(1.2, 15, 3, 'center')
+    np.savez_compressed(os.path.join(HERE, 'kernel_points.npz'), **g)
+    print('kernel_points.npz', {k: v.shape for k, v in g.items()})
+
+
 if __name__ == '__main__':
-    which = sys.argv[1:] or ['s1', 'reg', 'dataset']
+    which = sys.argv[1:] or ['s1', 'reg', 'dataset', 'kernels']
+    if 'kernels' in which:
+        kernels()
     if 'dataset' in which:
         dataset()
     if 'reg' in which:

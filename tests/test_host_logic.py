@@ -10,6 +10,7 @@ import d3feat_pytorch_amd as pkg
 from d3feat_pytorch_amd import config as cfgmod
 from d3feat_pytorch_amd import ops, synthetic
 from d3feat_pytorch_amd.datasets import dataloader as dl
+from d3feat_pytorch_amd.kernels import kernel_points as kp_mod
 from d3feat_pytorch_amd.kernels.kernel_points import base_disposition, load_kernels
 from d3feat_pytorch_amd.models import blocks
 from d3feat_pytorch_amd.models.architectures import KPFCNN
@@ -58,6 +59,25 @@ def test_kernel_points_contract():
     assert kp.dtype == np.float32 and kp.shape == (15, 3) and np.abs(kp).max() < 0.075
 
 
+def test_kernel_point_generators_equal_the_reference_runs():
+    """tests/golden/kernel_points.npz = reference kernels/kernel_points.py under fixed global seeds
+    (make_golden_extra.py kernels).  Same RNG draws, same arithmetic: equal to rounding of the last bits."""
+    g = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'kernel_points.npz'))
+    for tag in 'abc':
+        k, dim, f = (int(v) for v in g['opt.%s.args' % tag])
+        np.random.seed(11)
+        pts, hist = kp_mod.kernel_point_optimization(1.0, k, num_kernels=8, dimension=dim,
+                                                     fixed=['center', 'none', 'verticals'][f])
+        assert int((hist.max(axis=1) > 0).sum()) == int(g['opt.%s.iters' % tag]), tag
+        np.testing.assert_allclose(pts, g['opt.%s.points' % tag], rtol=0, atol=1e-12)
+        np.testing.assert_allclose(hist[-1], g['opt.%s.last' % tag], rtol=0, atol=1e-12)
+    np.random.seed(12)
+    np.testing.assert_allclose(kp_mod.spherical_lloyd(1.0, 32, max_iter=60), g['lloyd.points'], rtol=0, atol=1e-12)
+    np.random.seed(13)
+    assert np.array_equal(load_kernels(0.075, 15, 3, 'center'), g['load.15.a'])   # the shipped K=15 table + RNG order
+    assert np.array_equal(load_kernels(1.2, 15, 3, 'center'), g['load.15.b'])
+
+
 def test_model_state_dict_layout_matches_golden(golden_s0, golden_s1):
     np.random.seed(0)
     torch.manual_seed(0)
@@ -68,18 +88,17 @@ def test_model_state_dict_layout_matches_golden(golden_s0, golden_s1):
     for k, v in sd.items():
         assert tuple(v.shape) == tuple(gold[k]), k
     # identical construction order + same torch CPU RNG => identical initial weights as the reference model
+    # ... and same NumPy RNG + the shipped K=15 disposition => identical kernel points too
     for k, v in sd.items():
-        if not k.endswith('kernel_points'):
-            assert np.array_equal(v.numpy(), golden_s0['sd.' + k]), k
+        assert np.array_equal(v.numpy(), golden_s0['sd.' + k]), k
     np.random.seed(0)
     torch.manual_seed(0)
     full = KPFCNN(cfgmod.default_config())
     n_params = sum(p.numel() for p in full.parameters() if p.requires_grad)
     assert n_params == 24316320
     for k, v in full.state_dict().items():
-        if not k.endswith('kernel_points'):
-            s = golden_s1['sdsum.' + k]
-            assert abs(float(v.double().sum()) - s[0]) <= 1e-9 * max(1.0, s[1]), k
+        s = golden_s1['sdsum.' + k]
+        assert abs(float(v.double().sum()) - s[0]) <= 1e-9 * max(1.0, s[1]), k
 
 
 def test_lazy_list_and_loss_signatures():
