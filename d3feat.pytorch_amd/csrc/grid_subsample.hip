@@ -1,13 +1,18 @@
 // Voxel-grid barycentre subsampling of a stacked batch of clouds.
 //
-// Replaces reference cpp_wrappers/cpp_subsampling (grid_subsampling.cpp:5-106 per cloud, :109-211 batch loop),
-// points-only branch.  Bit-exact contract:
+// Replaces reference cpp_wrappers/cpp_subsampling (grid_subsampling.cpp:5-106 per cloud, :109-211 batch loop): the
+// points-only branch D3Feat's collate takes, and the feature / label branches of the same call (d3f_grid_subsample_ex).
+// Bit-exact contract:
 //   origin  = floor(min * (1/dl)) * dl                 float32, per cloud        (grid_subsampling.cpp:25-27)
 //   nX, nY  = (size_t)floor((max - origin)/dl) + 1                                (:30-31)
 //   key     = iX + nX*iY + nX*nY*iZ,  i* = (size_t)floor((p - origin)/dl)         (:53-56)
 //   bary    = (sequential float32 sum of member points IN INPUT ORDER) * (float)(1.0/count)   (:70,87)
 //   row order (D3F_ORDER_REFERENCE) = iteration order of libstdc++'s std::unordered_map<size_t,...> filled in
 //             point order (:48,59-60,85).
+//   feature = (sequential float32 sum of member features in input order) / (float)count        (grid_subsampling.h:50,:89-95)
+//   label   = per label column, the value with the most votes among the members; of several with the same count the
+//             one std::max_element meets first in the iteration order of the cell's std::unordered_map<int,int> filled
+//             in member order (grid_subsampling.h:51-56, .cpp:97-102) -- re-derived with the same list rule as the rows.
 //
 // Design (CDNA4): no global sort.  Cells live in an open-addressing hash table (atomicCAS on a 64-bit key =
 // batch id << 56 | cell key).  Members of a cell are gathered with atomic cursors and re-ordered per cell by
@@ -89,6 +94,7 @@ struct Layout {
   int32_t* bcnt;       // "
   int32_t* bcur;       // "
   int32_t* bbase;      // "
+  int32_t* row_slot;   // [N]  table slot of every emitted row (feature / label pass)
   size_t bytes;
 };
 
@@ -125,6 +131,7 @@ Layout layout(void* ws, int N, int B) {
   L.bcnt = c.take<int32_t>(nb);
   L.bcur = c.take<int32_t>(nb);
   L.bbase = c.take<int32_t>(nb);
+  L.row_slot = c.take<int32_t>(n);
   L.bytes = d3f::align_up(c.off, 256);
   return L;
 }
@@ -322,7 +329,7 @@ __global__ __launch_bounds__(kOrderThreads) void order_kernel(
     int32_t* __restrict__ tmpbk, int32_t* __restrict__ memberT, int32_t* __restrict__ bfirst,
     int32_t* __restrict__ bcnt, int32_t* __restrict__ bcur, int32_t* __restrict__ bbase,
     float* __restrict__ out_points, int32_t* __restrict__ out_len, int32_t* __restrict__ out_total, int out_cap,
-    int32_t* __restrict__ status) {
+    int32_t* __restrict__ row_slot, int32_t* __restrict__ status) {
   __shared__ int sh[16];
   const int b = blockIdx.x, tid = threadIdx.x, nthr = blockDim.x;
   const int pstart = d3f::batch_offset(len, b), n = len[b], pend = pstart + n;
@@ -454,9 +461,84 @@ __global__ __launch_bounds__(kOrderThreads) void order_kernel(
   }
   for (int pos = tid; pos < emit; pos += nthr) {
     if (obase + pos >= out_cap) continue;  // capacity overflow is reported through the status word
-    const float4 v = bary[sslot[cur[pos]]];
+    const int slot = sslot[cur[pos]];
+    const float4 v = bary[slot];
     float* o = out_points + 3 * (size_t)(obase + pos);
     o[0] = v.x; o[1] = v.y; o[2] = v.z;
+    if (row_slot) row_slot[obase + pos] = slot;
+  }
+}
+
+// thread per (emitted row, feature column): the reference's sequential sum over the cell's members, then / (float)count
+__global__ void cell_feature_kernel(const int32_t* __restrict__ out_total, int out_cap, int fdim,
+                                    const int32_t* __restrict__ row_slot, const int32_t* __restrict__ tcount,
+                                    const int32_t* __restrict__ tstart, const int32_t* __restrict__ members,
+                                    const float* __restrict__ features, float* __restrict__ out_features) {
+  const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int rows = min(*out_total, out_cap);
+  if (t >= (size_t)rows * fdim) return;
+  const int row = (int)(t / fdim), ch = (int)(t % fdim);
+  const int s = row_slot[row], c = tcount[s];
+  const int32_t* m = members + tstart[s];      // sorted by point index (cell_sum_kernel)
+  float acc = 0.0f;
+  for (int i = 0; i < c; ++i) acc = __fadd_rn(acc, features[(size_t)m[i] * fdim + ch]);
+  out_features[t] = __fdiv_rn(acc, (float)c);
+}
+
+// thread per emitted row: label votes.  Scratch (5 ints per member, at the cell's member range): distinct values in
+// first-appearance order, their counts, two list buffers and the first-appearance index of every element's bucket.
+__global__ void cell_label_kernel(const int32_t* __restrict__ out_total, int out_cap, int ldim, Schedule sched,
+                                  const int32_t* __restrict__ row_slot, const int32_t* __restrict__ tcount,
+                                  const int32_t* __restrict__ tstart, const int32_t* __restrict__ members,
+                                  const int32_t* __restrict__ classes, int32_t* __restrict__ vals_,
+                                  int32_t* __restrict__ cnts_, int32_t* __restrict__ listA, int32_t* __restrict__ listB,
+                                  int32_t* __restrict__ fst_, int32_t* __restrict__ out_classes) {
+  const int row = blockIdx.x * blockDim.x + threadIdx.x;
+  if (row >= min(*out_total, out_cap)) return;
+  const int s = row_slot[row], c = tcount[s], base = tstart[s];
+  const int32_t* m = members + base;
+  int32_t* vals = vals_ + base;
+  int32_t* cnts = cnts_ + base;
+  int32_t* fst = fst_ + base;
+  for (int ld = 0; ld < ldim; ++ld) {
+    int D = 0;
+    for (int i = 0; i < c; ++i) {                       // labels[ld][value] += 1 in member order (grid_subsampling.h:51-56)
+      const int v = classes[(size_t)m[i] * ldim + ld];
+      int j = 0;
+      while (j < D && vals[j] != v) ++j;
+      if (j == D) { vals[D] = v; cnts[D] = 0; ++D; }
+      ++cnts[j];
+    }
+    // iteration order of the unordered_map<int,int>: same list rule as the rows (see order_kernel)
+    int32_t* cur = listA + base;
+    int32_t* nxt = listB + base;
+    for (int j = 0; j < sched.n; ++j) {
+      const int e0 = sched.size[j];
+      if (e0 >= D) break;
+      const int e1 = (j + 1 < sched.n) ? sched.size[j + 1] : 0x7fffffff;
+      const int nj = min(e1, D);
+      const uint64_t Bk = (uint64_t)sched.bucket[j];
+      auto bucket_of = [&](int t) -> uint64_t {
+        const int el = t < e0 ? cur[t] : t;
+        return (uint64_t)(int64_t)vals[el] % Bk;        // std::hash<int> is the value converted to size_t
+      };
+      for (int t = 0; t < nj; ++t) {
+        const uint64_t bk = bucket_of(t);
+        int f = 0;
+        while (bucket_of(f) != bk) ++f;
+        fst[t] = f;
+      }
+      for (int t = 0; t < nj; ++t) {
+        int g = 0;
+        for (int u = 0; u < nj; ++u) g += (fst[u] < fst[t]) || (fst[u] == fst[t] && u < t);
+        nxt[nj - 1 - g] = t < e0 ? cur[t] : t;
+      }
+      int32_t* sw = cur; cur = nxt; nxt = sw;
+    }
+    int best = cur[0];
+    for (int pos = 1; pos < D; ++pos)                   // std::max_element keeps the FIRST of equal maxima (.cpp:100-101)
+      if (cnts[cur[pos]] > cnts[best]) best = cur[pos];
+    out_classes[(size_t)row * ldim + ld] = vals[best];
   }
 }
 
@@ -466,21 +548,28 @@ extern "C" {
 
 size_t d3f_grid_subsample_ws_bytes(int N, int B) { return layout(nullptr, N, B < 1 ? 1 : B).bytes; }
 
-int d3f_grid_subsample(const float* points, int N, const int32_t* len, int B, float sampleDl, int max_p, int order,
-                       float* out_points, int out_cap, int32_t* out_len, int32_t* out_total, void* ws, size_t ws_bytes,
-                       int32_t* status, void* stream_) {
+int d3f_grid_subsample_ex(const float* points, int N, const int32_t* len, int B, float sampleDl, int max_p, int order,
+                          const float* features, int fdim, const int32_t* classes, int ldim, float* out_points,
+                          int out_cap, int32_t* out_len, int32_t* out_total, float* out_features, int32_t* out_classes,
+                          void* ws, size_t ws_bytes, int32_t* status, void* stream_) {
   if (out_cap <= 0) out_cap = N;
   if (!points || !len || !out_points || !out_len || !out_total || !ws || !status || N < 1 || B < 1 ||
       B > D3F_MAX_BATCH || !(sampleDl > 0.0f) || (order != D3F_ORDER_REFERENCE && order != D3F_ORDER_FIRST_SEEN))
     return D3F_EINVAL;
+  if ((features && (fdim < 1 || !out_features)) || (classes && (ldim < 1 || !out_classes))) return D3F_EINVAL;
   hipStream_t stream = (hipStream_t)stream_;
   Layout L = layout(ws, N, B);
   if (ws_bytes < L.bytes) return D3F_EWORKSPACE;
   const Schedule& sched = host_schedule(N);
+  const bool attrs = features || classes;
   if (d3f::zero_async(L.tcount, sizeof(int32_t) * (L.M + 64 + (size_t)B), stream) != hipSuccess) return D3F_ELAUNCH;
   if (d3f::zero_async(L.bitmap, sizeof(uint64_t) * ((size_t)N / 64 + 2), stream) != hipSuccess) return D3F_ELAUNCH;
   // rows past the emitted total stay zero: a capacity-shaped consumer never sees uninitialised (NaN) coordinates
   if (d3f::zero_async(out_points, sizeof(float) * 3 * (size_t)out_cap, stream) != hipSuccess) return D3F_ELAUNCH;
+  if (features && d3f::zero_async(out_features, sizeof(float) * (size_t)fdim * out_cap, stream) != hipSuccess)
+    return D3F_ELAUNCH;
+  if (classes && d3f::zero_async(out_classes, sizeof(int32_t) * (size_t)ldim * out_cap, stream) != hipSuccess)
+    return D3F_ELAUNCH;
   init_kernel<<<d3f::cdiv(L.M, 256), 256, 0, stream>>>(L.M, L.tkey, L.tfirst);
   bbox_kernel<<<B, 1024, 0, stream>>>(points, len, sampleDl, L.grid);
   insert_kernel<<<d3f::cdiv(N, 256), 256, 0, stream>>>(points, N, len, B, sampleDl, L.grid, L.M - 1, L.tkey, L.tcount,
@@ -492,9 +581,24 @@ int d3f_grid_subsample(const float* points, int N, const int32_t* len, int B, fl
   order_kernel<<<B, kOrderThreads, 0, stream>>>(len, B, max_p, order, sched, L.bitmap, L.wprefix, L.slot_of, L.tkey,
                                                 L.bary, L.ncell, L.seq_key, L.seq_slot, L.curA, L.curB, L.tmpbk,
                                                 L.memberT, L.bfirst, L.bcnt, L.bcur, L.bbase, out_points, out_len,
-                                                out_total, out_cap, status);
+                                                out_total, out_cap, attrs ? L.row_slot : nullptr, status);
+  // the order pass is done with its per-point scratch: the label pass reuses five of those arrays
+  if (features)
+    cell_feature_kernel<<<d3f::cdiv((long long)out_cap * fdim, 256), 256, 0, stream>>>(
+        out_total, out_cap, fdim, L.row_slot, L.tcount, L.tstart, L.members, features, out_features);
+  if (classes)
+    cell_label_kernel<<<d3f::cdiv(out_cap, 64), 64, 0, stream>>>(out_total, out_cap, ldim, sched, L.row_slot, L.tcount,
+                                                                L.tstart, L.members, classes, L.curA, L.curB, L.tmpbk,
+                                                                L.memberT, L.seq_slot, out_classes);
   D3F_LAUNCH_CHECK();
   return D3F_OK;
+}
+
+int d3f_grid_subsample(const float* points, int N, const int32_t* len, int B, float sampleDl, int max_p, int order,
+                       float* out_points, int out_cap, int32_t* out_len, int32_t* out_total, void* ws, size_t ws_bytes,
+                       int32_t* status, void* stream_) {
+  return d3f_grid_subsample_ex(points, N, len, B, sampleDl, max_p, order, nullptr, 0, nullptr, 0, out_points, out_cap,
+                               out_len, out_total, nullptr, nullptr, ws, ws_bytes, status, stream_);
 }
 
 }  // extern "C"

@@ -37,20 +37,24 @@ def _to_dev(a, dtype, device):
 
 def batch_grid_subsampling_kpconv(points, batches_len, features=None, labels=None, sampleDl=0.1, max_p=0, verbose=0,
                                   random_grid_orient=True, order=ops.ORDER_REFERENCE):
-    """(s_points float32 [N',3], s_len int32 [B]) -- reference dataloader.py:12-22 (points-only branch).
+    """(s_points float32 [N',3], s_len int32 [B][, s_features float32 [N',d]][, s_labels int32 [N',l]]) -- reference
+    dataloader.py:12-50: barycentres per voxel, member-mean features, majority-vote labels.
 
-    Rows come in the reference's order (``order=ops.ORDER_REFERENCE``).  Feature / label averaging (the branches
-    D3Feat's collate never takes, dataloader.py:24-50) is not implemented on the device."""
-    if features is not None or labels is not None:
-        raise NotImplementedError("grid subsampling of features/labels is outside the D3Feat hot path")
+    Rows come in the reference's order (``order=ops.ORDER_REFERENCE``).  D3Feat's collate takes the points-only
+    branch; the feature / label branches are the same device call with two more passes."""
     dev = points.device if isinstance(points, torch.Tensor) and points.is_cuda else _device()
     p = _to_dev(points, torch.float32, dev)
-    out, out_len, total, status = ops.grid_subsample_raw(p, batches_len, sampleDl, max_p=max_p, order=order)
+    f = _to_dev(features, torch.float32, dev) if features is not None else None
+    c = _to_dev(labels, torch.int32, dev) if labels is not None else None
+    res = ops.grid_subsample_raw(p, batches_len, sampleDl, max_p=max_p, order=order, features=f, labels=c)
+    out, out_len, total, status = res[:4]
     n = int(total.item())  # the one read-back this standalone form needs
     status.raise_if_set()
     if n < 1:
         raise RuntimeError("Error")  # cpp_subsampling/wrapper.cpp:266
-    return out[:n], out_len
+    extra = [t[:n] for t in res[4:]]
+    # the reference returns classes as [N', ldim] even for a label vector (wrapper.cpp:282-284,308-310)
+    return (out[:n], out_len) + tuple(extra)
 
 
 def batch_neighbors_kpconv(queries, supports, q_batches, s_batches, radius, max_neighbors):

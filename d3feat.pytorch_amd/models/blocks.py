@@ -149,12 +149,21 @@ class BatchNormBlock(nn.Module):
     def reset_parameters(self):
         nn.init.zeros_(self.bias)
 
-    def forward(self, x):
+    def forward(self, x, slope=1.0):
+        """``slope`` != 1 fuses the block's LeakyReLU behind the normalisation (device path only)."""
         if self.use_bn:
-            return self.batch_norm(x.unsqueeze(2).transpose(0, 2)).transpose(0, 2).squeeze()
+            bn = self.batch_norm
+            if x.is_cuda and x.dim() == 2:
+                if self.training and bn.track_running_stats:
+                    bn.num_batches_tracked.add_(1)       # nn.BatchNorm1d's own counter (state_dict parity)
+                return ops.batch_norm(x, bn.weight, bn.bias, bn.running_mean, bn.running_var,
+                                      self.training or not bn.track_running_stats, bn.momentum, bn.eps, slope=slope)
+            y = bn(x.unsqueeze(2).transpose(0, 2)).transpose(0, 2).squeeze()
+            return y if slope == 1.0 else F.leaky_relu(y, slope)
         if x.is_cuda and x.dim() == 2:
-            return ops.bias_act(x, self.bias, slope=1.0)
-        return x + self.bias
+            return ops.bias_act(x, self.bias, slope=slope)
+        y = x + self.bias
+        return y if slope == 1.0 else F.leaky_relu(y, slope)
 
     def __repr__(self):
         return 'BatchNormBlock(in_feat: {:d}, momentum: {:.3f}, only_bias: {:s})'.format(
@@ -183,10 +192,12 @@ class UnaryBlock(nn.Module):
             return ops.linear_bias_act(x, self.mlp.weight, self.mlp.bias, residual, self.batch_norm.bias,
                                        slope=1.0 if (self.no_relu and residual is None) else 0.1,
                                        grad_holder=grad_holder, grad_deposit=grad_deposit)
+        if residual is None:                     # BN (+ LeakyReLU) in one normalisation pass on the device
+            return self.batch_norm(self.mlp(x), slope=1.0 if self.no_relu else 0.1)
         x = self.batch_norm(self.mlp(x))
-        if residual is not None:
-            return self.leaky_relu_res(x + residual)
-        return x if self.no_relu else self.leaky_relu(x)
+        if x.is_cuda and x.dim() == 2:
+            return ops.bias_act(x, add=residual, slope=0.1)
+        return self.leaky_relu_res(x + residual)
 
     @staticmethod
     def leaky_relu_res(x):
@@ -261,7 +272,7 @@ class SimpleBlock(nn.Module):
                                        self.KPConv.KP_extent, self.batch_norm.bias, slope=0.1,
                                        influence=self.KPConv.KP_influence, aggregation=self.KPConv.aggregation_mode)
         y = self.KPConv(q_pts, s_pts, inds, x)
-        return self.leaky_relu(self.batch_norm(y))
+        return self.batch_norm(y, slope=0.1)
 
 
 class ResnetBottleneckBlock(nn.Module):
@@ -318,8 +329,8 @@ class ResnetBottleneckBlock(nn.Module):
         shortcut = self.unary_shortcut(shortcut)
         if not self.use_bn:
             return self.unary2(x, residual=shortcut)  # leaky(unary2(x) + shortcut) in the epilogue of unary2
-        x = self.leaky_relu(self.batch_norm_conv(x))
-        return self.leaky_relu(self.unary2(x) + shortcut)
+        x = self.batch_norm_conv(x, slope=0.1)
+        return self.unary2(x, residual=shortcut)
 
 
 class GlobalAverageBlock(nn.Module):

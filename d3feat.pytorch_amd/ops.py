@@ -179,8 +179,11 @@ class RadiusGrid:
 # ---------------------------------------------------------------------------------------------------------------
 # grid subsampling (cpp_wrappers/cpp_subsampling; datasets/dataloader.py:12-22)
 # ---------------------------------------------------------------------------------------------------------------
-def grid_subsample_raw(points, lens, sampleDl, max_p=0, order=ORDER_REFERENCE, status=None, out_cap=0):
-    """Sync-free form: returns (out_points [capacity,3], out_len [B] int32, out_total [1] int32).
+def grid_subsample_raw(points, lens, sampleDl, max_p=0, order=ORDER_REFERENCE, status=None, out_cap=0, features=None,
+                       labels=None):
+    """Sync-free form: returns (out_points [capacity,3], out_len [B] int32, out_total [1] int32, status), followed by
+    out_features [capacity,fdim] / out_labels [capacity,ldim] int32 when ``features`` / ``labels`` are given
+    (reference grid_subsampling.cpp:89-102: member mean, majority vote).
 
     ``points`` may itself be a capacity buffer: only the first sum(lens) rows are read, so pyramid levels chain
     on the device without reading lengths back."""
@@ -191,6 +194,18 @@ def grid_subsample_raw(points, lens, sampleDl, max_p=0, order=ORDER_REFERENCE, s
     lens = _lens(lens, dev, "batches")
     status = status if status is not None else DeviceStatus(dev)
     N, B = int(p.shape[0]), int(lens.numel())
+    f = c = None
+    if features is not None:
+        f = _f32(features, "features")
+        if f.dim() != 2 or f.shape[0] != N:
+            raise RuntimeError("Wrong dimensions : features.shape is not (N, d)")      # wrapper.cpp:172-215
+    if labels is not None:
+        c = labels
+        if not (isinstance(c, torch.Tensor) and c.is_cuda and c.dtype == torch.int32):
+            raise RuntimeError("classes must be an int32 device tensor")
+        if c.dim() > 2 or c.shape[0] != N:
+            raise RuntimeError("Wrong dimensions : classes.shape is not (N,) or (N, d)")  # wrapper.cpp:182-224
+        c = c.reshape(N, -1).contiguous()
     L = _native.lib()
     nbytes = L.d3f_grid_subsample_ws_bytes(N, B)
     ws = _ws(nbytes, dev)
@@ -198,11 +213,22 @@ def grid_subsample_raw(points, lens, sampleDl, max_p=0, order=ORDER_REFERENCE, s
     out = torch.empty((cap, 3), dtype=torch.float32, device=dev)
     out_len = torch.empty(B, dtype=torch.int32, device=dev)
     total = torch.empty(1, dtype=torch.int32, device=dev)
+    of = torch.empty((cap, f.shape[1]), dtype=torch.float32, device=dev) if f is not None else None
+    oc = torch.empty((cap, c.shape[1]), dtype=torch.int32, device=dev) if c is not None else None
     with _region("grid_subsample[cap=%d]" % N, 24 * N):
-        _native.check(L.d3f_grid_subsample(_p(p), N, _p(lens), B, float(sampleDl), int(max_p), int(order), _p(out),
-                                           cap, _p(out_len), _p(total), _p(ws), nbytes, _p(status.word), _stream()),
-                      "d3f_grid_subsample")
-    return out, out_len, total, status
+        if f is None and c is None:
+            _native.check(L.d3f_grid_subsample(_p(p), N, _p(lens), B, float(sampleDl), int(max_p), int(order), _p(out),
+                                               cap, _p(out_len), _p(total), _p(ws), nbytes, _p(status.word), _stream()),
+                          "d3f_grid_subsample")
+        else:
+            _native.check(L.d3f_grid_subsample_ex(
+                _p(p), N, _p(lens), B, float(sampleDl), int(max_p), int(order), _p(f) if f is not None else None,
+                int(f.shape[1]) if f is not None else 0, _p(c) if c is not None else None,
+                int(c.shape[1]) if c is not None else 0, _p(out), cap, _p(out_len), _p(total),
+                _p(of) if of is not None else None, _p(oc) if oc is not None else None, _p(ws), nbytes, _p(status.word),
+                _stream()), "d3f_grid_subsample_ex")
+    extra = tuple(t for t in (of, oc) if t is not None)
+    return (out, out_len, total, status) + extra
 
 
 # ---------------------------------------------------------------------------------------------------------------
@@ -1144,6 +1170,66 @@ def bias_act(x, bias1=None, add=None, bias2=None, slope=0.1):
     if a is not None and a.shape != x.shape:
         raise RuntimeError("bias_act: residual shape %s != %s" % (tuple(a.shape), tuple(x.shape)))
     return _BiasActFn.apply(x, b1, a, b2, float(slope))
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# batch normalisation over the stacked points (models/blocks.py:454-471, use_bn=True) -- csrc/batchnorm.hip
+# ---------------------------------------------------------------------------------------------------------------
+class _BatchNormFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias, running_mean, running_var, training, momentum, eps, slope, n_live):
+        N, C = int(x.shape[0]), int(x.shape[1])
+        L = _native.lib()
+        y = torch.empty_like(x)
+        mean = torch.empty(C, dtype=torch.float32, device=x.device)
+        invstd = torch.empty(C, dtype=torch.float32, device=x.device)
+        nbytes = L.d3f_batchnorm_ws_bytes(N, C)
+        ws = _ws(nbytes, x.device)
+        with _region("batchnorm_fwd[N=%d,C=%d]" % (N, C), 16 * N * C):
+            _native.check(L.d3f_batchnorm_forward(_p(x), N, C, _p(n_live), _p(weight), _p(bias), _p(running_mean),
+                                                  _p(running_var), float(momentum), float(eps), 1 if training else 0,
+                                                  float(slope), _p(y), _p(mean), _p(invstd), _p(ws), nbytes, _stream()),
+                          "d3f_batchnorm_forward")
+        ctx.save_for_backward(x, weight, bias, mean, invstd)
+        ctx.n_live, ctx.slope, ctx.training = n_live, float(slope), bool(training)
+        ctx.mark_non_differentiable(mean, invstd)
+        return y, mean, invstd
+
+    @staticmethod
+    def backward(ctx, gy, _gm, _gi):
+        x, weight, bias, mean, invstd = ctx.saved_tensors
+        N, C = int(x.shape[0]), int(x.shape[1])
+        L = _native.lib()
+        gy = gy.contiguous()
+        gx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+        gw = torch.empty(C, dtype=torch.float32, device=x.device) if weight is not None else None
+        gb = torch.empty(C, dtype=torch.float32, device=x.device) if bias is not None else None
+        nbytes = L.d3f_batchnorm_ws_bytes(N, C)
+        ws = _ws(nbytes, x.device)
+        with _region("batchnorm_bwd[N=%d,C=%d]" % (N, C), 20 * N * C):
+            _native.check(L.d3f_batchnorm_backward(_p(x), N, C, _p(ctx.n_live), _p(weight), _p(bias), _p(mean),
+                                                   _p(invstd), ctx.slope, 1 if ctx.training else 0, _p(gy), _p(gx),
+                                                   _p(gw), _p(gb), _p(ws), nbytes, _stream()),
+                          "d3f_batchnorm_backward")
+        return gx, gw, gb, None, None, None, None, None, None, None
+
+
+def batch_norm(x, weight, bias, running_mean, running_var, training, momentum=0.1, eps=1e-5, slope=1.0, n_live=None):
+    """nn.BatchNorm1d over the N stacked points of x [N, C] (the reference's BatchNormBlock, blocks.py:465-471) with an
+    optional LeakyReLU(slope) fused behind it.  Training mode normalises with the batch statistics and updates
+    ``running_mean`` / ``running_var`` in place (momentum, unbiased variance); eval mode uses the running statistics.
+    ``n_live`` (int32 device scalar) bounds the live rows when x is a capacity-shaped buffer."""
+    x = _f32(x, "x")
+    if x.dim() != 2:
+        raise RuntimeError("batch_norm expects [N, C]")
+    if not training and (running_mean is None or running_var is None):
+        raise RuntimeError("batch_norm in eval mode needs running statistics")
+    if momentum is None:
+        raise RuntimeError("batch_norm: cumulative-average momentum (None) is not supported")
+    w = _f32(weight, "weight") if weight is not None else None
+    b = _f32(bias, "bias") if bias is not None else None
+    return _BatchNormFn.apply(x, w, b, running_mean, running_var, bool(training), float(momentum), float(eps),
+                              float(slope), n_live)[0]
 
 
 # ---------------------------------------------------------------------------------------------------------------

@@ -100,6 +100,18 @@ size_t d3f_grid_subsample_ws_bytes(int N, int B);
 int d3f_grid_subsample(const float* points, int N, const int32_t* len, int B, float sampleDl, int max_p, int order,
                        float* out_points, int out_cap /* rows of out_points; <= 0: N */, int32_t* out_len,
                        int32_t* out_total, void* ws, size_t ws_bytes, int32_t* status, void* stream);
+/* The same call with the reference's optional per-point features [N,fdim] (float) and classes [N,ldim] (int) --
+ *   subsample_batch(points, batches, features=, classes=) (wrapper.cpp:75-82,240-247; datasets/dataloader.py:24-50).
+ *   out_features [out_cap,fdim] = sequential float32 sum of the cell's member features in input order / (float)count
+ *   (grid_subsampling.h:50, .cpp:89-95); out_classes [out_cap,ldim] = per column the value with the most votes, ties
+ *   resolved like the reference's std::max_element over its std::unordered_map<int,int> (.cpp:97-102).  Either input
+ *   may be NULL (that output is then not written).  Rows follow out_points (same order, same max_p truncation).
+ *   NOTE reference bug kept out: with ldim > 1 AND more than one cloud the reference slices the classes of clouds
+ *   b > 0 with a wrong end iterator (.cpp:157-158, undefined behaviour); this entry point slices correctly. */
+int d3f_grid_subsample_ex(const float* points, int N, const int32_t* len, int B, float sampleDl, int max_p, int order,
+                          const float* features, int fdim, const int32_t* classes, int ldim, float* out_points,
+                          int out_cap, int32_t* out_len, int32_t* out_total, float* out_features, int32_t* out_classes,
+                          void* ws, size_t ws_bytes, int32_t* status, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * KPConv -- replaces models/blocks.py:237-382 (KPConv.forward, rigid / 'linear' / 'sum' path) and its
@@ -278,6 +290,29 @@ size_t d3f_bias_act_backward_ws_bytes(int N, int C);
 int d3f_bias_act_backward(const float* grad_out, const float* out, float slope, int N, int C, float* grad_x,
                           float* grad_bias, float* grad_bias2, int bias_prezeroed, const float* row_div, void* ws,
                           size_t ws_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Batch normalisation over the stacked points -- replaces the use_bn=True branch of BatchNormBlock
+ *   (models/blocks.py:454-455,465-471: nn.BatchNorm1d(C, momentum) over x [N, C] viewed as [1, C, N]).
+ *   training != 0: y = (x - mean) / sqrt(var + eps) * gamma + beta with the batch mean and BIASED batch variance;
+ *                  running_mean / running_var (optional) are updated in place: (1-m) old + m new, the variance
+ *                  UNBIASED (N/(N-1)), like torch.
+ *   training == 0: the running statistics normalise (both required).
+ *   slope: LeakyReLU fused behind (1 = none).  gamma / beta may be NULL (1 / 0).  save_mean / save_invstd [C]
+ *   (optional forward outputs) are what the backward needs.  n_live (optional int32 device scalar): only the first
+ *   min(N, *n_live) rows are live -- N is then a capacity; dead rows are written as zeros.
+ *   backward: grad_x (optional), grad_gamma, grad_beta (optional, OVERWRITTEN) for grad_y taken behind the activation.
+ * Deterministic (fixed-order partial sums in ws).
+ * ---------------------------------------------------------------------------------------------- */
+size_t d3f_batchnorm_ws_bytes(int N, int C);
+int d3f_batchnorm_forward(const float* x, int N, int C, const int32_t* n_live, const float* gamma, const float* beta,
+                          float* running_mean, float* running_var, float momentum, float eps, int training,
+                          float slope, float* y, float* save_mean, float* save_invstd, void* ws, size_t ws_bytes,
+                          void* stream);
+int d3f_batchnorm_backward(const float* x, int N, int C, const int32_t* n_live, const float* gamma, const float* beta,
+                           const float* save_mean, const float* save_invstd, float slope, int training,
+                           const float* grad_y, float* grad_x, float* grad_gamma, float* grad_beta, void* ws,
+                           size_t ws_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Detector score -- replaces KPFCNN.detection_scores (models/architectures.py:322-368).

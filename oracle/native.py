@@ -50,6 +50,8 @@ def _lib():
         _oracle.orc_radius_counts.argtypes = [_f32p, C.c_int, _f32p, C.c_int, _i32p, _i32p, C.c_int, C.c_float, _i32p]
         _oracle.orc_grid_subsample.argtypes = [_f32p, C.c_int, _i32p, C.c_int, C.c_float, C.c_int, _f32p, _i32p,
                                                _i32p, _i32p, _i64p]
+        _oracle.orc_grid_subsample_ex.argtypes = [_f32p, C.c_int, _i32p, C.c_int, C.c_float, C.c_int, _f32p, C.c_int,
+                                                  _i32p, C.c_int, _f32p, _i32p, _i32p, _i32p, _i64p, _f32p, _i32p]
         _oracle.orc_free.argtypes = [C.c_void_p]
     return _oracle
 
@@ -68,6 +70,10 @@ def _reflib():
                                          C.POINTER(_i32p), _i32p]
         _ref.ref_subsample_batch.argtypes = [_f32p, C.c_int, _i32p, C.c_int, C.c_float, C.c_int, C.POINTER(_f32p),
                                              _i32p, _i32p]
+        if hasattr(_ref, 'ref_subsample_batch_ex'):
+            _ref.ref_subsample_batch_ex.argtypes = [_f32p, C.c_int, _i32p, C.c_int, C.c_float, C.c_int, _f32p, C.c_int,
+                                                    _i32p, C.c_int, C.POINTER(_f32p), _i32p, _i32p, C.POINTER(_f32p),
+                                                    C.POINTER(_i32p)]
         _ref.ref_free.argtypes = [C.c_void_p]
     return _ref
 
@@ -146,6 +152,32 @@ def subsample_batch(points, batches, sampleDl=0.1, max_p=0, return_meta=False):
     return out[:n.value].copy(), ob
 
 
+def subsample_batch_ex(points, batches, features=None, classes=None, sampleDl=0.1, max_p=0):
+    """Restated ``subsample_batch(points, batches, features=, classes=)``: (points, batches[, features][, classes]);
+    classes come back as int32 [N', ldim] like the reference's (wrapper.cpp:282-310)."""
+    p, b = _f32(points), _i32(batches)
+    f = _f32(features) if features is not None else None
+    c = _i32(classes).reshape(p.shape[0], -1) if classes is not None else None
+    fd, ld = (f.shape[1] if f is not None else 0), (c.shape[1] if c is not None else 0)
+    out = np.zeros((p.shape[0], 3), dtype=np.float32)
+    of = np.zeros((p.shape[0], max(fd, 1)), dtype=np.float32)
+    oc = np.zeros((p.shape[0], max(ld, 1)), dtype=np.int32)
+    ob = np.zeros(b.shape[0], dtype=np.int32)
+    n = C.c_int(0)
+    rc = _lib().orc_grid_subsample_ex(_ptr(p, _f32p), p.shape[0], _ptr(b, _i32p), b.shape[0], float(sampleDl),
+                                      int(max_p), _ptr(f, _f32p) if f is not None else None, fd,
+                                      _ptr(c, _i32p) if c is not None else None, ld, _ptr(out, _f32p), C.byref(n),
+                                      _ptr(ob, _i32p), None, None, _ptr(of, _f32p), _ptr(oc, _i32p))
+    if rc != 0:
+        raise RuntimeError("Error")
+    res = [out[:n.value].copy(), ob]
+    if f is not None:
+        res.append(of[:n.value, :fd].copy())
+    if c is not None:
+        res.append(oc[:n.value, :ld].copy())
+    return tuple(res)
+
+
 # ---------------------------------------------------------------------------------------------
 # the real reference (compiled in place); same call shapes
 # ---------------------------------------------------------------------------------------------
@@ -173,3 +205,29 @@ def ref_subsample_batch(points, batches, sampleDl=0.1, max_p=0):
     pts = np.ctypeslib.as_array(out_p, shape=(n.value * 3,)).reshape(n.value, 3).copy()
     _reflib().ref_free(out_p)
     return pts, ob
+
+
+def ref_subsample_batch_ex(points, batches, features=None, classes=None, sampleDl=0.1, max_p=0):
+    """The reference's batch_grid_subsampling with features / classes.  Only meaningful for ldim == 1 or one cloud
+    (the reference slices the classes of later clouds wrongly otherwise, grid_subsampling.cpp:157-158)."""
+    p, b = _f32(points), _i32(batches)
+    f = _f32(features) if features is not None else None
+    c = _i32(classes).reshape(p.shape[0], -1) if classes is not None else None
+    fd, ld = (f.shape[1] if f is not None else 0), (c.shape[1] if c is not None else 0)
+    out_p, out_f, out_c, n = _f32p(), _f32p(), _i32p(), C.c_int(0)
+    ob = np.zeros(b.shape[0], dtype=np.int32)
+    rc = _reflib().ref_subsample_batch_ex(_ptr(p, _f32p), p.shape[0], _ptr(b, _i32p), b.shape[0], float(sampleDl),
+                                          int(max_p), _ptr(f, _f32p) if f is not None else None, fd,
+                                          _ptr(c, _i32p) if c is not None else None, ld, C.byref(out_p), C.byref(n),
+                                          _ptr(ob, _i32p), C.byref(out_f), C.byref(out_c))
+    if rc != 0:
+        raise RuntimeError("Error")
+    res = [np.ctypeslib.as_array(out_p, shape=(n.value * 3,)).reshape(n.value, 3).copy(), ob]
+    _reflib().ref_free(out_p)
+    if f is not None:
+        res.append(np.ctypeslib.as_array(out_f, shape=(n.value * fd,)).reshape(n.value, fd).copy())
+        _reflib().ref_free(out_f)
+    if c is not None:
+        res.append(np.ctypeslib.as_array(out_c, shape=(n.value * ld,)).reshape(n.value, ld).copy())
+        _reflib().ref_free(out_c)
+    return tuple(res)

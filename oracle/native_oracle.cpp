@@ -174,8 +174,15 @@ int orc_radius_counts(const float* queries, int Nq, const float* supports, int N
 
 // out_points: caller buffer [N*3]; out_batches [B]; optional out_first [N] = index (global) of the first
 // input point that fell into the emitted cell, optional out_key [N] = cell key (per element).
-int orc_grid_subsample(const float* points, int N, const int* batches, int B, float dl, int max_p,
-                       float* out_points, int* out_n, int* out_batches, int* out_first, int64_t* out_key) {
+// Optional features [N,fdim] / classes [N,ldim] with outputs out_features [N,fdim] / out_classes [N,ldim]: the
+// reference's update_all / update_features / update_classes (grid_subsampling.h:42-73) and its emission loop
+// (grid_subsampling.cpp:89-102).  Classes of cloud b are sliced at (off*ldim, (off+n)*ldim) -- the reference's own
+// end iterator (.cpp:157-158) is wrong for ldim > 1 and b > 0 (undefined behaviour), so parity is anchored at
+// ldim = 1 or B = 1.
+int orc_grid_subsample_ex(const float* points, int N, const int* batches, int B, float dl, int max_p,
+                          const float* features, int fdim, const int* classes, int ldim,
+                          float* out_points, int* out_n, int* out_batches, int* out_first, int64_t* out_key,
+                          float* out_features, int* out_classes) {
   const P3* p = (const P3*)points;
   int off = 0, n_out = 0;
   for (int b = 0; b < B; ++b) {
@@ -201,6 +208,8 @@ int orc_grid_subsample(const float* points, int N, const int* batches, int B, fl
     const size_t nX = (size_t)std::floor((mx.x - org.x) / dl) + 1;  // :30
     const size_t nY = (size_t)std::floor((mx.y - org.y) / dl) + 1;  // :31
     std::unordered_map<size_t, Acc> cells;                          // :48
+    std::unordered_map<size_t, std::vector<float>> fsum;            // SampledData::features  (grid_subsampling.h:19)
+    std::unordered_map<size_t, std::vector<std::unordered_map<int, int>>> votes;   // SampledData::labels (:20)
     for (int i = 0; i < n; ++i) {
       const size_t iX = (size_t)std::floor((c[i].x - org.x) / dl);  // :53-55
       const size_t iY = (size_t)std::floor((c[i].y - org.y) / dl);
@@ -211,6 +220,16 @@ int orc_grid_subsample(const float* points, int N, const int* batches, int B, fl
       Acc& a = it->second;                                          // grid_subsampling.h:74-79
       a.count += 1;
       a.sx += c[i].x; a.sy += c[i].y; a.sz += c[i].z;
+      if (features) {                                               // grid_subsampling.h:50 (float +=, input order)
+        std::vector<float>& f = fsum[key];
+        if (f.empty()) f.assign((size_t)fdim, 0.0f);
+        for (int d = 0; d < fdim; ++d) f[d] += features[(size_t)(off + i) * fdim + d];
+      }
+      if (classes) {                                                // grid_subsampling.h:51-56
+        std::vector<std::unordered_map<int, int>>& v = votes[key];
+        if (v.empty()) v.resize((size_t)ldim);
+        for (int d = 0; d < ldim; ++d) v[d][classes[(size_t)(off + i) * ldim + d]] += 1;
+      }
     }
     int emitted = 0;
     const int limit = (max_p < 1) ? N : max_p;                      // :134-135 (max_p<1 -> N of the whole call)
@@ -221,6 +240,20 @@ int orc_grid_subsample(const float* points, int N, const int* batches, int B, fl
       out_points[3 * (size_t)n_out + 0] = a.sx * w;
       out_points[3 * (size_t)n_out + 1] = a.sy * w;
       out_points[3 * (size_t)n_out + 2] = a.sz * w;
+      if (features) {                                               // :89-95  f / (float)count
+        const float cnt = (float)a.count;
+        const std::vector<float>& f = fsum[kv.first];
+        for (int d = 0; d < fdim; ++d) out_features[(size_t)n_out * fdim + d] = f[d] / cnt;
+      }
+      if (classes) {                                                // :97-102 first maximum in map iteration order
+        const std::vector<std::unordered_map<int, int>>& v = votes[kv.first];
+        for (int d = 0; d < ldim; ++d)
+          out_classes[(size_t)n_out * ldim + d] =
+              std::max_element(v[d].begin(), v[d].end(), [](const std::pair<const int, int>& x,
+                                                            const std::pair<const int, int>& y) {
+                return x.second < y.second;
+              })->first;
+      }
       if (out_first) out_first[n_out] = a.first;
       if (out_key) out_key[n_out] = (int64_t)kv.first;
       ++n_out; ++emitted;
@@ -230,6 +263,12 @@ int orc_grid_subsample(const float* points, int N, const int* batches, int B, fl
   }
   *out_n = n_out;
   return n_out < 1 ? -1 : 0;  // cpp_subsampling/wrapper.cpp:266: empty result is an error
+}
+
+int orc_grid_subsample(const float* points, int N, const int* batches, int B, float dl, int max_p,
+                       float* out_points, int* out_n, int* out_batches, int* out_first, int64_t* out_key) {
+  return orc_grid_subsample_ex(points, N, batches, B, dl, max_p, nullptr, 0, nullptr, 0, out_points, out_n, out_batches,
+                               out_first, out_key, nullptr, nullptr);
 }
 
 void orc_free(void* p) { std::free(p); }

@@ -58,6 +58,35 @@ int ref_subsample_batch(const float* points, int N, const int* batches, int B, f
   return 0;
 }
 
+// subsample_batch with features [N,fdim] and / or classes [N,ldim] (either may be NULL); outputs malloc'd.
+int ref_subsample_batch_ex(const float* points, int N, const int* batches, int B, float sampleDl, int max_p,
+                           const float* features, int fdim, const int* classes, int ldim, float** out_points,
+                           int* out_n, int* out_batches, float** out_features, int** out_classes) {
+  std::vector<PointXYZ> p((const PointXYZ*)points, (const PointXYZ*)points + N);
+  std::vector<int> b(batches, batches + B);
+  std::vector<PointXYZ> sp;
+  std::vector<float> f, sf;
+  std::vector<int> c, sc, sb;
+  if (features) f.assign(features, features + (size_t)N * fdim);
+  if (classes) c.assign(classes, classes + (size_t)N * ldim);
+  batch_grid_subsampling(p, sp, f, sf, c, sc, b, sb, sampleDl, max_p);
+  *out_points = nullptr; *out_features = nullptr; *out_classes = nullptr;
+  if (sp.size() < 1) { *out_n = 0; return -1; }
+  *out_n = (int)sp.size();
+  *out_points = (float*)std::malloc(sp.size() * 3 * sizeof(float));
+  std::memcpy(*out_points, sp.data(), sp.size() * 3 * sizeof(float));
+  if (features) {
+    *out_features = (float*)std::malloc(sf.size() * sizeof(float));
+    std::memcpy(*out_features, sf.data(), sf.size() * sizeof(float));
+  }
+  if (classes) {
+    *out_classes = (int*)std::malloc(sc.size() * sizeof(int));
+    std::memcpy(*out_classes, sc.data(), sc.size() * sizeof(int));
+  }
+  for (int i = 0; i < B; ++i) out_batches[i] = sb[i];
+  return 0;
+}
+
 void ref_free(void* p) { std::free(p); }
 
 }  // extern "C"

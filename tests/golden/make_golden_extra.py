@@ -238,10 +238,33 @@ def kernels():
     print('kernel_points.npz', {k: v.shape for k, v in g.items()})
 
 
+def bn():
+    """tests/golden/s0_bn.npz: the S0 mini pair (inputs and neighbor limits of s0_small.npz) through the reference
+    KPFCNN built with use_batch_norm=True (models/blocks.py:454-471, momentum 0.02): training-mode descriptors, scores,
+    losses and every parameter gradient, then eval-mode outputs -- which see the running statistics that one training
+    forward left behind."""
+    g0 = np.load(os.path.join(HERE, 's0_small.npz'))
+    cfg = mg.cfgmod.default_config(first_features_dim=16, use_batch_norm=True)
+    item = (g0['pts0'], g0['pts1'], np.ones((len(g0['pts0']), 1), np.float32), np.ones((len(g0['pts1']), 1), np.float32),
+            g0['sel_corr'], g0['dist_keypts_in'])
+    res, sd, grads, _, _ = mg.run_reference(item, cfg, [int(v) for v in g0['limits']], seed=0, capture_blocks=[])
+    g = {k: res[k] for k in ('features_train', 'scores_train', 'features_eval', 'scores_eval', 'desc_loss', 'det_loss',
+                             'accuracy', 'dists')}
+    for k, v in sd.items():
+        g['sdsum.' + k] = np.array([float(v.double().sum()), float(v.double().abs().sum())])
+    for k, v in grads.items():
+        g['grad.' + k] = v.numpy()
+    np.savez_compressed(os.path.join(HERE, 's0_bn.npz'), **g)
+    print('s0_bn.npz', os.path.getsize(os.path.join(HERE, 's0_bn.npz')) / 1e6, 'MB; losses', res['desc_loss'],
+          res['det_loss'])
+
+
 if __name__ == '__main__':
-    which = sys.argv[1:] or ['s1', 'reg', 'dataset', 'kernels']
+    which = sys.argv[1:] or ['s1', 'reg', 'dataset', 'kernels', 'bn']
     if 'kernels' in which:
         kernels()
+    if 'bn' in which:
+        bn()
     if 'dataset' in which:
         dataset()
     if 'reg' in which:

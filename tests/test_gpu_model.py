@@ -1,5 +1,7 @@
 """GPU: pyramid construction and the full KPFCNN forward/backward + losses against the committed golden vectors
 (generated from the real reference, tests/golden/make_golden.py) -- everything through the C ABI on cuda:0."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -169,6 +171,43 @@ def test_model_forward_backward_s0(golden_s0):
     got = build_correspondence(g['features_eval'][:n0][g['match.src_idx']], g['features_eval'][n0:][g['match.tgt_idx']])
     a, b = set(map(tuple, got.tolist())), set(map(tuple, g['match.corr250'].tolist()))
     assert len(a & b) >= len(b) - 2
+
+
+def test_model_with_batch_norm_matches_the_reference_run(golden_s0):
+    """use_batch_norm=True (reference blocks.py:454-471) on the device normalisation kernels: tests/golden/s0_bn.npz is
+    the reference network built with BatchNorm on the S0 pair -- training outputs, losses, all gradients, and eval
+    outputs (which depend on the running statistics the training forward left)."""
+    g0 = golden_s0
+    g = np.load(os.path.join(os.path.dirname(__file__), 'golden', 's0_bn.npz'))
+    cfg = cfgmod.default_config(first_features_dim=16, use_batch_norm=True)
+    np.random.seed(0)
+    torch.manual_seed(0)
+    model = KPFCNN(cfg)
+    for k, v in model.state_dict().items():
+        s = g['sdsum.' + k]
+        assert abs(float(v.double().sum()) - s[0]) <= 1e-9 * max(1.0, s[1]), k
+    model = model.to(DEV)
+    batch = dl.collate_fn_descriptor([_item(g0)], cfg, g0['limits'])
+    model.train()
+    feats, scores, desc, det, acc, fp, an, dists = _run_step(model, batch, cfg)
+    assert np.abs(feats.detach().cpu().numpy() - g['features_train']).max() < 1e-4
+    assert np.abs(scores.detach().cpu().numpy() - g['scores_train']).max() < 1e-4
+    assert abs(desc.item() - float(g['desc_loss'])) < 1e-4 and abs(det.item() - float(g['det_loss'])) < 1e-4
+    assert rel_err(dists.cpu().numpy(), g['dists']) < 1e-4
+    checked = 0
+    for k, p in model.named_parameters():
+        if p.grad is not None and ('grad.' + k) in g.files and np.abs(g['grad.' + k]).max() > 0:
+            assert rel_err(p.grad.cpu().numpy(), g['grad.' + k]) < 5e-3, k
+            checked += 1
+    assert checked > 60
+    assert int(model.encoder_blocks[0].batch_norm.batch_norm.num_batches_tracked) == 1
+    model.eval()
+    with torch.no_grad():
+        fe, se = model(batch)
+    assert np.abs(fe.cpu().numpy() - g['features_eval']).max() < 1e-4
+    ref, se = g['scores_eval'], se.cpu().numpy()
+    m = (se != 0) & (ref != 0)
+    assert ((se != 0) == (ref != 0)).mean() > 0.999 and np.abs(se[m] - ref[m]).max() < 1e-4
 
 
 def test_model_forward_backward_s1_full_width(golden_s1):

@@ -71,6 +71,32 @@ def test_grid_subsample_large_cloud_and_single_point(native):
     assert np.array_equal(p.cpu().numpy(), one) and b.tolist() == [1]
 
 
+@pytest.mark.parametrize("n,n_labels,ldim,dl_", [([2500, 1700, 900], 4, 1, 0.11), ([3000, 500], 40, 1, 0.45),
+                                                  ([4000], 40, 3, 0.5), ([1500, 800], 3, 2, 0.05)])
+def test_grid_subsample_features_and_labels_bitexact(native, n, n_labels, ldim, dl_):
+    """subsample_batch(points, batches, features=, classes=) (reference dataloader.py:24-50): member-mean features
+    and majority-vote labels, rows in the reference's order, ties of a vote resolved like the reference's
+    unordered_map<int,int> iteration (40 distinct labels in big voxels -> the map rehashes twice)."""
+    rng = np.random.default_rng(31)
+    pts = _cloud(rng, sum(n))
+    lens = np.array(n, np.int32)
+    feats = rng.normal(size=(sum(n), 5)).astype(np.float32)
+    labels = (rng.integers(0, n_labels, size=(sum(n), ldim)) * 7919 - 20000).astype(np.int32)
+    for mp in (0, 6):
+        ref = native.subsample_batch_ex(pts, lens, feats, labels, sampleDl=dl_, max_p=mp)
+        got = dl.batch_grid_subsampling_kpconv(cu(pts), cu(lens), features=cu(feats), labels=cu(labels), sampleDl=dl_,
+                                               max_p=mp)
+        assert len(got) == 4
+        for g, r in zip(got, ref):
+            g = g.cpu().numpy()
+            assert g.shape == r.shape and g.dtype == r.dtype and np.array_equal(g.view(np.uint32), r.view(np.uint32))
+    p, b, f = dl.batch_grid_subsampling_kpconv(cu(pts), cu(lens), features=cu(feats), sampleDl=dl_)
+    assert np.array_equal(f.cpu().numpy(), ref[2] if mp == 0 else native.subsample_batch_ex(pts, lens, feats, None,
+                                                                                             sampleDl=dl_)[2])
+    p, b, c = dl.batch_grid_subsampling_kpconv(cu(pts), cu(lens), labels=cu(labels[:, 0].copy()), sampleDl=dl_)
+    assert np.array_equal(c.cpu().numpy(), native.subsample_batch_ex(pts, lens, None, labels[:, :1], sampleDl=dl_)[2])
+
+
 @pytest.mark.parametrize("radius,limit", [(0.12, 40), (0.2, 64), (0.2, 0), (0.35, 130)])
 def test_radius_neighbors_exact(native, radius, limit):
     rng = np.random.default_rng(7)
@@ -795,3 +821,53 @@ def test_mutual_nn_at_full_size_on_the_reference_descriptors():
         assert len(a ^ b) <= 2 * (len(tie_r) + len(tie_c)), (k, len(a), len(b), len(a ^ b), len(tie_r), len(tie_c))
         print("top-%d: %d / %d mutual matches (ours / reference), %d differ; %d tie rows, %d tie columns" % (
             k, len(a), len(b), len(a ^ b), len(tie_r), len(tie_c)))
+
+
+# ------------------------------------------------------------------------------------------------ batch norm
+@pytest.mark.parametrize("N,C,slope,mean", [(5000, 64, 1.0, 0.0), (37, 48, 0.1, 3.0), (20000, 512, 0.1, 50.0),
+                                            (3, 7, 1.0, 0.0)])
+def test_batch_norm_matches_torch(N, C, slope, mean):
+    """ops.batch_norm vs torch's nn.BatchNorm1d semantics the reference block uses (blocks.py:465-471): training
+    statistics, running-stat update (momentum, unbiased variance), eval mode, and all three gradients, optionally with
+    the block's LeakyReLU fused behind.  fp32 tolerance 1e-5 relative (2e-4 on the gradients)."""
+    rng = np.random.default_rng(N + C)
+    x = (rng.normal(size=(N, C)) * rng.uniform(0.5, 2.0, size=C) + mean).astype(np.float32)
+    w = rng.uniform(0.5, 1.5, size=C).astype(np.float32)
+    b = rng.normal(size=C).astype(np.float32)
+    go = rng.normal(size=(N, C)).astype(np.float32)
+    rm0, rv0 = rng.normal(size=C).astype(np.float32), rng.uniform(0.5, 2.0, size=C).astype(np.float32)
+
+    def run(device_op, training):
+        dev = DEV if device_op else 'cpu'
+        dt = torch.float32 if device_op else torch.float64
+        xt = torch.tensor(x, dtype=dt, device=dev, requires_grad=True)
+        wt = torch.tensor(w, dtype=dt, device=dev, requires_grad=True)
+        bt = torch.tensor(b, dtype=dt, device=dev, requires_grad=True)
+        rm, rv = torch.tensor(rm0, dtype=dt, device=dev), torch.tensor(rv0, dtype=dt, device=dev)
+        if device_op:
+            y = ops.batch_norm(xt, wt, bt, rm, rv, training, momentum=0.02, eps=1e-5, slope=slope)
+        else:
+            y = torch.nn.functional.batch_norm(xt.t().unsqueeze(0), rm, rv, wt, bt, training, 0.02, 1e-5)
+            y = torch.nn.functional.leaky_relu(y.squeeze(0).t(), slope) if slope != 1.0 else y.squeeze(0).t()
+        y.backward(torch.tensor(go, dtype=dt, device=dev))
+        return [t.detach().cpu().double().numpy() for t in (y, rm, rv, xt.grad, wt.grad, bt.grad)]
+
+    for training in (True, False):
+        got, ref = run(True, training), run(False, training)
+        tol = 1e-5 if mean < 10 else 2e-4          # a mean of 50 costs fp32 digits in (x - mean)
+        assert rel_err(got[0], ref[0]) < tol
+        assert rel_err(got[1], ref[1]) < 1e-6 and rel_err(got[2], ref[2]) < 1e-5
+        for a, r in zip(got[3:], ref[3:]):
+            assert rel_err(a, r) < 20 * tol
+
+
+def test_batch_norm_live_rows_of_a_capacity_buffer():
+    rng = np.random.default_rng(9)
+    x = rng.normal(size=(700, 32)).astype(np.float32)
+    w, b = torch.ones(32, device=DEV), torch.zeros(32, device=DEV)
+    full = ops.batch_norm(cu(x[:500]), w, b, None, None, True, slope=0.1)
+    xc = cu(x).clone()
+    xc[500:] = float('nan')                       # rows past the live count must never be read
+    n_live = torch.tensor([500], dtype=torch.int32, device=DEV)
+    part = ops.batch_norm(xc, w, b, None, None, True, slope=0.1, n_live=n_live)
+    assert torch.equal(part[:500], full) and float(part[500:].abs().max()) == 0.0

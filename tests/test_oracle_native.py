@@ -106,6 +106,38 @@ def test_oracle_vs_compiled_reference(native):
             assert_neighbors_equal_tie_aware(a, pts, ours, ref, 'trial %d dl %g' % (trial, dl))
 
 
+def _attr_case(rng, n, n_labels, ldim):
+    pts = (rng.random((sum(n), 3)) * np.array([2.0, 1.5, 0.6])).astype(np.float32)
+    feats = rng.normal(size=(sum(n), 5)).astype(np.float32)
+    # label values spread over negative / large ints so that bucket = (size_t)(int) % B is exercised
+    labels = (rng.integers(0, n_labels, size=(sum(n), ldim)) * 7919 - 20000).astype(np.int32)
+    return pts, np.array(n, np.int32), feats, labels
+
+
+def test_subsample_features_and_labels_vs_compiled_reference(native):
+    """Feature / label branches (grid_subsampling.h:42-73, .cpp:89-102): the restatement equals the reference's C++ bit
+    for bit, including which label wins a tied vote (iteration order of the per-cell unordered_map<int,int>); big voxels
+    with up to 40 distinct labels drive that map through its rehashes."""
+    if not native.have_ref():
+        pytest.skip("oracle/_ref not built (reference tree absent)")
+    rng = np.random.default_rng(23)
+    for n, n_labels, ldim, dl in (([2500, 1700], 4, 1, 0.11), ([3000, 500], 40, 1, 0.45), ([4000], 40, 3, 0.5),
+                                  ([1500], 3, 2, 0.05)):
+        pts, lens, feats, labels = _attr_case(rng, n, n_labels, ldim)
+        for mp in (0, 6):
+            a = native.subsample_batch_ex(pts, lens, feats, labels, sampleDl=dl, max_p=mp)
+            b = native.ref_subsample_batch_ex(pts, lens, feats, labels, sampleDl=dl, max_p=mp)
+            assert len(a) == len(b) == 4
+            for x, y in zip(a, b):
+                assert x.shape == y.shape and x.dtype == y.dtype and np.array_equal(x.view(np.uint32), y.view(np.uint32))
+        fa = native.subsample_batch_ex(pts, lens, feats, None, sampleDl=dl)
+        fb = native.ref_subsample_batch_ex(pts, lens, feats, None, sampleDl=dl)
+        la = native.subsample_batch_ex(pts, lens, None, labels, sampleDl=dl)
+        lb = native.ref_subsample_batch_ex(pts, lens, None, labels, sampleDl=dl)
+        assert len(fa) == len(la) == 3 and np.array_equal(fa[2], fb[2]) and np.array_equal(la[2], lb[2])
+        assert la[2].shape[1] == ldim
+
+
 def test_s1_pyramid_hashes(golden_s1, native):
     """The benchmark pair: regenerate fragments with the oracle subsampler and check SHA-256 of every level."""
     from d3feat_pytorch_amd import synthetic
