@@ -10,37 +10,11 @@
 // This file holds the GENERAL path (any Cin/Cout/H/K<=16): wave-per-query aggregation into a [Nq,K*Cin] scratch +
 // MFMA GEMMs.  kpconv_fused.hip holds the LDS-tiled fused kernels used for the channel widths of the D3Feat net.
 #include "common.hpp"
+#include "kpconv_modes.hpp"
 
 namespace d3f {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
-
-// Influence of kernel point `kk` (one per lane of a 16-lane group) on a neighbor at squared distance d2, for the
-// modes of blocks.py:327-352.  mode bits 0-1: 0 'linear' max(0, 1 - d/extent), 1 'constant' 1, 2 'gaussian'
-// exp(-d2 / gauss_denom) with gauss_denom = 2 (0.3 extent)^2 + 1e-9 (blocks.py:66-73,341-342); bit 2 ('closest'
-// aggregation, :348-350): only the kernel point nearest to the neighbor keeps its weight (first index on ties).
-__device__ __forceinline__ float influence_weight(float d2, bool klive, int kk, float extent, float gauss_denom,
-                                                  int mode) {
-  float w;
-  switch (mode & 3) {
-    case 1: w = 1.0f; break;
-    case 2: w = expf(-__fdiv_rn(d2, gauss_denom)); break;
-    default: w = fmaxf(0.0f, 1.0f - __fdiv_rn(__fsqrt_rn(d2), extent)); break;
-  }
-  if (!klive) w = 0.0f;
-  if (mode & 4) {
-    float bd = klive ? d2 : __builtin_huge_valf();
-    int bk = kk;
-#pragma unroll
-    for (int o = 8; o > 0; o >>= 1) {
-      const float od = __shfl_xor(bd, o, 64);
-      const int ok = __shfl_xor(bk, o, 64);
-      if (od < bd || (od == bd && ok < bk)) { bd = od; bk = ok; }
-    }
-    if (kk != bk) w = 0.0f;
-  }
-  return w;
-}
 
 // ------------------------------------------------------------------------------------------------
 // Aggregation: one wave per query, lanes <-> input channels (CPL channels per lane).
@@ -237,11 +211,6 @@ int launch_gemm(const float* A, long sai, long sak, const float* B, long sbk, lo
                                                  split > 1);
   D3F_LAUNCH_CHECK();
   return D3F_OK;
-}
-
-static float gauss_denominator(float extent) {
-  const double sigma = 0.3 * (double)extent;
-  return (float)(2.0 * sigma * sigma + 1e-9);
 }
 
 template <bool NN>

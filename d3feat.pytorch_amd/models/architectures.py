@@ -15,6 +15,28 @@ from .. import ops
 from .blocks import KPConv, NearestUpsampleBlock, ResnetBottleneckBlock, UnaryBlock, block_decider  # noqa: F401
 
 
+def p2p_fitting_regularizer(net, deform_fitting_power=None, repulse_extent=None):
+    """Regulariser of the deformable kernel points (reference architectures.py:22-55; used by its classification
+    network, plain tensor algebra on what each deformable KPConv left on itself): 2 x the mean normalised squared
+    distance of every deformed kernel point to its nearest input point (``min_d2``, through which the gradient reaches
+    the offsets) + a repulsion between deformed kernel points of one query closer than ``repulse_extent``."""
+    power = net.deform_fitting_power if deform_fitting_power is None else deform_fitting_power
+    repulse = net.repulse_extent if repulse_extent is None else repulse_extent
+    fitting, repulsive = 0, 0
+    for m in net.modules():
+        if not (isinstance(m, KPConv) and m.deformable):
+            continue
+        fitting = fitting + (m.min_d2 / (m.KP_extent ** 2)).abs().mean()
+        locs = m.deformed_KP / m.KP_extent
+        K = locs.shape[1]
+        for i in range(K):
+            others = torch.cat([locs[:, :i, :], locs[:, i + 1:, :]], dim=1).detach()
+            dist = torch.sqrt(torch.sum((others - locs[:, i:i + 1, :]) ** 2, dim=2))
+            rep = torch.sum(torch.clamp_max(dist - repulse, max=0.0) ** 2, dim=1)
+            repulsive = repulsive + rep.abs().mean() / K
+    return power * (2 * fitting + repulsive)
+
+
 def _moves_level(block):
     return any(tag in block for tag in ('pool', 'strided', 'upsample', 'global'))
 

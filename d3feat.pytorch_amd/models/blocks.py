@@ -9,8 +9,9 @@ runs on top of it unchanged.  The operators themselves are the hand-written HIP 
 ``libd3feat_hip.so`` -- there is no PyTorch implementation of the hot path in this file.
 
 The 'constant' / 'gaussian' influences and the 'closest' aggregation (blocks.py:327-352; never enabled by D3Feat's
-config, config.py:39-41) run on the general-path kernels.  Out of scope: deformable / modulated KPConv
-(config.py:45-46), which raises NotImplementedError.
+config, config.py:39-41) run on the general-path kernels, and so does the deformable / modulated KPConv
+(blocks.py:187-203,243-324,365-366; config.py:45-46): offsets from a rigid KPConv on the ordinary kernels, aggregation
+with per-query kernel points and its gradients in csrc/kpconv_deform.hip.
 """
 import math
 
@@ -65,7 +66,7 @@ def global_average(x, batch_lengths):
 
 
 class KPConv(nn.Module):
-    """Kernel point convolution (reference blocks.py:143-387), rigid kernel."""
+    """Kernel point convolution (reference blocks.py:143-387), rigid or deformable (+ modulated)."""
 
     def __init__(self, kernel_size, p_dim, in_channels, out_channels, KP_extent, radius,
                  fixed_kernel_points='center', KP_influence='linear', aggregation_mode='sum',
@@ -85,29 +86,51 @@ class KPConv(nn.Module):
         self.min_d2 = None
         self.deformed_KP = None
         self.offset_features = None
-        self.offset_dim = None
-        self.offset_conv = None
-        self.offset_bias = None
-        if deformable or modulated and deformable:
-            raise NotImplementedError('deformable KPConv is outside the D3Feat hot path (config.py:45-46)')
         ops.kpconv_mode(KP_influence, aggregation_mode)   # unknown names raise like the reference (:344,:352)
         if p_dim != 3 or kernel_size > 16:
             raise NotImplementedError('HIP KPConv supports 3-D points and at most 16 kernel points')
         self.weights = Parameter(torch.zeros((self.K, in_channels, out_channels), dtype=torch.float32),
                                  requires_grad=True)
+        if deformable:
+            # construction order = the reference's (:187-203): the offset convolution draws its weights and its kernel
+            # points from the global RNGs BEFORE this layer initialises its own
+            self.offset_dim = (self.p_dim + 1) * self.K if modulated else self.p_dim * self.K
+            self.offset_conv = KPConv(self.K, self.p_dim, self.in_channels, self.offset_dim, KP_extent, radius,
+                                      fixed_kernel_points=fixed_kernel_points, KP_influence=KP_influence,
+                                      aggregation_mode=aggregation_mode)
+            self.offset_bias = Parameter(torch.zeros(self.offset_dim, dtype=torch.float32), requires_grad=True)
+        else:
+            self.offset_dim = None
+            self.offset_conv = None
+            self.offset_bias = None
         self.reset_parameters()
         self.kernel_points = self.init_KP()
 
     def reset_parameters(self):
         kaiming_uniform_(self.weights, a=math.sqrt(5))
+        if self.deformable:
+            nn.init.zeros_(self.offset_bias)
 
     def init_KP(self):
         kp = load_kernels(self.radius, self.K, dimension=self.p_dim, fixed=self.fixed_kernel_points)
         return Parameter(torch.tensor(kp, dtype=torch.float32), requires_grad=False)
 
     def forward(self, q_pts, s_pts, neighb_inds, x):
-        return ops.kpconv(q_pts, s_pts, neighb_inds, x, self.kernel_points, self.weights, self.KP_extent,
-                          self.KP_influence, self.aggregation_mode)
+        if not self.deformable:
+            return ops.kpconv(q_pts, s_pts, neighb_inds, x, self.kernel_points, self.weights, self.KP_extent,
+                              self.KP_influence, self.aggregation_mode)
+        # offsets (and modulations) from the rigid offset convolution (:244-256)
+        self.offset_features = self.offset_conv(q_pts, s_pts, neighb_inds, x) + self.offset_bias
+        if self.modulated:
+            unscaled = self.offset_features[:, :self.p_dim * self.K].reshape(-1, self.K, self.p_dim)
+            modulations = 2 * torch.sigmoid(self.offset_features[:, self.p_dim * self.K:])
+        else:
+            unscaled = self.offset_features.view(-1, self.K, self.p_dim)
+            modulations = None
+        out, self.min_d2, self.deformed_KP = ops.kpconv_deformable(
+            q_pts, s_pts, neighb_inds, x, self.kernel_points, self.weights, self.KP_extent,
+            unscaled * self.KP_extent, modulations, self.KP_influence, self.aggregation_mode)
+        return out
 
     def __repr__(self):
         return 'KPConv(radius: {:.2f}, extent: {:.2f}, in_feat: {:d}, out_feat: {:d})'.format(
@@ -267,7 +290,7 @@ class SimpleBlock(nn.Module):
 
     def forward(self, x, batch):
         q_pts, s_pts, inds = _layer_inputs(self.block_name, self.layer_ind, batch)
-        if not self.use_bn and x.is_cuda:
+        if not self.use_bn and x.is_cuda and not self.KPConv.deformable:
             return ops.kpconv_bias_act(q_pts, s_pts, inds, x, self.KPConv.kernel_points, self.KPConv.weights,
                                        self.KPConv.KP_extent, self.batch_norm.bias, slope=0.1,
                                        influence=self.KPConv.KP_influence, aggregation=self.KPConv.aggregation_mode)
@@ -301,7 +324,8 @@ class ResnetBottleneckBlock(nn.Module):
         q_pts, s_pts, inds = _layer_inputs(self.block_name, self.layer_ind, batch)
         # `features` feeds unary1 and the shortcut: the shortcut branch deposits its gradient, unary1's grad-input GEMM
         # adds it (ops.GradHolder) -- no separate accumulation launch
-        fuse = (not self.use_bn) and features.is_cuda and isinstance(self.unary1, UnaryBlock) and features.requires_grad
+        fuse = ((not self.use_bn) and features.is_cuda and isinstance(self.unary1, UnaryBlock) and
+                features.requires_grad and not self.KPConv.deformable)
         holder = ops.GradHolder() if fuse else None
         x = self.unary1(features, grad_holder=holder) if fuse else self.unary1(features)
         if fuse:
@@ -318,19 +342,16 @@ class ResnetBottleneckBlock(nn.Module):
                                     self.KPConv.KP_extent, self.batch_norm_conv.bias, slope=0.1,
                                     influence=self.KPConv.KP_influence, aggregation=self.KPConv.aggregation_mode)
             return self.unary2(x, residual=shortcut)
-        if not self.use_bn and x.is_cuda:
+        if not self.use_bn and x.is_cuda and not self.KPConv.deformable:
             x = ops.kpconv_bias_act(q_pts, s_pts, inds, x, self.KPConv.kernel_points, self.KPConv.weights,
                                     self.KPConv.KP_extent, self.batch_norm_conv.bias, slope=0.1,
                                     influence=self.KPConv.KP_influence, aggregation=self.KPConv.aggregation_mode)
         else:
-            x = self.KPConv(q_pts, s_pts, inds, x)
+            x = self.batch_norm_conv(self.KPConv(q_pts, s_pts, inds, x), slope=0.1)
         shortcut = ops.max_pool(features, inds, width=_pool_width(self.layer_ind, batch)) \
             if 'strided' in self.block_name else features
         shortcut = self.unary_shortcut(shortcut)
-        if not self.use_bn:
-            return self.unary2(x, residual=shortcut)  # leaky(unary2(x) + shortcut) in the epilogue of unary2
-        x = self.batch_norm_conv(x, slope=0.1)
-        return self.unary2(x, residual=shortcut)
+        return self.unary2(x, residual=shortcut)  # leaky(unary2(x) + shortcut); in unary2's epilogue without BN
 
 
 class GlobalAverageBlock(nn.Module):

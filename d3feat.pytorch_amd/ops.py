@@ -2,6 +2,7 @@
 has it).  Every function here launches hand-written HIP kernels from ``libd3feat_hip.so``; none has a PyTorch or
 CPU fallback.  Reference locations are cited per operator.
 """
+import numpy as np
 import torch
 
 from . import _native
@@ -636,6 +637,78 @@ def kpconv(q_pts, s_pts, neighb_inds, x, kernel_points, weights, extent, influen
     else:
         rev = None
     return _KPConvFn.apply(q_pts, s_pts, idx, x, kp, w, float(extent), rev)
+
+
+class _KPConvDeformAggFn(torch.autograd.Function):
+    """wf, nn, min-distance bookkeeping of a deformable KPConv (csrc/kpconv_deform.hip); differentiable w.r.t. the
+    features and the deformed kernel points."""
+
+    @staticmethod
+    def forward(ctx, q_pts, s_pts, idx, x, kp_def, extent, extent_sq, mode):
+        L = _native.lib()
+        Nq, Ns, H = int(q_pts.shape[0]), int(s_pts.shape[0]), int(idx.shape[1])
+        K, Cin = int(kp_def.shape[1]), int(x.shape[1])
+        wf = torch.empty((Nq, K, Cin), dtype=torch.float32, device=x.device)
+        nn_ = torch.empty((Nq,), dtype=torch.float32, device=x.device)
+        min_idx = torch.empty((Nq, K), dtype=torch.int32, device=x.device)
+        with _region("kpconv_deform_fwd[Nq=%d,Cin=%d,H=%d]" % (Nq, Cin, H), 4 * Nq * H * (4 + Cin)):
+            _native.check(L.d3f_kpconv_deform_aggregate(_p(q_pts), Nq, _p(s_pts), Ns, _p(idx), H, _p(x), Cin,
+                                                        _p(kp_def), K, extent, extent_sq, mode, _p(wf), _p(nn_), None,
+                                                        _p(min_idx), _stream()), "d3f_kpconv_deform_aggregate")
+        ctx.save_for_backward(q_pts, s_pts, idx, x, kp_def)
+        ctx.extent, ctx.extent_sq, ctx.mode = extent, extent_sq, mode
+        ctx.mark_non_differentiable(nn_, min_idx)
+        return wf, nn_, min_idx
+
+    @staticmethod
+    def backward(ctx, gwf, _gnn, _gidx):
+        q_pts, s_pts, idx, x, kp_def = ctx.saved_tensors
+        L = _native.lib()
+        Nq, Ns, H = int(q_pts.shape[0]), int(s_pts.shape[0]), int(idx.shape[1])
+        K, Cin = int(kp_def.shape[1]), int(x.shape[1])
+        gx = torch.empty((Ns, Cin), dtype=torch.float32, device=x.device) if ctx.needs_input_grad[3] else None
+        gkp = torch.empty((Nq, K, 3), dtype=torch.float32, device=x.device) if ctx.needs_input_grad[4] else None
+        if gx is None and gkp is None:
+            return (None,) * 8
+        gwf = gwf.contiguous()
+        with _region("kpconv_deform_bwd[Nq=%d,Cin=%d,H=%d]" % (Nq, Cin, H), 12 * Nq * H * Cin):
+            _native.check(L.d3f_kpconv_deform_grad(_p(q_pts), Nq, _p(s_pts), Ns, _p(idx), H, _p(x), Cin, _p(kp_def), K,
+                                                   ctx.extent, ctx.extent_sq, ctx.mode, _p(gwf), _p(gx), _p(gkp),
+                                                   _stream()), "d3f_kpconv_deform_grad")
+        return None, None, None, gx, gkp, None, None, None
+
+
+def kpconv_deformable(q_pts, s_pts, neighb_inds, x, kernel_points, weights, extent, offsets, modulations=None,
+                      influence='linear', aggregation='sum'):
+    """Deformable (and modulated) KPConv, the deformable=True branch of KPConv.forward (blocks.py:243-387).
+
+    ``offsets`` [Nq,K,3] are the SCALED kernel-point shifts (unscaled offsets * KP_extent, :256), ``modulations``
+    [Nq,K] the 2*sigmoid factors (:250) or None.  Returns (out [Nq,Cout], min_d2 [Nq,K], deformed_KP [Nq,K,3]) --
+    the last two are what the reference keeps on the module for its fitting / repulsive regulariser
+    (architectures.py:22-55); min_d2 carries its gradient to the offsets."""
+    mode = kpconv_mode(influence, aggregation)
+    q_pts, s_pts, x = _f32(q_pts, "q_pts"), _f32(s_pts, "s_pts"), _f32(x, "x")
+    idx = _i32(neighb_inds, "neighb_inds")
+    kp, w = _f32(kernel_points, "kernel_points"), _f32(weights, "weights")
+    K, Cin, Cout = (int(v) for v in w.shape)
+    Nq = int(q_pts.shape[0])
+    if x.shape[0] != s_pts.shape[0] or x.shape[1] != Cin or idx.shape[0] != Nq or tuple(offsets.shape) != (Nq, K, 3):
+        raise RuntimeError("deformable KPConv: inconsistent shapes q%s s%s idx%s x%s W%s offsets%s" % (
+            tuple(q_pts.shape), tuple(s_pts.shape), tuple(idx.shape), tuple(x.shape), tuple(w.shape),
+            tuple(offsets.shape)))
+    deformed = offsets + kp                                              # blocks.py:287
+    extent = float(extent)
+    extent_sq = float(np.float32(extent ** 2))                           # the float32 scalar of `sq_distances < ext**2`
+    wf, nn_, min_idx = _KPConvDeformAggFn.apply(q_pts, s_pts, idx, x, deformed.contiguous(), extent, extent_sq, mode)
+    # min over the neighbors of d2 (blocks.py:301), re-evaluated at the arg-min support so that autograd carries its
+    # gradient to the offsets (the selection itself has none); the shadow support sits at 1e6 like the reference's
+    s_pad = torch.cat((s_pts, torch.zeros_like(s_pts[:1, :]) + 1e6), 0)
+    nearest = s_pad[min_idx.long()] - q_pts.unsqueeze(1)                 # [Nq,K,3]
+    min_d2 = torch.sum((nearest - deformed) ** 2, dim=2)
+    if modulations is not None:
+        wf = wf * modulations.unsqueeze(2)                               # :365-366
+    out = torch.mm(wf.reshape(Nq, K * Cin), w.reshape(K * Cin, Cout)) / nn_[:, None]
+    return out, min_d2, deformed
 
 
 # ---------------------------------------------------------------------------------------------------------------

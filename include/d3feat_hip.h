@@ -292,6 +292,28 @@ int d3f_bias_act_backward(const float* grad_out, const float* out, float slope, 
                           size_t ws_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * Deformable KPConv -- replaces the deformable=True branch of KPConv.forward (models/blocks.py:243-257,286-324,365-366).
+ *   kp_def [Nq,K,3] = offsets * 1 + kernel_points, the per-query kernel points (offsets come from the rigid
+ *   `offset_conv`, :190-199,244-254, which runs on d3f_kpconv_forward).  A neighbor is live when it is a real support
+ *   AND within `extent` of at least one deformed kernel point (extent_sq = the float32 the reference compares against,
+ *   (float)(KP_extent**2), :304); dead neighbors count neither for the weights nor for the neighbor number (:304-321).
+ *   aggregate: wf [Nq,K*Cin] = sum_{h live} w_mode x[idx],  nn [Nq] = max(1, #live neighbors with a positive feature
+ *              sum), min_d2 [Nq,K] = min_h d2[n,h,k] and min_idx [Nq,K] = the support attaining it (Ns when the row has
+ *              no real neighbor; min_d2 is then the distance to the reference's shadow point at 1e6) -- both optional.
+ *   grad:      from gwf = dL/dwf: grad_x [Ns,Cin] (OVERWRITTEN; optional) and grad_kp [Nq,K,3] (optional), the
+ *              gradient w.r.t. the deformed kernel points through the influence weights.
+ *   The caller applies the modulations, the contraction with the kernel weights and the division by nn.
+ *   mode as d3f_kpconv_aggregate_modes.
+ * ---------------------------------------------------------------------------------------------- */
+int d3f_kpconv_deform_aggregate(const float* q_pts, int Nq, const float* s_pts, int Ns, const int32_t* idx, int H,
+                                const float* x, int Cin, const float* kp_def, int K, float extent, float extent_sq,
+                                int mode, float* wf_out, float* nn_out, float* min_d2_out, int32_t* min_idx_out,
+                                void* stream);
+int d3f_kpconv_deform_grad(const float* q_pts, int Nq, const float* s_pts, int Ns, const int32_t* idx, int H,
+                           const float* x, int Cin, const float* kp_def, int K, float extent, float extent_sq, int mode,
+                           const float* gwf, float* grad_x, float* grad_kp, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Batch normalisation over the stacked points -- replaces the use_bn=True branch of BatchNormBlock
  *   (models/blocks.py:454-455,465-471: nn.BatchNorm1d(C, momentum) over x [N, C] viewed as [1, C, N]).
  *   training != 0: y = (x - mean) / sqrt(var + eps) * gamma + beta with the batch mean and BIASED batch variance;

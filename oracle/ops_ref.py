@@ -41,6 +41,49 @@ def kpconv(q_pts, s_pts, neighb_inds, x, kernel_points, weights, extent, influen
     return out / nn[:, None].to(out.dtype)
 
 
+def kpconv_deformable(q_pts, s_pts, neighb_inds, x, kernel_points, weights, extent, offset_features, modulated=False,
+                      influence='linear', aggregation='sum'):
+    """models/blocks.py:243-387, deformable=True: ``offset_features`` [n, (3 or 4) K] is the output of the offset
+    convolution plus its bias (:244).  Returns (out, min_d2 [n,K], deformed_KP [n,K,3]).  Instead of compacting the
+    in-range neighbors with topk (:305-321, an order-only device) the out-of-range ones are masked to the shadow."""
+    K = kernel_points.shape[0]
+    idx = neighb_inds.long()
+    if modulated:                                                            # :247-250
+        unscaled = offset_features[:, :3 * K].reshape(-1, K, 3)
+        modulations = 2 * torch.sigmoid(offset_features[:, 3 * K:])
+    else:                                                                    # :252-253
+        unscaled, modulations = offset_features.reshape(-1, K, 3), None
+    deformed = unscaled * extent + kernel_points                             # :256,287
+    ns = s_pts.shape[0]
+    s_pad = torch.cat([s_pts, torch.full_like(s_pts[:1], 1e6)], 0)
+    rel = s_pad[idx] - q_pts[:, None, :]
+    sq = ((rel[:, :, None, :] - deformed[:, None, :, :]) ** 2).sum(dim=3)    # :293-297  [n,H,K]
+    min_d2 = sq.min(dim=1)[0]                                                # :301
+    in_range = (sq < extent ** 2).any(dim=2)                                 # :304
+    idx = torch.where(in_range, idx, torch.full_like(idx, ns))               # :316-321
+    sq = torch.where(in_range[:, :, None], sq, torch.full_like(sq, 1e12))    # (the shadow rows topk would have dropped)
+    if influence == 'constant':
+        w = torch.ones_like(sq).transpose(1, 2)
+    elif influence == 'linear':
+        w = torch.clamp(1 - torch.sqrt(sq) / extent, min=0.0).transpose(1, 2)
+    elif influence == 'gaussian':
+        w = torch.exp(-sq / (2 * (extent * 0.3) ** 2 + 1e-9)).transpose(1, 2)
+    else:
+        raise ValueError('Unknown influence function type (config.KP_influence)')
+    if aggregation == 'closest':
+        w = w * F.one_hot(torch.argmin(sq, dim=2), K).transpose(1, 2)
+    elif aggregation != 'sum':
+        raise ValueError("Unknown convolution mode. Should be 'closest' or 'sum'")
+    x_pad = torch.cat([x, torch.zeros_like(x[:1])], 0)
+    nx = x_pad[idx]
+    wf = torch.matmul(w, nx)
+    if modulations is not None:
+        wf = wf * modulations.unsqueeze(2)                                   # :365-366
+    out = torch.einsum('nkc,kco->no', wf, weights)
+    nn = torch.clamp((nx.sum(dim=-1) > 0).sum(dim=-1), min=1)
+    return out / nn[:, None].to(out.dtype), min_d2, deformed
+
+
 def max_pool(x, inds):
     """models/blocks.py:94-110."""
     x_pad = torch.cat([x, torch.zeros_like(x[:1])], 0)

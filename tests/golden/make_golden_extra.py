@@ -259,12 +259,45 @@ def bn():
           res['det_loss'])
 
 
+DEFORM_ARCH = ['simple', 'resnetb', 'resnetb_strided', 'resnetb', 'resnetb_deformable', 'resnetb_deformable_strided',
+               'resnetb_deformable', 'nearest_upsample', 'unary', 'nearest_upsample', 'last_unary']
+
+
+def deform():
+    """tests/golden/s0_deform.npz: the S0 mini pair through the reference KPFCNN on a 3-level architecture whose deeper
+    blocks are deformable and modulated (block names of models/blocks.py:409-423; radii of the deformable layers follow
+    config.deform_radius, datasets/dataloader.py:118-119,141-142): neighbor limits from calibrate_neighbors, the
+    collated tables, training outputs, losses, all gradients, eval outputs."""
+    g0 = np.load(os.path.join(HERE, 's0_small.npz'))
+    cfg = mg.cfgmod.default_config(first_features_dim=16, num_layers=3, architecture=list(DEFORM_ARCH), modulated=True)
+    item = (g0['pts0'], g0['pts1'], np.ones((len(g0['pts0']), 1), np.float32), np.ones((len(g0['pts1']), 1), np.float32),
+            g0['sel_corr'], g0['dist_keypts_in'])
+    limits = mg.calibrate_neighbors(mg.OnePair(item, cfg), cfg, collate_fn=mg.collate_fn_descriptor,
+                                    samples_threshold=10 ** 9)
+    res, sd, grads, _, _ = mg.run_reference(item, cfg, limits, seed=0, capture_blocks=[])
+    g = {k: res[k] for k in ('features_train', 'scores_train', 'features_eval', 'scores_eval', 'desc_loss', 'det_loss',
+                             'accuracy', 'dists')}
+    g['limits'] = np.asarray(limits, np.int64)
+    for l in range(3):
+        g['neighbors.%d.shape' % l] = np.asarray(res['batch.neighbors.%d' % l].shape)
+    for k, v in sd.items():
+        g['sdsum.' + k] = np.array([float(v.double().sum()), float(v.double().abs().sum())])
+    for k, v in grads.items():
+        g['grad.' + k] = v.numpy()
+    np.savez_compressed(os.path.join(HERE, 's0_deform.npz'), **g)
+    print('s0_deform.npz', os.path.getsize(os.path.join(HERE, 's0_deform.npz')) / 1e6, 'MB; limits', limits, 'losses',
+          res['desc_loss'], res['det_loss'], 'offset grads',
+          {k: float(np.abs(v).max()) for k, v in g.items() if 'offset' in k and k.startswith('grad.')})
+
+
 if __name__ == '__main__':
-    which = sys.argv[1:] or ['s1', 'reg', 'dataset', 'kernels', 'bn']
+    which = sys.argv[1:] or ['s1', 'reg', 'dataset', 'kernels', 'bn', 'deform']
     if 'kernels' in which:
         kernels()
     if 'bn' in which:
         bn()
+    if 'deform' in which:
+        deform()
     if 'dataset' in which:
         dataset()
     if 'reg' in which:

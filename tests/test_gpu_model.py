@@ -210,6 +210,51 @@ def test_model_with_batch_norm_matches_the_reference_run(golden_s0):
     assert ((se != 0) == (ref != 0)).mean() > 0.999 and np.abs(se[m] - ref[m]).max() < 1e-4
 
 
+DEFORM_ARCH = ['simple', 'resnetb', 'resnetb_strided', 'resnetb', 'resnetb_deformable', 'resnetb_deformable_strided',
+               'resnetb_deformable', 'nearest_upsample', 'unary', 'nearest_upsample', 'last_unary']
+
+
+def test_deformable_network_matches_the_reference_run(golden_s0):
+    """A 3-level KPFCNN whose deeper blocks are deformable + modulated (reference blocks.py:409-423,187-203,243-324):
+    tests/golden/s0_deform.npz is the reference's run on the S0 pair -- calibrated limits (the deformable layers search
+    with config.deform_radius), training outputs, losses, all gradients including the offset convolutions', eval
+    outputs."""
+    g0 = golden_s0
+    g = np.load(os.path.join(os.path.dirname(__file__), 'golden', 's0_deform.npz'))
+    cfg = cfgmod.default_config(first_features_dim=16, num_layers=3, architecture=list(DEFORM_ARCH), modulated=True)
+    limits = dl.calibrate_neighbors(_Pair(_item(g0), cfg), cfg, samples_threshold=10 ** 9)
+    assert [int(x) for x in limits] == [int(x) for x in g['limits']]
+    np.random.seed(0)
+    torch.manual_seed(0)
+    model = KPFCNN(cfg)
+    for k, v in model.state_dict().items():
+        s = g['sdsum.' + k]
+        assert abs(float(v.double().sum()) - s[0]) <= 1e-9 * max(1.0, s[1]), k
+    model = model.to(DEV)
+    batch = dl.collate_fn_descriptor([_item(g0)], cfg, limits)
+    for l in range(3):
+        assert list(batch['neighbors'][l].shape) == [int(v) for v in g['neighbors.%d.shape' % l]]
+    model.train()
+    feats, scores, desc, det, acc, fp, an, dists = _run_step(model, batch, cfg)
+    assert np.abs(feats.detach().cpu().numpy() - g['features_train']).max() < 1e-4
+    assert np.abs(scores.detach().cpu().numpy() - g['scores_train']).max() < 1e-4
+    assert abs(desc.item() - float(g['desc_loss'])) < 1e-4 and abs(det.item() - float(g['det_loss'])) < 1e-4
+    checked = offs = 0
+    for k, p in model.named_parameters():
+        if p.grad is not None and ('grad.' + k) in g.files and np.abs(g['grad.' + k]).max() > 0:
+            assert rel_err(p.grad.cpu().numpy(), g['grad.' + k]) < 5e-3, k
+            checked += 1
+            offs += 'offset' in k
+    assert checked > 30 and offs == 6
+    model.eval()
+    with torch.no_grad():
+        fe, se = model(batch)
+    assert np.abs(fe.cpu().numpy() - g['features_eval']).max() < 1e-4
+    ref, se = g['scores_eval'], se.cpu().numpy()
+    m = (se != 0) & (ref != 0)
+    assert ((se != 0) == (ref != 0)).mean() > 0.999 and np.abs(se[m] - ref[m]).max() < 1e-4
+
+
 def test_model_forward_backward_s1_full_width(golden_s1):
     """Full-width network (24.3M parameters re-created from the seed, kernel points from the fixture) on the 38k-point
     benchmark pair: sampled descriptors / scores, losses and gradient norms vs the reference."""

@@ -871,3 +871,65 @@ def test_batch_norm_live_rows_of_a_capacity_buffer():
     n_live = torch.tensor([500], dtype=torch.int32, device=DEV)
     part = ops.batch_norm(xc, w, b, None, None, True, slope=0.1, n_live=n_live)
     assert torch.equal(part[:500], full) and float(part[500:].abs().max()) == 0.0
+
+
+# ------------------------------------------------------------------------------------------------ deformable KPConv
+@pytest.mark.parametrize("influence,aggregation,modulated", [('linear', 'sum', 0), ('linear', 'sum', 1),
+                                                              ('gaussian', 'sum', 1), ('linear', 'closest', 0)])
+def test_deformable_kpconv_matches_reference_vectors(influence, aggregation, modulated):
+    """KPConv(deformable=True[, modulated=True]) through the module API (offset convolution on the ordinary kernels,
+    per-query kernel points in csrc/kpconv_deform.hip) against vectors computed by the real reference
+    (tests/golden/kpconv_deform.npz): outputs, min_d2, deformed_KP, and the gradients of the reference's two loss
+    routes (output and fitting term) w.r.t. features, kernel weights, offset weights and offset bias.
+    Tolerance 1e-4 abs/rel (fp32)."""
+    import os
+    from d3feat_pytorch_amd.models import blocks
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'kpconv_deform.npz'))
+    tag = '%s.%s.%d.' % (influence, aggregation, modulated)
+    K, cin, cout = g[tag + 'sd.weights'].shape
+    conv = blocks.KPConv(K, 3, cin, cout, float(g['extent']), float(g['radius']), KP_influence=influence,
+                         aggregation_mode=aggregation, deformable=True, modulated=bool(modulated))
+    sd = {k[len(tag) + 3:]: torch.from_numpy(g[k]) for k in g.files if k.startswith(tag + 'sd.')}
+    assert set(sd) == set(conv.state_dict())
+    conv.load_state_dict(sd)
+    conv = conv.to(DEV)
+    x = torch.from_numpy(g['x']).to(DEV).requires_grad_(True)
+    out = conv(cu(g['q_pts']), cu(g['s_pts']), cu(g['inds']), x)
+    ((out * cu(g['gout'])).sum() + 0.7 * (conv.min_d2 * cu(g['gmin'])).sum()).backward()
+    checks = [(out.detach(), 'out'), (conv.min_d2.detach(), 'min_d2'), (conv.deformed_KP.detach(), 'deformed_KP'),
+              (x.grad, 'grad_x'), (conv.weights.grad, 'grad.weights'),
+              (conv.offset_conv.weights.grad, 'grad.offset_conv.weights'), (conv.offset_bias.grad, 'grad.offset_bias')]
+    for got, key in checks:
+        want = g[tag + key]
+        err = np.abs(got.cpu().numpy() - want).max()
+        assert err <= 1e-4 * max(1.0, np.abs(want).max()), (key, err)
+
+
+def test_deformable_kpconv_wide_channels_vs_oracle():
+    """Two channel chunks per lane group, shadow-heavy table, offsets large enough to push a third of the neighbors
+    out of range -- against the oracle restatement (pinned to the reference vectors in test_oracle_ops.py)."""
+    gen = torch.Generator().manual_seed(12)
+    ns, nq, H, ci, co, K = 900, 700, 33, 80, 24, 15
+    s_pts = torch.rand((ns, 3), generator=gen)
+    q_pts = s_pts[torch.randperm(ns, generator=gen)[:nq]].contiguous()
+    d2 = ((q_pts[:, None] - s_pts[None]) ** 2).sum(-1)
+    dist, order = torch.sort(d2, dim=1)
+    inds = torch.where(dist[:, :H] < 0.2 ** 2, order[:, :H], torch.full_like(order[:, :H], ns))
+    kp = (torch.rand((K, 3), generator=gen) - 0.5) * 0.16
+    w = torch.randn((K, ci, co), generator=gen) * 0.1
+    xx = torch.randn((ns, ci), generator=gen)
+    off = torch.randn((nq, 4 * K), generator=gen) * 0.5
+    go, gm = torch.randn((nq, co), generator=gen), torch.randn((nq, K), generator=gen)
+    ext = 0.1
+
+    def run(dev, fn):
+        a = [t.clone().to(dev).requires_grad_(True) for t in (xx, w, off)]
+        o, m, dk = fn(q_pts.to(dev), s_pts.to(dev), inds.to(dev), a[0], kp.to(dev), a[1], a[2])
+        ((o * go.to(dev)).sum() + (m * gm.to(dev)).sum()).backward()
+        return [o.detach().cpu(), m.detach().cpu()] + [t.grad.cpu() for t in a]
+
+    ref = run('cpu', lambda q, s, i, x, k, ww, of: ops_ref.kpconv_deformable(q, s, i, x, k, ww, ext, of, True))
+    got = run(DEV, lambda q, s, i, x, k, ww, of: ops.kpconv_deformable(
+        q, s, i, x, k, ww, ext, of[:, :3 * K].reshape(-1, K, 3) * ext, 2 * torch.sigmoid(of[:, 3 * K:])))
+    for name, u, v in zip(("out", "min_d2", "grad_x", "grad_w", "grad_offsets"), got, ref):
+        assert rel_err(u.numpy(), v.numpy()) < 2e-4, name

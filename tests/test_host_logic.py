@@ -126,7 +126,13 @@ def test_synthetic_is_deterministic_and_shaped(native):
 
 def test_unsupported_modes_raise():
     with pytest.raises(NotImplementedError):
-        blocks.KPConv(15, 3, 8, 8, 0.06, 0.075, deformable=True)
+        blocks.KPConv(20, 3, 8, 8, 0.06, 0.075)              # more kernel points than a 16-lane group
+    np.random.seed(1)
+    torch.manual_seed(1)
+    d = blocks.KPConv(15, 3, 8, 12, 0.06, 0.075, deformable=True, modulated=True)   # reference blocks.py:187-203
+    assert d.offset_dim == 60 and tuple(d.offset_conv.weights.shape) == (15, 8, 60) and d.offset_bias.shape == (60,)
+    assert set(d.state_dict()) == {'weights', 'kernel_points', 'offset_bias', 'offset_conv.weights',
+                                   'offset_conv.kernel_points'}
     with pytest.raises(ValueError, match='Unknown influence'):
         blocks.KPConv(15, 3, 8, 8, 0.06, 0.075, KP_influence='cubic')
     with pytest.raises(ValueError, match='Unknown convolution mode'):

@@ -125,3 +125,32 @@ def test_kpconv_modes_against_reference_vectors(influence, aggregation):
         assert np.abs(got.numpy() - want).max() <= 1e-5 * max(1.0, np.abs(want).max()), key
     if (influence, aggregation) != ('linear', 'sum'):
         assert np.abs(g[tag + 'out'] - g['linear.sum.out']).max() > 1e-3    # the modes really differ on this input
+
+
+DEFORM_CASES = [('linear', 'sum', 0), ('linear', 'sum', 1), ('gaussian', 'sum', 1), ('linear', 'closest', 0)]
+
+
+@pytest.mark.parametrize("influence,aggregation,modulated", DEFORM_CASES)
+def test_deformable_kpconv_against_reference_vectors(influence, aggregation, modulated):
+    """Oracle restatement of the deformable / modulated KPConv (blocks.py:243-387) vs vectors from the real reference
+    (tests/golden/make_golden_modes.py -> kpconv_deform.npz): outputs, min_d2, deformed_KP and every gradient of
+    sum(out * gout) + 0.7 sum(min_d2 * gmin)."""
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'kpconv_deform.npz'))
+    tag = '%s.%s.%d.' % (influence, aggregation, modulated)
+    t = lambda k: torch.from_numpy(g[k])  # noqa: E731
+    x = t('x').requires_grad_(True)
+    w = t(tag + 'sd.weights').requires_grad_(True)
+    ow = t(tag + 'sd.offset_conv.weights').requires_grad_(True)
+    ob = t(tag + 'sd.offset_bias').requires_grad_(True)
+    ext = float(g['extent'])
+    off = ops_ref.kpconv(t('q_pts'), t('s_pts'), t('inds'), x, t(tag + 'sd.offset_conv.kernel_points'), ow, ext,
+                         influence, aggregation) + ob
+    out, min_d2, dkp = ops_ref.kpconv_deformable(t('q_pts'), t('s_pts'), t('inds'), x, t(tag + 'sd.kernel_points'), w,
+                                                 ext, off, bool(modulated), influence, aggregation)
+    ((out * t('gout')).sum() + 0.7 * (min_d2 * t('gmin')).sum()).backward()
+    for got, key in ((out.detach(), 'out'), (min_d2.detach(), 'min_d2'), (dkp.detach(), 'deformed_KP'),
+                     (x.grad, 'grad_x'), (w.grad, 'grad.weights'), (ow.grad, 'grad.offset_conv.weights'),
+                     (ob.grad, 'grad.offset_bias')):
+        want = g[tag + key]
+        assert np.abs(got.numpy() - want).max() <= 2e-5 * max(1.0, np.abs(want).max()), key
+    assert 0.5 < float(g[tag + 'live_fraction']) < 0.995      # the range filter dropped some neighbors, not all
