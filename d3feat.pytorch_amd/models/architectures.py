@@ -105,8 +105,8 @@ class KPFCNN(nn.Module):
         """A skip tensor is consumed by the decoder (first in backward) and by the strided block `op` that follows it:
         the decoder deposits its gradient, the block's pooling backward accumulates on top of it (ops.GradHolder)
         instead of autograd adding the two."""
-        if x.is_cuda and x.requires_grad and isinstance(op, ResnetBottleneckBlock) and 'strided' in op.block_name \
-                and not op.use_bn:
+        if x.requires_grad and isinstance(op, ResnetBottleneckBlock) and 'strided' in op.block_name \
+                and op.fuses_gradients(x):
             x._d3f_grad_in = ops.GradHolder()
         return x
 

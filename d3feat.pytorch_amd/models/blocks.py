@@ -320,12 +320,17 @@ class ResnetBottleneckBlock(nn.Module):
             self.unary_shortcut = nn.Identity()
         self.leaky_relu = nn.LeakyReLU(0.1)
 
+    def fuses_gradients(self, features):
+        """Whether forward(features) takes the training path that routes the gradients of `features` through
+        ops.GradHolder (a skip tensor may only be marked for it, architectures.KPFCNN.mark_skip, when this holds)."""
+        return ((not self.use_bn) and features.is_cuda and isinstance(self.unary1, UnaryBlock) and
+                features.requires_grad and not self.KPConv.deformable)
+
     def forward(self, features, batch):
         q_pts, s_pts, inds = _layer_inputs(self.block_name, self.layer_ind, batch)
         # `features` feeds unary1 and the shortcut: the shortcut branch deposits its gradient, unary1's grad-input GEMM
         # adds it (ops.GradHolder) -- no separate accumulation launch
-        fuse = ((not self.use_bn) and features.is_cuda and isinstance(self.unary1, UnaryBlock) and
-                features.requires_grad and not self.KPConv.deformable)
+        fuse = self.fuses_gradients(features)
         holder = ops.GradHolder() if fuse else None
         x = self.unary1(features, grad_holder=holder) if fuse else self.unary1(features)
         if fuse:

@@ -61,5 +61,17 @@ def rel_err(a, b):
     return float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-30))
 
 
+def grad_mismatch(a, b, elem_tol=5e-3):
+    """(fraction of elements off by more than elem_tol * max|b|, relative L2 error).  A training step is not smooth
+    where a LeakyReLU input is ~0: a 1e-7 rounding difference there picks the other branch, which moves one column of
+    that layer's bias gradient by ~1/sqrt(rows) and everything upstream by a little.  Networks with BatchNorm (zero-mean
+    activations, few-row levels) hit such edges in almost every run, so their gradients are compared by these two
+    statistics instead of the max norm: a wrong formula moves most elements, a branch flip moves few."""
+    a = np.asarray(a, np.float64).ravel()
+    b = np.asarray(b, np.float64).ravel()
+    scale = max(np.abs(b).max(), 1e-30)
+    return float((np.abs(a - b) > elem_tol * scale).mean()), float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-30))
+
+
 class Cfg:
     pass
