@@ -498,6 +498,53 @@ def main():
                                               "launch": "hipGraph replay, pyramid of the next pair on a side stream"}
         except Exception as e:  # pragma: no cover - the headline number must not depend on this leg
             evaluation["top250_pipelined"] = {"error": "%s: %s" % (type(e).__name__, e)}
+        # BASELINE configs[3]: 8 fragment pairs per inference batch -- 16 clouds stacked into one forward graph (per-pair
+        # detector normaliser / table widths), top-250 keypoints of all 16 clouds by one launch, the 8 matchings by one
+        # pair of launches; and the dense all-points matching of the 8 pairs (8 x 19k x 19k x 32 on the f32 matrix cores)
+        try:
+            from d3feat_pytorch_amd.infer import InferStep
+            eng8 = InferStep(ts.model, cfg, limits, dev, clouds=16, group=2)
+            one = ts.caps if use_graph else TrainStep.capacities_for(
+                [[int(t.shape[0]) for t in ts.build_batch(it)['points']] for it in items], slack=1.0)
+            eng8.enable_graph([8 * int(c) for c in one])
+            stacks = [tuple(c for j in range(8) for c in items[(j + s0) % len(items)][:2]) for s0 in range(2)]
+
+            def batch8(k):
+                cur, nxt = stacks[k % 2], stacks[(k + 1) % 2]
+                feats, scores = eng8.describe(cur, nxt)
+                return cur, feats, scores, eng8.match(cur, feats, scores, num_points=250)
+            for k in range(3):
+                cur, feats8, scores8, m8 = batch8(k)
+            torch.cuda.synchronize()
+            t80 = time.perf_counter()
+            for k in range(6):
+                cur, feats8, scores8, m8 = batch8(3 + k)
+            torch.cuda.synchronize()
+            ms8 = (time.perf_counter() - t80) / 6 * 1e3
+            eng8.check_status()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            for _ in range(2):
+                dense = eng8.match(cur, feats8, scores8)
+            e0.record()
+            for _ in range(3):
+                dense = eng8.match(cur, feats8, scores8)
+            e1.record()
+            torch.cuda.synchronize()
+            dms = e0.elapsed_time(e1) / 3
+            dfl = sum(2 * (2.0 * int(cur[2 * j].shape[0]) * int(cur[2 * j + 1].shape[0]) * 32) for j in range(8))
+            evaluation["batched_8_pairs"] = {
+                "workload": "16 clouds (%d points) in one forward graph + top-250 keypoints + 8 mutual-NN matchings"
+                            % sum(int(c.shape[0]) for c in cur),
+                "ms_per_batch": round(ms8, 3), "pairs_per_s": round(8e3 / ms8, 1),
+                "mutual_matches_top250": int(m8[1].sum()),
+                "dense_matching": {"workload": "8 x (19k x 19k x 32) row + column arg-min, one pair of launches",
+                                   "ms": round(dms, 3), "bound": "mfma",
+                                   "achieved": round(dfl / (dms * 1e-3) / 1e12, 2), "peak": F32_MFMA_PEAK_TFLOPS,
+                                   "unit": "TFLOP/s", "frac": round(dfl / (dms * 1e-3) / 1e12 / F32_MFMA_PEAK_TFLOPS, 4),
+                                   "pairs_per_s": round(8e3 / dms, 1), "mutual_matches": int(dense[1].sum())}}
+            del eng8
+        except Exception as e:  # pragma: no cover
+            evaluation["batched_8_pairs"] = {"error": "%s: %s" % (type(e).__name__, e)}
         ts.model.train()
 
     if rank == 0:

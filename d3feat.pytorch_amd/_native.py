@@ -27,7 +27,7 @@ SIGNATURES = {
     "d3f_radius_grid_ws_bytes": (_sz, [_i]),
     "d3f_radius_grid_build": (_i, [_vp, _i, _vp, _i, _f, _vp, _sz, _vp, _vp]),
     "d3f_radius_query": (_i, [_vp, _vp, _i, _vp, _vp, _i, _vp, _i, _f, _i, _vp, _vp, _vp, _vp, _vp]),
-    "d3f_radius_query_ex": (_i, [_vp, _vp, _i, _vp, _i, _vp, _i, _f, _f, _i, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp]),
+    "d3f_radius_query_ex": (_i, [_vp, _vp, _i, _vp, _i, _vp, _i, _f, _f, _i, _vp, _vp, _vp, _vp, _i, _vp, _i, _vp, _vp]),
     "d3f_grid_subsample_ws_bytes": (_sz, [_i, _i]),
     "d3f_grid_subsample": (_i, [_vp, _i, _vp, _i, _f, _i, _i, _vp, _i, _vp, _vp, _vp, _sz, _vp, _vp]),
     "d3f_grid_subsample_ex": (_i, [_vp, _i, _vp, _i, _f, _i, _i, _vp, _i, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _sz,
@@ -62,7 +62,7 @@ SIGNATURES = {
     "d3f_linear_grad_weight": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _sz, _vp]),
     "d3f_gemm_ws_bytes": (_sz, [_i, _i, _i, _i]),
     "d3f_gemm": (_i, [_vp, _vp, _sz, _vp]),
-    "d3f_max_pool_forward": (_i, [_vp, _i, _i, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp]),
+    "d3f_max_pool_forward": (_i, [_vp, _i, _i, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp]),
     "d3f_max_pool_backward": (_i, [_vp, _vp, _i, _i, _i, _vp, _i, _vp]),
     "d3f_closest_pool_forward": (_i, [_vp, _i, _i, _vp, _i, _i, _vp, _i, _vp, _vp, _vp]),
     "d3f_closest_pool_backward": (_i, [_vp, _i, _vp, _i, _i, _i, _i, _vp, _i, _vp]),
@@ -71,8 +71,9 @@ SIGNATURES = {
     "d3f_bias_act_backward": (_i, [_vp, _vp, _f, _i, _i, _vp, _vp, _vp, _i, _vp, _vp, _sz, _vp]),
     "d3f_global_max": (_i, [_vp, _sz, _vp, _vp, _sz, _vp]),
     "d3f_global_max_rows": (_i, [_vp, _i, _i, _vp, _i, _vp, _vp, _sz, _vp]),
+    "d3f_global_max_groups": (_i, [_vp, _i, _i, _vp, _i, _i, _vp, _vp, _sz, _vp]),
     "d3f_detection_scores_aux_floats": (_i, [_i]),
-    "d3f_detection_scores_forward": (_i, [_vp, _i, _i, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp]),
+    "d3f_detection_scores_forward": (_i, [_vp, _i, _i, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _i, _i, _vp]),
     "d3f_detection_scores_ws_bytes": (_sz, [_i, _i]),
     "d3f_detection_scores_backward": (_i, [_vp, _i, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "d3f_circle_det_loss_stats_floats": (_sz, [_i]),
@@ -85,6 +86,9 @@ SIGNATURES = {
     "d3f_select_normalize_backward": (_i, [_vp, _i, _i, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "d3f_mutual_nn_ws_bytes": (_sz, [_i, _i]),
     "d3f_mutual_nn": (_i, [_vp, _i, _vp, _i, _i, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "d3f_mutual_nn_batched_ws_bytes": (_sz, [_i, _i]),
+    "d3f_mutual_nn_batched": (_i, [_vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "d3f_topk_scores": (_i, [_vp, _i, _vp, _i, _i, _vp, _vp]),
     "d3f_sgd_guarded_step": (_i, [_vp, _vp, _vp, _sz, _f, _f, _f, _vp, _vp, _vp, _vp]),
     "d3f_poison_gradient_if_status": (_i, [_vp, _vp, _vp, _vp]),
 }

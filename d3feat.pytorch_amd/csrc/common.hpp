@@ -64,6 +64,21 @@ __device__ __forceinline__ int batch_offset(const int32_t* __restrict__ len, int
   return s;
 }
 
+// Rows of a stacked batch partitioned into groups of `group` consecutive clouds (e.g. the 2 fragments of a pair when 8
+// pairs are stacked for inference): per-group scalars (feature maximum, table width) are indexed by group_of_row.
+// len == nullptr: one group.
+struct RowGroups {
+  const int32_t* len;
+  int B;
+  int group;
+};
+__device__ __forceinline__ int group_of_row(const RowGroups& rg, int row) {
+  if (!rg.len || rg.group <= 0) return 0;
+  int b, st;
+  locate_batch(rg.len, rg.B, row, b, st);
+  return b / rg.group;
+}
+
 // squared distance with the reference's float32 evaluation order and NO fused multiply-add:
 // d2 = dx*dx; d2 += dy*dy; d2 += dz*dz   (nanoflann.hpp:433-441).  NOTE: on AMD the __f*_rn intrinsics are plain
 // operators, so this is only exact because the library is compiled with -ffp-contract=off (see _native.build).

@@ -67,11 +67,15 @@ template <int CP>
 __global__ __launch_bounds__(256) void det_fwd_kernel(const float* __restrict__ feat, int N, int C,
                                                       const int32_t* __restrict__ idx, int H,
                                                       const float* __restrict__ fmax, int training,
-                                                      float* __restrict__ scores, const int32_t* __restrict__ width) {
+                                                      float* __restrict__ scores, const int32_t* __restrict__ width,
+                                                      d3f::RowGroups rg) {
   const int lane = threadIdx.x & 63;
   const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (n >= N) return;
   const int c = lane % CP, g = lane / CP;
+  const int gi = d3f::group_of_row(rg, n);   // stacked pairs: the normaliser and the table width of the row's own pair
+  fmax += gi;
+  if (width) width += gi;
   const float denom = fmaxf(*fmax, 0.0f) + 1e-6f;  // the reference's max includes its zero shadow row (:336-342)
   // columns of the table the reference would have built: min(H, max neighbor count) (dataloader.py:64-66); the columns
   // past it are all shadow and only matter to the local-maximum gate (a zero candidate the reference does not have)
@@ -141,12 +145,15 @@ __global__ __launch_bounds__(256) void det_fwd_v4_kernel(const float* __restrict
                                                          const int32_t* __restrict__ idx, int H,
                                                          const float* __restrict__ fmax, int training,
                                                          float* __restrict__ scores, float* __restrict__ aux,
-                                                         const int32_t* __restrict__ width) {
+                                                         const int32_t* __restrict__ width, d3f::RowGroups rg) {
   constexpr int C = 4 * LP, G = 64 / LP;
   const int lane = threadIdx.x & 63;
   const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (n >= N) return;
   const int c4 = lane % LP, g = lane / LP;
+  const int gi = d3f::group_of_row(rg, n);   // see det_fwd_kernel
+  fmax += gi;
+  if (width) width += gi;
   const float denom = fmaxf(*fmax, 0.0f) + 1e-6f;  // the reference's max includes its zero shadow row (:336-342)
   const int32_t* row = idx + (size_t)n * H;
   float4 msum = make_float4(0.f, 0.f, 0.f, 0.f), lmax = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
@@ -283,19 +290,23 @@ __global__ __launch_bounds__(256) void gmax_partial_kernel(const float* __restri
   m = block_max256(m);
   if (threadIdx.x == 0) atomicMax(enc, f2ord(m));
 }
+// blockIdx.y = group of `group` consecutive clouds (group <= 0: all B clouds are one group)
 __global__ __launch_bounds__(256) void gmax_rows_kernel(const float* __restrict__ x, int cap_rows, int C,
-                                                        const int32_t* __restrict__ len, int B,
+                                                        const int32_t* __restrict__ len, int B, int group,
                                                         uint32_t* __restrict__ enc) {
-  int rows = d3f::batch_offset(len, B);
-  if (rows > cap_rows) rows = cap_rows;
-  const size_t n = (size_t)rows * C;
+  const int b0 = group > 0 ? blockIdx.y * group : 0, b1 = group > 0 ? min(B, b0 + group) : B;
+  const int r0 = min(cap_rows, d3f::batch_offset(len, b0)), r1 = min(cap_rows, d3f::batch_offset(len, b1));
+  const size_t beg = (size_t)r0 * C, n = (size_t)r1 * C;
   float m = -INFINITY;
-  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+  for (size_t i = beg + (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
     m = fmaxf(m, x[i]);
   m = block_max256(m);
-  if (threadIdx.x == 0) atomicMax(enc, f2ord(m));
+  if (threadIdx.x == 0) atomicMax(enc + blockIdx.y, f2ord(m));
 }
-__global__ void gmax_final_kernel(const uint32_t* __restrict__ enc, float* __restrict__ out) { *out = ord2f(*enc); }
+__global__ void gmax_final_kernel(const uint32_t* __restrict__ enc, float* __restrict__ out, int n = 1) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = ord2f(enc[i]);
+}
 
 // S = sum(df * f), ties = #{feat == fmax}
 __global__ __launch_bounds__(256) void det_reduce_kernel(const float* __restrict__ feat, const float* __restrict__ df,
@@ -349,38 +360,51 @@ int d3f_global_max(const float* x, size_t n, float* out_max, void* ws, size_t ws
   return D3F_OK;
 }
 
-int d3f_global_max_rows(const float* x, int cap_rows, int C, const int32_t* len, int B, float* out_max, void* ws,
-                        size_t ws_bytes, void* stream_) {
-  if (!x || !out_max || !ws || !len || ws_bytes < 4 || cap_rows < 1 || C < 1 || B < 1) return D3F_EINVAL;
+int d3f_global_max_groups(const float* x, int cap_rows, int C, const int32_t* len, int B, int group, float* out_max,
+                          void* ws, size_t ws_bytes, void* stream_) {
+  if (!x || !out_max || !ws || !len || cap_rows < 1 || C < 1 || B < 1 || B > D3F_MAX_BATCH || group < 0)
+    return D3F_EINVAL;
+  const int G = group > 0 ? d3f::cdiv(B, group) : 1;
+  if (ws_bytes < 4 * (size_t)G) return D3F_EWORKSPACE;
   hipStream_t stream = (hipStream_t)stream_;
-  if (d3f::zero_async(ws, 4, stream) != hipSuccess) return D3F_ELAUNCH;
-  int blocks = d3f::cdiv((long long)cap_rows * C, 256 * 8);
+  if (d3f::zero_async(ws, 4 * (size_t)G, stream) != hipSuccess) return D3F_ELAUNCH;
+  int blocks = d3f::cdiv((long long)cap_rows * C, 256 * 8 * G);
   if (blocks > 128) blocks = 128;
-  gmax_rows_kernel<<<blocks, 256, 0, stream>>>(x, cap_rows, C, len, B, (uint32_t*)ws);
-  gmax_final_kernel<<<1, 1, 0, stream>>>((const uint32_t*)ws, out_max);
+  if (blocks < 1) blocks = 1;
+  gmax_rows_kernel<<<dim3(blocks, G), 256, 0, stream>>>(x, cap_rows, C, len, B, group, (uint32_t*)ws);
+  gmax_final_kernel<<<d3f::cdiv(G, 64), 64, 0, stream>>>((const uint32_t*)ws, out_max, G);
   D3F_LAUNCH_CHECK();
   return D3F_OK;
+}
+
+int d3f_global_max_rows(const float* x, int cap_rows, int C, const int32_t* len, int B, float* out_max, void* ws,
+                        size_t ws_bytes, void* stream_) {
+  if (ws_bytes < 4) return D3F_EINVAL;
+  return d3f_global_max_groups(x, cap_rows, C, len, B, 0, out_max, ws, ws_bytes, stream_);
 }
 
 int d3f_detection_scores_aux_floats(int C) { return (C == 16 || C == 32 || C == 64) ? 8 : 0; }  /* and H <= 64 */
 
 int d3f_detection_scores_forward(const float* feat, int N, int C, const int32_t* idx, int H, const float* feat_max,
-                                 int training, float* scores, float* aux, const int32_t* width, void* stream_) {
+                                 int training, float* scores, float* aux, const int32_t* width, const int32_t* len,
+                                 int B, int group, void* stream_) {
   if (!feat || !idx || !feat_max || !scores || N < 0 || C < 1 || C > 64 || H < 1) return D3F_EINVAL;
+  if (len && (B < 1 || B > D3F_MAX_BATCH || group < 1 || aux)) return D3F_EINVAL;   // grouped form: forward only
+  const d3f::RowGroups rg = {len, B, group};
   if (aux && (!training || !d3f_detection_scores_aux_floats(C) || H > 64)) return D3F_EINVAL;
   if (N == 0) return D3F_OK;
   hipStream_t stream = (hipStream_t)stream_;
   const int grid = d3f::cdiv(N, 4);
   if ((C == 16 || C == 32 || C == 64) && H <= 64) {
-    if (C == 16) det_fwd_v4_kernel<4><<<grid, 256, 0, stream>>>(feat, N, idx, H, feat_max, training, scores, aux, width);
-    else if (C == 32) det_fwd_v4_kernel<8><<<grid, 256, 0, stream>>>(feat, N, idx, H, feat_max, training, scores, aux, width);
-    else det_fwd_v4_kernel<16><<<grid, 256, 0, stream>>>(feat, N, idx, H, feat_max, training, scores, aux, width);
+    if (C == 16) det_fwd_v4_kernel<4><<<grid, 256, 0, stream>>>(feat, N, idx, H, feat_max, training, scores, aux, width, rg);
+    else if (C == 32) det_fwd_v4_kernel<8><<<grid, 256, 0, stream>>>(feat, N, idx, H, feat_max, training, scores, aux, width, rg);
+    else det_fwd_v4_kernel<16><<<grid, 256, 0, stream>>>(feat, N, idx, H, feat_max, training, scores, aux, width, rg);
     D3F_LAUNCH_CHECK();
     return D3F_OK;
   }
-  if (C <= 16) det_fwd_kernel<16><<<grid, 256, 0, stream>>>(feat, N, C, idx, H, feat_max, training, scores, width);
-  else if (C <= 32) det_fwd_kernel<32><<<grid, 256, 0, stream>>>(feat, N, C, idx, H, feat_max, training, scores, width);
-  else det_fwd_kernel<64><<<grid, 256, 0, stream>>>(feat, N, C, idx, H, feat_max, training, scores, width);
+  if (C <= 16) det_fwd_kernel<16><<<grid, 256, 0, stream>>>(feat, N, C, idx, H, feat_max, training, scores, width, rg);
+  else if (C <= 32) det_fwd_kernel<32><<<grid, 256, 0, stream>>>(feat, N, C, idx, H, feat_max, training, scores, width, rg);
+  else det_fwd_kernel<64><<<grid, 256, 0, stream>>>(feat, N, C, idx, H, feat_max, training, scores, width, rg);
   D3F_LAUNCH_CHECK();
   return D3F_OK;
 }

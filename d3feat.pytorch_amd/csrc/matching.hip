@@ -38,11 +38,25 @@ __global__ void unpack_arg_kernel(const unsigned long long* __restrict__ best, i
   if (i < n) out[i] = (int32_t)(best[i] & 0xffffffffull);
 }
 
+// seg != nullptr: blockIdx.z = pair; {S rows, T rows} of the pair are segments of the stacked matrices (seg [P,4] =
+// {src_off, src_len, tgt_off, tgt_len}; swap = 1 exchanges the roles for the column pass); `best` is indexed by the row
+// of the stacked source matrix, the winning column stays pair-local.
 template <int C, int RT, bool PF>
 __global__ __launch_bounds__(256) void row_argmin_kernel(const float* __restrict__ S, int Ns,
                                                          const float* __restrict__ T, int Nt, int cols_per_chunk,
-                                                         unsigned long long* __restrict__ best) {
+                                                         unsigned long long* __restrict__ best,
+                                                         const int32_t* __restrict__ seg = nullptr, int swap = 0) {
   static_assert(C % 16 == 0, "descriptor width must be a multiple of 16");
+  if (seg) {
+    const int32_t* e = seg + 4 * blockIdx.z;
+    const int so = e[swap ? 2 : 0], sn = e[swap ? 3 : 1], to = e[swap ? 0 : 2], tn = e[swap ? 1 : 3];
+    S += (size_t)so * C;
+    T += (size_t)to * C;
+    best += so;
+    Ns = sn;
+    Nt = tn;
+    if (Ns < 1 || Nt < 1) return;
+  }
   constexpr int KS = C / 16;  // float4 chunks per lane: reduction index c = 16*u + 4*(lane>>4) + t
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int li = lane & 15, lk = lane >> 4;
@@ -202,6 +216,124 @@ int run(const float* S, int Ns, const float* T, int Nt, int32_t* ra, int32_t* ca
   return D3F_OK;
 }
 
+__global__ void fill_seg_kernel(unsigned long long* __restrict__ p, const int32_t* __restrict__ seg, int which,
+                                int max_len) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int32_t* e = seg + 4 * blockIdx.y;
+  if (i < e[which + 1] && i < max_len) p[e[which] + i] = ~0ull;
+}
+__global__ void unpack_seg_kernel(const unsigned long long* __restrict__ best, const int32_t* __restrict__ seg,
+                                  int which, int max_len, int32_t* __restrict__ out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int32_t* e = seg + 4 * blockIdx.y;
+  if (i < e[which + 1] && i < max_len) out[e[which] + i] = (int32_t)(best[e[which] + i] & 0xffffffffull);
+}
+__global__ void mutual_seg_kernel(const int32_t* __restrict__ row_arg, const int32_t* __restrict__ col_arg,
+                                  const int32_t* __restrict__ seg, int max_len, int32_t* __restrict__ mutual) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int32_t* e = seg + 4 * blockIdx.y;
+  if (i >= e[1] || i >= max_len) return;
+  const int j = row_arg[e[0] + i];
+  mutual[e[0] + i] = (j >= 0 && j < e[3] && col_arg[e[2] + j] == i) ? 1 : 0;
+}
+
+template <int C>
+int one_pass_batched(const float* S, const float* T, const int32_t* seg, int P, int swap, int max_s, int max_t,
+                     int32_t* out, unsigned long long* best, hipStream_t stream) {
+  constexpr int RT = C <= 64 ? 2 : 1;
+  const int gx = d3f::cdiv(max_s, 64 * RT);
+  int chunks = d3f::cdiv(2048, gx * P);  // the P pairs together fill the chip
+  const int max_chunks = d3f::cdiv(max_t, 4 * kColsPerTile);
+  if (chunks > max_chunks) chunks = max_chunks;
+  if (chunks < 1) chunks = 1;
+  int cpc = d3f::cdiv(max_t, chunks);
+  cpc = d3f::cdiv(cpc, kColsPerTile) * kColsPerTile;
+  chunks = d3f::cdiv(max_t, cpc);
+  const int which = swap ? 2 : 0;
+  fill_seg_kernel<<<dim3(d3f::cdiv(max_s, 256), P), 256, 0, stream>>>(best, seg, which, max_s);
+  row_argmin_kernel<C, RT, false><<<dim3(gx, chunks, P), 256, 0, stream>>>(S, 0, T, 0, cpc, best, seg, swap);
+  unpack_seg_kernel<<<dim3(d3f::cdiv(max_s, 256), P), 256, 0, stream>>>(best, seg, which, max_s, out);
+  D3F_LAUNCH_CHECK();
+  return D3F_OK;
+}
+
+template <int C>
+int run_batched(const float* S, const float* T, const int32_t* seg, int P, int max_s, int max_t, int32_t* ra,
+                int32_t* ca, int32_t* mu, void* ws, size_t half, hipStream_t stream) {
+  unsigned long long* best_s = (unsigned long long*)ws;
+  unsigned long long* best_t = (unsigned long long*)((char*)ws + half);
+  int rc = one_pass_batched<C>(S, T, seg, P, 0, max_s, max_t, ra, best_s, stream);
+  if (rc) return rc;
+  rc = one_pass_batched<C>(T, S, seg, P, 1, max_t, max_s, ca, best_t, stream);
+  if (rc) return rc;
+  if (mu) mutual_seg_kernel<<<dim3(d3f::cdiv(max_s, 256), P), 256, 0, stream>>>(ra, ca, seg, max_s, mu);
+  D3F_LAUNCH_CHECK();
+  return D3F_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// top-k rows of every cloud by (score, index), ascending: one workgroup per cloud
+// ------------------------------------------------------------------------------------------------
+constexpr int kTopThreads = 1024;
+
+__device__ __forceinline__ unsigned long long score_key(float s, int i) {
+  return ((unsigned long long)ord_bits(s) << 32) | (uint32_t)i;
+}
+
+__global__ __launch_bounds__(kTopThreads) void topk_kernel(const float* __restrict__ scores,
+                                                           const int32_t* __restrict__ seg, int k,
+                                                           int32_t* __restrict__ out) {
+  __shared__ unsigned long long keys[D3F_TOPK_MAX];
+  __shared__ int hist[256];
+  __shared__ unsigned long long prefix_sh;
+  __shared__ int want_sh, count_sh;
+  const int off = seg[2 * blockIdx.x], n = seg[2 * blockIdx.x + 1];
+  const float* sc = scores + off;
+  int32_t* o = out + (size_t)blockIdx.x * k;
+  const int kk = min(k, max(n, 0));
+  for (int i = threadIdx.x; i < k - kk; i += blockDim.x) o[i] = -1;
+  if (kk == 0) return;
+  // radix select, most significant byte first: the kk-th largest key (keys are distinct: the index is part of them)
+  if (threadIdx.x == 0) { prefix_sh = 0ull; want_sh = kk; }
+  __syncthreads();
+  for (int byte = 7; byte >= 0; --byte) {
+    for (int b = threadIdx.x; b < 256; b += blockDim.x) hist[b] = 0;
+    __syncthreads();
+    const unsigned long long prefix = prefix_sh;
+    const unsigned long long hi_mask = byte == 7 ? 0ull : (~0ull << (8 * (byte + 1)));
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+      const unsigned long long key = score_key(sc[i], i);
+      if ((key & hi_mask) == prefix) atomicAdd(&hist[(int)((key >> (8 * byte)) & 0xffull)], 1);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      int want = want_sh, b = 255;
+      for (; b > 0; --b) {        // walk down from the largest byte value until the wanted rank falls into a bin
+        if (hist[b] >= want) break;
+        want -= hist[b];
+      }
+      want_sh = want;
+      prefix_sh = prefix | ((unsigned long long)b << (8 * byte));
+    }
+    __syncthreads();
+  }
+  const unsigned long long kth = prefix_sh;   // survivors: key >= kth, exactly kk of them
+  if (threadIdx.x == 0) count_sh = 0;
+  __syncthreads();
+  for (int i = threadIdx.x; i < n; i += blockDim.x) {
+    const unsigned long long key = score_key(sc[i], i);
+    if (key >= kth) keys[atomicAdd(&count_sh, 1)] = key;
+  }
+  __syncthreads();
+  // rank sort (ascending): kk <= 6144 keys, every thread ranks its own against all (LDS broadcast reads)
+  for (int i = threadIdx.x; i < kk; i += blockDim.x) {
+    const unsigned long long mine = keys[i];
+    int rank = 0;
+    for (int j = 0; j < kk; ++j) rank += keys[j] < mine;
+    o[k - kk + rank] = (int32_t)(mine & 0xffffffffull);
+  }
+}
+
 }  // namespace
 
 extern "C" {
@@ -220,6 +352,36 @@ int d3f_mutual_nn(const float* src_desc, int Ns, const float* tgt_desc, int Nt, 
     case 128: return run<128>(src_desc, Ns, tgt_desc, Nt, row_argmin, col_argmin, mutual, ws, s);
     default: return D3F_EINVAL;
   }
+}
+
+size_t d3f_mutual_nn_batched_ws_bytes(int src_rows, int tgt_rows) {
+  return d3f::align_up(8 * (size_t)(src_rows > 0 ? src_rows : 1), 256) +
+         d3f::align_up(8 * (size_t)(tgt_rows > 0 ? tgt_rows : 1), 256);
+}
+
+int d3f_mutual_nn_batched(const float* src_desc, int src_rows, const float* tgt_desc, int tgt_rows, const int32_t* seg,
+                          int P, int max_src, int max_tgt, int C, int32_t* row_argmin, int32_t* col_argmin,
+                          int32_t* mutual, void* ws, size_t ws_bytes, void* stream) {
+  if (!src_desc || !tgt_desc || !seg || !row_argmin || !col_argmin || !ws || src_rows < 1 || tgt_rows < 1 || P < 1 ||
+      P > 65535 || max_src < 1 || max_tgt < 1)
+    return D3F_EINVAL;
+  if (ws_bytes < d3f_mutual_nn_batched_ws_bytes(src_rows, tgt_rows)) return D3F_EWORKSPACE;
+  const size_t half = d3f::align_up(8 * (size_t)src_rows, 256);
+  hipStream_t s = (hipStream_t)stream;
+  switch (C) {
+    case 16: return run_batched<16>(src_desc, tgt_desc, seg, P, max_src, max_tgt, row_argmin, col_argmin, mutual, ws, half, s);
+    case 32: return run_batched<32>(src_desc, tgt_desc, seg, P, max_src, max_tgt, row_argmin, col_argmin, mutual, ws, half, s);
+    case 64: return run_batched<64>(src_desc, tgt_desc, seg, P, max_src, max_tgt, row_argmin, col_argmin, mutual, ws, half, s);
+    case 128: return run_batched<128>(src_desc, tgt_desc, seg, P, max_src, max_tgt, row_argmin, col_argmin, mutual, ws, half, s);
+    default: return D3F_EINVAL;
+  }
+}
+
+int d3f_topk_scores(const float* scores, int rows, const int32_t* seg, int P, int k, int32_t* out, void* stream) {
+  if (!scores || !seg || !out || rows < 1 || P < 1 || k < 1 || k > D3F_TOPK_MAX) return D3F_EINVAL;
+  topk_kernel<<<P, kTopThreads, 0, (hipStream_t)stream>>>(scores, seg, k, out);
+  D3F_LAUNCH_CHECK();
+  return D3F_OK;
 }
 
 }  // extern "C"

@@ -13,12 +13,27 @@ namespace {
 // backward needs no fill launch of its own.
 __global__ void max_pool_fwd_kernel(const float* __restrict__ x, int Ns, int C, const int32_t* __restrict__ idx,
                                     int Nq, int H, float* __restrict__ out, int32_t* __restrict__ argmax,
-                                    float* __restrict__ clear, const int32_t* __restrict__ width) {
+                                    float* __restrict__ clear, const int32_t* __restrict__ width, d3f::RowGroups rg) {
   const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (clear)
     for (size_t i = t; i < (size_t)Ns * C; i += (size_t)gridDim.x * blockDim.x) clear[i] = 0.0f;
   if (t >= (size_t)Nq * C) return;
   const int n = (int)(t / C), c = (int)(t % C);
+  if (rg.len) {  // stacked pairs: every group of clouds has the width of the table its own batch would have had
+    const int Hg = width ? min(H, max(1, width[d3f::group_of_row(rg, n)])) : H;
+    const int32_t* grow = idx + (size_t)n * H;
+    float gbest = -INFINITY;
+    int garg = Ns;
+    for (int h = 0; h < Hg; ++h) {
+      const int m = grow[h];
+      const bool real = m >= 0 && m < Ns;
+      const float v = real ? x[(size_t)m * C + c] : 0.0f;
+      if (v > gbest || h == 0) { gbest = v; garg = real ? m : Ns; }
+    }
+    out[(size_t)n * C + c] = gbest;
+    if (argmax) argmax[(size_t)n * C + c] = garg;
+    return;
+  }
   const int32_t* row = idx + (size_t)n * H;
   float best = -INFINITY;
   int arg = Ns;
@@ -80,15 +95,18 @@ __global__ void closest_pool_bwd_kernel(const float* __restrict__ go, int ld, co
 extern "C" {
 
 int d3f_max_pool_forward(const float* x, int Ns, int C, const int32_t* idx, int Nq, int H, float* out,
-                         int32_t* argmax_out, float* grad_x_clear, const int32_t* width_dev, void* stream) {
+                         int32_t* argmax_out, float* grad_x_clear, const int32_t* width_dev, const int32_t* q_len,
+                         int B, int group, void* stream) {
   if (!x || !idx || !out || Ns < 0 || C < 1 || Nq < 0 || H < 1) return D3F_EINVAL;
+  if (q_len && (B < 1 || B > D3F_MAX_BATCH || group < 1)) return D3F_EINVAL;
+  const d3f::RowGroups rg = {q_len, B, group};
   if (Nq == 0) {
     if (grad_x_clear && d3f::zero_async(grad_x_clear, sizeof(float) * (size_t)Ns * C, (hipStream_t)stream) != hipSuccess)
       return D3F_ELAUNCH;
     return D3F_OK;
   }
   max_pool_fwd_kernel<<<d3f::cdiv((long long)Nq * C, 256), 256, 0, (hipStream_t)stream>>>(
-      x, Ns, C, idx, Nq, H, out, argmax_out, grad_x_clear, width_dev);
+      x, Ns, C, idx, Nq, H, out, argmax_out, grad_x_clear, width_dev, rg);
   D3F_LAUNCH_CHECK();
   return D3F_OK;
 }

@@ -130,7 +130,8 @@ __global__ __launch_bounds__(kQueryWaves * 64) void radius_query_kernel(
     int Ns, double inv_cell, float r2, uint32_t mask, const int32_t* __restrict__ start,
     const int32_t* __restrict__ end, const float4* __restrict__ pts, const uint64_t* __restrict__ key, int width,
     int32_t* __restrict__ out_idx, int32_t* __restrict__ out_counts, int32_t* __restrict__ max_count,
-    int32_t* __restrict__ status, int32_t* __restrict__ out_wide, int wide_width, uint64_t* __restrict__ out_last_key) {
+    int32_t* __restrict__ status, int32_t* __restrict__ out_wide, int wide_width, uint64_t* __restrict__ out_last_key,
+    int max_count_group) {
   __shared__ WaveScratch scratch[kQueryWaves];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int qi = blockIdx.x * kQueryWaves + wave;
@@ -206,7 +207,10 @@ __global__ __launch_bounds__(kQueryWaves * 64) void radius_query_kernel(
     if (out_counts) out_counts[qi] = T;
     // (the pre-check reads past the CU's L1, which another CU's atomic never refreshes: with a plain load thousands of
     // waves kept seeing the initial 0 and queued their atomics on the one word -- 71 us for 8000 queries, 12 us now)
-    if (max_count && T > __hip_atomic_load(max_count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(max_count, T);
+    if (max_count) {
+      int32_t* mc = max_count + (max_count_group > 0 ? b / max_count_group : 0);   // per group of clouds, or one word
+      if (T > __hip_atomic_load(mc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(mc, T);
+    }
     if (T > kCand) atomicOr(status, D3F_ST_CAND_OVERFLOW);
     if (out_wide && T > wide_width) atomicOr(status, D3F_ST_WIDE_OVERFLOW);
   }
@@ -301,8 +305,9 @@ int d3f_radius_grid_build(const float* supports, int Ns, const int32_t* s_len, i
 int d3f_radius_query_ex(const void* grid_ws, const float* queries, int Nq, const int32_t* q_len, int Ns,
                         const int32_t* s_len, int B, float grid_radius, float radius, int width, int32_t* out_idx,
                         int32_t* out_counts, int32_t* max_count, int32_t* out_wide, int wide_width,
-                        uint64_t* out_last_key, int32_t* status, void* stream_) {
+                        uint64_t* out_last_key, int max_count_group, int32_t* status, void* stream_) {
   if (!grid_ws || !queries || !q_len || !s_len || (!out_idx && !out_wide) || !status || Nq < 0 || Ns < 0 || B < 1 ||
+      max_count_group < 0 ||
       B > D3F_MAX_BATCH || width < 1 || width > kCand || !(radius > 0.0f) || !(grid_radius >= radius) ||
       (out_wide && (wide_width < 1 || wide_width > kCand)))
     return D3F_EINVAL;
@@ -313,7 +318,7 @@ int d3f_radius_query_ex(const void* grid_ws, const float* queries, int Nq, const
   const float r2 = radius * radius;  // float32 product, like neighbors.cpp:226
   radius_query_kernel<<<d3f::cdiv(Nq, kQueryWaves), kQueryWaves * 64, 0, stream>>>(
       queries, Nq, q_len, s_len, B, Ns, inv_cell, r2, g.M - 1, g.start, g.end, g.pts, g.key, width, out_idx,
-      out_counts, max_count, status, out_wide, wide_width, out_last_key);
+      out_counts, max_count, status, out_wide, wide_width, out_last_key, max_count_group);
   D3F_LAUNCH_CHECK();
   return D3F_OK;
 }
@@ -323,7 +328,7 @@ int d3f_radius_query(const void* grid_ws, const float* queries, int Nq, const in
                      int32_t* out_counts, int32_t* max_count, int32_t* status, void* stream_) {
   (void)supports;
   return d3f_radius_query_ex(grid_ws, queries, Nq, q_len, Ns, s_len, B, radius, radius, width, out_idx, out_counts,
-                             max_count, nullptr, 0, nullptr, status, stream_);
+                             max_count, nullptr, 0, nullptr, 0, status, stream_);
 }
 
 }  // extern "C"

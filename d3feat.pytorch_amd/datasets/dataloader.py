@@ -115,7 +115,7 @@ class _Walk:
             layer_blocks = []
 
 
-def _conv_table(grid_for, pts, lens, level, e, lim, reverse_tables, want_max=False):
+def _conv_table(grid_for, pts, lens, level, e, lim, reverse_tables, want_max=False, group=0):
     """neighbors[l] (dataloader.py:122-128); with ``want_max`` a pair (table, device max neighbor count).  With ``reverse_tables`` the same search also leaves the table's transpose
     in search form (its whole ranked list + the key of the last kept entry): the in-radius relation of a cloud with
     itself is symmetric, so the list of s IS the candidate set of rev(s) -- no transposition pass."""
@@ -125,14 +125,15 @@ def _conv_table(grid_for, pts, lens, level, e, lim, reverse_tables, want_max=Fal
     grid = grid_for(level, e['conv_r'])
     n = pts[level].shape[0]
     if not (reverse_tables and ops.wants_reverse_table(n)):
-        return grid.query(pts[level], lens[level], lim, want_max=want_max)
-    res = grid.query(pts[level], lens[level], lim, want_max=want_max, wide=ops.REV_WIDTH_CONV, want_last_key=True)
+        return grid.query(pts[level], lens[level], lim, want_max=want_max, max_group=group)
+    res = grid.query(pts[level], lens[level], lim, want_max=want_max, wide=ops.REV_WIDTH_CONV, want_last_key=True,
+                     max_group=group)
     tab, wide, lkey = res[0], res[-2], res[-1]
     ops.attach_reverse_table(tab, ops.ReverseTable(wide, n, lim, n, last_key=lkey))
     return (tab, res[1]) if want_max else tab
 
 
-def _pool_tables(grid_for, pts, lens, level, e, lim, reverse_tables, status):
+def _pool_tables(grid_for, pts, lens, level, e, lim, reverse_tables, status, group=0):
     """(pools[l], device max count, upsamples[l]) (dataloader.py:141-152).  The transpose of the pooling table (coarse
     points around every fine point, radius r) is the leading part of the rows of the upsampling table (same point
     pairs, radius 2r, nearest first): nothing extra is searched, the pooling query only adds its last-kept keys."""
@@ -140,22 +141,28 @@ def _pool_tables(grid_for, pts, lens, level, e, lim, reverse_tables, status):
     ns = pts[level].shape[0]
     up = grid_for(level + 1, e['up_r']).query(pts[level], lens[level], lim)
     if not (reverse_tables and ops.wants_reverse_table(ns)):
-        tab, mx = grid.query(pts[level + 1], lens[level + 1], lim, want_max=True)
+        tab, mx = grid.query(pts[level + 1], lens[level + 1], lim, want_max=True, max_group=group)
         return tab, mx, up
-    tab, mx, lkey = grid.query(pts[level + 1], lens[level + 1], lim, want_max=True, want_last_key=True)
+    tab, mx, lkey = grid.query(pts[level + 1], lens[level + 1], lim, want_max=True, want_last_key=True,
+                               max_group=group)
     ops.attach_reverse_table(tab, ops.ReverseTable(up, pts[level + 1].shape[0], lim, ns, last_key=lkey,
                                                    radius=e['pool_r'], status=status))
     return tab, mx, up
 
 
 def build_pyramid_static(points, lengths, config, neighborhood_limits, capacities, order=ops.ORDER_REFERENCE,
-                         reverse_tables=False, status=None, conv_widths=True):
+                         reverse_tables=False, status=None, conv_widths=True, group=0):
     """Capacity-shaped pyramid: every level l has ``capacities[l]`` rows, the live row counts stay on the device.
 
     No host synchronisation at all (hipGraph-capturable): voxel levels write into fixed-capacity buffers (rows past
     the live count are zero), searches give rows past the live count an all-shadow row, and the shadow index of a
     table is the support CAPACITY, so the operators run unchanged on the padded shapes and padded rows never reach a
-    live row.  A level outgrowing its capacity sets D3F_ST_CAPACITY in the returned status word."""
+    live row.  A level outgrowing its capacity sets D3F_ST_CAPACITY in the returned status word.
+
+    ``group`` > 0: the batch stacks several reference batches of ``group`` clouds each (8 fragment pairs: 16 clouds,
+    group 2).  Clouds never see each other in any search; what a reference batch shares is the WIDTH of its tables
+    (min(limit, max count of that batch), dataloader.py:64-66) and the detector's normaliser, so the width entries come
+    per group (int32 [B/group]) and the batch carries ``_group`` for the operators that need it."""
     dev = points.device
     walk = _Walk(config)
     status = status if status is not None else ops.DeviceStatus(dev)   # (a caller's word collects flags across builds)
@@ -182,7 +189,7 @@ def build_pyramid_static(points, lengths, config, neighborhood_limits, capacitie
         # the level-0 table's max count is what the detector's eval-mode gate needs (conv_widths=False: training only --
         # 38k waves reducing into one word cost the level-0 search 25 us)
         if li == 0 and conv_widths:
-            tab, tab_max = _conv_table(grid_for, pts, lens, level, e, lim, reverse_tables, want_max=True)
+            tab, tab_max = _conv_table(grid_for, pts, lens, level, e, lim, reverse_tables, want_max=True, group=group)
         else:
             tab, tab_max = _conv_table(grid_for, pts, lens, level, e, lim, reverse_tables), None
         neighbors.append(tab)
@@ -190,7 +197,7 @@ def build_pyramid_static(points, lengths, config, neighborhood_limits, capacitie
         if e['pool']:
             # static width = the limit; the reference trims to min(limit, max_count) (dataloader.py:64-66).  Only max_pool
             # can tell the difference (a full row gains zero-valued shadow candidates): it gets max_count, on the device
-            tab, mx, up = _pool_tables(grid_for, pts, lens, level, e, lim, reverse_tables, status)
+            tab, mx, up = _pool_tables(grid_for, pts, lens, level, e, lim, reverse_tables, status, group=group)
             pools.append(tab)
             pools_width.append(mx)
             upsamples.append(up)
@@ -202,7 +209,8 @@ def build_pyramid_static(points, lengths, config, neighborhood_limits, capacitie
     n_levels = len(neighbors)
     return {'points': [pts[min(i, len(pts) - 1)] for i in range(n_levels)], 'neighbors': neighbors, 'pools': pools,
             'pools_width': pools_width, 'neighbors_width': neighbors_width, 'upsamples': upsamples,
-            'stack_lengths': [lens[min(i, len(lens) - 1)] for i in range(n_levels)], '_status': status, '_static': True}
+            'stack_lengths': [lens[min(i, len(lens) - 1)] for i in range(n_levels)], '_status': status, '_static': True,
+            '_group': int(group)}
 
 
 def build_pyramid(points, lengths, config, neighborhood_limits, index_dtype=torch.int32, exact_width=False,

@@ -145,4 +145,4 @@ class KPFCNN(nn.Module):
         lens = inputs['stack_lengths'][0] if inputs.get('_static', False) else None  # capacity-shaped batch
         widths = inputs.get('neighbors_width')   # full-limit tables: the level-0 table's max count, on the device
         return ops.detection_scores(features, inputs['neighbors'][0], training=self.training, lens=lens,
-                                    width=widths[0] if widths else None)
+                                    width=widths[0] if widths else None, group=inputs.get('_group', 0) if lens is not None else 0)

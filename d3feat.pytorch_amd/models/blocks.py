@@ -259,10 +259,17 @@ def _layer_inputs(block_name, layer_ind, batch):
 
 
 def _pool_width(layer_ind, batch):
-    """Device int32[1] max neighbor count of the pooling table when the batch keeps its tables wider than the
-    reference would (static shapes): ops.max_pool then reads the columns the reference's table has."""
+    """Keyword arguments for ops.max_pool of a strided block: the device-resident max neighbor count of the pooling
+    table when the batch keeps its tables wider than the reference would (static shapes) -- ops.max_pool then reads the
+    columns the reference's table has -- and, for a batch that stacks several reference batches (``_group``), the stack
+    lengths of the pooled level so that every group uses its own width."""
     w = batch.get('pools_width') if isinstance(batch, dict) else None
-    return w[layer_ind] if w is not None else None
+    if w is None:
+        return {}
+    group = batch.get('_group', 0)
+    if group:
+        return {'width': w[layer_ind], 'groups': (batch['stack_lengths'][layer_ind + 1], group)}
+    return {'width': w[layer_ind]}
 
 
 def _make_kpconv(block_name, in_dim, out_dim, radius, config):
@@ -338,7 +345,7 @@ class ResnetBottleneckBlock(nn.Module):
             # a skip tensor also feeds the decoder, whose gradient arrives first: the pooling backward scatters on top
             incoming = getattr(features, '_d3f_grad_in', None) if strided else None
             shortcut = ops.max_pool(features, inds, grad_deposit=holder, grad_incoming=incoming,
-                                    width=_pool_width(self.layer_ind, batch)) if strided else features
+                                    **_pool_width(self.layer_ind, batch)) if strided else features
             if isinstance(self.unary_shortcut, UnaryBlock):
                 shortcut = self.unary_shortcut(shortcut, grad_deposit=None if strided else holder)
             elif not strided:
@@ -353,7 +360,7 @@ class ResnetBottleneckBlock(nn.Module):
                                     influence=self.KPConv.KP_influence, aggregation=self.KPConv.aggregation_mode)
         else:
             x = self.batch_norm_conv(self.KPConv(q_pts, s_pts, inds, x), slope=0.1)
-        shortcut = ops.max_pool(features, inds, width=_pool_width(self.layer_ind, batch)) \
+        shortcut = ops.max_pool(features, inds, **_pool_width(self.layer_ind, batch)) \
             if 'strided' in self.block_name else features
         shortcut = self.unary_shortcut(shortcut)
         return self.unary2(x, residual=shortcut)  # leaky(unary2(x) + shortcut); in unary2's epilogue without BN
@@ -387,4 +394,4 @@ class MaxPoolBlock(nn.Module):
         self.layer_ind = layer_ind
 
     def forward(self, x, batch):
-        return ops.max_pool(x, batch['pools'][self.layer_ind + 1], width=_pool_width(self.layer_ind + 1, batch))
+        return ops.max_pool(x, batch['pools'][self.layer_ind + 1], **_pool_width(self.layer_ind + 1, batch))

@@ -143,13 +143,14 @@ class RadiusGrid:
                                                   _p(self.status.word), _stream()), "d3f_radius_grid_build")
 
     def query(self, queries, q_len, width, want_counts=False, want_max=False, radius=None, wide=0, want_last_key=False,
-              table=True):
+              table=True, max_group=0):
         """int32 [Nq, width] neighbor table (+ per-query uncapped counts, + device max count).
 
         ``radius`` (<= the grid's): search radius when it differs from the one the cell list was built for.
         ``wide`` > 0: additionally the whole ranked list of every query as an int32 [Nq, wide] table; ``want_last_key``:
         uint64 [Nq] rank key of the last entry each capped row keeps -- together the transposed form of a table for the
-        gather-form KPConv grad-input (d3f_radius_query_ex).  ``table=False`` skips the capped table itself."""
+        gather-form KPConv grad-input (d3f_radius_query_ex).  ``table=False`` skips the capped table itself.
+        ``max_group`` > 0: the max count comes per group of that many consecutive clouds (int32 [ceil(B/max_group)])."""
         q = _f32(queries, "queries")
         if q.dim() != 2 or q.shape[1] != 3:
             raise RuntimeError("Wrong dimensions : query.shape is not (N, 3)")
@@ -162,14 +163,16 @@ class RadiusGrid:
             raise RuntimeError("search radius %g exceeds the cell list's %g" % (r, self.radius))
         out = torch.empty((Nq, int(width)), dtype=torch.int32, device=q.device) if table else None
         counts = torch.empty(Nq, dtype=torch.int32, device=q.device) if want_counts else None
-        mx = torch.zeros(1, dtype=torch.int32, device=q.device) if want_max else None
+        n_mx = -(-int(q_len.numel()) // int(max_group)) if max_group else 1
+        mx = torch.zeros(n_mx, dtype=torch.int32, device=q.device) if want_max else None
         wtab = torch.empty((Nq, int(wide)), dtype=torch.int32, device=q.device) if wide else None
         lkey = torch.empty(Nq, dtype=torch.int64, device=q.device) if want_last_key else None
         with _region("radius_query[Nq=%d,Ns=%d]" % (Nq, self.Ns), 12 * Nq + 12 * self.Ns + 4 * Nq * (int(width) + int(wide))):
             _native.check(_native.lib().d3f_radius_query_ex(_p(self.ws), _p(q), Nq, _p(q_len), self.Ns, _p(self.s_len),
                                                             int(q_len.numel()), self.radius, r, int(width), _p(out),
                                                             _p(counts), _p(mx), _p(wtab), int(wide), _p(lkey),
-                                                            _p(self.status.word), _stream()), "d3f_radius_query_ex")
+                                                            int(max_group), _p(self.status.word), _stream()),
+                          "d3f_radius_query_ex")
         res = (out,) if table else ()
         for flag, t in ((want_counts, counts), (want_max, mx), (wide, wtab), (want_last_key, lkey)):
             if flag:
@@ -1076,8 +1079,9 @@ def linear_nobias(x, weight, grad_holder=None, grad_deposit=None):
 # ---------------------------------------------------------------------------------------------------------------
 class _MaxPoolFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, idx, deposit=None, incoming=None, width=None):
+    def forward(ctx, x, idx, deposit=None, incoming=None, width=None, groups=None):
         ctx.dep, ctx.incoming = deposit, incoming
+        g_len, g_n = groups if groups is not None else (None, 0)
         Ns, C = int(x.shape[0]), int(x.shape[1])
         Nq, H = int(idx.shape[0]), int(idx.shape[1])
         out = torch.empty((Nq, C), dtype=torch.float32, device=x.device)
@@ -1085,7 +1089,9 @@ class _MaxPoolFn(torch.autograd.Function):
         gx_buf = torch.empty_like(x) if ctx.needs_input_grad[0] else None  # cleared by the forward launch
         with _region("max_pool_fwd[Nq=%d,C=%d]" % (Nq, C), 4 * Nq * H + 4 * Nq * H * C + 4 * Nq * C):
             _native.check(_native.lib().d3f_max_pool_forward(_p(x), Ns, C, _p(idx), Nq, H, _p(out), _p(arg),
-                                                             _p(gx_buf), _p(width), _stream()), "d3f_max_pool_forward")
+                                                             _p(gx_buf), _p(width), _p(g_len),
+                                                             int(g_len.numel()) if g_len is not None else 0, int(g_n),
+                                                             _stream()), "d3f_max_pool_forward")
         ctx.save_for_backward(arg)
         ctx.shape = (Ns, C)
         ctx.gx_buf = gx_buf
@@ -1110,16 +1116,33 @@ class _MaxPoolFn(torch.autograd.Function):
             gx.add_(c)
         if ctx.dep is not None and ctx.dep.deposit(gx):
             gx = None
-        return gx, None, None, None, None
+        return gx, None, None, None, None, None
 
 
-def max_pool(x, inds, grad_deposit=None, grad_incoming=None, width=None):
+def _check_groups(width, groups, what):
+    """(q_lens int32 [B] on the device, clouds per group) of a batch that stacks several reference batches; ``width``
+    then holds one entry per group."""
+    if groups is None:
+        if width is not None and not (width.is_cuda and width.dtype == torch.int32 and width.numel() == 1):
+            raise ValueError("width must be a device int32[1] tensor")
+        return None
+    g_len, g_n = groups
+    if not (isinstance(g_len, torch.Tensor) and g_len.is_cuda and g_len.dtype == torch.int32) or int(g_n) < 1:
+        raise ValueError("%s: groups = (device int32 stack lengths, clouds per group)" % what)
+    n_groups = -(-int(g_len.numel()) // int(g_n))
+    if width is not None and not (width.is_cuda and width.dtype == torch.int32 and width.numel() == n_groups):
+        raise ValueError("%s: width must hold one device int32 per group (%d)" % (what, n_groups))
+    return g_len, int(g_n)
+
+
+def max_pool(x, inds, grad_deposit=None, grad_incoming=None, width=None, groups=None):
     """max over the neighbors of every query row, zero shadow row included (blocks.py:94-110).  ``width``: device
     int32[1] = the table's max neighbor count; only the first min(H, width) columns count -- the table the reference
-    would have built (dataloader.py:64-66) when ``inds`` is kept at a wider, static width."""
-    if width is not None and not (width.is_cuda and width.dtype == torch.int32 and width.numel() == 1):
-        raise ValueError("width must be a device int32[1] tensor")
-    return _MaxPoolFn.apply(_f32(x, "x"), _i32(inds, "inds"), grad_deposit, grad_incoming, width)
+    would have built (dataloader.py:64-66) when ``inds`` is kept at a wider, static width.  ``groups`` = (stack lengths
+    of the QUERY level, clouds per group): the batch stacks several reference batches (8 pairs: groups of 2) and
+    ``width`` holds one entry per group."""
+    groups = _check_groups(width, groups, "max_pool")
+    return _MaxPoolFn.apply(_f32(x, "x"), _i32(inds, "inds"), grad_deposit, grad_incoming, width, groups)
 
 
 class _ClosestPoolFn(torch.autograd.Function):
@@ -1308,9 +1331,18 @@ def batch_norm(x, weight, bias, running_mean, running_var, training, momentum=0.
 # ---------------------------------------------------------------------------------------------------------------
 # detector score (models/architectures.py:322-368)
 # ---------------------------------------------------------------------------------------------------------------
-def global_max(x, lens=None):
-    """max(x) as a device scalar; with ``lens`` (int32 stack lengths) only the first sum(lens) rows count."""
+def global_max(x, lens=None, group=0):
+    """max(x) as a device scalar; with ``lens`` (int32 stack lengths) only the first sum(lens) rows count; with
+    ``group`` > 0 one maximum per group of that many consecutive clouds (float32 [ceil(B/group)])."""
     x = _f32(x, "x")
+    if group:
+        G = -(-int(lens.numel()) // int(group))
+        out = torch.empty(G, dtype=torch.float32, device=x.device)
+        ws = _ws(4 * G, x.device)
+        _native.check(_native.lib().d3f_global_max_groups(_p(x), int(x.shape[0]), int(x.shape[1]), _p(lens),
+                                                          int(lens.numel()), int(group), _p(out), _p(ws),
+                                                          max(4 * G, 256), _stream()), "d3f_global_max_groups")
+        return out
     out = torch.empty(1, dtype=torch.float32, device=x.device)
     ws = _ws(256, x.device)
     if lens is None:
@@ -1325,16 +1357,20 @@ def global_max(x, lens=None):
 
 class _DetScoreFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, feat, idx, training, lens=None, width=None):
+    def forward(ctx, feat, idx, training, lens=None, width=None, group=0):
         N, C, H = int(feat.shape[0]), int(feat.shape[1]), int(idx.shape[1])
-        fmax = global_max(feat, lens)
+        if group and (lens is None or ctx.needs_input_grad[0]):
+            raise RuntimeError("detection_scores: the grouped form needs stack lengths and is forward-only")
+        fmax = global_max(feat, lens, group)
         scores = torch.empty((N, 1), dtype=torch.float32, device=feat.device)
         na = _native.lib().d3f_detection_scores_aux_floats(C) if (training and ctx.needs_input_grad[0] and H <= 64) else 0
         aux = torch.empty((N, na), dtype=torch.float32, device=feat.device) if na else None
         with _region("detection_fwd[N=%d]" % N, 4 * N * H + 4 * N * H * C + 4 * N * C + 4 * N):
             _native.check(_native.lib().d3f_detection_scores_forward(_p(feat), N, C, _p(idx), H, _p(fmax),
                                                                      1 if training else 0, _p(scores), _p(aux),
-                                                                     _p(width), _stream()), "d3f_detection_scores_forward")
+                                                                     _p(width), _p(lens) if group else None,
+                                                                     int(lens.numel()) if group else 0, int(group),
+                                                                     _stream()), "d3f_detection_scores_forward")
         ctx.aux = aux
         ctx.save_for_backward(feat, idx, fmax)
         ctx.training = bool(training)
@@ -1353,17 +1389,19 @@ class _DetScoreFn(torch.autograd.Function):
             _native.check(_native.lib().d3f_detection_scores_backward(_p(feat), N, C, _p(idx), H, _p(fmax), _p(gs),
                                                                       _p(ctx.aux), _p(gf), _p(ws), 256, _stream()),
                           "d3f_detection_scores_backward")
-        return gf, None, None, None, None
+        return gf, None, None, None, None, None
 
 
-def detection_scores(features, neighbors, training=True, lens=None, width=None):
+def detection_scores(features, neighbors, training=True, lens=None, width=None, group=0):
     """scores [N,1] from un-normalised descriptors [N,C] and the layer-0 neighbor table.  ``lens`` (device int32
     stack lengths) restricts the global-max normaliser to the live rows of a capacity-shaped batch; ``width`` (device
     int32[1], the table's max neighbor count) makes a table kept at the full limit behave like the reference's
-    min(limit, max_count)-column table in the eval-mode local-maximum gate (as for max_pool)."""
-    if width is not None and not (width.is_cuda and width.dtype == torch.int32 and width.numel() == 1):
-        raise ValueError("width must be a device int32[1] tensor")
-    return _DetScoreFn.apply(_f32(features, "features"), _i32(neighbors, "neighbors"), bool(training), lens, width)
+    min(limit, max_count)-column table in the eval-mode local-maximum gate (as for max_pool).  ``group`` > 0: the batch
+    stacks several reference batches of that many clouds (8 pairs: 2); the normaliser (architectures.py:342 takes the
+    maximum of ONE pair) and ``width`` are then per group (forward only)."""
+    _check_groups(width, (lens, group) if group else None, "detection_scores")
+    return _DetScoreFn.apply(_f32(features, "features"), _i32(neighbors, "neighbors"), bool(training), lens, width,
+                             int(group))
 
 
 # ---------------------------------------------------------------------------------------------------------------
@@ -1591,6 +1629,44 @@ def mutual_nn(source_desc, target_desc):
     _native.check(_native.lib().d3f_mutual_nn(_p(s), Ns, _p(t), Nt, C, _p(ra), _p(ca), _p(mu), _p(ws), nbytes,
                                               _stream()), "d3f_mutual_nn")
     return ra, ca, mu
+
+
+def mutual_nn_batched(source_desc, target_desc, seg, max_src, max_tgt):
+    """P matchings by one pair of launches.  ``seg`` int32 [P,4] on the device = (src_off, src_len, tgt_off, tgt_len) per
+    pair into the rows of the (possibly identical) stacked descriptor matrices; ``max_src`` / ``max_tgt`` host upper
+    bounds of the lengths.  Returns (row_argmin [src rows], col_argmin [tgt rows], mutual [src rows]) indexed by stacked
+    row, holding pair-local indices; rows outside every segment hold -1 / 0."""
+    s, t = _f32(source_desc, "source_desc"), _f32(target_desc, "target_desc")
+    if not (seg.is_cuda and seg.dtype == torch.int32 and seg.dim() == 2 and seg.shape[1] == 4 and seg.is_contiguous()):
+        raise ValueError("seg must be a contiguous device int32 [P,4] tensor")
+    Ns, Nt, C, P = int(s.shape[0]), int(t.shape[0]), int(s.shape[1]), int(seg.shape[0])
+    ra = torch.full((Ns,), -1, dtype=torch.int32, device=s.device)
+    ca = torch.full((Nt,), -1, dtype=torch.int32, device=s.device)
+    mu = torch.zeros(Ns, dtype=torch.int32, device=s.device)
+    nbytes = _native.lib().d3f_mutual_nn_batched_ws_bytes(Ns, Nt)
+    ws = _ws(nbytes, s.device)
+    _native.check(_native.lib().d3f_mutual_nn_batched(_p(s), Ns, _p(t), Nt, _p(seg), P, int(max_src), int(max_tgt), C,
+                                                      _p(ra), _p(ca), _p(mu), _p(ws), nbytes, _stream()),
+                  "d3f_mutual_nn_batched")
+    return ra, ca, mu
+
+
+TOPK_MAX = 6144
+
+
+def topk_scores(scores, seg, k):
+    """int32 [P,k]: the k highest-scoring rows of every cloud (cloud-local indices), ascending (score, index) like the
+    tail of a stable argsort (test.py:56-57); ``seg`` int32 [P,2] on the device = (offset, length) per cloud; a cloud
+    with fewer than k rows leads with -1."""
+    sc = _f32(scores, "scores").reshape(-1)
+    if not (seg.is_cuda and seg.dtype == torch.int32 and seg.dim() == 2 and seg.shape[1] == 2 and seg.is_contiguous()):
+        raise ValueError("seg must be a contiguous device int32 [P,2] tensor")
+    if not 1 <= int(k) <= TOPK_MAX:
+        raise ValueError("k must be in 1..%d" % TOPK_MAX)
+    out = torch.empty((int(seg.shape[0]), int(k)), dtype=torch.int32, device=sc.device)
+    _native.check(_native.lib().d3f_topk_scores(_p(sc), int(sc.numel()), _p(seg), int(seg.shape[0]), int(k), _p(out),
+                                                _stream()), "d3f_topk_scores")
+    return out
 
 
 # ---------------------------------------------------------------------------------------------------------------

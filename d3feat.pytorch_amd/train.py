@@ -461,7 +461,8 @@ class TrainStep:
             st.status.word.zero_()   # the word describes THIS pair; what it caused is kept by the optimizer (state[2:4])
         batch = dl.build_pyramid_static(st.pts, st.lens, self.config, self.limits, self.caps,
                                         reverse_tables=self.reverse_tables, status=st.status,
-                                        conv_widths=not self.reverse_tables)   # (the eval-mode gate's input: inference)
+                                        conv_widths=not self.reverse_tables,   # (the eval-mode gate's input: inference)
+                                        group=getattr(self, 'group', 0))
         batch.pop('_status')
         if st.batch is None or adopt:
             st.batch = batch

@@ -77,11 +77,13 @@ int d3f_radius_query(const void* grid_ws, const float* queries, int Nq, const in
  *   out_last_key [Nq] uint64: rank key (d2 bits << 32 | index) of the last entry the capped row (width) keeps, ~0 when
  *     the row keeps every candidate.  s is listed by query q  <=>  d2(q,s) < r2 and key(q,s) <= last_key[q], which
  *     makes the wide list of a point s over the QUERY cloud, filtered by that test, the transpose of the capped
- *     table (the in-radius relation is symmetric and d2 is bit-identical both ways). */
+ *     table (the in-radius relation is symmetric and d2 is bit-identical both ways).
+ *   max_count_group > 0: max_count is an array of ceil(B / max_count_group) words, one per group of that many
+ *     consecutive clouds (8 stacked pairs -> the max count each pair's own table would have had); 0: one word. */
 int d3f_radius_query_ex(const void* grid_ws, const float* queries, int Nq, const int32_t* q_len, int Ns,
                         const int32_t* s_len, int B, float grid_radius, float radius, int width, int32_t* out_idx,
                         int32_t* out_counts, int32_t* max_count, int32_t* out_wide, int wide_width,
-                        uint64_t* out_last_key, int32_t* status, void* stream);
+                        uint64_t* out_last_key, int max_count_group, int32_t* status, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Grid subsampling -- replaces grid_subsampling.subsample_batch, points-only branch
@@ -216,9 +218,12 @@ int d3f_linear_grad_weight(const float* x, const float* grad_out, int N, int Cin
  * is then called with grad_x_precleared = 1 and launches no fill. */
 /* width_dev (optional, device int32[1]): the table's max neighbor count as d3f_radius_query reports it; only the
  * first min(H, *width_dev) columns take part, which is the table the reference would have built
- * (dataloader.py:64-66 trims to the max count) when idx is kept at a wider, static width. */
+ * (dataloader.py:64-66 trims to the max count) when idx is kept at a wider, static width.
+ * q_len (optional, [B]) + group: the batch stacks several reference batches (groups of `group` consecutive clouds, e.g.
+ * 8 pairs); width_dev is then an array with one entry per group and every query row uses its own group's. */
 int d3f_max_pool_forward(const float* x, int Ns, int C, const int32_t* idx, int Nq, int H, float* out,
-                         int32_t* argmax_out, float* grad_x_clear, const int32_t* width_dev, void* stream);
+                         int32_t* argmax_out, float* grad_x_clear, const int32_t* width_dev, const int32_t* q_len,
+                         int B, int group, void* stream);
 int d3f_max_pool_backward(const float* grad_out, const int32_t* argmax, int Nq, int C, int Ns, float* grad_x,
                           int grad_x_precleared, void* stream);
 /* out[n,:] = x'[idx[n,0],:]  (idx has row stride H); backward: grad_out has row stride ld >= C (a column slice of
@@ -346,14 +351,22 @@ int d3f_global_max(const float* x, size_t n, float* out_max, void* ws /* >= 4 by
 /* same over the first sum(len) rows of x [cap_rows, C] (row count read on the device) */
 int d3f_global_max_rows(const float* x, int cap_rows, int C, const int32_t* len, int B, float* out_max, void* ws,
                         size_t ws_bytes, void* stream);
+/* one maximum per group of `group` consecutive clouds: out_max [ceil(B/group)] (ws >= 4 bytes per group).  The
+ * reference normalises the detector features by the maximum of ITS batch (one pair, architectures.py:342); with 8
+ * pairs stacked the normaliser has to stay per pair. */
+int d3f_global_max_groups(const float* x, int cap_rows, int C, const int32_t* len, int B, int group, float* out_max,
+                          void* ws, size_t ws_bytes, void* stream);
 /* aux (optional, training only, [N, d3f_detection_scores_aux_floats(C)]): per-point scalars of the winning channel,
  * left behind so that the backward pass does not gather features again. */
 int d3f_detection_scores_aux_floats(int C); /* 8 for C in {16, 32, 64}, 0 (aux unsupported) otherwise */
 /* width (optional, device int32[1]): max neighbor count of the table when idx is kept wider than the reference would
  * build it (min(limit, max_count) columns, dataloader.py:64-66): the extra all-shadow columns are then ignored -- they
- * would give the eval-mode local-maximum gate a zero candidate the reference does not have. */
+ * would give the eval-mode local-maximum gate a zero candidate the reference does not have.
+ * len (optional, [B]) + group: stacked reference batches (see d3f_max_pool_forward): feat_max and width are arrays with
+ * one entry per group (d3f_global_max_groups; d3f_radius_query_ex max_count_group); forward only (aux must be NULL). */
 int d3f_detection_scores_forward(const float* feat, int N, int C, const int32_t* idx, int H, const float* feat_max,
-                                 int training, float* scores, float* aux, const int32_t* width, void* stream);
+                                 int training, float* scores, float* aux, const int32_t* width, const int32_t* len,
+                                 int B, int group, void* stream);
 /* grad_feat [N,C] is OVERWRITTEN.  Includes the gradient through the global max normaliser.  aux: the forward's
  * (optional; without it the neighborhood statistics are recomputed). */
 int d3f_detection_scores_backward(const float* feat, int N, int C, const int32_t* idx, int H, const float* feat_max,
@@ -412,6 +425,25 @@ int d3f_select_normalize_backward(const float* x, int N, int C, const int64_t* i
 size_t d3f_mutual_nn_ws_bytes(int Ns, int Nt);
 int d3f_mutual_nn(const float* src_desc, int Ns, const float* tgt_desc, int Nt, int C, int32_t* row_argmin,
                   int32_t* col_argmin, int32_t* mutual, void* ws, size_t ws_bytes, void* stream);
+/* P independent matchings by ONE pair of launches (BASELINE configs[3]: 8 fragment pairs per inference batch).
+ * seg [P,4] int32 ON THE DEVICE = {src_off, src_len, tgt_off, tgt_len} per pair: rows of src_desc / tgt_desc (which
+ * may be the same stacked matrix).  max_src / max_tgt: host upper bounds of the lengths (they size the grid).
+ * row_argmin [src_rows] / col_argmin [tgt_rows] / mutual [src_rows] are indexed by the row of the stacked matrix and
+ * hold PAIR-LOCAL indices (what P separate d3f_mutual_nn calls return); rows outside every segment are untouched. */
+size_t d3f_mutual_nn_batched_ws_bytes(int src_rows, int tgt_rows);
+int d3f_mutual_nn_batched(const float* src_desc, int src_rows, const float* tgt_desc, int tgt_rows, const int32_t* seg,
+                          int P, int max_src, int max_tgt, int C, int32_t* row_argmin, int32_t* col_argmin,
+                          int32_t* mutual, void* ws, size_t ws_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Keypoint selection -- replaces np.argsort(scores)[-k:] (test.py:56-57, geometric_registration/evaluate): the k
+ * highest-scoring rows of every cloud of a stacked batch, in ascending (score, index) order like a stable argsort's
+ * tail.  scores [rows]; seg [P,2] int32 on the device = {offset, length} per cloud; out [P,k] int32 CLOUD-LOCAL row
+ * indices; a cloud with fewer than k rows fills its leading k - len slots with -1.  k <= D3F_TOPK_MAX.  One workgroup
+ * per cloud: radix select of the k-th largest (score, index) key, then a rank sort of the survivors in LDS.
+ * ---------------------------------------------------------------------------------------------- */
+#define D3F_TOPK_MAX 6144
+int d3f_topk_scores(const float* scores, int rows, const int32_t* seg, int P, int k, int32_t* out, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * KPConv with the non-default influence / aggregation modes -- models/blocks.py:327-352 (KP_influence 'constant' /

@@ -319,6 +319,45 @@ def deform():
           {k: float(np.abs(v).max()) for k, v in g.items() if 'offset' in k and k.startswith('grad.')})
 
 
+def batch8():
+    """tests/golden/batch8.npz -- BASELINE configs[3]: 8 fragment pairs, each through the reference ON ITS OWN (one pair
+    per batch, as test.py / the reference's loaders run it): synthetic pairs (1,2), (3,4) ... (15,16) at full size, the
+    full-width network of s1_full.npz (seed 0) in eval mode with the S1 neighbor limits.  Per pair: point counts and
+    SHA-256 of the fragments, all detector scores, 256 sampled descriptor rows, and the reference's top-250 selection
+    (np.argsort(scores)[-250:], test.py:56-57) with the selected descriptors and build_correspondence of them."""
+    cfg = mg.cfgmod.default_config()
+    g1 = np.load(os.path.join(HERE, 's1_full.npz'))
+    limits = [int(v) for v in g1['limits']]
+    np.random.seed(0)
+    torch.manual_seed(0)
+    model = mg.KPFCNN(cfg)
+    model.eval()
+    g = {'limits': np.asarray(limits, np.int64)}
+    rs = np.random.RandomState(8)
+    for p in range(8):
+        item = mg.synthetic.make_pair(2 * p + 1, 2 * p + 2, mg.ref_subsample)
+        batch = mg.collate_fn_descriptor([item], cfg, limits)
+        with torch.no_grad():
+            feats, scores = model(batch)
+        fe, se = feats.numpy().astype(np.float32), scores.numpy().reshape(-1).astype(np.float32)
+        n0, n1 = int(batch['stack_lengths'][0][0]), int(batch['stack_lengths'][0][1])
+        tag = 'p%d.' % p
+        g[tag + 'n'] = np.array([n0, n1], np.int64)
+        g[tag + 'sha'] = np.array([mg.sha(item[0]), mg.sha(item[1])])
+        g[tag + 'scores'] = se
+        rows = np.sort(rs.choice(n0 + n1, 256, replace=False))
+        g[tag + 'feat_rows'], g[tag + 'feat_sample'] = rows, fe[rows]
+        si, ti = np.argsort(se[:n0])[-250:], np.argsort(se[n0:])[-250:]
+        g[tag + 'src_idx250'], g[tag + 'tgt_idx250'] = si, ti
+        g[tag + 'src_desc250'], g[tag + 'tgt_desc250'] = fe[:n0][si], fe[n0:][ti]
+        g[tag + 'corr250'] = mg.build_correspondence(fe[:n0][si], fe[n0:][ti])
+        g[tag + 'width0'] = np.int64(batch['neighbors'][0].shape[1])
+        print('pair', p, (n0, n1), 'nonzero scores', int((se != 0).sum()), 'corr250', g[tag + 'corr250'].shape,
+              'table widths', [int(t.shape[1]) for t in batch['neighbors']], [int(t.shape[1]) for t in batch['pools'][:-1]])
+    np.savez_compressed(os.path.join(HERE, 'batch8.npz'), **g)
+    print('batch8.npz', os.path.getsize(os.path.join(HERE, 'batch8.npz')) / 1e6, 'MB')
+
+
 if __name__ == '__main__':
     which = sys.argv[1:] or ['s1', 'reg', 'dataset', 'kernels', 'bn', 'deform']
     if 'kernels' in which:
@@ -327,6 +366,8 @@ if __name__ == '__main__':
         bn()
     if 'deform' in which:
         deform()
+    if 'batch8' in which:
+        batch8()
     if 'dataset' in which:
         dataset()
     if 'reg' in which:

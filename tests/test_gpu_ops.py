@@ -935,3 +935,88 @@ def test_deformable_kpconv_wide_channels_vs_oracle():
         q, s, i, x, k, ww, ext, of[:, :3 * K].reshape(-1, K, 3) * ext, 2 * torch.sigmoid(of[:, 3 * K:])))
     for name, u, v in zip(("out", "min_d2", "grad_x", "grad_w", "grad_offsets"), got, ref):
         assert rel_err(u.numpy(), v.numpy()) < 2e-4, name
+
+
+# ------------------------------------------------------------------------------------------------ 8 pairs per batch
+def test_topk_scores_equals_the_stable_argsort_tail():
+    """ops.topk_scores vs np.argsort(kind='stable')[-k:] per cloud (test.py:56-57 selects keypoints that way): gated
+    eval scores are mostly exact zeros, so ties decide; k larger than a cloud pads with -1 in front."""
+    rng = np.random.default_rng(41)
+    lens = [19000, 3, 700, 5000, 1]
+    sc = rng.random(sum(lens)).astype(np.float32)
+    sc[rng.random(sc.size) < 0.6] = 0.0
+    sc[100:140] = sc[100]                                    # a run of equal non-zero scores
+    offs = np.concatenate([[0], np.cumsum(lens)[:-1]])
+    seg = cu(np.stack([offs, lens], 1).astype(np.int32))
+    for k in (1, 250, 5000, ops.TOPK_MAX):
+        got = ops.topk_scores(cu(sc), seg, k).cpu().numpy()
+        for c, (o, n) in enumerate(zip(offs, lens)):
+            want = np.argsort(sc[o:o + n], kind='stable')[-k:]
+            assert np.array_equal(got[c, k - len(want):], want), (k, c)
+            assert np.all(got[c, :k - len(want)] == -1)
+
+
+@pytest.mark.parametrize("C", [32, 64])
+def test_mutual_nn_batched_equals_per_pair_calls(C):
+    """One pair of launches over 5 stacked pairs (one of them empty on the target side, sizes from 1 to 6000 rows) gives
+    exactly what 5 separate ops.mutual_nn calls give -- same arg-min rule, same tie order."""
+    gen = torch.Generator().manual_seed(5)
+    sizes = [(6000, 5500), (1, 300), (257, 64), (1000, 0), (4100, 4099)]
+    total = sum(a + b for a, b in sizes)
+    desc = torch.nn.functional.normalize(torch.randn((total, C), generator=gen), dim=1)
+    desc[10] = desc[3]                                       # exact duplicates: distance ties
+    desc[6000 + 7] = desc[6000 + 2]
+    d = desc.to(DEV)
+    seg, off = [], 0
+    for a, b in sizes:
+        seg.append([off, a, off + a, b])
+        off += a + b
+    ra, ca, mu = ops.mutual_nn_batched(d, d, cu(np.asarray(seg, np.int32)), 6000, 5500)
+    for so, sn, to, tn in seg:
+        if tn == 0:
+            assert int(mu[so:so + sn].sum()) == 0
+            continue
+        r1, c1, m1 = ops.mutual_nn(d[so:so + sn], d[to:to + tn])
+        assert torch.equal(ra[so:so + sn], r1) and torch.equal(ca[to:to + tn], c1) and torch.equal(mu[so:so + sn], m1)
+
+
+def test_grouped_max_pool_and_detection_equal_per_group_calls():
+    """A batch that stacks 3 reference batches of 2 clouds: max_pool with one table width per group and the detector
+    score with one normaliser + width per group equal the calls on each group alone (widths below the static table
+    width, so the trimmed columns matter; negative features make the shadow's zero a live candidate)."""
+    rng = np.random.default_rng(6)
+    lens_s = np.array([300, 280, 150, 160, 90, 400], np.int32)          # supports per cloud
+    lens_q = np.array([120, 100, 60, 70, 30, 150], np.int32)            # queries per cloud
+    ns, nq, H, C = int(lens_s.sum()), int(lens_q.sum()), 12, 32
+    so, qo = np.concatenate([[0], np.cumsum(lens_s)]), np.concatenate([[0], np.cumsum(lens_q)])
+    widths = np.array([5, 9, 12], np.int32)
+    idx = np.full((nq, H), ns, np.int32)
+    for c in range(6):
+        w = widths[c // 2]
+        for r in range(qo[c], qo[c + 1]):
+            cnt = rng.integers(1, w + 1)
+            idx[r, :cnt] = rng.integers(so[c], so[c + 1], cnt)
+        idx[qo[c], :w] = rng.integers(so[c], so[c + 1], w)              # one full row per cloud
+    x = -np.abs(rng.normal(size=(ns, C))).astype(np.float32)
+    got = ops.max_pool(cu(x), cu(idx), width=cu(widths), groups=(cu(lens_q), 2)).cpu().numpy()
+    for g in range(3):
+        q0, q1, s0, s1 = qo[2 * g], qo[2 * g + 2], so[2 * g], so[2 * g + 2]
+        sub = np.where(idx[q0:q1] >= ns, s1 - s0, idx[q0:q1] - s0).astype(np.int32)
+        want = ops.max_pool(cu(x[s0:s1]), cu(sub), width=cu(widths[g:g + 1])).cpu().numpy()
+        assert np.array_equal(got[q0:q1], want), g
+    # detector: self tables over the support clouds
+    tab = np.full((ns, H), ns, np.int32)
+    for c in range(6):
+        w = widths[c // 2]
+        for r in range(so[c], so[c + 1]):
+            cnt = rng.integers(1, w + 1)
+            tab[r, :cnt] = rng.integers(so[c], so[c + 1], cnt)
+            tab[r, 0] = r
+    f = rng.normal(size=(ns, C)).astype(np.float32) * np.repeat([1.0, 1.0, 3.0, 3.0, 0.2, 0.2], lens_s)[:, None]
+    for training in (True, False):
+        got = ops.detection_scores(cu(f), cu(tab), training=training, lens=cu(lens_s), width=cu(widths), group=2)
+        for g in range(3):
+            s0, s1 = so[2 * g], so[2 * g + 2]
+            sub = np.where(tab[s0:s1] >= ns, s1 - s0, tab[s0:s1] - s0).astype(np.int32)
+            want = ops.detection_scores(cu(f[s0:s1]), cu(sub), training=training, width=cu(widths[g:g + 1]))
+            assert torch.equal(got[s0:s1], want), (training, g)
