@@ -552,11 +552,18 @@ def main():
         summary = prof.summary()
         roofline = None
         if dx_t is not None:
-            traffic = None
+            traffic, traffic_stale = None, None
             tpath = os.path.join(REPO, "profiles", "pmc_traffic.json")
             if os.path.exists(tpath):
                 with open(tpath) as f:
-                    traffic = json.load(f).get(KERNEL_NAMES[dom].split(" ")[0], {}).get("hbm_bytes_per_launch")
+                    entry = json.load(f).get(KERNEL_NAMES[dom].split(" ")[0], {})
+                traffic = entry.get("hbm_bytes_per_launch")
+                # the counters were collected on the kernel source whose SHA is stored with them (profiles/pmc_traffic.py)
+                src = entry.get("source")
+                if traffic is not None and src:
+                    import hashlib
+                    with open(os.path.join(REPO, "d3feat.pytorch_amd", "csrc", src), "rb") as fh:
+                        traffic_stale = hashlib.sha256(fh.read()).hexdigest()[:16] != entry.get("source_sha16")
             f_hbm = dx_t["gbs"] / HBM_PEAK_GBS
             f_mfma = dx_t["tflops"] / F32_MFMA_PEAK_TFLOPS
             mfma_bound = f_mfma > f_hbm
@@ -567,7 +574,7 @@ def main():
                 "peak": F32_MFMA_PEAK_TFLOPS if mfma_bound else HBM_PEAK_GBS,
                 "unit": "TFLOP/s" if mfma_bound else "GB/s",
                 "frac": round(max(f_mfma, f_hbm), 4),
-                "traffic": traffic,
+                "traffic": traffic, "traffic_source_stale": traffic_stale,
                 "avg_us": round(dx_t["avg_us"], 2), "launches_timed": dx_t["launches"],
                 "us_per_step": round(dx_t["us_per_step"], 1),
                 "algorithmic_bytes_per_launch": int(dx_t["bytes_per_launch"]),

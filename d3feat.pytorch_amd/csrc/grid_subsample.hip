@@ -33,6 +33,7 @@ constexpr uint64_t kEmpty = ~0ull;
 constexpr uint64_t kKeyMask = (1ull << 56) - 1;
 constexpr int kOrderThreads = 1024;
 constexpr int kMaxPhases = 40;
+constexpr int kLdsBuckets = 5120;   // covers libstdc++'s bucket counts up to 5087, i.e. clouds of up to 5087 cells
 
 struct ElemGrid {
   float ox, oy, oz;
@@ -136,18 +137,26 @@ Layout layout(void* ws, int N, int B) {
   return L;
 }
 
-__global__ void init_kernel(uint32_t M, uint64_t* __restrict__ tkey, int32_t* __restrict__ tfirst) {
-  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < M) {
-    tkey[i] = kEmpty;
-    tfirst[i] = 0x7fffffff;
-  }
-}
-
-// one workgroup per cloud: component-wise min/max, then the voxel frame of that cloud
-__global__ __launch_bounds__(1024) void bbox_kernel(const float* __restrict__ p, const int32_t* __restrict__ len,
-                                                    float dl, ElemGrid* __restrict__ grid) {
+// First launch of a call.  Workgroups 0..B-1: component-wise min/max of one cloud each, then its voxel frame.  The
+// others re-initialise the call's state -- empty hash table, zeroed counters / bitmap / output rows -- which used to be
+// four launches of their own (three fills + init) in front of every level.
+__global__ __launch_bounds__(1024) void prep_kernel(const float* __restrict__ p, const int32_t* __restrict__ len, int B,
+                                                    float dl, ElemGrid* __restrict__ grid, uint32_t M,
+                                                    uint64_t* __restrict__ tkey, int32_t* __restrict__ tfirst,
+                                                    int32_t* __restrict__ tcount, size_t n_count,
+                                                    uint64_t* __restrict__ bitmap, size_t n_bitmap,
+                                                    float* __restrict__ out_points, size_t n_out) {
   __shared__ float smin[3][16], smax[3][16];
+  if ((int)blockIdx.x >= B) {
+    const size_t stride = (size_t)(gridDim.x - B) * blockDim.x;
+    const size_t t0 = (size_t)(blockIdx.x - B) * blockDim.x + threadIdx.x;
+    for (size_t i = t0; i < M; i += stride) { tkey[i] = kEmpty; tfirst[i] = 0x7fffffff; }
+    for (size_t i = t0; i < n_count; i += stride) tcount[i] = 0;
+    for (size_t i = t0; i < n_bitmap; i += stride) bitmap[i] = 0ull;
+    // rows past the emitted total stay zero: a capacity-shaped consumer never sees uninitialised (NaN) coordinates
+    for (size_t i = t0; i < n_out; i += stride) out_points[i] = 0.0f;
+    return;
+  }
   const int b = blockIdx.x;
   const int start = d3f::batch_offset(len, b), n = len[b];
   float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
@@ -230,13 +239,16 @@ __global__ void insert_kernel(const float* __restrict__ p, int N, const int32_t*
   slot_of[i] = (int32_t)s;
 }
 
-// member-list ranges: the total is one word, so the reservation is aggregated per wave (inclusive scan of the counts,
-// ONE atomic by the last lane) -- a per-cell atomic on a single word serialises (46 us for 12k cells)
-__global__ void alloc_kernel(uint32_t M, int B, const uint64_t* __restrict__ tkey, int32_t* __restrict__ tcount,
-                             const int32_t* __restrict__ tfirst, int32_t* __restrict__ tstart,
-                             int32_t* __restrict__ tfill, uint64_t* __restrict__ bitmap, int32_t* __restrict__ ncell) {
+// member-list ranges: the total is one word, so the reservation is aggregated per WORKGROUP (wave scans, the four wave
+// totals combined through LDS, ONE atomic by the workgroup) -- a per-cell atomic on a single word serialises (46 us for
+// 12k cells), a per-wave one still queues 2048 of them at level 0 (50 us); the per-cloud cell counts likewise
+__global__ __launch_bounds__(256) void alloc_kernel(uint32_t M, int B, const uint64_t* __restrict__ tkey,
+                                                    int32_t* __restrict__ tcount, const int32_t* __restrict__ tfirst,
+                                                    int32_t* __restrict__ tstart, int32_t* __restrict__ tfill,
+                                                    uint64_t* __restrict__ bitmap, int32_t* __restrict__ ncell) {
+  __shared__ int wtot[4], wbase[4], cells[4][D3F_MAX_BATCH];
   const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
-  const int lane = threadIdx.x & 63;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int c = s < M ? tcount[s] : 0;
   int incl = c;
 #pragma unroll
@@ -244,17 +256,28 @@ __global__ void alloc_kernel(uint32_t M, int B, const uint64_t* __restrict__ tke
     const int t = __shfl_up(incl, o, 64);
     if (lane >= o) incl += t;
   }
-  const int total = __shfl(incl, 63, 64);
-  int base = 0;
-  if (lane == 63 && total > 0) base = atomicAdd(&tcount[M], total);
-  base = __shfl(base, 63, 64);
+  if (lane == 63) wtot[wave] = incl;
   const int b = c > 0 ? (int)(tkey[s] >> 56) : -1;
   for (int k = 0; k < B; ++k) {
     const unsigned long long m = __ballot(b == k);
-    if (lane == 0 && m) atomicAdd(&ncell[k], __popcll(m));
+    if (lane == 0) cells[wave][k] = __popcll(m);
   }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const int total = wtot[0] + wtot[1] + wtot[2] + wtot[3];
+    const int base = total > 0 ? atomicAdd(&tcount[M], total) : 0;
+    wbase[0] = base;
+    wbase[1] = base + wtot[0];
+    wbase[2] = base + wtot[0] + wtot[1];
+    wbase[3] = base + wtot[0] + wtot[1] + wtot[2];
+  }
+  if ((int)threadIdx.x < B) {
+    const int n = cells[0][threadIdx.x] + cells[1][threadIdx.x] + cells[2][threadIdx.x] + cells[3][threadIdx.x];
+    if (n) atomicAdd(&ncell[threadIdx.x], n);
+  }
+  __syncthreads();
   if (c == 0) return;
-  const int st = base + incl - c;
+  const int st = wbase[wave] + incl - c;
   tstart[s] = st;
   tfill[s] = st;
   const int f = tfirst[s];
@@ -329,8 +352,9 @@ __global__ __launch_bounds__(kOrderThreads) void order_kernel(
     int32_t* __restrict__ tmpbk, int32_t* __restrict__ memberT, int32_t* __restrict__ bfirst,
     int32_t* __restrict__ bcnt, int32_t* __restrict__ bcur, int32_t* __restrict__ bbase,
     float* __restrict__ out_points, int32_t* __restrict__ out_len, int32_t* __restrict__ out_total, int out_cap,
-    int32_t* __restrict__ row_slot, int32_t* __restrict__ status) {
+    int32_t* __restrict__ row_slot, int32_t* __restrict__ status, int lds_cap) {
   __shared__ int sh[16];
+  extern __shared__ int32_t lds_buckets[];   // 4 x kLdsBuckets: the bucket tables of the phases that fit (LDS atomics)
   const int b = blockIdx.x, tid = threadIdx.x, nthr = blockDim.x;
   const int pstart = d3f::batch_offset(len, b), n = len[b], pend = pstart + n;
   const int Mc = ncell[b];
@@ -395,16 +419,18 @@ __global__ __launch_bounds__(kOrderThreads) void order_kernel(
     int32_t* tb = tmpbk + pstart;
     int32_t* mt = memberT + pstart;
     const size_t boff = 3 * (size_t)pstart + 1024 * (size_t)b;  // bucket count <= ~2.3 x cells (libstdc++ prime table)
-    int32_t* bf = bfirst + boff;
-    int32_t* bc = bcnt + boff;
-    int32_t* bu = bcur + boff;
-    int32_t* bb = bbase + boff;
     for (int j = 0; j < sched.n; ++j) {
       const int e0 = sched.size[j];
       if (e0 >= Mc) break;
       const int e1 = (j + 1 < sched.n) ? sched.size[j + 1] : 0x7fffffff;
       const int nj = min(e1, Mc);
       const int Bk = sched.bucket[j];
+      // a phase is ~6 barriers with bucket atomics in between: in LDS a phase costs a few us, through L2 ten times that
+      const bool in_lds = lds_cap > 0 && Bk <= lds_cap;
+      int32_t* bf = in_lds ? lds_buckets : bfirst + boff;
+      int32_t* bc = in_lds ? lds_buckets + lds_cap : bcnt + boff;
+      int32_t* bu = in_lds ? lds_buckets + 2 * lds_cap : bcur + boff;
+      int32_t* bb = in_lds ? lds_buckets + 3 * lds_cap : bbase + boff;
       for (int k = tid; k < Bk; k += nthr) {
         bf[k] = 0x7fffffff;
         bc[k] = 0;
@@ -562,26 +588,36 @@ int d3f_grid_subsample_ex(const float* points, int N, const int32_t* len, int B,
   if (ws_bytes < L.bytes) return D3F_EWORKSPACE;
   const Schedule& sched = host_schedule(N);
   const bool attrs = features || classes;
-  if (d3f::zero_async(L.tcount, sizeof(int32_t) * (L.M + 64 + (size_t)B), stream) != hipSuccess) return D3F_ELAUNCH;
-  if (d3f::zero_async(L.bitmap, sizeof(uint64_t) * ((size_t)N / 64 + 2), stream) != hipSuccess) return D3F_ELAUNCH;
-  // rows past the emitted total stay zero: a capacity-shaped consumer never sees uninitialised (NaN) coordinates
-  if (d3f::zero_async(out_points, sizeof(float) * 3 * (size_t)out_cap, stream) != hipSuccess) return D3F_ELAUNCH;
   if (features && d3f::zero_async(out_features, sizeof(float) * (size_t)fdim * out_cap, stream) != hipSuccess)
     return D3F_ELAUNCH;
   if (classes && d3f::zero_async(out_classes, sizeof(int32_t) * (size_t)ldim * out_cap, stream) != hipSuccess)
     return D3F_ELAUNCH;
-  init_kernel<<<d3f::cdiv(L.M, 256), 256, 0, stream>>>(L.M, L.tkey, L.tfirst);
-  bbox_kernel<<<B, 1024, 0, stream>>>(points, len, sampleDl, L.grid);
+  {
+    int init_blocks = d3f::cdiv(L.M, 1024);
+    if (init_blocks > 512) init_blocks = 512;
+    prep_kernel<<<B + init_blocks, 1024, 0, stream>>>(points, len, B, sampleDl, L.grid, L.M, L.tkey, L.tfirst, L.tcount,
+                                                      (size_t)L.M + 64 + (size_t)B, L.bitmap, (size_t)N / 64 + 2,
+                                                      out_points, 3 * (size_t)out_cap);
+  }
   insert_kernel<<<d3f::cdiv(N, 256), 256, 0, stream>>>(points, N, len, B, sampleDl, L.grid, L.M - 1, L.tkey, L.tcount,
                                                        L.tfirst, L.slot_of, status);
   alloc_kernel<<<d3f::cdiv(L.M, 256), 256, 0, stream>>>(L.M, B, L.tkey, L.tcount, L.tfirst, L.tstart, L.tfill, L.bitmap,
                                                         L.ncell);
   scatter_kernel<<<d3f::cdiv(N, 256), 256, 0, stream>>>(N, len, B, L.slot_of, L.tfill, L.members);
   cell_sum_kernel<<<d3f::cdiv(L.M, 256), 256, 0, stream>>>(L.M, points, L.tcount, L.tstart, L.members, L.bary);
-  order_kernel<<<B, kOrderThreads, 0, stream>>>(len, B, max_p, order, sched, L.bitmap, L.wprefix, L.slot_of, L.tkey,
-                                                L.bary, L.ncell, L.seq_key, L.seq_slot, L.curA, L.curB, L.tmpbk,
-                                                L.memberT, L.bfirst, L.bcnt, L.bcur, L.bbase, out_points, out_len,
-                                                out_total, out_cap, attrs ? L.row_slot : nullptr, status);
+  static int lds_cap = -1;   // 80 KB of dynamic LDS needs the opt-in; without it the bucket tables stay in global memory
+  if (lds_cap < 0) {
+    const size_t want = 4 * sizeof(int32_t) * (size_t)kLdsBuckets;
+    lds_cap = hipFuncSetAttribute((const void*)order_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)want) ==
+                      hipSuccess
+                  ? kLdsBuckets
+                  : 0;
+    (void)hipGetLastError();
+  }
+  order_kernel<<<B, kOrderThreads, 4 * sizeof(int32_t) * (size_t)lds_cap, stream>>>(
+      len, B, max_p, order, sched, L.bitmap, L.wprefix, L.slot_of, L.tkey, L.bary, L.ncell, L.seq_key, L.seq_slot,
+      L.curA, L.curB, L.tmpbk, L.memberT, L.bfirst, L.bcnt, L.bcur, L.bbase, out_points, out_len, out_total, out_cap,
+      attrs ? L.row_slot : nullptr, status, lds_cap);
   // the order pass is done with its per-point scratch: the label pass reuses five of those arrays
   if (features)
     cell_feature_kernel<<<d3f::cdiv((long long)out_cap * fdim, 256), 256, 0, stream>>>(

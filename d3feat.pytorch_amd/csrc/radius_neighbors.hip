@@ -79,12 +79,14 @@ __global__ void grid_count_kernel(const float* __restrict__ s, int Ns, const int
   atomicAdd(&cnt[bucket_of(key, mask)], 1);
 }
 
-__global__ void grid_alloc_kernel(uint32_t M, int32_t* __restrict__ cnt, int32_t* __restrict__ start,
-                                  int32_t* __restrict__ end) {
-  // ranges need to be disjoint, not ordered; the running total is ONE word, so a wave reserves its buckets together
-  // (inclusive scan of the counts, one atomic by the last lane) -- per-bucket atomics on it serialise
+__global__ __launch_bounds__(1024) void grid_alloc_kernel(uint32_t M, int32_t* __restrict__ cnt,
+                                                          int32_t* __restrict__ start, int32_t* __restrict__ end) {
+  // ranges need to be disjoint, not ordered; the running total is ONE word, so a whole workgroup of 16 waves reserves
+  // its buckets together (wave scans, wave totals combined through LDS, one atomic) -- per-bucket atomics on that word
+  // serialise, per-wave ones still queued 2048 deep at level 0 (23 us)
+  __shared__ int wtot[16], wbase[16];
   const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
-  const int lane = threadIdx.x & 63;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int c = b < M ? cnt[b] : 0;
   int incl = c;
 #pragma unroll
@@ -92,12 +94,17 @@ __global__ void grid_alloc_kernel(uint32_t M, int32_t* __restrict__ cnt, int32_t
     const int t = __shfl_up(incl, o, 64);
     if (lane >= o) incl += t;
   }
-  const int total = __shfl(incl, 63, 64);
-  int base = 0;
-  if (lane == 63 && total > 0) base = atomicAdd(&cnt[M], total);
-  base = __shfl(base, 63, 64);
+  if (lane == 63) wtot[wave] = incl;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int total = 0;
+    for (int w = 0; w < 16; ++w) { wbase[w] = total; total += wtot[w]; }
+    const int base = total > 0 ? atomicAdd(&cnt[M], total) : 0;
+    for (int w = 0; w < 16; ++w) wbase[w] += base;
+  }
+  __syncthreads();
   if (b >= M) return;
-  const int s = c ? base + incl - c : 0;
+  const int s = c ? wbase[wave] + incl - c : 0;
   start[b] = s;
   end[b] = s;
 }
@@ -292,7 +299,7 @@ int d3f_radius_grid_build(const float* supports, int Ns, const int32_t* s_len, i
                                                              g.key_tmp, status);
     D3F_LAUNCH_CHECK();
   }
-  grid_alloc_kernel<<<d3f::cdiv(g.M, 256), 256, 0, stream>>>(g.M, g.cnt, g.start, g.end);
+  grid_alloc_kernel<<<d3f::cdiv(g.M, 1024), 1024, 0, stream>>>(g.M, g.cnt, g.start, g.end);
   D3F_LAUNCH_CHECK();
   if (Ns > 0) {
     grid_scatter_kernel<<<d3f::cdiv(Ns, 256), 256, 0, stream>>>(supports, Ns, s_len, B, g.M - 1, g.key_tmp, g.end, g.pts,

@@ -9,9 +9,26 @@ The counters are memory-side request tallies (TCC_EA*), reported in KiB.  MI355X
 FETCH_SIZE under-reports wide coalesced reads by 2x and that WRITE_SIZE is uncalibrated, so both are CALIBRATED here on
 a kernel of the same run whose traffic is known exactly: sgd_kernel streams 12 B/parameter in and 8 B/parameter out
 (float4 accesses over the 24.3M-parameter flat buffers).  The scale factors are stored next to the results."""
+import hashlib
 import json
+import os
 import sqlite3
 import sys
+
+CSRC = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "d3feat.pytorch_amd", "csrc")
+# kernel -> the source file it lives in (the file's SHA-256 is stored with the counters so that bench.py can tell a
+# traffic figure measured on an older kernel from a current one)
+KERNEL_FILES = {"kpconv_bwd_dx_kernel": "kpconv_fused.hip", "kpconv_fwd_fused_kernel": "kpconv_fused.hip",
+                "kpconv_dx_gather_kernel": "kpconv_dx_gather.hip", "atb_partial_kernel": "linear.hip",
+                "bias_act_bwd_kernel": "elementwise.hip", "bias_act_fwd_kernel": "elementwise.hip",
+                "pack_supports_kernel": "kpconv_fused.hip", "radius_query_kernel": "radius_neighbors.hip",
+                "order_kernel": "grid_subsample.hip"}
+
+
+def source_sha(kernel):
+    path = os.path.join(CSRC, KERNEL_FILES[kernel])
+    with open(path, "rb") as fh:
+        return hashlib.sha256(fh.read()).hexdigest()[:16]
 
 
 def per_kernel(db_path, counter):
@@ -46,15 +63,15 @@ def main(fetch_db, write_db, out_path, n_params=24304993):
     out = {"_calibration": {"kernel": "sgd_kernel", "n_params": n_params, "FETCH_SIZE_raw_KiB": sgd_f,
                             "WRITE_SIZE_raw_KiB": sgd_w, "fetch_scale": f_scale, "write_scale": w_scale,
                             "note": "bytes = raw KiB * 1024 * scale; scales from sgd_kernel's exactly known streams"}}
-    for key in ("kpconv_bwd_dx_kernel", "kpconv_fwd_fused_kernel", "atb_partial_kernel", "bias_act_bwd_kernel",
-                "bias_act_fwd_kernel", "pack_supports_kernel", "radius_query_kernel", "order_kernel"):
+    for key in KERNEL_FILES:
         f, nf = pick(fetch, key)
         w, nw = pick(write, key)
         if f is None or w is None:
             continue
         fb, wb = f * kib * (f_scale or 1.0), w * kib * (w_scale or 1.0)
         out[key] = {"launches": nf, "FETCH_SIZE_raw_KiB": f, "WRITE_SIZE_raw_KiB": w, "fetch_bytes_per_launch": fb,
-                    "write_bytes_per_launch": wb, "hbm_bytes_per_launch": fb + wb}
+                    "write_bytes_per_launch": wb, "hbm_bytes_per_launch": fb + wb,
+                    "source": KERNEL_FILES[key], "source_sha16": source_sha(key)}
     with open(out_path, "w") as fh:
         json.dump(out, fh, indent=1)
     print(json.dumps(out, indent=1))
