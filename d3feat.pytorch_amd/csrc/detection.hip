@@ -249,7 +249,15 @@ __global__ __launch_bounds__(256) void det_bwd_aux_kernel(const float* __restric
                                                           const float* __restrict__ gscore, float* __restrict__ df) {
   const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= (size_t)N * H) return;
-  const int n = (int)(t / H), h = (int)(t % H);
+  int n, h;
+  if ((size_t)N * H < (1ull << 32)) {   // 32-bit division (the 64-bit one is a long software routine per thread)
+    const uint32_t q = (uint32_t)t / (uint32_t)H;
+    n = (int)q;
+    h = (int)((uint32_t)t - q * (uint32_t)H);
+  } else {
+    n = (int)(t / H);
+    h = (int)(t % H);
+  }
   const float4 a0 = *(const float4*)(aux + (size_t)n * 8);      // f*, alpha*, beta*, u*
   const float4 a1 = *(const float4*)(aux + (size_t)n * 8 + 4);  // dmax, num, c*, c'
   const int cstar = __float_as_int(a1.z);

@@ -25,14 +25,25 @@ __global__ __launch_bounds__(256) void bias_act_fwd_kernel(const float* __restri
   if (zinit)  // side job: clear the caller's backward targets (a few bias rows up to a pooled-gradient matrix)
     for (size_t t = i; t < (size_t)zn; t += (size_t)gridDim.x * blockDim.x) zinit[t] = 0.0f;
   if (i >= n4) return;
-  const int c = (int)((i * 4) % (size_t)C);
+  // (row, first column) of this float4; 32-bit arithmetic whenever the matrix has fewer than 2^32 elements -- a 64-bit
+  // division by the run-time C costs more than the rest of the thread
+  size_t row;
+  int c;
+  if (n4 <= 0x3fffffffull) {
+    const uint32_t e = (uint32_t)i * 4u, r32 = e / (uint32_t)C;
+    row = r32;
+    c = (int)(e - r32 * (uint32_t)C);
+  } else {
+    row = (i * 4) / (size_t)C;
+    c = (int)((i * 4) % (size_t)C);
+  }
   float4 v = ((const float4*)x)[i];
-  if (row_div) { const float d = row_div[(i * 4) / (size_t)C]; v.x /= d; v.y /= d; v.z /= d; v.w /= d; }
+  if (row_div) { const float d = row_div[row]; v.x /= d; v.y /= d; v.z /= d; v.w /= d; }
   if (b1) { const float4 b = *(const float4*)(b1 + c); v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w; }
   if (add) {
     float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
     if (add_idx) {  // add is a COARSE matrix, row n takes the row of its nearest coarse point (shadow -> zeros)
-      const int m = add_idx[((i * 4) / (size_t)C) * (size_t)idx_stride];
+      const int m = add_idx[row * (size_t)idx_stride];
       if (m >= 0 && m < add_rows) a = *(const float4*)(add + (size_t)m * C + c);
     } else {
       a = ((const float4*)add)[i];
