@@ -270,11 +270,15 @@ __global__ __launch_bounds__(256) void kpconv_bwd_dx_kernel(
     const float* __restrict__ q_pts, const float4* __restrict__ spack, const int32_t* __restrict__ idx,
     const float* __restrict__ kp, const float* __restrict__ W, const float* __restrict__ nn,
     const float* __restrict__ gout, int Nq, int Ns, int H, int Cin, int Cout, int K, float extent,
-    float* __restrict__ gx, const float* __restrict__ gwf_in, int dbg) {
+    float* __restrict__ gx, const float* __restrict__ gwf_in, int dbg, int qsplit = 1, int hsplit = 1) {
   constexpr int CC = 16 * CV;
   extern __shared__ __attribute__((aligned(16))) float lds[];
   constexpr int RS = 16 * CC + 4;
   const int GS = Cout + 4;
+  // few-point layers (GEMM-fed form): blockIdx.z splits the tile's work further -- query i of every wave's four
+  // (i % qsplit) and the 16-neighbor chunks (chunk % hsplit) -- so that a 159-point layer runs on ~1000 workgroups
+  // instead of 80: the scatter is bound by atomic latency per workgroup, not by their total number
+  const int iq = blockIdx.z % qsplit, ih = blockIdx.z / qsplit;
   float* gw = lds;            // [16][RS]   gW tile of this channel chunk
   float* gl = lds + 16 * RS;  // [16][GS]   (grad_out / nn) tile
 
@@ -290,6 +294,7 @@ __global__ __launch_bounds__(256) void kpconv_bwd_dx_kernel(
     constexpr int V = CC / 4;
     for (int t = threadIdx.x; t < 16 * K * V; t += 256) {
       const int v = t % V, k = (t / V) % K, ql = t / (V * K);
+      if ((ql & 3) % qsplit != iq) continue;   // rows of queries another workgroup of the split handles
       const int q = q0 + ql;
       const float4 val = q < Nq ? *(const float4*)(gwf_in + ((size_t)q * K + k) * Cin + cbase + 4 * v)
                                 : make_float4(0.f, 0.f, 0.f, 0.f);
@@ -336,7 +341,7 @@ __global__ __launch_bounds__(256) void kpconv_bwd_dx_kernel(
     kpz[s] = live ? kp[3 * k + 2] : kFarKernelPoint;
   }
 #pragma unroll 1
-  for (int i = 0; i < 4; ++i) {
+  for (int i = iq; i < 4; i += qsplit) {
     const int ql = wave * 4 + i;
     const int q = q0 + ql;
     if (q >= Nq || (dbg & 32)) continue;
@@ -346,7 +351,7 @@ __global__ __launch_bounds__(256) void kpconv_bwd_dx_kernel(
     for (int s = 0; s < 4; ++s) { cx[s] = qx + kpx[s]; cy[s] = qy + kpy[s]; cz[s] = qz + kpz[s]; }
     const int32_t* row = idx + (size_t)q * H;
     const float* gq = gw + ql * RS;
-    for (int h0 = 0; h0 < H; h0 += 16) {
+    for (int h0 = 16 * ih; h0 < H; h0 += 16 * hsplit) {
       const int h = h0 + li;
       const int n = (int)min((unsigned)(h < H ? row[h] : Ns), (unsigned)Ns);
       const float4 sp = buf_load_f4(rs_sp, (unsigned)n * 16u);
@@ -623,11 +628,18 @@ int kpconv_grad_input_from_gw(const float* q_pts, int Nq, const float* s_pts, in
   const int CV = Cin == 16 ? 1 : (Cin == 32 ? 2 : 4);
   const int CC = 16 * CV;
   const size_t lds = sizeof(float) * (size_t)(16 * (16 * CC + 4));
-  dim3 grid(cdiv(Nq, 16), Cin / CC);
+  // fill the chip: split the 16-neighbor chunks first, then the four queries of a wave (measured on the 159 / 581 /
+  // 2053-point layers of S1: see DESIGN.md, few-point grad-input)
+  const int base = cdiv(Nq, 16) * (Cin / CC);
+  const int hchunks = cdiv(H, 16);
+  int hsplit = 1, qsplit = 1;
+  while (hsplit < hchunks && base * hsplit < 1024) ++hsplit;
+  while (qsplit < 4 && base * hsplit * qsplit < 1024) qsplit <<= 1;
+  dim3 grid(cdiv(Nq, 16), Cin / CC, hsplit * qsplit);
   TimingScope timing(2, stream, Nq, Ns, H, Cin, 0, K);  // Cout = 0: gW comes from the caller's GEMM
 #define D3F_DXG(CVV)                                                                                                  \
   kpconv_bwd_dx_kernel<CVV><<<grid, 256, lds, stream>>>(q_pts, spack, idx, kp, nullptr, nullptr, nullptr, Nq, Ns, H, Cin, \
-                                                        0, K, extent, gx, gwf, 0)
+                                                        0, K, extent, gx, gwf, 0, qsplit, hsplit)
   if (CV == 1) D3F_DXG(1);
   else if (CV == 2) D3F_DXG(2);
   else D3F_DXG(4);
