@@ -241,7 +241,7 @@ int kpconv_forward_fused(const float* q_pts, int Nq, const float* s_pts, int Ns,
                          hipStream_t stream);
 size_t atb_ws_bytes(int R, int M, int N);
 int atb_splitk(const float* A, const float* B, const float* row_div, int R, int M, int N, float* C, void* ws,
-               hipStream_t stream);
+               hipStream_t stream, int M_out = 0);
 int kpconv_grad_input_from_gw(const float* q_pts, int Nq, const float* s_pts, int Ns, const int32_t* idx, int H,
                               const float* x, int Cin, const float* kp, int K, float extent, const float* gwf,
                               const void* spack_kept, int gx_precleared, float* gx, void* ws, hipStream_t stream);
@@ -253,7 +253,7 @@ bool kpconv_small_supported(int Cin, int Cout, int K, int H);
 int kpconv_small_dispatch(bool fwd, const float* q_pts, const float* s_pts, const int32_t* idx, const float* x,
                           const float* kp, const float* W, const float* nn_in, const float* gout, int Nq, int Ns, int H,
                           int Cin, int Cout, int K, float extent, float* out, float* nn_out, float* gW,
-                          hipStream_t stream);
+                          hipStream_t stream, float* wf_save = nullptr);
 int kpconv_backward_fused(const float* q_pts, int Nq, const float* s_pts, int Ns, const int32_t* idx, int H,
                           const float* x, int Cin, const float* kp, int K, const float* W, int Cout, float extent,
                           const float* nn, const float* gout, const float* wf_saved, const void* spack_kept,
@@ -289,7 +289,9 @@ size_t d3f_kpconv_ws_bytes(int Nq, int Ns, int H, int K, int Cin, int Cout) {
   const size_t gw = align_up(sizeof(float) * n * (kc > (size_t)Cout ? kc : (size_t)Cout), 256);  // gW / scaled grad
   const size_t generic = wf + gw + 256;
   const size_t fused = kpconv_fused_ws_bytes(Ns) + atb_ws_bytes(Nq, K * Cin, Cout) + 256;
-  return generic > fused ? generic : fused;
+  const size_t small = atb_ws_bytes(Nq, 16 * Cin, Cout) + 256;   // input-layer path: dW from the saved 16-slot wf
+  const size_t m = generic > fused ? generic : fused;
+  return m > small ? m : small;
 }
 
 static int kp_args_ok(const void* q_pts, int Nq, const void* s_pts, int Ns, const void* idx, int H, const void* x,
@@ -303,8 +305,12 @@ int d3f_kpconv_packs_supports(int Cin, int Cout, int K, int H, int Ns) {
   return (!kpconv_small_supported(Cin, Cout, K, H) && kpconv_fused_supported(Cin, Cout, K, H, Ns)) ? 1 : 0;
 }
 
-// 1 when the forward for these shapes fills wf_save (every path except the tiny-Cin input-layer kernels)
-int d3f_kpconv_saves_wf(int Cin, int Cout, int K, int H) { return kpconv_small_supported(Cin, Cout, K, H) ? 0 : 1; }
+// floats per query the forward leaves in wf_save (0: these shapes save nothing): K*Cin, except the tiny-Cin input-layer
+// kernels, whose rows are padded to 16 kernel-point slots (the A^T B kernel wants multiples of 16)
+int d3f_kpconv_saves_wf(int Cin, int Cout, int K, int H) {
+  if (!kpconv_small_supported(Cin, Cout, K, H)) return K * Cin;
+  return (Cout % 16 == 0) ? 16 * Cin : 0;
+}
 
 int d3f_kpconv_forward(const float* q_pts, int Nq, const float* s_pts, int Ns, const int32_t* idx, int H,
                        const float* x, int Cin, const float* kernel_points, int K, const float* weights, int Cout,
@@ -322,7 +328,8 @@ int d3f_kpconv_forward(const float* q_pts, int Nq, const float* s_pts, int Ns, c
   if (Nq == 0) return D3F_OK;
   if (kpconv_small_supported(Cin, Cout, K, H))
     return kpconv_small_dispatch(true, q_pts, s_pts, idx, x, kernel_points, weights, nullptr, nullptr, Nq, Ns, H, Cin,
-                                 Cout, K, extent, out, nn_out, nullptr, stream);
+                                 Cout, K, extent, out, nn_out, nullptr, stream,
+                                 d3f_kpconv_saves_wf(Cin, Cout, K, H) ? wf_save : nullptr);
   if (kpconv_fused_supported(Cin, Cout, K, H, Ns))
     return kpconv_forward_fused(q_pts, Nq, s_pts, Ns, idx, H, x, Cin, kernel_points, K, weights, Cout, extent, out,
                                 nn_out, wf_save, spack_keep, grad_x_clear, ws, stream);
@@ -360,6 +367,12 @@ int d3f_kpconv_backward(const float* q_pts, int Nq, const float* s_pts, int Ns, 
     return kpconv_backward_fused(q_pts, Nq, s_pts, Ns, idx, H, x, Cin, kernel_points, K, weights, Cout, extent, nn,
                                  grad_out, wf_saved, spack_kept, grad_x_precleared, grad_x, grad_w, ws, stream);
   int rc;
+  if (grad_w && kpconv_small_supported(Cin, Cout, K, H) && wf_saved && d3f_kpconv_saves_wf(Cin, Cout, K, H)) {
+    // grad_W = wf^T (g/nn) over the saved 16-slot rows; only the K live slots are written (deterministic, no atomics)
+    rc = atb_splitk(wf_saved, grad_out, nn, Nq, 16 * Cin, Cout, grad_w, ws, stream, KC);
+    if (rc) return rc;
+    grad_w = nullptr;
+  }
   if (grad_w && kpconv_small_supported(Cin, Cout, K, H)) {
     if (d3f::zero_async(grad_w, sizeof(float) * (size_t)KC * Cout, stream) != hipSuccess) return D3F_ELAUNCH;
     rc = kpconv_small_dispatch(false, q_pts, s_pts, idx, x, kernel_points, weights, nn, grad_out, Nq, Ns, H, Cin, Cout,

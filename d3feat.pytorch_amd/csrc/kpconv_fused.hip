@@ -468,7 +468,7 @@ bool kpconv_fused_supported(int Cin, int Cout, int K, int H, int Ns) {
 bool atb_supported(int R, int M, int N);
 size_t atb_ws_bytes(int R, int M, int N);
 int atb_splitk(const float* A, const float* B, const float* row_div, int R, int M, int N, float* C, void* ws,
-               hipStream_t stream);
+               hipStream_t stream, int M_out = 0);
 
 size_t kpconv_fused_ws_bytes(int Ns) { return align_up(sizeof(float4) * (size_t)(Ns > 0 ? Ns : 1), 256); }
 

@@ -65,7 +65,8 @@ __global__ __launch_bounds__(256) void kpconv_small_fwd_kernel(const float* __re
                                                                const float* __restrict__ kp,
                                                                const float* __restrict__ W, int Nq, int Ns, int H,
                                                                int Cout, int K, float extent, float* __restrict__ out,
-                                                               float* __restrict__ nn_out) {
+                                                               float* __restrict__ nn_out,
+                                                               float* __restrict__ wf_save) {
   const int lane = threadIdx.x & 63;
   const int li = lane & 15;
   const int gw = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nw = (gridDim.x * blockDim.x) >> 6;
@@ -105,6 +106,12 @@ __global__ __launch_bounds__(256) void kpconv_small_fwd_kernel(const float* __re
       if (o < Cout) out[(size_t)q * Cout + o] = acc[j] / nn;
     }
     if (lane == 0) nn_out[q] = nn;
+    // training: the weighted features [16 kernel-point slots x CIN] of the query (slot k lives on lane k; slots >= K are
+    // zero) stay behind, so the weight gradient is the reduction-parallel A^T B kernel instead of a second aggregation
+    if (wf_save && lane < 16) {
+#pragma unroll
+      for (int c = 0; c < CIN; ++c) wf_save[((size_t)q * 16 + lane) * CIN + c] = klive ? wf[c] : 0.0f;
+    }
   }
 }
 
@@ -178,7 +185,8 @@ bool kpconv_small_supported(int Cin, int Cout, int K, int H) {
 template <int CIN, int OPL>
 static int launch_small(bool fwd, const float* q_pts, const float* s_pts, const int32_t* idx, const float* x,
                         const float* kp, const float* W, const float* nn_in, const float* gout, int Nq, int Ns, int H,
-                        int Cout, int K, float extent, float* out, float* nn_out, float* gW, hipStream_t stream) {
+                        int Cout, int K, float extent, float* out, float* nn_out, float* gW, hipStream_t stream,
+                        float* wf_save) {
   // persistent waves: 4 per workgroup, ~8 workgroups per CU so the per-wave weight registers are loaded once per ~5 queries
   int blocks = cdiv(Nq, 4 * 4);
   if (blocks > 2048) blocks = 2048;
@@ -186,7 +194,7 @@ static int launch_small(bool fwd, const float* q_pts, const float* s_pts, const 
   if (blocks < 1) blocks = 1;
   if (fwd)
     kpconv_small_fwd_kernel<CIN, OPL><<<blocks, 256, 0, stream>>>(q_pts, s_pts, idx, x, kp, W, Nq, Ns, H, Cout, K, extent,
-                                                                  out, nn_out);
+                                                                  out, nn_out, wf_save);
   else
     kpconv_small_dw_kernel<CIN, OPL><<<blocks, 256, 0, stream>>>(q_pts, s_pts, idx, x, kp, nn_in, gout, Nq, Ns, H, Cout, K,
                                                                  extent, gW);
@@ -197,10 +205,11 @@ static int launch_small(bool fwd, const float* q_pts, const float* s_pts, const 
 int kpconv_small_dispatch(bool fwd, const float* q_pts, const float* s_pts, const int32_t* idx, const float* x,
                           const float* kp, const float* W, const float* nn_in, const float* gout, int Nq, int Ns, int H,
                           int Cin, int Cout, int K, float extent, float* out, float* nn_out, float* gW,
-                          hipStream_t stream) {
+                          hipStream_t stream, float* wf_save) {
   const int opl = (Cout + 63) / 64;
 #define D3F_S(C, O) \
-  return launch_small<C, O>(fwd, q_pts, s_pts, idx, x, kp, W, nn_in, gout, Nq, Ns, H, Cout, K, extent, out, nn_out, gW, stream)
+  return launch_small<C, O>(fwd, q_pts, s_pts, idx, x, kp, W, nn_in, gout, Nq, Ns, H, Cout, K, extent, out, nn_out, gW, stream, \
+                            wf_save)
   if (Cin == 1 && opl == 1) D3F_S(1, 1);
   if (Cin == 1 && opl == 2) D3F_S(1, 2);
   if (Cin == 2 && opl == 1) D3F_S(2, 1);

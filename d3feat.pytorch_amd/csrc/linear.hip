@@ -86,8 +86,9 @@ __global__ __launch_bounds__(256) void atb_partial_kernel(const float* __restric
 }
 
 // C[e] = sum_p part[p][e]: 4 threads per element each sum a strided quarter of the slabs, combined in a fixed order
+// (only the first MN_out elements are written: a caller whose C holds fewer rows than the padded M)
 __global__ __launch_bounds__(256) void atb_reduce_kernel(const float* __restrict__ part, int P, size_t MN,
-                                                         float* __restrict__ C) {
+                                                         float* __restrict__ C, size_t MN_out) {
   const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   const size_t e = (t >> 8 << 6) | (t & 63);  // 64 consecutive elements per wave, 4 waves of a block share them
   const int sub = (int)((t >> 6) & 3);
@@ -104,7 +105,7 @@ __global__ __launch_bounds__(256) void atb_reduce_kernel(const float* __restrict
   const float s = s0 + s1;
   if (sub > 0) sh[sub - 1][threadIdx.x & 63] = s;
   __syncthreads();
-  if (sub == 0 && e < MN) C[e] = ((s + sh[0][threadIdx.x]) + sh[1][threadIdx.x]) + sh[2][threadIdx.x];
+  if (sub == 0 && e < MN_out) C[e] = ((s + sh[0][threadIdx.x]) + sh[1][threadIdx.x]) + sh[2][threadIdx.x];
 }
 
 #ifndef D3F_ATB_TARGET_WGS
@@ -132,7 +133,7 @@ size_t atb_ws_bytes(int R, int M, int N) {
 
 // C [M,N] = A^T [M,R] (B [R,N] / row_div [R]); ws >= atb_ws_bytes
 int atb_splitk(const float* A, const float* B, const float* row_div, int R, int M, int N, float* C, void* ws,
-               hipStream_t stream) {
+               hipStream_t stream, int M_out = 0) {
   if (!atb_supported(R, M, N)) return D3F_EINVAL;
   const int ti = tile_width(M), tj = tile_width(N);
   const int P = atb_partitions(R, M, N);
@@ -155,7 +156,8 @@ int atb_splitk(const float* A, const float* B, const float* row_div, int R, int 
 #undef D3F_ATB
   D3F_LAUNCH_CHECK();
   const size_t MN = (size_t)M * N;
-  atb_reduce_kernel<<<cdiv((long long)MN, 64), 256, 0, stream>>>(part, P, MN, C);
+  const size_t MN_out = (M_out > 0 && M_out < M) ? (size_t)M_out * N : MN;
+  atb_reduce_kernel<<<cdiv((long long)MN, 64), 256, 0, stream>>>(part, P, MN, C, MN_out);
   D3F_LAUNCH_CHECK();
   return D3F_OK;
 }

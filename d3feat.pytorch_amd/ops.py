@@ -363,8 +363,9 @@ class _KPConvFn(torch.autograd.Function):
         # training: keep the weighted features [Nq, K*Cin] for the backward pass (K*Cin*4 B per query of HBM) so the
         # weight gradient is one tall-skinny GEMM and the neighbor aggregation is not recomputed
         wf = None
-        if SAVE_WEIGHTED_FEATURES and ctx.needs_input_grad[5] and Nq > 0 and L.d3f_kpconv_saves_wf(Cin, Cout, K, H):
-            wf = torch.empty((Nq, K * Cin), dtype=torch.float32, device=x.device)
+        wf_row = L.d3f_kpconv_saves_wf(Cin, Cout, K, H)   # floats per query (the input-layer kernels pad K to 16 slots)
+        if SAVE_WEIGHTED_FEATURES and ctx.needs_input_grad[5] and Nq > 0 and wf_row:
+            wf = torch.empty((Nq, wf_row), dtype=torch.float32, device=x.device)
         # training: the packed supports are kept for the backward pass and its scatter target is cleared on the side
         keep = gx_buf = None
         if (ctx.needs_input_grad[3] or ctx.needs_input_grad[5]) and Nq > 0 and Ns > 0 and \
@@ -417,7 +418,7 @@ class _KPConvFn(torch.autograd.Function):
                                                              _stream()),
                               "d3f_kpconv_grad_input_gather")
             gx_native = None
-        if need_w and wf is not None and Nq < _SPLITK_MIN_ROWS:
+        if need_w and wf is not None and Nq < _SPLITK_MIN_ROWS and wf.shape[1] == K * Cin:
             # few points, wide layers (bottom of the U-Net): grad_W = wf^T (g/nn) is an ordinary GEMM with a short
             # reduction -- a library call; the reduction-parallel kernel is for the tall-skinny upper levels
             gon = go / nn.unsqueeze(1)

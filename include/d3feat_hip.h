@@ -121,9 +121,10 @@ int d3f_grid_subsample_ex(const float* points, int N, const int32_t* len, int B,
  *   out[n,:] = ( sum_k ( sum_h w[n,h,k] * x[idx[n,h],:] ) @ W[k] ) / nn[n]
  *   w = max(0, 1 - |(s[idx[n,h]] - q[n]) - kp[k]| / extent),  nn[n] = max(1, #{h : sum_c x[idx[n,h],c] > 0})
  * nn_out [Nq] float32 is saved for the backward pass.
- * wf_save (optional, [Nq, K*Cin] float32): the weighted features sum_h w[n,h,k] x[idx[n,h],c] are left there for
- *   the backward pass (what autograd keeps alive in the reference as `weighted_features`, blocks.py:375); whether
- *   the forward for a given shape fills it is answered by d3f_kpconv_saves_wf.
+ * wf_save (optional, [Nq, d3f_kpconv_saves_wf(...)] float32): the weighted features sum_h w[n,h,k] x[idx[n,h],c] are
+ *   left there for the backward pass (what autograd keeps alive in the reference as `weighted_features`,
+ *   blocks.py:375).  d3f_kpconv_saves_wf returns the floats per query: K*Cin, except for the Cin <= 4 input-layer
+ *   kernels, whose rows are padded to 16 kernel-point slots (16*Cin; slots >= K are zero), and 0 when nothing is saved.
  * spack_keep (optional, 16*Ns bytes) / grad_x_clear (optional, [Ns, Cin]): the forward packs the supports as
  *   float4 {x, y, z, [sum_c feat > 0]}; with spack_keep the packed array is left in the caller's buffer and handed
  *   back to the backward pass (spack_kept), which then launches no packing kernel of its own; grad_x_clear is the
