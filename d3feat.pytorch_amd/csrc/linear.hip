@@ -15,7 +15,7 @@
 
 namespace d3f {
 
-template <int TI, int TJ>
+template <int TI, int TJ, int U>
 __global__ __launch_bounds__(256) void atb_partial_kernel(const float* __restrict__ A, const float* __restrict__ B,
                                                           const float* __restrict__ row_div, int R, int M, int N,
                                                           int rows_per_wg, float* __restrict__ part) {
@@ -34,7 +34,7 @@ __global__ __launch_bounds__(256) void atb_partial_kernel(const float* __restric
   for (int t = 0; t < TI; ++t)
 #pragma unroll
     for (int u = 0; u < TJ; ++u) acc[t][u] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  constexpr int U = (TI * TJ >= 8) ? 2 : 4;  // k-steps whose loads are issued together
+  // U = k-steps whose loads are issued together
   // the 4 waves interleave groups of 4*U rows
   for (int base = r0 + wave * 4 * U; base < r1; base += 16 * U) {
     VA a[U];
@@ -85,27 +85,32 @@ __global__ __launch_bounds__(256) void atb_partial_kernel(const float* __restric
     }
 }
 
-// C[e] = sum_p part[p][e]: 4 threads per element each sum a strided quarter of the slabs, combined in a fixed order
-// (only the first MN_out elements are written: a caller whose C holds fewer rows than the padded M)
-__global__ __launch_bounds__(256) void atb_reduce_kernel(const float* __restrict__ part, int P, size_t MN,
-                                                         float* __restrict__ C, size_t MN_out) {
-  const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const size_t e = (t >> 8 << 6) | (t & 63);  // 64 consecutive elements per wave, 4 waves of a block share them
-  const int sub = (int)((t >> 6) & 3);
-  __shared__ float sh[3][64];
+// C[e] = sum_p part[p][e]: SUBS threads per element each sum a strided share of the slabs, combined in a fixed order
+// (SUBS = 16 when the output is small and the slabs are many: 4 threads walking 128 slabs each took 21 us for a
+// 32 x 32 gradient).  Only the first MN_out elements are written (a caller whose C holds fewer rows than the padded M).
+template <int SUBS>
+__global__ __launch_bounds__(64 * SUBS) void atb_reduce_kernel(const float* __restrict__ part, int P, size_t MN,
+                                                               float* __restrict__ C, size_t MN_out) {
+  const size_t e = (size_t)blockIdx.x * 64 + (threadIdx.x & 63);  // 64 consecutive elements per workgroup
+  const int sub = threadIdx.x >> 6;
+  __shared__ float sh[SUBS][64];
   float s0 = 0.f, s1 = 0.f;
   if (e < MN) {
     int p = sub;
-    for (; p + 4 < P; p += 8) {
+    for (; p + SUBS < P; p += 2 * SUBS) {
       s0 += part[(size_t)p * MN + e];
-      s1 += part[(size_t)(p + 4) * MN + e];
+      s1 += part[(size_t)(p + SUBS) * MN + e];
     }
     if (p < P) s0 += part[(size_t)p * MN + e];
   }
-  const float s = s0 + s1;
-  if (sub > 0) sh[sub - 1][threadIdx.x & 63] = s;
+  sh[sub][threadIdx.x & 63] = s0 + s1;
   __syncthreads();
-  if (sub == 0 && e < MN_out) C[e] = ((s + sh[0][threadIdx.x]) + sh[1][threadIdx.x]) + sh[2][threadIdx.x];
+  if (sub == 0 && e < MN_out) {
+    float s = sh[0][threadIdx.x];
+#pragma unroll
+    for (int k = 1; k < SUBS; ++k) s += sh[k][threadIdx.x];
+    C[e] = s;
+  }
 }
 
 #ifndef D3F_ATB_TARGET_WGS
@@ -116,9 +121,17 @@ static inline int tile_width(int n) { return n % 64 == 0 ? 4 : (n % 32 == 0 ? 2 
 bool atb_supported(int R, int M, int N) { return R >= 1 && tile_width(M) && tile_width(N); }
 
 // number of row partitions = workgroups along the reduction
+static int atb_tunable(const char* name, int dflt) {
+  const char* v = getenv(name);
+  return v ? atoi(v) : dflt;
+}
 static int atb_partitions(int R, int M, int N) {
+  static const int forced = atb_tunable("D3F_ATB_WGS", 0);
   const long long nblocks = (long long)(M / (16 * tile_width(M))) * (N / (16 * tile_width(N)));
-  long long wgs = (D3F_ATB_TARGET_WGS + nblocks - 1) / nblocks;  // workgroups over the whole launch (256 CUs)
+  // one workgroup per CU is enough unless the operands are long AND wide (profiles/atb_microbench.py: 512 partitions'
+  // worth of slabs cost the small outputs 3 us each in the reduce pass; the 38k x 480 x 32 KPConv gradient wants them)
+  const int target = forced ? forced : ((R >= 30000 && nblocks >= 8) ? D3F_ATB_TARGET_WGS : 256);
+  long long wgs = (target + nblocks - 1) / nblocks;  // workgroups over the whole launch (256 CUs)
   const long long max_by_rows = (R + 63) / 64;            // >= 16 rows (4 MFMA k-steps) per wave
   if (wgs > max_by_rows) wgs = max_by_rows;
   if (wgs > 512) wgs = 512;
@@ -141,7 +154,14 @@ int atb_splitk(const float* A, const float* B, const float* row_div, int R, int 
   rpw = (rpw + 3) / 4 * 4;
   dim3 grid(P, (M / (16 * ti)) * (N / (16 * tj)));
   float* part = (float*)ws;
-#define D3F_ATB(I, J) atb_partial_kernel<I, J><<<grid, 256, 0, stream>>>(A, B, row_div, R, M, N, rpw, part)
+  static const int deep = atb_tunable("D3F_ATB_U", 0);   // 0: the measured default per tile shape
+#define D3F_ATB(I, J)                                                                                      \
+  {                                                                                                        \
+    const int u = deep ? deep : (((I) * (J) >= 8) ? 2 : 4);                                                \
+    if (u >= 8) atb_partial_kernel<I, J, 8><<<grid, 256, 0, stream>>>(A, B, row_div, R, M, N, rpw, part);  \
+    else if (u >= 4) atb_partial_kernel<I, J, 4><<<grid, 256, 0, stream>>>(A, B, row_div, R, M, N, rpw, part); \
+    else atb_partial_kernel<I, J, 2><<<grid, 256, 0, stream>>>(A, B, row_div, R, M, N, rpw, part);         \
+  }
   switch (ti * 8 + tj) {
     case 1 * 8 + 1: D3F_ATB(1, 1); break;
     case 1 * 8 + 2: D3F_ATB(1, 2); break;
@@ -157,7 +177,11 @@ int atb_splitk(const float* A, const float* B, const float* row_div, int R, int 
   D3F_LAUNCH_CHECK();
   const size_t MN = (size_t)M * N;
   const size_t MN_out = (M_out > 0 && M_out < M) ? (size_t)M_out * N : MN;
-  atb_reduce_kernel<<<cdiv((long long)MN, 64), 256, 0, stream>>>(part, P, MN, C, MN_out);
+  static const int fan = atb_tunable("D3F_ATB_FAN", 0);
+  if (fan ? fan >= 16 : (P >= 64 && MN <= 65536))
+    atb_reduce_kernel<16><<<cdiv((long long)MN, 64), 1024, 0, stream>>>(part, P, MN, C, MN_out);
+  else
+    atb_reduce_kernel<4><<<cdiv((long long)MN, 64), 256, 0, stream>>>(part, P, MN, C, MN_out);
   D3F_LAUNCH_CHECK();
   return D3F_OK;
 }
