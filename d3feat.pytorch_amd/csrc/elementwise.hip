@@ -128,6 +128,59 @@ __global__ __launch_bounds__(256) void bias_act_bwd_kernel(const float* __restri
   }
 }
 
+// Many-row form for C = 16..256 (two-pass mode only): a thread owns one float4 of a row (TPR = C/4 threads per row,
+// 256/TPR rows per workgroup step), so a 32-column matrix keeps every lane busy (the column-per-thread kernel above
+// idles half of them) and every access is 16 bytes; the per-column partial sums are combined over the row lanes by
+// shuffles, over the 4 waves through LDS, and land in part[block][C] for bias_sum_kernel.
+template <int TPR>
+__global__ __launch_bounds__(256) void bias_act_bwd_v4_kernel(const float4* __restrict__ go,
+                                                              const float4* __restrict__ out, float slope, int N,
+                                                              int rows_per_block, float4* __restrict__ gx,
+                                                              const float* __restrict__ row_div,
+                                                              float4* __restrict__ part) {
+  constexpr int RL = 256 / TPR;
+  __shared__ float4 red[4][TPR];
+  const int cl = threadIdx.x % TPR, rl = threadIdx.x / TPR;
+  const int r0 = blockIdx.x * rows_per_block, r1 = min(N, r0 + rows_per_block);
+  float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int r = r0 + rl; r < r1; r += RL) {
+    const size_t i = (size_t)r * TPR + cl;
+    const float4 g0 = go[i], o = out[i];
+    float4 g;
+    g.x = g0.x * (o.x > 0.0f ? 1.0f : slope);
+    g.y = g0.y * (o.y > 0.0f ? 1.0f : slope);
+    g.z = g0.z * (o.z > 0.0f ? 1.0f : slope);
+    g.w = g0.w * (o.w > 0.0f ? 1.0f : slope);
+    if (gx) {
+      if (row_div) {
+        const float d = row_div[r];
+        gx[i] = make_float4(g.x / d, g.y / d, g.z / d, g.w / d);  // the bias sums stay undivided
+      } else {
+        gx[i] = g;
+      }
+    }
+    s.x += g.x; s.y += g.y; s.z += g.z; s.w += g.w;
+  }
+  if (!part) return;
+#pragma unroll
+  for (int o = TPR; o < 64; o <<= 1) {
+    s.x += __shfl_xor(s.x, o, 64); s.y += __shfl_xor(s.y, o, 64);
+    s.z += __shfl_xor(s.z, o, 64); s.w += __shfl_xor(s.w, o, 64);
+  }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane < TPR) red[wave][lane] = s;
+  __syncthreads();
+  if (threadIdx.x < TPR) {
+    float4 v = red[0][threadIdx.x];
+#pragma unroll
+    for (int w = 1; w < 4; ++w) {
+      v.x += red[w][threadIdx.x].x; v.y += red[w][threadIdx.x].y;
+      v.z += red[w][threadIdx.x].z; v.w += red[w][threadIdx.x].w;
+    }
+    part[(size_t)blockIdx.x * TPR + threadIdx.x] = v;
+  }
+}
+
 // gb[c] = sum_b part[b][c]: with thousands of row blocks the per-column atomics of the one-pass form all hit the same C
 // addresses and serialise (38k x 32: 32 us for 15 MB); 4 waves each sum a quarter of the blocks, combined through LDS
 __global__ __launch_bounds__(1024) void bias_sum_kernel(const float* __restrict__ part, int nblocks, int C,
@@ -197,6 +250,19 @@ int d3f_bias_act_backward(const float* grad_out, const float* out, float slope, 
     // many rows: per-block partial column sums + a second, tiny launch instead of contended atomics (deterministic)
     const int rows = 64;
     dim3 grid(d3f::cdiv(N, rows), d3f::cdiv(C, 64));
+    const int tpr = C / 4;
+    const bool v4 = C % 4 == 0 && (tpr == 4 || tpr == 8 || tpr == 16 || tpr == 32 || tpr == 64) &&
+                    ((uintptr_t)grad_out | (uintptr_t)out | (uintptr_t)grad_x | (uintptr_t)ws) % 16 == 0;
+#define D3F_BAB(T)                                                                                                  \
+  bias_act_bwd_v4_kernel<T><<<grid.x, 256, 0, (hipStream_t)stream>>>((const float4*)grad_out, (const float4*)out, slope, \
+                                                                     N, rows, (float4*)grad_x, row_div, (float4*)ws)
+    if (v4 && tpr == 4) D3F_BAB(4);
+    else if (v4 && tpr == 8) D3F_BAB(8);
+    else if (v4 && tpr == 16) D3F_BAB(16);
+    else if (v4 && tpr == 32) D3F_BAB(32);
+    else if (v4 && tpr == 64) D3F_BAB(64);
+    else
+#undef D3F_BAB
     bias_act_bwd_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(grad_out, out, slope, N, C, rows, grad_x, grad_bias,
                                                                grad_bias2, row_div, (float*)ws);
     bias_sum_kernel<<<d3f::cdiv(C, 64), 1024, 0, (hipStream_t)stream>>>((const float*)ws, (int)grid.x, C, grad_bias,
