@@ -74,10 +74,33 @@ class CircleLoss(nn.Module):
         self.neg_optimal = neg_margin
         self.dist_type = dist_type
         self.safe_radius = safe_radius
-        if dist_type != 'euclidean':
-            raise NotImplementedError("HIP CircleLoss implements dist_type='euclidean' (config.py:50 default)")
+        if dist_type not in ('euclidean', 'cosine', 'arccosine', 'sqeuclidean', 'cityblock'):
+            raise NotImplementedError('The following metric is not implemented by `cdist` yet: {}'.format(dist_type))
+
+    def _forward_other_metric(self, anchor, positive, dist_keypts):
+        """dist_type other than the configuration's 'euclidean' (config.py:50): the fused kernel is written for that
+        metric; the rest of loss.py:111-141 is metric-agnostic tensor algebra on the [M, M] matrix (M = 128 rows), run
+        as such on the device."""
+        dists = cdist(anchor, positive, metric=self.dist_type)
+        m = dists.shape[0]
+        eye = torch.eye(m, dtype=torch.float32, device=dists.device)
+        far = (dist_keypts.to(dists.device) > self.safe_radius)
+        furthest_positive = (dists * eye).max(dim=1)[0]
+        closest_negative = (dists + 1e5 * eye).min(dim=1)[0]
+        average_negative = (dists.sum(dim=-1) - furthest_positive) / (m - 1)
+        accuracy = ((furthest_positive - closest_negative) < 0).sum() * 100.0 / m
+        pos = dists - 1e5 * far.float()
+        pos_arg = self.log_scale * (pos - self.pos_margin) * torch.clamp((pos - self.pos_optimal).detach(), min=0)
+        neg = dists + 1e5 * (~far).float()
+        neg_arg = self.log_scale * (self.neg_margin - neg) * torch.clamp((self.neg_optimal - neg).detach(), min=0)
+        by_row = torch.nn.functional.softplus(torch.logsumexp(pos_arg, dim=-1) + torch.logsumexp(neg_arg, dim=-1))
+        by_col = torch.nn.functional.softplus(torch.logsumexp(pos_arg, dim=-2) + torch.logsumexp(neg_arg, dim=-2))
+        loss = (by_row + by_col) / self.log_scale
+        return torch.mean(loss), accuracy, LazyList(furthest_positive), LazyList(average_negative), 0, dists
 
     def forward(self, anchor, positive, dist_keypts, anc_score=None, pos_score=None):
+        if self.dist_type != 'euclidean':
+            return self._forward_other_metric(anchor, positive, dist_keypts)
         M = anchor.shape[0]
         zeros = None
         if anc_score is None or pos_score is None:
@@ -104,9 +127,12 @@ class DetLoss(nn.Module):
             return fused[0][1]  # already evaluated by the same launch as the circle loss
         ctx = getattr(dists, '_d3f_ctx', None)
         if ctx is None:
-            raise RuntimeError("DetLoss expects the `dists` returned by CircleLoss.forward (trainer.py:96-97): the "
-                               "HIP loss kernel derives the detector term from the descriptors, not from a detached "
-                               "distance matrix")
+            # a plain distance matrix (CircleLoss with a non-default metric, or a caller's own): loss.py:149-158 as is
+            m = dists.shape[0]
+            eye = torch.eye(m, dtype=torch.float32, device=dists.device)
+            furthest_positive = (dists * eye).max(dim=1)[0]
+            closest_negative = (dists + 1e5 * eye).min(dim=1)[0]
+            return torch.mean((furthest_positive - closest_negative) * (anc_score + pos_score).squeeze(-1))
         # the reference's call order (desc loss first, det loss second): run the fused kernel again with the scores;
         # only the detector scalar is used, so its backward carries exactly the detector term's gradients.
         anchor, positive, dist_keypts, s, sr, pm, nm = ctx

@@ -120,9 +120,26 @@ def cdist_euclidean(a, b):
     return torch.sqrt((d ** 2).sum(dim=-1) + 1e-12)
 
 
-def circle_loss(anchor, positive, dist_keypts, log_scale=10.0, safe_radius=0.1, pos_margin=0.1, neg_margin=1.4):
+def cdist(a, b, metric='euclidean'):
+    """utils/loss.py:8-44, every metric."""
+    if metric == 'cosine':
+        return torch.sqrt(2 - 2 * a @ b.t())
+    if metric == 'arccosine':
+        return torch.acos(a @ b.t())
+    d = a[:, None, :] - b[None, :, :]
+    if metric == 'sqeuclidean':
+        return (d ** 2).sum(-1)
+    if metric == 'euclidean':
+        return torch.sqrt((d ** 2).sum(-1) + 1e-12)
+    if metric == 'cityblock':
+        return d.abs().sum(-1)
+    raise NotImplementedError('The following metric is not implemented by `cdist` yet: {}'.format(metric))
+
+
+def circle_loss(anchor, positive, dist_keypts, log_scale=10.0, safe_radius=0.1, pos_margin=0.1, neg_margin=1.4,
+                metric='euclidean'):
     """utils/loss.py:111-141 -> (loss, accuracy, furthest_positive, average_negative, dists)."""
-    dists = cdist_euclidean(anchor, positive)
+    dists = cdist_euclidean(anchor, positive) if metric == 'euclidean' else cdist(anchor, positive, metric)
     m = dists.shape[0]
     eye = torch.eye(m, dtype=torch.bool)
     neg_mask = dist_keypts > safe_radius

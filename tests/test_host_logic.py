@@ -109,9 +109,52 @@ def test_lazy_list_and_loss_signatures():
     c = CircleLoss(dist_type='euclidean', log_scale=10, safe_radius=0.1, pos_margin=0.1, neg_margin=1.4)
     assert c.pos_optimal == 0.1 and c.neg_optimal == 1.4
     with pytest.raises(NotImplementedError):
-        CircleLoss(dist_type='cosine')
-    with pytest.raises(RuntimeError):
-        DetLoss()(torch.zeros(4, 4), torch.zeros(4, 1), torch.zeros(4, 1))
+        CircleLoss(dist_type='chebyshev')                       # the reference's cdist rejects it too (loss.py:42-44)
+
+
+@pytest.mark.parametrize("metric", ["cosine", "arccosine", "sqeuclidean", "cityblock"])
+def test_losses_with_the_other_cdist_metrics(metric):
+    """CircleLoss / DetLoss with the metrics of the reference's cdist other than the configured 'euclidean'
+    (loss.py:8-44; CircleLoss' constructor default is 'cosine'): metric-agnostic tensor algebra, equal to the oracle
+    restatement -- and, where the reference tree is mounted, to the reference's own modules -- values and gradients."""
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
+    from oracle import ops_ref
+    gen = torch.Generator().manual_seed(3)
+    a0 = torch.nn.functional.normalize(torch.randn(48, 32, generator=gen), dim=1) * 0.98
+    p0 = torch.nn.functional.normalize(a0 + 0.3 * torch.randn(48, 32, generator=gen), dim=1) * 0.98
+    dk = torch.rand(48, 48, generator=gen) * 0.3
+    sa, sp = torch.rand(48, 1, generator=gen), torch.rand(48, 1, generator=gen)
+
+    def run(circle_fn, det_fn):
+        a, p = a0.clone().requires_grad_(True), p0.clone().requires_grad_(True)
+        out = circle_fn(a, p, dk)
+        loss, dists = out[0], out[-1]
+        det = det_fn(dists, sa, sp)
+        (loss + det).backward()
+        return [loss.detach(), det.detach(), torch.as_tensor(float(out[1])), torch.as_tensor(list(out[2])),
+                torch.as_tensor(list(out[3])), a.grad, p.grad]
+
+    ours = run(CircleLoss(dist_type=metric, log_scale=10, safe_radius=0.1, pos_margin=0.1, neg_margin=1.4), DetLoss())
+    orc = run(lambda a, p, d: ops_ref.circle_loss(a, p, d, metric=metric), ops_ref.det_loss)
+    for u, v in zip(ours, orc):
+        assert torch.allclose(u.float(), v.float(), rtol=1e-5, atol=1e-6)
+    if os.path.isdir(REF):
+        saved = {k: sys.modules.get(k) for k in list(sys.modules) if k == 'utils' or k.startswith('utils.')}
+        for k in saved:
+            sys.modules.pop(k, None)
+        sys.path.insert(0, REF)
+        try:
+            import importlib
+            ref_loss = importlib.import_module('utils.loss')
+            ref = run(ref_loss.CircleLoss(dist_type=metric, log_scale=10, safe_radius=0.1, pos_margin=0.1,
+                                          neg_margin=1.4), ref_loss.DetLoss())
+        finally:
+            sys.path.remove(REF)
+            for k in [k for k in sys.modules if k == 'utils' or k.startswith('utils.')]:
+                sys.modules.pop(k, None)
+            sys.modules.update({k: v for k, v in saved.items() if v is not None})
+        for u, v in zip(ours, ref):
+            assert torch.allclose(u.float(), v.float(), rtol=1e-5, atol=1e-6)
 
 
 def test_synthetic_is_deterministic_and_shaped(native):
