@@ -849,6 +849,16 @@ def test_eight_pairs_per_batch_match_the_reference_runs(golden_s1):
             cut = np.sort(ref[base:base + n])[-250]
             assert all(ref[base + i] > cut - 1e-4 for i in have - want), (p, key)
         off += n0 + n1
+    # dense all-points matching of the 8 pairs by one pair of launches == per-pair calls (19k x 19k each)
+    row, mutual, seg = eng.match(stacked, feats, scores)
+    off = 0
+    for p, it in enumerate(items):
+        n0, n1 = it[0].shape[0], it[1].shape[0]
+        if p in (0, 5):
+            r1, _, m1 = ops.mutual_nn(feats[off:off + n0], feats[off + n0:off + n0 + n1])
+            assert torch.equal(row[off:off + n0], r1) and torch.equal(mutual[off:off + n0], m1), p
+        assert int(mutual[off + n0:off + n0 + n1].sum()) == 0          # target rows carry no source-side flag
+        off += n0 + n1
     # matching of all 8 pairs at once, on the reference's keypoint descriptors
     desc = np.concatenate([np.concatenate([g['p%d.src_desc250' % p], g['p%d.tgt_desc250' % p]]) for p in range(8)])
     seg = np.asarray([[500 * p, 250, 500 * p + 250, 250] for p in range(8)], np.int32)
