@@ -496,6 +496,23 @@ def main():
             evaluation["top250_pipelined"] = {"ms_per_pair": round((time.perf_counter() - t_g0) / 10 * 1e3, 3),
                                               "mutual_matches": int(corr_g.shape[0]),
                                               "launch": "hipGraph replay, pyramid of the next pair on a side stream"}
+            # the same with keypoints and matches left on the device (d3f_topk_scores + d3f_mutual_nn_batched, P = 1):
+            # no torch.nonzero, hence no host synchronisation per pair -- the pipeline runs ahead
+            def eval_device(k):
+                cur, nxt = clouds[k % len(clouds)], clouds[(k + 1) % len(clouds)]
+                feats, scores = eng.describe(cur, nxt)
+                return eng.match(cur, feats, scores, num_points=250)
+            for k in range(3):
+                m_dev = eval_device(k)
+            torch.cuda.synchronize()
+            t_d0 = time.perf_counter()
+            for k in range(20):
+                m_dev = eval_device(3 + k)
+            torch.cuda.synchronize()
+            evaluation["top250_pipelined_device_outputs"] = {
+                "ms_per_pair": round((time.perf_counter() - t_d0) / 20 * 1e3, 3), "mutual_matches": int(m_dev[1].sum()),
+                "note": "keypoint table [2,250] and mutual flags stay on the device (one read-back per scene instead of "
+                        "one per pair)"}
         except Exception as e:  # pragma: no cover - the headline number must not depend on this leg
             evaluation["top250_pipelined"] = {"error": "%s: %s" % (type(e).__name__, e)}
         # BASELINE configs[3]: 8 fragment pairs per inference batch -- 16 clouds stacked into one forward graph (per-pair
