@@ -35,6 +35,8 @@ SIGNATURES = {
     "d3f_kpconv_deform_aggregate": (_i, [_vp, _i, _vp, _i, _vp, _i, _vp, _i, _vp, _i, _f, _f, _i, _vp, _vp, _vp, _vp,
                                          _vp]),
     "d3f_kpconv_deform_grad": (_i, [_vp, _i, _vp, _i, _vp, _i, _vp, _i, _vp, _i, _f, _f, _i, _vp, _vp, _vp, _vp]),
+    "d3f_bias_act_packs": (_i, [_i]),
+    "d3f_bias_act_forward_pack": (_i, [_vp, _vp, _vp, _vp, _f, _i, _i, _vp, _vp, _i, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp]),
     "d3f_batchnorm_ws_bytes": (_sz, [_i, _i]),
     "d3f_batchnorm_forward": (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _f, _f, _i, _f, _vp, _vp, _vp, _vp, _sz, _vp]),
     "d3f_batchnorm_backward": (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _f, _i, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),

@@ -19,11 +19,48 @@ __global__ __launch_bounds__(256) void bias_act_fwd_kernel(const float* __restri
                                                            int C, float* __restrict__ out, float* __restrict__ zinit,
                                                            int zn, const float* __restrict__ row_div,
                                                            const int32_t* __restrict__ add_idx, int idx_stride,
-                                                           int add_rows) {
+                                                           int add_rows, const float* __restrict__ s_pts = nullptr,
+                                                           float4* __restrict__ spack_out = nullptr,
+                                                           float* __restrict__ zero_like_out = nullptr) {
   // C % 4 == 0: one float4 per thread, columns of a float4 are c .. c+3
+  __shared__ float rowpart[4];
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (zinit)  // side job: clear the caller's backward targets (a few bias rows up to a pooled-gradient matrix)
     for (size_t t = i; t < (size_t)zn; t += (size_t)gridDim.x * blockDim.x) zinit[t] = 0.0f;
+  if (spack_out) {
+    // the output is the feature matrix of a KPConv: leave its packed supports {x, y, z, [row sum > 0]} behind (what
+    // pack_supports_kernel would compute in a launch of its own) and clear that KPConv's scatter target.  A row is
+    // TPR = C/4 consecutive threads (a power of two <= 128); whole rows never straddle a workgroup.
+    const int TPR = C >> 2;
+    const bool live = i < n4;
+    const size_t row = live ? (size_t)((uint32_t)i / (uint32_t)TPR) : 0;
+    const int c = live ? (int)(((uint32_t)i - (uint32_t)row * (uint32_t)TPR) * 4u) : 0;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (live) {
+      v = ((const float4*)x)[i];
+      if (row_div) { const float d = row_div[row]; v.x /= d; v.y /= d; v.z /= d; v.w /= d; }
+      if (b1) { const float4 b = *(const float4*)(b1 + c); v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w; }
+      if (add) { const float4 a = ((const float4*)add)[i]; v.x += a.x; v.y += a.y; v.z += a.z; v.w += a.w; }
+      if (b2) { const float4 b = *(const float4*)(b2 + c); v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w; }
+      v.x = v.x > 0.0f ? v.x : v.x * slope;
+      v.y = v.y > 0.0f ? v.y : v.y * slope;
+      v.z = v.z > 0.0f ? v.z : v.z * slope;
+      v.w = v.w > 0.0f ? v.w : v.w * slope;
+      ((float4*)out)[i] = v;
+      if (zero_like_out) ((float4*)zero_like_out)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    float s = (v.x + v.y) + (v.z + v.w);
+    for (int o = 1; o < min(TPR, 64); o <<= 1) s += __shfl_xor(s, o, 64);
+    if (TPR == 128) {   // a row spans two waves
+      const int wave = threadIdx.x >> 6;
+      if ((threadIdx.x & 63) == 0) rowpart[wave] = s;
+      __syncthreads();
+      s = rowpart[wave & ~1] + rowpart[wave | 1];
+    }
+    if (live && c == 0)
+      spack_out[row] = make_float4(s_pts[3 * row], s_pts[3 * row + 1], s_pts[3 * row + 2], s > 0.0f ? 1.0f : 0.0f);
+    return;
+  }
   if (i >= n4) return;
   // (row, first column) of this float4; 32-bit arithmetic whenever the matrix has fewer than 2^32 elements -- a 64-bit
   // division by the run-time C costs more than the rest of the thread
@@ -231,6 +268,25 @@ int d3f_bias_act_forward(const float* x, const float* bias1, const float* add, c
   else
     bias_act_fwd_scalar_kernel<<<d3f::cdiv((long long)n, 256), 256, 0, (hipStream_t)stream>>>(
         x, bias1, add, bias2, slope, n, C, out, zero_init, zero_n, row_div, add_idx, idx_stride, add_rows);
+  D3F_LAUNCH_CHECK();
+  return D3F_OK;
+}
+
+int d3f_bias_act_packs(int C) { return (C == 16 || C == 32 || C == 64 || C == 128 || C == 256 || C == 512) ? 1 : 0; }
+
+int d3f_bias_act_forward_pack(const float* x, const float* bias1, const float* add, const float* bias2, float slope,
+                              int N, int C, float* out, float* zero_init, int zero_n, const float* row_div,
+                              const int32_t* add_idx, int idx_stride, int add_rows, const float* s_pts,
+                              void* spack_out, float* zero_like_out, void* stream) {
+  if (!s_pts || !spack_out) return D3F_EINVAL;
+  if (!x || !out || N < 1 || !d3f_bias_act_packs(C) || (zero_init && zero_n < 1) || add_idx ||
+      (long long)N * C >= (1ll << 32))
+    return D3F_EINVAL;
+  (void)idx_stride; (void)add_rows;
+  const size_t n = (size_t)N * C;
+  bias_act_fwd_kernel<<<d3f::cdiv((long long)(n / 4), 256), 256, 0, (hipStream_t)stream>>>(
+      x, bias1, add, bias2, slope, n / 4, C, out, zero_init, zero_n, row_div, nullptr, 0, 0, s_pts, (float4*)spack_out,
+      zero_like_out);
   D3F_LAUNCH_CHECK();
   return D3F_OK;
 }

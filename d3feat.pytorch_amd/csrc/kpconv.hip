@@ -322,6 +322,7 @@ int d3f_kpconv_forward(const float* q_pts, int Nq, const float* s_pts, int Ns, c
   if (ws_bytes < d3f_kpconv_ws_bytes(Nq, Ns, H, K, Cin, Cout)) return D3F_EWORKSPACE;
   hipStream_t stream = (hipStream_t)stream_;
   const bool packs = Nq > 0 && Ns > 0 && !kpconv_small_supported(Cin, Cout, K, H) && kpconv_fused_supported(Cin, Cout, K, H, Ns);
+  if (grad_x_clear == D3F_SPACK_READY && !packs) return D3F_EINVAL;   // nothing to be "ready" on the other paths
   if (grad_x_clear && !packs &&  // only the fused path clears it while packing
       d3f::zero_async(grad_x_clear, sizeof(float) * (size_t)Ns * Cin, stream) != hipSuccess)
     return D3F_ELAUNCH;

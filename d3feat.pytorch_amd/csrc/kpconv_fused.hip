@@ -528,8 +528,10 @@ int kpconv_forward_fused(const float* q_pts, int Nq, const float* s_pts, int Ns,
   // spack_keep: the packed supports are written to the caller's buffer (kept for the backward pass, which then skips
   // its own packing launch); grad_x_clear: the backward's scatter target, cleared here on the side
   float4* spack = (float4*)(spack_keep ? spack_keep : ws);
-  int rc = pack_supports(s_pts, x, Ns, Cin, spack, stream, grad_x_clear);
-  if (rc) return rc;
+  if (!(grad_x_clear == D3F_SPACK_READY && spack_keep)) {   // (else: packed by the epilogue that produced x)
+    int rc = pack_supports(s_pts, x, Ns, Cin, spack, stream, grad_x_clear == D3F_SPACK_READY ? nullptr : grad_x_clear);
+    if (rc) return rc;
+  }
   if (Cin == 16) return launch_fused_cv<1>(q_pts, spack, idx, x, kp, W, Nq, Ns, H, Cin, Cout, K, extent, out, nn_out, wf_save, stream);
   if (Cin == 32) return launch_fused_cv<2>(q_pts, spack, idx, x, kp, W, Nq, Ns, H, Cin, Cout, K, extent, out, nn_out, wf_save, stream);
   return launch_fused_cv<4>(q_pts, spack, idx, x, kp, W, Nq, Ns, H, Cin, Cout, K, extent, out, nn_out, wf_save, stream);
@@ -594,8 +596,11 @@ int kpconv_aggregate(const float* q_pts, int Nq, const float* s_pts, int Ns, con
                      int Cin, const float* kp, int K, float extent, float* wf_out, float* nn_out, void* spack_keep,
                      float* grad_x_clear, void* ws, hipStream_t stream) {
   float4* spack = (float4*)(spack_keep ? spack_keep : ws);
-  int rc = pack_supports(s_pts, x, Ns, Cin, spack, stream, grad_x_clear);
-  if (rc) return rc;
+  int rc = D3F_OK;
+  if (!(grad_x_clear == D3F_SPACK_READY && spack_keep)) {   // (else: packed by the epilogue that produced x)
+    rc = pack_supports(s_pts, x, Ns, Cin, spack, stream, grad_x_clear == D3F_SPACK_READY ? nullptr : grad_x_clear);
+    if (rc) return rc;
+  }
   const int CV = Cin == 16 ? 1 : (Cin == 32 ? 2 : 4);
   const int CC = 16 * CV;
   const size_t lds = sizeof(float) * (size_t)(16 * (16 * CC + 4) + 16);

@@ -208,13 +208,14 @@ class UnaryBlock(nn.Module):
         if not no_relu:
             self.leaky_relu = nn.LeakyReLU(0.1)
 
-    def forward(self, x, batch=None, residual=None, grad_holder=None, grad_deposit=None):
+    def forward(self, x, batch=None, residual=None, grad_holder=None, grad_deposit=None, pack_for=None):
         if not self.use_bn and x.is_cuda and x.dim() == 2:
             # Linear without its bias; both biases (+ residual) + LeakyReLU go into ONE epilogue launch whose backward
-            # also yields the (shared) bias gradient -- no separate add / leaky / column-reduce kernels
+            # also yields the (shared) bias gradient -- no separate add / leaky / column-reduce kernels.  pack_for: the
+            # output feeds a KPConv; the epilogue leaves its packed supports behind (ops.bias_act)
             return ops.linear_bias_act(x, self.mlp.weight, self.mlp.bias, residual, self.batch_norm.bias,
                                        slope=1.0 if (self.no_relu and residual is None) else 0.1,
-                                       grad_holder=grad_holder, grad_deposit=grad_deposit)
+                                       grad_holder=grad_holder, grad_deposit=grad_deposit, pack_for=pack_for)
         if residual is None:                     # BN (+ LeakyReLU) in one normalisation pass on the device
             return self.batch_norm(self.mlp(x), slope=1.0 if self.no_relu else 0.1)
         x = self.batch_norm(self.mlp(x))
@@ -339,7 +340,16 @@ class ResnetBottleneckBlock(nn.Module):
         # adds it (ops.GradHolder) -- no separate accumulation launch
         fuse = self.fuses_gradients(features)
         holder = ops.GradHolder() if fuse else None
-        x = self.unary1(features, grad_holder=holder) if fuse else self.unary1(features)
+        pack = None
+        if not self.use_bn and features.is_cuda and isinstance(self.unary1, UnaryBlock) and not self.KPConv.deformable:
+            # unary1's epilogue packs the supports of the KPConv it feeds; the grad_x scatter target is cleared along
+            # with it unless that layer's grad-input is the gather form (reverse table present, many rows)
+            gather = getattr(inds, '_d3f_rev', None) is not None and ops.wants_reverse_table(s_pts.shape[0])
+            pack = (s_pts, features.requires_grad and not gather)
+        if isinstance(self.unary1, UnaryBlock):
+            x = self.unary1(features, grad_holder=holder, pack_for=pack)
+        else:
+            x = self.unary1(features)
         if fuse:
             strided = 'strided' in self.block_name
             # a skip tensor also feeds the decoder, whose gradient arrives first: the pooling backward scatters on top

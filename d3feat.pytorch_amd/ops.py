@@ -107,6 +107,23 @@ def _p(t):
     return t.data_ptr() if t is not None else None
 
 
+SPACK_READY = 1   # D3F_SPACK_READY of the C ABI: "spack_keep already holds the packed supports"
+
+
+class PackedSupports(object):
+    """What the epilogue that produced a KPConv's input features left behind for it (d3f_bias_act_forward_pack): the
+    packed supports {x, y, z, [row sum > 0]} of (s_pts, x) and, optionally, the cleared grad_x scatter target.  Rides on
+    the feature tensor as ``x._d3f_spack``; the KPConv operators use it instead of launching their own packing kernel."""
+    __slots__ = ("spack", "gx_buf", "s_ptr", "rows", "cols")
+
+    def __init__(self, spack, gx_buf, s_pts, rows, cols):
+        self.spack, self.gx_buf, self.s_ptr, self.rows, self.cols = spack, gx_buf, s_pts.data_ptr(), int(rows), int(cols)
+
+    def fits(self, s_pts, x):
+        return self.s_ptr == s_pts.data_ptr() and self.rows == int(x.shape[0]) == int(s_pts.shape[0]) and \
+            self.cols == int(x.shape[1])
+
+
 class DeviceStatus:
     """int32 device word the kernels OR error bits into; checked at the caller's next natural sync."""
 
@@ -349,7 +366,7 @@ _GEMM_DX_MAX_ROWS = 4096
 
 class _KPConvFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, q_pts, s_pts, idx, x, kernel_points, weights, extent, rev=None):
+    def forward(ctx, q_pts, s_pts, idx, x, kernel_points, weights, extent, rev=None, ready=None):
         L = _native.lib()
         Nq, Ns, H = int(q_pts.shape[0]), int(s_pts.shape[0]), int(idx.shape[1])
         K, Cin, Cout = int(weights.shape[0]), int(weights.shape[1]), int(weights.shape[2])
@@ -368,17 +385,22 @@ class _KPConvFn(torch.autograd.Function):
             wf = torch.empty((Nq, wf_row), dtype=torch.float32, device=x.device)
         # training: the packed supports are kept for the backward pass and its scatter target is cleared on the side
         keep = gx_buf = None
-        if (ctx.needs_input_grad[3] or ctx.needs_input_grad[5]) and Nq > 0 and Ns > 0 and \
-                L.d3f_kpconv_packs_supports(Cin, Cout, K, H, Ns):
+        packs = Nq > 0 and Ns > 0 and L.d3f_kpconv_packs_supports(Cin, Cout, K, H, Ns)
+        need_clear = ctx.needs_input_grad[3] and rev is None   # (the gather form writes every row: nothing to clear)
+        # the epilogue that produced x may have packed the supports already (PackedSupports): no packing launch then
+        use_ready = packs and ready is not None and (not need_clear or ready.gx_buf is not None)
+        if use_ready:
+            keep, gx_buf = ready.spack, (ready.gx_buf if need_clear else None)
+        elif (ctx.needs_input_grad[3] or ctx.needs_input_grad[5]) and packs:
             keep = torch.empty(16 * Ns, dtype=torch.uint8, device=x.device)
-            if ctx.needs_input_grad[3] and rev is None:   # (the gather form writes every row: nothing to clear)
+            if need_clear:
                 gx_buf = torch.empty_like(x)
         with _region("kpconv_fwd[Nq=%d,Cin=%d,Cout=%d,H=%d]" % (Nq, Cin, Cout, H),
                      kpconv_fwd_bytes(Nq, Ns, H, K, Cin, Cout)):
             _native.check(L.d3f_kpconv_forward(_p(q_pts), Nq, _p(s_pts), Ns, _p(idx), H, _p(x), Cin,
                                                _p(kernel_points), K, _p(weights), Cout, float(extent), _p(out),
-                                               _p(nn), _p(wf), _p(keep), _p(gx_buf), _p(ws), nbytes, _stream()),
-                          "d3f_kpconv_forward")
+                                               _p(nn), _p(wf), _p(keep), SPACK_READY if use_ready else _p(gx_buf),
+                                               _p(ws), nbytes, _stream()), "d3f_kpconv_forward")
         ctx.keep, ctx.gx_buf = keep, gx_buf
         ctx.gw_slot = _grad_slot(weights)
         ctx.has_wf = wf is not None
@@ -447,7 +469,7 @@ class _KPConvFn(torch.autograd.Function):
                                                     _p(go), _p(wf), _p(keep), pre, _p(gx_native), _p(gw_native),
                                                     _p(ws), nbytes, _stream()),
                               "d3f_kpconv_backward")
-        return None, None, None, gx, None, (_adoptable(gw, ctx.gw_slot) if gw is not None else None), None, None
+        return None, None, None, gx, None, (_adoptable(gw, ctx.gw_slot) if gw is not None else None), None, None, None
 
 
 class _KPConvGemmBiasActFn(torch.autograd.Function):
@@ -459,7 +481,7 @@ class _KPConvGemmBiasActFn(torch.autograd.Function):
     backward saves the separate g/nn pass."""
 
     @staticmethod
-    def forward(ctx, q_pts, s_pts, idx, x, kernel_points, weights, bias, extent, slope, rev=None):
+    def forward(ctx, q_pts, s_pts, idx, x, kernel_points, weights, bias, extent, slope, rev=None, ready=None):
         L = _native.lib()
         Nq, Ns, H = int(q_pts.shape[0]), int(s_pts.shape[0]), int(idx.shape[1])
         K, Cin, Cout = int(weights.shape[0]), int(weights.shape[1]), int(weights.shape[2])
@@ -472,13 +494,19 @@ class _KPConvGemmBiasActFn(torch.autograd.Function):
         nbytes = L.d3f_kpconv_ws_bytes(Nq, Ns, H, K, Cin, 64)
         ws = _ws(nbytes, dev)
         keep = gx_buf = None
-        if ctx.needs_input_grad[3] and rev is None:
+        need_clear = ctx.needs_input_grad[3] and rev is None
+        # the epilogue that produced x may have packed the supports already (PackedSupports): no packing launch then
+        use_ready = ready is not None and (not need_clear or ready.gx_buf is not None)
+        if use_ready:
+            keep, gx_buf = ready.spack, (ready.gx_buf if need_clear else None)
+        elif need_clear:
             keep = torch.empty(16 * Ns, dtype=torch.uint8, device=dev)
             gx_buf = torch.empty_like(x)
         with _region("kpconv_aggregate[Nq=%d,Cin=%d,H=%d]" % (Nq, Cin, H), 4 * Nq * H * (4 + Cin) + 4 * Nq * K * Cin):
             _native.check(L.d3f_kpconv_aggregate(_p(q_pts), Nq, _p(s_pts), Ns, _p(idx), H, _p(x), Cin,
                                                  _p(kernel_points), K, float(extent), _p(wf), _p(nn), _p(keep),
-                                                 _p(gx_buf), _p(ws), nbytes, _stream()), "d3f_kpconv_aggregate")
+                                                 SPACK_READY if use_ready else _p(gx_buf), _p(ws), nbytes, _stream()),
+                          "d3f_kpconv_aggregate")
         ctx.keep, ctx.gx_buf = keep, gx_buf
         raw = torch.mm(wf, weights.view(K * Cin, Cout))
         out = torch.empty_like(raw)
@@ -538,7 +566,13 @@ class _KPConvGemmBiasActFn(torch.autograd.Function):
                                                       _p(kernel_points), K, ctx.extent, _p(gwf), _p(ctx.keep), pre,
                                                       _p(gx), _p(ws), nbytes, _stream()), "d3f_kpconv_grad_input")
         return (None, None, None, gx, None, (_adoptable(gw, ctx.gw_slot) if gw is not None else None),
-                (gb.view(-1) if gb is not None else None), None, None, None)
+                (gb.view(-1) if gb is not None else None), None, None, None, None)
+
+
+def _ready_supports(x, s_pts):
+    """The PackedSupports the producer of ``x`` left on it, if they belong to exactly this (s_pts, x)."""
+    ready = getattr(x, '_d3f_spack', None)
+    return ready if (ready is not None and ready.fits(s_pts, x)) else None
 
 
 def kpconv_bias_act(q_pts, s_pts, neighb_inds, x, kernel_points, weights, extent, bias, slope=0.1, influence='linear',
@@ -560,7 +594,8 @@ def kpconv_bias_act(q_pts, s_pts, neighb_inds, x, kernel_points, weights, extent
                 tuple(q_pts.shape), tuple(s_pts.shape), tuple(idx.shape), tuple(x.shape), tuple(w.shape)))
         b = _f32(bias, "bias") if bias is not None else None
         rev = reverse_table_of(neighb_inds, Nq, H, int(s_pts.shape[0]), rev) if x.requires_grad else None
-        return _KPConvGemmBiasActFn.apply(q_pts, s_pts, idx, x, kp, w, b, float(extent), float(slope), rev)
+        return _KPConvGemmBiasActFn.apply(q_pts, s_pts, idx, x, kp, w, b, float(extent), float(slope), rev,
+                                          _ready_supports(x, s_pts))
     return bias_act(kpconv(q_pts, s_pts, neighb_inds, x, kernel_points, weights, extent, rev=rev), bias, slope=slope)
 
 
@@ -640,7 +675,7 @@ def kpconv(q_pts, s_pts, neighb_inds, x, kernel_points, weights, extent, influen
         rev = reverse_table_of(neighb_inds, int(q_pts.shape[0]), int(idx.shape[1]), int(s_pts.shape[0]), rev)
     else:
         rev = None
-    return _KPConvFn.apply(q_pts, s_pts, idx, x, kp, w, float(extent), rev)
+    return _KPConvFn.apply(q_pts, s_pts, idx, x, kp, w, float(extent), rev, _ready_supports(x, s_pts))
 
 
 class _KPConvDeformAggFn(torch.autograd.Function):
@@ -1054,10 +1089,12 @@ def upsample_linear_bias_act(x_coarse, inds, skip, weight, bias1=None, bias2=Non
 _FUSED_LINEAR_MIN_ROWS = 4096
 
 
-def linear_bias_act(x, weight, bias1=None, add=None, bias2=None, slope=0.1, grad_holder=None, grad_deposit=None):
+def linear_bias_act(x, weight, bias1=None, add=None, bias2=None, slope=0.1, grad_holder=None, grad_deposit=None,
+                    pack_for=None):
     """act(x @ weight^T + bias1 + add + bias2) -- the whole unary block (reference blocks.py:481-541,686).
     grad_holder: the gradient a sibling branch deposited for `x` is added by this op's grad-input GEMM;
-    grad_deposit: this op hands its own grad_x to the sibling instead of returning it (see GradHolder)."""
+    grad_deposit: this op hands its own grad_x to the sibling instead of returning it (see GradHolder);
+    pack_for: see bias_act (honoured on the library-GEMM + epilogue path)."""
     x, weight = _f32(x, "x"), _f32(weight, "weight")
     N, Cin, Cout = int(x.shape[0]), int(x.shape[1]), int(weight.shape[0])
     # measured (profiles/unary_gemm_microbench.py): the fused kernel beats library GEMM + epilogue launch for
@@ -1067,7 +1104,8 @@ def linear_bias_act(x, weight, bias1=None, add=None, bias2=None, slope=0.1, grad
         b2 = _f32(bias2, "bias2") if bias2 is not None else None
         a = _f32(add, "add") if add is not None else None
         return _LinearBiasActFn.apply(x, weight, b1, a, b2, float(slope), grad_holder, grad_deposit)
-    return bias_act(linear_nobias(x, weight, grad_holder, grad_deposit), bias1, add, bias2, slope=slope)
+    return bias_act(linear_nobias(x, weight, grad_holder, grad_deposit), bias1, add, bias2, slope=slope,
+                    pack_for=pack_for)
 
 
 def linear_nobias(x, weight, grad_holder=None, grad_deposit=None):
@@ -1206,9 +1244,25 @@ def _bias_bwd_ws(N, C, device):
 
 class _BiasActFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, b1, add, b2, slope):
+    def forward(ctx, x, b1, add, b2, slope, pack=None):
         N, C = int(x.shape[0]), int(x.shape[1])
         out = torch.empty_like(x)
+        if pack is not None:
+            s_pts, want_clear = pack
+            nb = int(b1 is not None and ctx.needs_input_grad[1]) + int(b2 is not None and ctx.needs_input_grad[3])
+            gbuf = torch.empty((nb, C), dtype=torch.float32, device=x.device) if nb else None
+            spack = torch.empty(16 * N, dtype=torch.uint8, device=x.device)
+            gx_clear = torch.empty_like(x) if want_clear else None
+            _native.check(_native.lib().d3f_bias_act_forward_pack(
+                _p(x), _p(b1), _p(add), _p(b2), float(slope), N, C, _p(out), _p(gbuf), nb * C, None, None, 0, 0,
+                _p(s_pts), _p(spack), _p(gx_clear), _stream()), "d3f_bias_act_forward_pack")
+            ctx.save_for_backward(out)
+            ctx.gbuf, ctx.slope = gbuf, float(slope)
+            ctx.has = (b1 is not None, add is not None, b2 is not None)
+            ctx.mark_non_differentiable(spack)
+            if gx_clear is not None:
+                ctx.mark_non_differentiable(gx_clear)
+            return out, spack, gx_clear
         # the backward's bias-gradient accumulators [2, C] are cleared by the forward kernel on the side: no fill
         # launch in backward, and the two bias parameters get separate buffers (autograd would clone a shared one)
         nb = int(b1 is not None and ctx.needs_input_grad[1]) + int(b2 is not None and ctx.needs_input_grad[3])
@@ -1223,7 +1277,7 @@ class _BiasActFn(torch.autograd.Function):
         return out
 
     @staticmethod
-    def backward(ctx, grad_out):
+    def backward(ctx, grad_out, *_unused):
         (out,) = ctx.saved_tensors
         N, C = int(out.shape[0]), int(out.shape[1])
         go = grad_out.contiguous()
@@ -1253,11 +1307,14 @@ class _BiasActFn(torch.autograd.Function):
             if identity:
                 gx = go
         return (gx if ctx.needs_input_grad[0] else None, g1, gx if ctx.has[1] and ctx.needs_input_grad[2] else None,
-                g2, None)
+                g2, None, None)
 
 
-def bias_act(x, bias1=None, add=None, bias2=None, slope=0.1):
-    """act(x + bias1 + add + bias2) with act = LeakyReLU(slope) (slope = 1.0: no activation); one launch each way."""
+def bias_act(x, bias1=None, add=None, bias2=None, slope=0.1, pack_for=None):
+    """act(x + bias1 + add + bias2) with act = LeakyReLU(slope) (slope = 1.0: no activation); one launch each way.
+    ``pack_for`` = (s_pts, want_clear): the result is the feature matrix of a KPConv over the supports ``s_pts``; the
+    same launch leaves that KPConv's packed supports (and, with ``want_clear``, its cleared grad_x target) behind as
+    ``result._d3f_spack`` (PackedSupports) -- one launch less per KPConv layer."""
     x = _f32(x, "x")
     if x.dim() != 2:
         raise RuntimeError("bias_act expects [N, C]")
@@ -1266,6 +1323,12 @@ def bias_act(x, bias1=None, add=None, bias2=None, slope=0.1):
     a = _f32(add, "add") if add is not None else None
     if a is not None and a.shape != x.shape:
         raise RuntimeError("bias_act: residual shape %s != %s" % (tuple(a.shape), tuple(x.shape)))
+    if pack_for is not None and x.shape[0] > 0 and _native.lib().d3f_bias_act_packs(int(x.shape[1])) and \
+            x.numel() < 2 ** 32 and int(pack_for[0].shape[0]) == int(x.shape[0]):
+        s_pts = _f32(pack_for[0], "s_pts")
+        out, spack, gx_clear = _BiasActFn.apply(x, b1, a, b2, float(slope), (s_pts, bool(pack_for[1])))
+        out._d3f_spack = PackedSupports(spack, gx_clear, s_pts, x.shape[0], x.shape[1])
+        return out
     return _BiasActFn.apply(x, b1, a, b2, float(slope))
 
 

@@ -130,7 +130,11 @@ int d3f_grid_subsample_ex(const float* points, int N, const int32_t* len, int B,
  *   back to the backward pass (spack_kept), which then launches no packing kernel of its own; grad_x_clear is the
  *   backward's scatter target, cleared here on the side (pass grad_x_precleared = 1 to the backward).  Honoured when
  *   d3f_kpconv_packs_supports says so (otherwise pass NULL / 0).
+ *   grad_x_clear == D3F_SPACK_READY: spack_keep ALREADY holds the packed supports of (s_pts, x) -- written by the
+ *   epilogue that produced x (d3f_bias_act_forward, spack_out) -- and whatever needed clearing was cleared there; the
+ *   forward then launches no packing kernel at all.  Same convention for d3f_kpconv_aggregate.
  * ---------------------------------------------------------------------------------------------- */
+#define D3F_SPACK_READY ((float*)(uintptr_t)1)
 int d3f_kpconv_forward(const float* q_pts, int Nq, const float* s_pts, int Ns, const int32_t* idx, int H,
                        const float* x, int Cin, const float* kernel_points, int K, const float* weights, int Cout,
                        float extent, float* out, float* nn_out, float* wf_save, void* spack_keep, float* grad_x_clear,
@@ -290,6 +294,15 @@ int d3f_gemm(const d3f_gemm_args* args, void* ws, size_t ws_bytes, void* stream)
 int d3f_bias_act_forward(const float* x, const float* bias1, const float* add, const float* bias2, float slope, int N,
                          int C, float* out, float* zero_init, int zero_n, const float* row_div, const int32_t* add_idx,
                          int idx_stride, int add_rows, void* stream);
+/* The same launch, additionally preparing the KPConv that consumes `out` as its input features: spack_out [N] float4 =
+ * {s_pts[n], (sum_c out[n,c] > 0)} (the packed supports d3f_kpconv_forward would otherwise build with a launch of its
+ * own) and zero_like_out (optional, [N,C]) cleared (that KPConv's grad_x scatter target).  C in {16,...,512} with C/4 a
+ * power of two (d3f_bias_act_packs(C)). */
+int d3f_bias_act_packs(int C);
+int d3f_bias_act_forward_pack(const float* x, const float* bias1, const float* add, const float* bias2, float slope,
+                              int N, int C, float* out, float* zero_init, int zero_n, const float* row_div,
+                              const int32_t* add_idx, int idx_stride, int add_rows, const float* s_pts,
+                              void* spack_out, float* zero_like_out, void* stream);
 /* ws (optional, d3f_bias_act_backward_ws_bytes): with it, N >= 4096 uses per-block partial sums + a second tiny
  * launch for the bias gradient instead of atomics on C addresses (which serialise: 32 us at 38k x 32), deterministic. */
 size_t d3f_bias_act_backward_ws_bytes(int N, int C);

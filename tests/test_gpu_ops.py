@@ -1020,3 +1020,36 @@ def test_grouped_max_pool_and_detection_equal_per_group_calls():
             sub = np.where(tab[s0:s1] >= ns, s1 - s0, tab[s0:s1] - s0).astype(np.int32)
             want = ops.detection_scores(cu(f[s0:s1]), cu(sub), training=training, width=cu(widths[g:g + 1]))
             assert torch.equal(got[s0:s1], want), (training, g)
+
+
+@pytest.mark.parametrize("ns,nq,cin", [(700, 500, 64), (700, 700, 512), (5000, 5000, 128), (4500, 1200, 32)])
+def test_epilogue_packed_supports_equal_the_packing_launch(ns, nq, cin):
+    """ops.bias_act(..., pack_for=(s_pts, clear)) leaves the packed supports of the KPConv it feeds behind
+    (d3f_bias_act_forward_pack): the KPConv that picks them up (no packing launch, D3F_SPACK_READY) gives the same
+    output and gradients as the one that packs for itself -- few-point GEMM-fed path and fused path, rows spanning
+    8 lanes up to two waves."""
+    gen = torch.Generator().manual_seed(ns + cin)
+    H, K, cout = 20, 15, 64
+    s_pts = torch.rand((ns, 3), generator=gen)
+    q_pts = s_pts[torch.randperm(ns, generator=gen)[:nq]].contiguous()
+    d2 = ((q_pts[:, None] - s_pts[None]) ** 2).sum(-1)
+    dist, order = torch.sort(d2, dim=1)
+    inds = torch.where(dist[:, :H] < 0.15 ** 2, order[:, :H], torch.full_like(order[:, :H], ns)).to(torch.int32)
+    z = torch.randn((ns, cin), generator=gen)
+    b = torch.randn(cin, generator=gen) * 0.1
+    kp = (torch.rand((K, 3), generator=gen) - 0.5) * 0.16
+    w = torch.randn((K, cin, cout), generator=gen) * 0.05
+    bias = torch.randn(cout, generator=gen) * 0.1
+    go = torch.randn((nq, cout), generator=gen)
+    res = []
+    for pack in (False, True):
+        zt, bt = z.clone().to(DEV).requires_grad_(True), b.clone().to(DEV).requires_grad_(True)
+        wt = w.clone().to(DEV).requires_grad_(True)
+        sp = s_pts.to(DEV)
+        x = ops.bias_act(zt, bt, slope=0.1, pack_for=(sp, True) if pack else None)
+        assert (getattr(x, '_d3f_spack', None) is not None) == pack
+        y = ops.kpconv_bias_act(q_pts.to(DEV), sp, inds.to(DEV), x, kp.to(DEV), wt, 0.08, bias.to(DEV), slope=0.1)
+        y.backward(go.to(DEV))
+        res.append([y.detach().cpu(), zt.grad.cpu(), bt.grad.cpu(), wt.grad.cpu()])
+    for name, u, v in zip(("out", "grad_x", "grad_bias", "grad_w"), res[1], res[0]):
+        assert rel_err(u.numpy(), v.numpy()) < 1e-6, name
