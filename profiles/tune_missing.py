@@ -39,8 +39,9 @@ res = torch.cuda.tunable.get_results()
 print("entries before", before, "after", len(res))
 for r in res[before:]:
     print("  new:", r)
-try:
-    torch.cuda.tunable.write_file(out)
-except AttributeError:       # older spelling: the table is written when the process exits
-    torch.cuda.tunable.set_filename(out)
-    torch.cuda.tunable.write_file_on_exit(True)
+with open(out, "w") as fh:          # the table format PyTorch reads back: validators, then one line per tuned shape
+    for k, v in torch.cuda.tunable.get_validators():
+        fh.write("Validator,%s,%s\n" % (k, v))
+    for r in res:
+        fh.write("%s,%s,%s,%s\n" % (r[0], r[1], r[2], r[3]))
+print("wrote", out, len(res), "entries")
