@@ -22,6 +22,7 @@ SIGNATURES = {
     "d3f_device_arch_ok": (_i, []),
     "d3f_device_arch_name": (_i, [C.c_char_p, _i]),
     "d3f_debug_set_flags": (None, [_i]),
+    "d3f_debug_set_gemm_plan": (None, [_i, _i, _i, _i]),
     "d3f_debug_kernel_timing_begin": (_i, [_i, _i]),
     "d3f_debug_kernel_timing_end": (_i, [_vp, _vp, _i]),
     "d3f_radius_grid_ws_bytes": (_sz, [_i]),

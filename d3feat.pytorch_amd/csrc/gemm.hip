@@ -2,47 +2,41 @@
 // of the D3Feat network (reference models/blocks.py:481-541 nn.Linear + BatchNormBlock bias + LeakyReLU, :598,:676,:686
 // block epilogues, and the `weighted_features @ weights` contraction of KPConv.forward, blocks.py:375-380).
 //
-// Why an own kernel: the layers below the first pyramid level are GEMMs with 150..8000 rows against 64..7680 columns.
-// In the training step they were 116 library launches (28 % of the f32-MFMA peak on these shapes) plus ~110 separate
-// bias / activation / mask / column-sum launches at the ~4.5 us launch floor.  One kernel family here does
+// Why an own kernel: below the first pyramid level the layers are GEMMs with 150..8000 rows against 64..7680 columns.
+// A BLAS heuristic puts them on 100..250 workgroups that each walk the whole reduction (the 159 x 7680 x 512 KPConv
+// contraction: 38 us on 192 workgroups, 120 dependent k-iterations each), and every one of them is followed by a
+// separate bias / activation / mask / column-sum launch.  One kernel family here does
 //   C = epi( op_A(A) . op_B(B) )
 // with the elementwise work folded into the operand loads and the accumulator store:
 //   operands   : each of A, B is either "KC" (reduction index contiguous in memory) or "KS" (reduction index = row),
 //                so x W^T, g W, g^T x, wf W, g W^T all run without a transposed copy;
 //   prologue   : A' = A * (mask > 0 ? 1 : slope)   -- the LeakyReLU backward mask evaluated on the saved activation
-//                while the tile is staged (no masked-gradient tensor, no separate launch);
+//                while the operand is loaded (no masked-gradient tensor, no separate launch);
 //   by-product : row sums of A' (the bias gradient when A' = masked-gradient^T in the weight-gradient GEMM);
 //   epilogue   : (/ row_div[m]) + bias1[n] + add[m,n] (or add[idx[m],n]: nearest-upsampled coarse term) + bias2[n],
 //                LeakyReLU, store; a side job clears the caller's scratch (backward accumulators).
-// Mapping to gfx950: workgroup = 4 waves = 64 x 64 (or 32 x 64) tile of C, each wave FM x 2 accumulators of
-// v_mfma_f32_16x16x4_f32 (independent accumulators hide the 40-cycle dependent latency).  Tiles of 64 reduction
-// indices are staged through LDS (double buffered, one barrier per tile, the next tile's buffer loads in flight
-// during the MFMAs).  LDS layouts per operand kind:
-//   KC operand: [rows][68]  (row = 64 k + 4 pad), staged with ds_write_b128 (16 lanes = one 256-B row), fragments by
-//               8-byte reads: lane (i = l & 15, g = l >> 4) reads k = 8 kk + 2 g, +1  -> two MFMA k-steps per read;
-//   KS operand: [64 k][rows + 8], staged with ds_write_b128, fragments by two ds_read_b32 (k = 8 kk + 2 g + t): the
-//               stride = 8 mod 16 puts the two lane groups of a half-wave 16 banks apart.
-// Few-row / deep-reduction shapes (571 x 3072 x 1024, 154 x 7680 x 512) have too few tiles for 256 CUs: the
-// reduction is split over grid.z, partial tiles go to a slab and a second launch sums them in a fixed order and
-// applies the epilogue (bit-reproducible; no atomics).
+//
+// Mapping to gfx950 (round 3: register-direct form, no LDS, no barriers).  v_mfma_f32_16x16x4_f32 runs at the f32
+// vector rate (32 cycles per instruction per SIMD), i.e. these GEMMs are matrix-pipe bound long before they are
+// bandwidth bound: 16 x the time per operand byte of a bf16 GEMM.  What the small shapes lack is PARALLELISM and
+// latency cover, not staging bandwidth.  So:
+//   * the unit of work is ONE WAVE = a (16 FA) x (16 FB) tile of C over one slice of the reduction.  The 8 waves of a
+//     workgroup are KW x MW: KW waves split the reduction of the SAME tile (a 1024-deep reduction is a chain of 256
+//     dependent-latency-bound chunk steps for one wave, 32 for eight) and combine their accumulators through LDS in wave
+//     order -- no slab, no second launch, bit-reproducible --, MW such groups are stacked along M;
+//   * operand fragments go straight from memory to the MFMA operand registers as 16-byte loads, using the freedom to
+//     permute the reduction index consistently in A and B: within a 16-deep chunk, MFMA step s (0..3) and k-slot
+//     g = lane >> 4 stand for k = 4 g + s.  A KC operand then loads ONE float4 per fragment and chunk (lane (i, g) <-
+//     X[i][4g .. 4g+3], 64 contiguous bytes per row) and a KS operand ONE float4 per step (lane (i, g) <- X[4g+s][4i ..
+//     4i+3]: four consecutive output indices, which become the lane's element of FOUR fragments -- the tile's output
+//     index is permuted, idx = 4 i + f, and so float4 stores come out of the epilogue);
+//   * two register sets alternate (loads of chunk c+1 in flight under the 16..64 MFMAs of chunk c), 3-4 waves per SIMD
+//     cover the rest of the latency;
+//   * only when that still leaves the chip idle (192 rows x 7680 deep) the reduction is also split over grid.z; partial
+//     tiles go to a slab and a second launch sums them in slice order and applies the epilogue (no atomics).
 #include "kpconv_tile.hpp"
 
 namespace d3f {
-
-constexpr int G_BK = 64;                // reduction indices per staged tile
-constexpr int G_KQ = G_BK / 4;          // float4 per row of a KC tile
-constexpr int G_KC_LD = G_BK + 2;   // floats per row of a KC tile: row stride 2 mod 32 banks -> the 16 rows of a fragment
-                                    // read (8 B per lane) fall on 16 distinct bank pairs, conflict-free also when hipcc
-                                    // merges two reads into ds_read2_b64 (banks mod 32); rows are only 8-B aligned,
-                                    // so a staged float4 goes in as two 8-byte writes
-
-// ROWS = 64 or 32 output rows/columns of the operand tile; a KS tile row (one reduction index) holds ROWS + 8 floats
-template <int ROWS>
-struct GTile {
-  static constexpr int KS_LD = ROWS + 8;
-  static constexpr int FLOATS = (ROWS * G_KC_LD > G_BK * KS_LD) ? ROWS * G_KC_LD : G_BK * KS_LD;  // either layout fits
-  static constexpr int NV = ROWS * G_BK / 1024;  // float4 per thread per tile
-};
 
 struct GemmP {
   const float* A; const float* B; float* C;
@@ -56,74 +50,316 @@ struct GemmP {
   float* slab;                                 // split-K: [S][M*N (+ M)] partial results
 };
 
-// Operand tiles are fetched with raw buffer loads: an offset past the operand's extent returns zeros, which is the
-// zero padding of the ragged last row tile (KC) / last reduction tile (KS) without a branch around the load -- the
-// loads stay unconditional, so the compiler keeps them in flight behind counted vmcnt waits.  The other ragged
-// direction (reduction tail of a KC operand, row tail of a KS operand) is a select on the loaded value.
-template <bool KS, int ROWS>
-__device__ __forceinline__ void g_load(__amdgpu_buffer_rsrc_t rs, int ld, int r0, int rows, int k0, int K, int tid,
-                                       float4 (&v)[GTile<ROWS>::NV]) {
-#pragma unroll
-  for (int j = 0; j < GTile<ROWS>::NV; ++j) {
-    const int f = tid + 256 * j;
-    unsigned off;
-    bool ok;
-    if (!KS) {
-      const int gr = r0 + f / G_KQ, gk = k0 + 4 * (f % G_KQ);
-      ok = gk < K;
-      off = ((unsigned)gr * (unsigned)ld + (unsigned)gk) * 4u;
-      if (gr >= rows) off = 0xfffffff0u;
+__device__ __forceinline__ float f4c(const float4& v, int c) { return c == 0 ? v.x : (c == 1 ? v.y : (c == 2 ? v.z : v.w)); }
+
+// One operand of one wave.  KC: NV = F float4 per chunk (fragment f <- row base + 16 f + li, k = kb + 4 lg ..), the
+// per-fragment byte offsets are lane constants and the chunk's k offset rides in the scalar offset of the buffer load.
+// KS: NV = 4 float4 per chunk (step s <- row k = kb + 4 lg + s, output indices base + 4 li ..).
+template <bool KS, int F>
+struct Operand {
+  static constexpr int NV = KS ? 4 : F;
+  __amdgpu_buffer_rsrc_t rs;
+  unsigned voff[KS ? 1 : F];
+  unsigned ld4;   // row stride in bytes
+
+  __device__ __forceinline__ void init(const float* p, int ld, int outer, int K, int base, int li, int lg) {
+    // outer = number of output indices (rows of a KC operand, columns of a KS operand)
+    ld4 = (unsigned)ld * 4u;
+    const size_t bytes = KS ? ((size_t)(K - 1) * ld + outer) * 4 : ((size_t)(outer - 1) * ld + K) * 4;
+    rs = make_rsrc(p, (unsigned)bytes);
+    if (KS) {
+      const int col = min(base + 4 * li, outer - 4);   // clamped: a tile past the edge recomputes the last columns
+      voff[0] = (unsigned)(4 * lg) * ld4 + (unsigned)col * 4u;
     } else {
-      constexpr int Q = ROWS / 4;  // float4 per reduction index
-      const int gk = k0 + f / Q, gr = r0 + 4 * (f % Q);
-      ok = gr < rows;
-      off = ((unsigned)gk * (unsigned)ld + (unsigned)gr) * 4u;
-      if (gk >= K) off = 0xfffffff0u;
+#pragma unroll
+      for (int f = 0; f < F; ++f) {
+        const int row = min(base + 16 * f + li, outer - 1);
+        voff[f] = (unsigned)row * ld4 + (unsigned)(4 * lg) * 4u;
+      }
     }
-    (void)ok;
-    v[j] = buf_load_f4(rs, off);
   }
-}
 
-// the select half of g_load, applied when the tile is staged (a use right after the load would wait for it)
-template <bool KS, int ROWS>
-__device__ __forceinline__ void g_fix(int r0, int rows, int k0, int K, int tid, float4 (&v)[GTile<ROWS>::NV]) {
-#pragma unroll
-  for (int j = 0; j < GTile<ROWS>::NV; ++j) {
-    const int f = tid + 256 * j;
-    bool ok;
-    if (!KS) ok = k0 + 4 * (f % G_KQ) < K;
-    else ok = r0 + 4 * (f % (ROWS / 4)) < rows;
-    if (!ok) v[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-  }
-}
-
-template <bool KS, int ROWS>
-__device__ __forceinline__ void g_store(float* __restrict__ T, int tid, const float4 (&v)[GTile<ROWS>::NV]) {
-#pragma unroll
-  for (int j = 0; j < GTile<ROWS>::NV; ++j) {
-    const int f = tid + 256 * j;
-    constexpr int Q = ROWS / 4;
+  // TAIL: the chunk reaches past K (K % 16 != 0): out-of-range pieces read zeros.  !live (wave-uniform): the chunk lies
+  // past the wave's range -- the loads are still ISSUED (every path through the pipelined loop then carries the same
+  // number of outstanding loads, which is what lets the compiler count them instead of draining the queue) but their
+  // scalar offset points past the operand, so they return zeros without touching memory.
+  template <bool TAIL>
+  __device__ __forceinline__ void load(int kb, int K, int lg, float4 (&v)[NV], bool live = true) const {
+    constexpr unsigned kPast = 0x7ffffff0u;
     if (!KS) {
-      float* dst = T + (f / G_KQ) * G_KC_LD + 4 * (f % G_KQ);
-      *(float2*)dst = make_float2(v[j].x, v[j].y);
-      *(float2*)(dst + 2) = make_float2(v[j].z, v[j].w);
+      const unsigned so = live ? (unsigned)kb * 4u : kPast;
+#pragma unroll
+      for (int f = 0; f < F; ++f) {
+        if (TAIL) {
+          const unsigned vo = (kb + 4 * lg < K) ? voff[f] + so : 0xfffffff0u;
+          v[f] = buf_load_f4(rs, vo);
+        } else {
+          const u32x4v r = __builtin_amdgcn_raw_buffer_load_b128(rs, voff[f], so, 0);
+          v[f] = make_float4(__uint_as_float(r[0]), __uint_as_float(r[1]), __uint_as_float(r[2]), __uint_as_float(r[3]));
+        }
+      }
+    } else {
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        const unsigned so = live ? (unsigned)(kb + s) * ld4 : kPast;
+        if (TAIL) {
+          const unsigned vo = (kb + 4 * lg + s < K) ? voff[0] + so : 0xfffffff0u;
+          v[s] = buf_load_f4(rs, vo);
+        } else {
+          const u32x4v r = __builtin_amdgcn_raw_buffer_load_b128(rs, voff[0], so, 0);
+          v[s] = make_float4(__uint_as_float(r[0]), __uint_as_float(r[1]), __uint_as_float(r[2]), __uint_as_float(r[3]));
+        }
+      }
     }
-    else *(float4*)(T + (f / Q) * GTile<ROWS>::KS_LD + 4 * (f % Q)) = v[j];
   }
-}
 
-// fragment values of lane (li, lg) for the two MFMA k-steps of sub-step kk: rows/columns base .. base+15
-template <bool KS, int ROWS>
-__device__ __forceinline__ void g_frag(const float* __restrict__ T, int base, int kk, int li, int lg, float (&o)[2]) {
-  if (!KS) {
-    const float2 v = *(const float2*)(T + (base + li) * G_KC_LD + kk * 8 + 2 * lg);
-    o[0] = v.x;
-    o[1] = v.y;
-  } else {
-    o[0] = T[(kk * 8 + 2 * lg) * GTile<ROWS>::KS_LD + base + li];
-    o[1] = T[(kk * 8 + 2 * lg + 1) * GTile<ROWS>::KS_LD + base + li];
+  // MFMA operand of fragment f at step s
+  __device__ __forceinline__ static float frag(const float4 (&v)[NV], int f, int s) {
+    return KS ? f4c(v[s], f) : f4c(v[f], s);
   }
+};
+
+// FA / FB = fragments per wave along M / N (a KS operand always spans 4).  Workgroup = NW waves = KW (reduction split of
+// one tile) x NW / KW (tiles stacked along M).
+constexpr int G_NW = 8;
+template <bool AKS, bool BKS, int FA, int FB, bool MASK>
+__global__ __launch_bounds__(64 * G_NW) void gemm_direct_kernel(const GemmP p, const int kw_shift, const int per_z,
+                                                                const int per_w) {
+  // kw_shift = log2(KW); per_z / per_w = chunks per grid slice / per wave of a slice (rounded up) -- computed on the host:
+  // integer divisions by run-time values are ~100-instruction sequences each, and this kernel's shortest launches are
+  // a few thousand cycles long
+  static_assert(!AKS || FA == 4, "a KS operand spans four fragments");
+  static_assert(!BKS || FB == 4, "a KS operand spans four fragments");
+  constexpr int TM = 16 * FA, TN = 16 * FB;
+  typedef Operand<AKS, FA> OA;
+  typedef Operand<BKS, FB> OB;
+  // (the wave id IS wave-uniform, but anything derived from threadIdx is divergent to the compiler: without the
+  // readfirstlane every buffer load whose scalar offset depends on it is wrapped in a waterfall loop)
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int li = lane & 15, lg = lane >> 4;
+  const int KW = 1 << kw_shift, MW = G_NW >> kw_shift, kw = wave & (KW - 1), mw = wave >> kw_shift;
+  const int m0 = (blockIdx.y * MW + mw) * TM, n0 = blockIdx.x * TN;
+  const int S = gridDim.z, z = blockIdx.z;
+  extern __shared__ __attribute__((aligned(16))) float4 red[];   // [NW][FA*FB + 1][64]: accumulators of the waves kw > 0
+  constexpr int SLOTS = FA * FB + 1;
+  if (p.zero_init && blockIdx.x == 0 && blockIdx.y == 0 && z == 0)
+    for (int t = threadIdx.x; t < p.zero_n; t += 64 * G_NW) p.zero_init[t] = 0.0f;
+  const bool active = m0 < p.M;  // (a whole wave past the last row idles up to the barrier)
+
+  OA oa;
+  OB ob;
+  OA om;  // mask, addressed like A
+  oa.init(p.A, p.lda, p.M, p.K, m0, li, lg);
+  ob.init(p.B, p.ldb, p.N, p.K, n0, li, lg);
+  if (MASK) om.init(p.a_mask, p.lda, p.M, p.K, m0, li, lg);
+
+  const int chunks = (p.K + 15) >> 4;
+  const int zb = min(z * per_z, chunks), ze = min(zb + per_z, chunks);
+  // this wave's part of the slice (an inactive wave gets an empty range)
+  const int cb = active ? min(zb + kw * per_w, ze) : 0;
+  const int ce = active ? min(cb + per_w, ze) : 0;
+  const bool has_tail = (p.K & 15) != 0 && ce == chunks && ce > cb;
+  const int full_end = has_tail ? ce - 1 : ce;
+
+  f32x4 acc[FA][FB];
+#pragma unroll
+  for (int a = 0; a < FA; ++a)
+#pragma unroll
+    for (int b = 0; b < FB; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  float4 asum = make_float4(0.f, 0.f, 0.f, 0.f);  // AKS: running sums of this lane's 4 A' rows over its k slots
+  const bool want_sum = AKS && p.rowsum != nullptr && blockIdx.x == 0;
+  const float mslope = p.mask_slope;
+
+  // epilogue operands of the tile are fetched up front (their latency runs under the reduction loop instead of in
+  // front of the stores): both biases, the row divisors and the residual's row indices
+  float b1v[FB], b2v[FB], dvv[FA][4];
+  int arowv[FA][4];
+#pragma unroll
+  for (int fb = 0; fb < FB; ++fb) {
+    const int col = min(n0 + (BKS ? 4 * li + fb : 16 * fb + li), p.N - 1);
+    b1v[fb] = (p.bias1 && S == 1) ? p.bias1[col] : 0.0f;
+    b2v[fb] = (p.bias2 && S == 1) ? p.bias2[col] : 0.0f;
+  }
+#pragma unroll
+  for (int fa = 0; fa < FA; ++fa)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int i = 4 * lg + r;
+      const int row = min(m0 + (AKS ? 4 * i + fa : 16 * fa + i), p.M - 1);
+      dvv[fa][r] = (p.row_div && S == 1) ? p.row_div[row] : 1.0f;
+      arowv[fa][r] = (p.add_idx && S == 1) ? p.add_idx[(size_t)row * p.idx_stride] : row;
+    }
+
+  // register ring: NST chunk-sized operand sets; the loads of chunk c + NST - 1 are issued before the MFMAs of chunk c
+  constexpr int NM = MASK ? OA::NV : 1;
+  constexpr int STAGE_REGS = 4 * (OA::NV * (MASK ? 2 : 1) + OB::NV);
+  constexpr int NST = STAGE_REGS <= 24 ? 4 : (STAGE_REGS <= 32 ? 3 : 2);
+  float4 va[NST][OA::NV], vb[NST][OB::NV], vm[NST][NM];
+
+  auto compute = [&](float4 (&va)[OA::NV], const float4 (&vb)[OB::NV], const float4 (&vm)[NM]) {
+    if (MASK) {
+#pragma unroll
+      for (int j = 0; j < OA::NV; ++j) {
+        va[j].x *= vm[j % NM].x > 0.0f ? 1.0f : mslope;
+        va[j].y *= vm[j % NM].y > 0.0f ? 1.0f : mslope;
+        va[j].z *= vm[j % NM].z > 0.0f ? 1.0f : mslope;
+        va[j].w *= vm[j % NM].w > 0.0f ? 1.0f : mslope;
+      }
+    }
+    if (AKS && want_sum) {
+#pragma unroll
+      for (int j = 0; j < OA::NV; ++j) { asum.x += va[j].x; asum.y += va[j].y; asum.z += va[j].z; asum.w += va[j].w; }
+    }
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+#pragma unroll
+      for (int fa = 0; fa < FA; ++fa)
+#pragma unroll
+        for (int fb = 0; fb < FB; ++fb)
+          acc[fa][fb] = __builtin_amdgcn_mfma_f32_16x16x4f32(OA::frag(va, fa, s), OB::frag(vb, fb, s), acc[fa][fb], 0, 0, 0);
+  };
+#define D3F_LOAD(TAIL, chunk, va, vb, vm)                                                       \
+  {                                                                                             \
+    const bool live_ = TAIL || (chunk) < full_end;                                              \
+    oa.template load<TAIL>((chunk) * 16, p.K, lg, va, live_);                                   \
+    if (MASK) om.template load<TAIL>((chunk) * 16, p.K, lg, reinterpret_cast<float4(&)[OA::NV]>(vm), live_); \
+    ob.template load<TAIL>((chunk) * 16, p.K, lg, vb, live_);                                   \
+  }
+
+  // chunk cb + t lives in set t % NST
+#pragma unroll
+  for (int j = 0; j < NST - 1; ++j) D3F_LOAD(false, cb + j, va[j], vb[j], vm[j])
+  int c = cb;
+  for (; c + NST <= full_end; c += NST) {          // steady state: NST chunks per trip, no branch inside
+#pragma unroll
+    for (int j = 0; j < NST; ++j) {
+      D3F_LOAD(false, c + j + NST - 1, va[(j + NST - 1) % NST], vb[(j + NST - 1) % NST], vm[(j + NST - 1) % NST])
+      __builtin_amdgcn_sched_barrier(0);           // (hipcc otherwise sinks the loads between later MFMAs: the ring
+      compute(va[j], vb[j], vm[j]);                //  would run one to two chunks ahead instead of NST - 1)
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < NST - 1; ++j)                // the last < NST chunks (their loads are already in flight)
+    if (c + j < full_end) compute(va[j], vb[j], vm[j]);
+  if (has_tail) {
+    D3F_LOAD(true, ce - 1, va[0], vb[0], vm[0])
+    compute(va[0], vb[0], vm[0]);
+  }
+#undef D3F_LOAD
+
+  // ---- by-product: row sums of A' over this wave's reduction range.  Lane (li, lg) holds rows m0 + 4 li .. + 3 summed
+  // over its k slots; the four slots are combined in a fixed order.
+  float4 rs4 = asum;
+  if (want_sum) {
+#pragma unroll
+    for (int o = 16; o <= 32; o <<= 1) {
+      rs4.x += __shfl_xor(rs4.x, o, 64); rs4.y += __shfl_xor(rs4.y, o, 64);
+      rs4.z += __shfl_xor(rs4.z, o, 64); rs4.w += __shfl_xor(rs4.w, o, 64);
+    }
+  }
+  // ---- the KW waves of a tile: wave kw > 0 parks its accumulators in LDS, wave kw = 0 adds them in wave order
+  if (KW > 1) {
+    if (kw > 0 && active) {
+      float4* dst = red + (size_t)wave * SLOTS * 64 + lane;
+#pragma unroll
+      for (int fa = 0; fa < FA; ++fa)
+#pragma unroll
+        for (int fb = 0; fb < FB; ++fb)
+          dst[(fa * FB + fb) * 64] = make_float4(acc[fa][fb][0], acc[fa][fb][1], acc[fa][fb][2], acc[fa][fb][3]);
+      if (want_sum) dst[FA * FB * 64] = rs4;
+    }
+    __syncthreads();
+    if (kw == 0 && active) {
+      for (int k2 = 1; k2 < KW; ++k2) {
+        const float4* src = red + (size_t)(wave + k2) * SLOTS * 64 + lane;
+#pragma unroll
+        for (int fa = 0; fa < FA; ++fa)
+#pragma unroll
+          for (int fb = 0; fb < FB; ++fb) {
+            const float4 v = src[(fa * FB + fb) * 64];
+            acc[fa][fb][0] += v.x; acc[fa][fb][1] += v.y; acc[fa][fb][2] += v.z; acc[fa][fb][3] += v.w;
+          }
+        if (want_sum) {
+          const float4 v = src[FA * FB * 64];
+          rs4.x += v.x; rs4.y += v.y; rs4.z += v.z; rs4.w += v.w;
+        }
+      }
+    }
+  }
+  if (kw != 0 || !active) return;
+  if (want_sum) {
+    const int m = m0 + 4 * li;
+    if (lg == 0 && m < p.M) {  // M % 4 == 0 for a KS operand
+      if (S == 1) {
+        *(float4*)(p.rowsum + m) = rs4;
+        if (p.rowsum2) *(float4*)(p.rowsum2 + m) = rs4;
+      } else {
+        *(float4*)(p.slab + (size_t)z * ((size_t)p.M * p.N + p.M) + (size_t)p.M * p.N + m) = rs4;
+      }
+    }
+  }
+
+  // ---- accumulator store.  acc[fa][fb][r] = D[i = 4 lg + r][li] of fragment (fa, fb):
+  //   row = m0 + (AKS ? 4 i + fa : 16 fa + i),  col = n0 + (BKS ? 4 li + fb : 16 fb + li)
+  if (S > 1) {
+    float* slab = p.slab + (size_t)z * ((size_t)p.M * p.N + (p.rowsum ? p.M : 0));
+#pragma unroll
+    for (int fa = 0; fa < FA; ++fa)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int i = 4 * lg + r;
+        const int row = m0 + (AKS ? 4 * i + fa : 16 * fa + i);
+        if (row >= p.M) continue;
+        if (BKS) {
+          const int col = n0 + 4 * li;
+          if (col < p.N)
+            *(float4*)(slab + (size_t)row * p.N + col) = make_float4(acc[fa][0][r], acc[fa][FB > 1 ? 1 : 0][r],
+                                                                     acc[fa][FB > 2 ? 2 : 0][r], acc[fa][FB > 3 ? 3 : 0][r]);
+        } else {
+#pragma unroll
+          for (int fb = 0; fb < FB; ++fb) {
+            const int col = n0 + 16 * fb + li;
+            if (col < p.N) slab[(size_t)row * p.N + col] = acc[fa][fb][r];
+          }
+        }
+      }
+    return;
+  }
+  // (bias1 and bias2 enter the reference's sum at different points: kept apart)
+#pragma unroll
+  for (int fa = 0; fa < FA; ++fa)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int i = 4 * lg + r;
+      const int row = m0 + (AKS ? 4 * i + fa : 16 * fa + i);
+      if (row >= p.M) continue;
+      const float dv = dvv[fa][r];
+      const int arow = arowv[fa][r];
+      const bool alive = p.add != nullptr && (!p.add_idx || (arow >= 0 && arow < p.add_rows));
+      float v[FB];
+#pragma unroll
+      for (int fb = 0; fb < FB; ++fb) {
+        const int col = n0 + (BKS ? 4 * li + fb : 16 * fb + li);
+        float t = acc[fa][fb][r];
+        if (p.row_div) t /= dv;
+        if (p.bias1) t += b1v[fb];
+        if (alive && col < p.N) t += p.add[(size_t)arow * p.ldadd + col];
+        if (p.bias2) t += b2v[fb];
+        v[fb] = t > 0.0f ? t : t * p.slope;
+      }
+      if (BKS) {
+        const int col = n0 + 4 * li;
+        if (col < p.N)
+          *(float4*)(p.C + (size_t)row * p.ldc + col) = make_float4(v[0], v[FB > 1 ? 1 : 0], v[FB > 2 ? 2 : 0], v[FB > 3 ? 3 : 0]);
+      } else {
+#pragma unroll
+        for (int fb = 0; fb < FB; ++fb) {
+          const int col = n0 + 16 * fb + li;
+          if (col < p.N) p.C[(size_t)row * p.ldc + col] = v[fb];
+        }
+      }
+    }
 }
 
 __device__ __forceinline__ float g_epilogue(const GemmP& p, float v, int row, int col) {
@@ -139,214 +375,6 @@ __device__ __forceinline__ float g_epilogue(const GemmP& p, float v, int row, in
   }
   if (p.bias2) v += p.bias2[col];
   return v > 0.0f ? v : v * p.slope;
-}
-
-// FM = accumulator fragments per wave along M: 2 -> 64 x 64 tile per workgroup, 1 -> 32 x 64 (twice the workgroups
-// for the few-row levels).  Waves are laid out 2 x 2; every wave owns FM x 2 fragments (16*FM rows x 32 columns).
-template <bool AKS, bool BKS, bool MASK, int FM>
-__global__ __launch_bounds__(256) void gemm_tile_kernel(const GemmP p) {
-  constexpr int BM = 32 * FM;
-  typedef GTile<BM> TA;
-  typedef GTile<64> TB;
-  __shared__ __attribute__((aligned(16))) float lds[2][TA::FLOATS + TB::FLOATS];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int li = lane & 15, lg = lane >> 4;
-  const int wr = wave >> 1, wc = wave & 1;
-  const int n0 = blockIdx.x * 64, m0 = blockIdx.y * BM;
-  const int S = gridDim.z, z = blockIdx.z;
-  if (p.zero_init && blockIdx.x == 0 && blockIdx.y == 0 && z == 0)
-    for (int t = tid; t < p.zero_n; t += 256) p.zero_init[t] = 0.0f;
-  const int ktiles = (p.K + G_BK - 1) / G_BK;
-  const int t_begin = (int)((long long)ktiles * z / S), t_end = (int)((long long)ktiles * (z + 1) / S);
-  const int T = t_end - t_begin;
-
-  f32x4 acc[FM][2];
-#pragma unroll
-  for (int a = 0; a < FM; ++a)
-#pragma unroll
-    for (int b = 0; b < 2; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  float4 asum = make_float4(0.f, 0.f, 0.f, 0.f);  // AKS: running sums of this thread's 4 A' rows
-  const bool want_sum = AKS && p.rowsum != nullptr && blockIdx.x == 0;
-
-  // extents in bytes: (outer - 1) * ld + inner elements
-  const unsigned a_bytes = (unsigned)(((size_t)((AKS ? p.K : p.M) - 1) * p.lda + (AKS ? p.M : p.K)) * 4);
-  const unsigned b_bytes = (unsigned)(((size_t)((BKS ? p.K : p.N) - 1) * p.ldb + (BKS ? p.N : p.K)) * 4);
-  const __amdgpu_buffer_rsrc_t rs_a = make_rsrc(p.A, a_bytes);
-  const __amdgpu_buffer_rsrc_t rs_m = make_rsrc(MASK ? p.a_mask : p.A, a_bytes);
-  const __amdgpu_buffer_rsrc_t rs_b = make_rsrc(p.B, b_bytes);
-
-  // two register sets: the loads of tile t+2 are issued before the MFMAs of tile t and consumed (staged into the
-  // other LDS buffer) after the MFMAs of tile t+1 -- two compute phases of latency cover
-  // one register set: the loads of tile t+1 are issued before the MFMAs of tile t (64 per wave = 2048 cycles, which
-  // is what covers their latency) and staged into the other LDS buffer after them.  (A second register set for a
-  // two-tile look-ahead was tried: hipcc drains vmcnt at the loop header, so it bought nothing.)
-  constexpr int NM = MASK ? TA::NV : 1;
-  float4 va0[TA::NV], vb0[TB::NV], vm0[NM];
-  auto fetch = [&](int t, float4 (&va)[TA::NV], float4 (&vb)[TB::NV], float4 (&vm)[NM]) {
-    const int k0 = (t_begin + t) * G_BK;
-    g_load<AKS, BM>(rs_a, p.lda, m0, p.M, k0, p.K, tid, va);
-    if (MASK) {
-      float4 (&vmm)[TA::NV] = reinterpret_cast<float4 (&)[TA::NV]>(vm);
-      g_load<AKS, BM>(rs_m, p.lda, m0, p.M, k0, p.K, tid, vmm);
-    }
-    g_load<BKS, 64>(rs_b, p.ldb, n0, p.N, k0, p.K, tid, vb);
-  };
-  auto stage = [&](int t, float4 (&va)[TA::NV], float4 (&vb)[TB::NV], const float4 (&vm)[NM]) {
-    const int k0 = (t_begin + t) * G_BK, buf = t & 1;
-    if (MASK) {
-#pragma unroll
-      for (int j = 0; j < TA::NV; ++j) {
-        va[j].x *= vm[j % NM].x > 0.0f ? 1.0f : p.mask_slope;
-        va[j].y *= vm[j % NM].y > 0.0f ? 1.0f : p.mask_slope;
-        va[j].z *= vm[j % NM].z > 0.0f ? 1.0f : p.mask_slope;
-        va[j].w *= vm[j % NM].w > 0.0f ? 1.0f : p.mask_slope;
-      }
-    }
-    g_fix<AKS, BM>(m0, p.M, k0, p.K, tid, va);
-    g_fix<BKS, 64>(n0, p.N, k0, p.K, tid, vb);
-    g_store<AKS, BM>(lds[buf], tid, va);
-    g_store<BKS, 64>(lds[buf] + TA::FLOATS, tid, vb);
-    if (want_sum) {
-#pragma unroll
-      for (int j = 0; j < TA::NV; ++j) { asum.x += va[j].x; asum.y += va[j].y; asum.z += va[j].z; asum.w += va[j].w; }
-    }
-  };
-  // Fragments are double-buffered in registers: the LDS reads of step ps+1 are issued BEFORE the MFMAs of step ps
-  // (pinned with sched_barrier: hipcc otherwise sinks them behind the MFMAs), so their latency runs under 8*FM matrix
-  // instructions.  `mid` runs after the first step's MFMAs are issued: the staging stores of the NEXT tile go there,
-  // into the other LDS buffer, and execute in the LDS pipe while the matrix pipe works.
-  auto compute = [&](int buf, auto&& mid) {
-    const float* As = lds[buf];
-    const float* Bs = lds[buf] + TA::FLOATS;
-    constexpr int NP = G_BK / 16;         // pipeline steps of two sub-steps (16 reduction indices) each
-    float a[2][2][FM][2], b[2][2][2][2];  // [register set][sub-step][fragment][k-step]
-    auto read = [&](int pstep, int slot) {
-#pragma unroll
-      for (int h = 0; h < 2; ++h) {
-#pragma unroll
-        for (int f = 0; f < FM; ++f) g_frag<AKS, BM>(As, wr * 16 * FM + f * 16, 2 * pstep + h, li, lg, a[slot][h][f]);
-#pragma unroll
-        for (int f = 0; f < 2; ++f) g_frag<BKS, 64>(Bs, wc * 32 + f * 16, 2 * pstep + h, li, lg, b[slot][h][f]);
-      }
-    };
-    read(0, 0);
-#pragma unroll
-    for (int ps = 0; ps < NP; ++ps) {
-      const int cur = ps & 1;
-      if (ps + 1 < NP) read(ps + 1, cur ^ 1);
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int h = 0; h < 2; ++h)
-#pragma unroll
-        for (int s = 0; s < 2; ++s)
-#pragma unroll
-          for (int fa = 0; fa < FM; ++fa)
-#pragma unroll
-            for (int fb = 0; fb < 2; ++fb)
-              acc[fa][fb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[cur][h][fa][s], b[cur][h][fb][s], acc[fa][fb], 0, 0, 0);
-      __builtin_amdgcn_sched_barrier(0);
-      if (ps == 0) mid();
-    }
-  };
-  // Schedule (one barrier per tile; tile t is computed from LDS buffer t & 1):
-  //   the registers hold tile t+1, loaded during the previous iteration (a whole compute phase of latency cover);
-  //   they are staged into the buffer tile t-1 has left, behind the first MFMAs of tile t, and refilled with the
-  //   loads of tile t+2.
-  if (T > 0) {
-    fetch(0, va0, vb0, vm0);
-    stage(0, va0, vb0, vm0);
-    if (T > 1) fetch(1, va0, vb0, vm0);
-  }
-  __syncthreads();
-  for (int t = 0; t < T; ++t) {
-    compute(t & 1, [&]() {
-      if (t + 1 < T) stage(t + 1, va0, vb0, vm0);
-      if (t + 2 < T) fetch(t + 2, va0, vb0, vm0);
-    });
-    __syncthreads();
-  }
-
-  // ---- by-product: row sums of A' over this workgroup's reduction range (fixed summation order)
-  if (want_sum) {
-    constexpr int Q = BM / 4, KL = 256 / Q;  // threads per reduction index, reduction lanes
-    float* red = lds[0];                     // [KL][BM]; every fragment read is behind the loop's last barrier
-    *(float4*)(red + (tid / Q) * BM + 4 * (tid % Q)) = asum;
-    __syncthreads();
-    if (tid < BM && m0 + tid < p.M) {
-      float s = 0.0f;
-#pragma unroll
-      for (int j = 0; j < KL; ++j) s += red[j * BM + tid];
-      if (S == 1) {
-        p.rowsum[m0 + tid] = s;
-        if (p.rowsum2) p.rowsum2[m0 + tid] = s;
-      } else {
-        p.slab[(size_t)z * ((size_t)p.M * p.N + p.M) + (size_t)p.M * p.N + m0 + tid] = s;
-      }
-    }
-  }
-
-  // ---- accumulator store: D[4 lg + r][li] of fragment (fa, fb).  Every epilogue operand of the thread's FM*8
-  // outputs is loaded up front (independent loads in flight together), then combined and stored.
-  if (S > 1) {
-    float* slab = p.slab + (size_t)z * ((size_t)p.M * p.N + (p.rowsum ? p.M : 0));
-#pragma unroll
-    for (int fa = 0; fa < FM; ++fa)
-#pragma unroll
-      for (int fb = 0; fb < 2; ++fb) {
-        const int col = n0 + wc * 32 + fb * 16 + li;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int row = m0 + wr * 16 * FM + fa * 16 + 4 * lg + r;
-          if (row < p.M && col < p.N) slab[(size_t)row * p.N + col] = acc[fa][fb][r];
-        }
-      }
-    return;
-  }
-  float bia1[2], bia2[2], dv[FM][4], ad[FM][2][4];
-  int arow[FM][4];
-#pragma unroll
-  for (int fb = 0; fb < 2; ++fb) {
-    const int col = min(n0 + wc * 32 + fb * 16 + li, p.N - 1);
-    bia1[fb] = p.bias1 ? p.bias1[col] : 0.0f;
-    bia2[fb] = p.bias2 ? p.bias2[col] : 0.0f;
-  }
-#pragma unroll
-  for (int fa = 0; fa < FM; ++fa)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int row = min(m0 + wr * 16 * FM + fa * 16 + 4 * lg + r, p.M - 1);
-      dv[fa][r] = p.row_div ? p.row_div[row] : 1.0f;
-      arow[fa][r] = p.add_idx ? p.add_idx[(size_t)row * p.idx_stride] : row;
-    }
-#pragma unroll
-  for (int fa = 0; fa < FM; ++fa)
-#pragma unroll
-    for (int fb = 0; fb < 2; ++fb) {
-      const int col = min(n0 + wc * 32 + fb * 16 + li, p.N - 1);
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int m = arow[fa][r];
-        const bool live = p.add && (!p.add_idx || (m >= 0 && m < p.add_rows));
-        ad[fa][fb][r] = live ? p.add[(size_t)m * p.ldadd + col] : 0.0f;
-      }
-    }
-#pragma unroll
-  for (int fa = 0; fa < FM; ++fa)
-#pragma unroll
-    for (int fb = 0; fb < 2; ++fb) {
-      const int col = n0 + wc * 32 + fb * 16 + li;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int row = m0 + wr * 16 * FM + fa * 16 + 4 * lg + r;
-        float v = acc[fa][fb][r];
-        if (p.row_div) v /= dv[fa][r];
-        if (p.bias1) v += bia1[fb];
-        if (p.add) v += ad[fa][fb][r];
-        if (p.bias2) v += bia2[fb];
-        v = v > 0.0f ? v : v * p.slope;
-        if (row < p.M && col < p.N) p.C[(size_t)row * p.ldc + col] = v;
-      }
-    }
 }
 
 // C = epilogue(sum_z slab[z]) and rowsum = sum_z partial row sums, slabs added in index order
@@ -378,33 +406,61 @@ __global__ __launch_bounds__(256) void gemm_reduce_kernel(const GemmP p, int S) 
   }
 }
 
-// Work decomposition.  FM = 2 (64-row tiles) when that alone fills the chip; otherwise 32-row tiles; the reduction is
-// split (second launch for the fixed-order sum + epilogue: ~4.5 us) only when the launch would still leave most
-// CUs idle AND each slice keeps >= 4 reduction tiles (256 indices).
-struct GemmPlan { int fm, split; };
-static GemmPlan gemm_plan(int M, int N, int K) {
-  const long long nt = cdiv(N, 64);
-  const int ktiles = cdiv(K, G_BK);
+// Work decomposition: the wave tile (fa x fb fragments), the in-workgroup reduction split kw (1, 2, 4 or 8 of the
+// workgroup's 8 waves; the other 8 / kw stack along M) and the grid-level split.  A KS operand fixes its side at 4
+// fragments.  Target: ~3 waves per SIMD on 256 CUs with at least 4 chunks (64 reduction indices) per wave; the
+// in-workgroup split is free (LDS), the grid split costs a slab round trip and a second launch.
+struct GemmPlan { int fa, fb, kw, split; };
+static int g_force_fa = 0, g_force_fb = 0, g_force_kw = 0, g_force_split = 0;   // measurement aid (d3f_debug_set_gemm_plan)
+
+static GemmPlan gemm_plan(int M, int N, int K, bool aks, bool bks) {
   GemmPlan pl;
-  pl.fm = ((long long)cdiv(M, 64) * nt >= 384) ? 2 : 1;
-  const long long tiles = (long long)cdiv(M, 32 * pl.fm) * nt;
+  pl.fb = bks ? 4 : (N <= 32 ? 2 : 4);
+  if (!bks && (g_force_fb == 2 || g_force_fb == 4)) pl.fb = g_force_fb;
+  if (aks) pl.fa = 4;
+  else pl.fa = ((long long)cdiv(M, 32) * cdiv(N, 16 * pl.fb) >= 4096) ? 2 : 1;
+  if (!aks && (g_force_fa == 1 || g_force_fa == 2)) pl.fa = g_force_fa;
+  const long long tiles = (long long)cdiv(M, 16 * pl.fa) * cdiv(N, 16 * pl.fb);
+  const int chunks = cdiv(K, 16);
+  long long want = (3072 + tiles - 1) / tiles;          // waves per tile that fill the chip
+  if (want > chunks / 4) want = chunks / 4;             // >= 4 chunks per wave
+  pl.kw = want >= 8 ? 8 : (want >= 4 ? 4 : (want >= 2 ? 2 : 1));
+  if (g_force_kw == 1 || g_force_kw == 2 || g_force_kw == 4 || g_force_kw == 8) pl.kw = g_force_kw;
   pl.split = 1;
-  if (tiles < 160 && ktiles >= 8) {
-    long long s = (512 + tiles - 1) / tiles;
-    if (s > ktiles / 4) s = ktiles / 4;
-    if (s > 32) s = 32;
-    if (s >= 2) pl.split = (int)s;
+  if (pl.kw == 8 && want >= 24) {                       // the second launch has to buy >= 3x the waves
+    long long s = want / 8;
+    if (s > 16) s = 16;
+    pl.split = (int)s;
   }
+  if (g_force_split >= 1) pl.split = g_force_split > chunks ? chunks : g_force_split;
   return pl;
 }
 
 size_t gemm_ws_bytes(int M, int N, int K, bool rowsum) {
-  const int S = gemm_plan(M, N, K).split;
+  int S = 1;
+  for (int a = 0; a < 2; ++a)
+    for (int b = 0; b < 2; ++b) {
+      const int s = gemm_plan(M, N, K, a != 0, b != 0).split;
+      if (s > S) S = s;
+    }
   if (S == 1) return 0;
   return align_up(sizeof(float) * (size_t)S * ((size_t)M * N + (rowsum ? M : 0)), 256);
 }
 
 static bool aligned16(const void* p) { return ((uintptr_t)p & 15u) == 0; }
+
+template <bool AKS, bool BKS, int FA, int FB>
+static void gemm_launch_t(const GemmP& p, dim3 grid, int kw, bool mask, hipStream_t stream) {
+  const int kw_shift = kw >= 8 ? 3 : (kw >= 4 ? 2 : (kw >= 2 ? 1 : 0));
+  const int per_z = cdiv(cdiv(p.K, 16), (int)grid.z), per_w = cdiv(per_z, kw);
+  const size_t lds = kw > 1 ? sizeof(float4) * (size_t)G_NW * (FA * FB + 1) * 64 : 0;
+  if (lds > 65536) {  // (64 x 64 wave tiles: 136 KB) -- the opt-in is per kernel and cheap
+    if (mask) (void)hipFuncSetAttribute((const void*)gemm_direct_kernel<AKS, BKS, FA, FB, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    else (void)hipFuncSetAttribute((const void*)gemm_direct_kernel<AKS, BKS, FA, FB, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  }
+  if (mask) gemm_direct_kernel<AKS, BKS, FA, FB, true><<<grid, 64 * G_NW, lds, stream>>>(p, kw_shift, per_z, per_w);
+  else gemm_direct_kernel<AKS, BKS, FA, FB, false><<<grid, 64 * G_NW, lds, stream>>>(p, kw_shift, per_z, per_w);
+}
 
 int gemm_launch(GemmP p, bool a_ks, bool b_ks, void* ws, size_t ws_bytes, hipStream_t stream) {
   if (!p.A || !p.B || !p.C || p.M < 0 || p.N < 1 || p.K < 1) return D3F_EINVAL;
@@ -412,34 +468,42 @@ int gemm_launch(GemmP p, bool a_ks, bool b_ks, void* ws, size_t ws_bytes, hipStr
   const int a_cont = a_ks ? p.M : p.K, b_cont = b_ks ? p.N : p.K;
   if (a_cont % 4 || b_cont % 4 || p.lda % 4 || p.ldb % 4 || p.N % 4 || p.ldc < p.N) return D3F_EINVAL;
   if (!aligned16(p.A) || !aligned16(p.B) || (p.a_mask && !aligned16(p.a_mask))) return D3F_EINVAL;
-  if (p.rowsum && !a_ks) return D3F_EINVAL;  // row sums ride on the KS staging pattern (weight-gradient GEMM)
+  if (b_ks && (!aligned16(p.C) || p.ldc % 4)) return D3F_EINVAL;                // float4 stores of the permuted columns
+  if (p.rowsum && (!a_ks || !aligned16(p.rowsum) || (p.rowsum2 && !aligned16(p.rowsum2)))) return D3F_EINVAL;
   if (p.rowsum2 && !p.rowsum) return D3F_EINVAL;
   if (p.add && p.ldadd < p.N) return D3F_EINVAL;
+  // 32-bit byte offsets inside the operands
+  const double a_ext = ((double)((a_ks ? p.K : p.M) - 1) * p.lda + (a_ks ? p.M : p.K)) * 4.0;
+  const double b_ext = ((double)((b_ks ? p.K : p.N) - 1) * p.ldb + (b_ks ? p.N : p.K)) * 4.0;
+  if (a_ext >= 4294967280.0 || b_ext >= 4294967280.0) return D3F_EINVAL;
   if (p.M == 0) {
     if (p.zero_init && p.zero_n > 0 && zero_async(p.zero_init, sizeof(float) * (size_t)p.zero_n, stream) != hipSuccess)
       return D3F_ELAUNCH;
     return D3F_OK;
   }
-  const GemmPlan pl = gemm_plan(p.M, p.N, p.K);
+  const GemmPlan pl = gemm_plan(p.M, p.N, p.K, a_ks, b_ks);
   const int S = pl.split;
   if (S > 1) {
-    if (!ws || ws_bytes < gemm_ws_bytes(p.M, p.N, p.K, p.rowsum != nullptr)) return D3F_EWORKSPACE;
+    const size_t need = align_up(sizeof(float) * (size_t)S * ((size_t)p.M * p.N + (p.rowsum ? p.M : 0)), 256);
+    if (!ws || ws_bytes < need) return D3F_EWORKSPACE;
     p.slab = (float*)ws;
   }
-  dim3 grid(cdiv(p.N, 64), cdiv(p.M, 32 * pl.fm), S);
+  const int kw = pl.kw;
+  dim3 grid(cdiv(p.N, 16 * pl.fb), cdiv(p.M, 16 * pl.fa * (G_NW / kw)), S);
   const bool mask = p.a_mask != nullptr;
-#define D3F_G3(AK, BK, MK)                                                        \
-  {                                                                               \
-    if (pl.fm == 2) gemm_tile_kernel<AK, BK, MK, 2><<<grid, 256, 0, stream>>>(p); \
-    else gemm_tile_kernel<AK, BK, MK, 1><<<grid, 256, 0, stream>>>(p);            \
+  if (a_ks) {
+    if (b_ks) gemm_launch_t<true, true, 4, 4>(p, grid, kw, mask, stream);
+    else if (pl.fb == 4) gemm_launch_t<true, false, 4, 4>(p, grid, kw, mask, stream);
+    else gemm_launch_t<true, false, 4, 2>(p, grid, kw, mask, stream);
+  } else if (pl.fa == 2) {
+    if (b_ks) gemm_launch_t<false, true, 2, 4>(p, grid, kw, mask, stream);
+    else if (pl.fb == 4) gemm_launch_t<false, false, 2, 4>(p, grid, kw, mask, stream);
+    else gemm_launch_t<false, false, 2, 2>(p, grid, kw, mask, stream);
+  } else {
+    if (b_ks) gemm_launch_t<false, true, 1, 4>(p, grid, kw, mask, stream);
+    else if (pl.fb == 4) gemm_launch_t<false, false, 1, 4>(p, grid, kw, mask, stream);
+    else gemm_launch_t<false, false, 1, 2>(p, grid, kw, mask, stream);
   }
-#define D3F_G(AK, BK) { if (mask) D3F_G3(AK, BK, true) else D3F_G3(AK, BK, false) }
-  if (!a_ks && !b_ks) D3F_G(false, false)
-  else if (!a_ks && b_ks) D3F_G(false, true)
-  else if (a_ks && !b_ks) D3F_G(true, false)
-  else D3F_G(true, true)
-#undef D3F_G
-#undef D3F_G3
   D3F_LAUNCH_CHECK();
   if (S > 1) {
     const long long work = (long long)((size_t)p.M * p.N + 3) / 4 + (p.rowsum ? p.M : 0);
@@ -454,6 +518,13 @@ int gemm_launch(GemmP p, bool a_ks, bool b_ks, void* ws, size_t ws_bytes, hipStr
 extern "C" {
 
 size_t d3f_gemm_ws_bytes(int M, int N, int K, int with_rowsum) { return d3f::gemm_ws_bytes(M, N, K, with_rowsum != 0); }
+
+void d3f_debug_set_gemm_plan(int fa, int fb, int kw, int split) {
+  d3f::g_force_fa = fa;
+  d3f::g_force_fb = fb;
+  d3f::g_force_kw = kw;
+  d3f::g_force_split = split;
+}
 
 int d3f_gemm(const d3f_gemm_args* a, void* ws, size_t ws_bytes, void* stream) {
   if (!a) return D3F_EINVAL;

@@ -36,29 +36,19 @@ struct RevTest {
                              // layer, radius 2r): only its entries with d2 < r2 belong to the transposed table
 };
 
+// Feature gathers + MFMAs of one prepared chunk: lane l holds entry l of the (compacted) list -- its query index n_c
+// (Nq = none), that query's position and 1/nn (0 = none); `NSTEPS` 16-entry MFMA steps cover the live prefix.
 template <int CV, int NSTEPS>
-__device__ __forceinline__ void dxg_chunk(int n_lane, bool lane_live, __amdgpu_buffer_rsrc_t rs_q,
-                                          __amdgpu_buffer_rsrc_t rs_nn, __amdgpu_buffer_rsrc_t rs_g,
-                                          unsigned row_bytes, unsigned col_off, float cx, float cy, float cz,
-                                          float inv_extent, int lg, bool has_nn, const RevTest& rt, f32x4 (&acc)[CV]) {
+__device__ __forceinline__ void dxg_core(int n_c, float qx, float qy, float qz, float inn, __amdgpu_buffer_rsrc_t rs_g,
+                                         unsigned row_bytes, unsigned col_off, float cx, float cy, float cz,
+                                         float inv_extent, int lg, f32x4 (&acc)[CV]) {
   constexpr int NG = 4 * NSTEPS;
-  // the lane's own reverse neighbor: position and 1/nn (a shadow lane reads zeros and gets weight 0)
-  const float qx = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs_q, (unsigned)n_lane * 12u, 0, 0));
-  const float qy = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs_q, (unsigned)n_lane * 12u + 4u, 0, 0));
-  const float qz = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs_q, (unsigned)n_lane * 12u + 8u, 0, 0));
-  const float nnv = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs_nn, (unsigned)n_lane * 4u, 0, 0));
   typename VecT<CV>::type xv[NG];
 #pragma unroll
   for (int g = 0; g < NG; ++g) {
-    const unsigned n = (unsigned)__shfl(n_lane, 4 * g + lg, 64);
+    const unsigned n = (unsigned)__shfl(n_c, 4 * g + lg, 64);
     xv[g] = buf_load_vec<CV>(rs_g, n * row_bytes + col_off);
   }
-  if (rt.last_key && lane_live) {
-    const float d2 = sqdist_exact(qx, qy, qz, rt.sx, rt.sy, rt.sz);
-    const uint64_t key = ((uint64_t)__float_as_uint(d2) << 32) | rt.s;
-    lane_live = key <= rt.last_key[n_lane] && (rt.r2 <= 0.0f || d2 < rt.r2);
-  }
-  const float inn = lane_live ? (has_nn ? 1.0f / nnv : 1.0f) : 0.0f;
 #pragma unroll
   for (int g = 0; g < NG; ++g) {
     float4 sp;
@@ -73,6 +63,50 @@ __device__ __forceinline__ void dxg_chunk(int n_lane, bool lane_live, __amdgpu_b
   }
 }
 
+template <int CV>
+__device__ __forceinline__ void dxg_core_n(int steps, int n_c, float qx, float qy, float qz, float inn,
+                                           __amdgpu_buffer_rsrc_t rs_g, unsigned row_bytes, unsigned col_off, float cx,
+                                           float cy, float cz, float inv_extent, int lg, f32x4 (&acc)[CV]) {
+  if (steps == 1) dxg_core<CV, 1>(n_c, qx, qy, qz, inn, rs_g, row_bytes, col_off, cx, cy, cz, inv_extent, lg, acc);
+  else if (steps == 2) dxg_core<CV, 2>(n_c, qx, qy, qz, inn, rs_g, row_bytes, col_off, cx, cy, cz, inv_extent, lg, acc);
+  else if (steps == 3) dxg_core<CV, 3>(n_c, qx, qy, qz, inn, rs_g, row_bytes, col_off, cx, cy, cz, inv_extent, lg, acc);
+  else dxg_core<CV, 4>(n_c, qx, qy, qz, inn, rs_g, row_bytes, col_off, cx, cy, cz, inv_extent, lg, acc);
+}
+
+// Table form, one 64-entry chunk of the row of support s: membership of every entry FIRST (position + last key of the
+// entry's query: 20 bytes), live entries compacted to the front of the wave through a 64-entry LDS scratch, and only
+// then the Cout-wide gradient rows of the LIVE entries are gathered -- a pooling layer's transpose is the d2 < r2 head
+// of a row of the (radius 2r) upsampling table: 4x fewer gathers and one MFMA step instead of three.
+template <int CV>
+__device__ __forceinline__ void dxg_table_chunk(int n, float qx, float qy, float qz, float nnv, uint64_t lk, bool has_nn,
+                                                const RevTest& rt, int Nq, int last_lane, int32_t* status,
+                                                float4* scr4, float* scr1, __amdgpu_buffer_rsrc_t rs_g,
+                                                unsigned row_bytes, unsigned col_off, float cx, float cy, float cz,
+                                                float inv_extent, int lane, int lg, f32x4 (&acc)[CV]) {
+  const float d2 = sqdist_exact(qx, qy, qz, rt.sx, rt.sy, rt.sz);
+  const uint64_t key = ((uint64_t)__float_as_uint(d2) << 32) | rt.s;
+  const bool in_r = rt.r2 <= 0.0f || d2 < rt.r2;
+  const bool member = n < Nq && key <= lk && in_r;
+  // a full row of the wider search whose LAST entry is still within r: members may have been cut off
+  if (rt.r2 > 0.0f && status && lane == last_lane && n < Nq && d2 < rt.r2) atomicOr(status, D3F_ST_WIDE_OVERFLOW);
+  const uint64_t m = __ballot(member);
+  const int cnt = __popcll(m);
+  if (cnt == 0) return;
+  const int rank = __popcll(m & ((1ull << lane) - 1ull));
+  if (member) {
+    scr4[rank] = make_float4(qx, qy, qz, __int_as_float(n));
+    scr1[rank] = has_nn ? 1.0f / nnv : 1.0f;
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  const bool mine = lane < cnt;
+  const float4 c = scr4[mine ? lane : 0];
+  const float inn = mine ? scr1[lane] : 0.0f;
+  const int n_c = mine ? __float_as_int(c.w) : Nq;
+  __builtin_amdgcn_wave_barrier();
+  dxg_core_n<CV>((cnt + 15) >> 4, n_c, c.x, c.y, c.z, inn, rs_g, row_bytes, col_off, cx, cy, cz, inv_extent, lg, acc);
+}
+
 template <int CV, int NBW, int WK>
 __global__ __launch_bounds__(256) void kpconv_dx_gather_kernel(
     const float* __restrict__ s_pts, const float* __restrict__ q_pts, const int32_t* __restrict__ rev_ptr,
@@ -85,7 +119,9 @@ __global__ __launch_bounds__(256) void kpconv_dx_gather_kernel(
   extern __shared__ __attribute__((aligned(16))) float lds[];
   constexpr int RS = 16 * CC + 4;
   float* tile = lds;            // [16 rows][RS]: aggregated gradients A[s][k*CC + o]
-  float* red = lds + 16 * RS;   // [16][SLAB] when WK > 1
+  float4* scr4 = (float4*)(lds + 16 * RS) + (threadIdx.x >> 6) * 64;              // per wave: 64 compacted entries
+  float* scr1 = lds + 16 * RS + 4 * 256 + (threadIdx.x >> 6) * 64;                // (table form; 5 KB per workgroup)
+  float* red = lds + 16 * RS + 5 * 256;   // [16][SLAB] when WK > 1
 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int li = lane & 15, lg = lane >> 4;
@@ -118,6 +154,75 @@ __global__ __launch_bounds__(256) void kpconv_dx_gather_kernel(
     const int cbase = ch * CC;
     const unsigned col_off = (unsigned)(cbase + li * CV) * 4u;
     // ------------------------------------------------------------------ phase A: 4 rows per wave
+    if (last_key) {
+      // table form.  The index rows of the wave's four supports (two 64-entry chunks each) are fetched together, then
+      // position / last key / 1/nn of every first-chunk entry of all four rows: two memory round trips for four rows.
+      const int W = rev_width;
+      const __amdgpu_buffer_rsrc_t rs_lk = make_rsrc(last_key, (unsigned)Nq * 8u);
+      int nA[4], nB[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int s = s0 + wave * 4 + i;
+        const size_t rb = (size_t)min(s, Ns - 1) * W;
+        nA[i] = (s < Ns && lane < W) ? rev_ent[rb + lane] : Nq;
+        nB[i] = (s < Ns && 64 + lane < W) ? rev_ent[rb + 64 + lane] : Nq;
+      }
+      float qx[4], qy[4], qz[4], nv[4];
+      int lklo[4], lkhi[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        nA[i] = min(max(nA[i], 0), Nq);
+        nB[i] = min(max(nB[i], 0), Nq);
+        const unsigned n = (unsigned)nA[i];
+        qx[i] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs_q, n * 12u, 0, 0));
+        qy[i] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs_q, n * 12u + 4u, 0, 0));
+        qz[i] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs_q, n * 12u + 8u, 0, 0));
+        nv[i] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs_nn, n * 4u, 0, 0));
+        const u32x2v k2 = __builtin_amdgcn_raw_buffer_load_b64(rs_lk, n * 8u, 0, 0);
+        lklo[i] = (int)k2[0];
+        lkhi[i] = (int)k2[1];
+      }
+#pragma unroll 1
+      for (int i = 0; i < 4; ++i) {
+        const int s = s0 + wave * 4 + i;
+        f32x4 acc[CV];
+#pragma unroll
+        for (int r = 0; r < CV; ++r) acc[r] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (s < Ns) {
+          const float sx = s_pts[3 * (size_t)s + 0], sy = s_pts[3 * (size_t)s + 1], sz = s_pts[3 * (size_t)s + 2];
+          const float cx = sx - kx, cy = sy - ky, cz = sz - kz;
+          const RevTest rt = {last_key, sx, sy, sz, (unsigned)s, rev_r2};
+          int32_t* st = ch == 0 ? status : nullptr;
+          const uint64_t lk_i = ((uint64_t)(unsigned)lkhi[0] << 32) | (unsigned)lklo[0];
+          dxg_table_chunk<CV>(nA[0], qx[0], qy[0], qz[0], nv[0], lk_i,
+                              nn != nullptr, rt, Nq, W <= 64 ? W - 1 : -1, st, scr4, scr1, rs_g, row_bytes, col_off,
+                              cx, cy, cz, inv_extent, lane, lg, acc);
+          // rows longer than 64 entries (rare): further chunks on demand (the second one's indices are already here);
+          // entries are ranked with the shadow entries last, so the first all-shadow chunk ends the row
+          int nb = nB[0];
+          for (int c0 = 64; c0 < W; c0 += 64) {
+            if (c0 > 64) nb = (c0 + lane < W) ? min(max(rev_ent[(size_t)s * W + c0 + lane], 0), Nq) : Nq;
+            if (__ballot(nb < Nq) == 0ull) break;
+            const unsigned n = (unsigned)nb;
+            const float bx = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs_q, n * 12u, 0, 0));
+            const float by = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs_q, n * 12u + 4u, 0, 0));
+            const float bz = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs_q, n * 12u + 8u, 0, 0));
+            const float bn = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs_nn, n * 4u, 0, 0));
+            const u32x2v k2 = __builtin_amdgcn_raw_buffer_load_b64(rs_lk, n * 8u, 0, 0);
+            const int last = (W - 1 >= c0 && W - 1 < c0 + 64) ? W - 1 - c0 : -1;
+            dxg_table_chunk<CV>(nb, bx, by, bz, bn, ((uint64_t)k2[1] << 32) | k2[0], nn != nullptr, rt, Nq, last, st,
+                                scr4, scr1, rs_g, row_bytes, col_off, cx, cy, cz, inv_extent, lane, lg, acc);
+          }
+        }
+        store_wf_tile<CV>(tile + (wave * 4 + i) * RS, li, lg, acc);
+        // next row's registers move to slot 0 (a run-time index into the register arrays would put them in scratch)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+          nA[j] = nA[j + 1]; nB[j] = nB[j + 1]; qx[j] = qx[j + 1]; qy[j] = qy[j + 1]; qz[j] = qz[j + 1];
+          nv[j] = nv[j + 1]; lklo[j] = lklo[j + 1]; lkhi[j] = lkhi[j + 1];
+        }
+      }
+    } else
 #pragma unroll 1
     for (int i = 0; i < 4; ++i) {
       const int s = s0 + wave * 4 + i;
@@ -125,38 +230,21 @@ __global__ __launch_bounds__(256) void kpconv_dx_gather_kernel(
 #pragma unroll
       for (int r = 0; r < CV; ++r) acc[r] = (f32x4){0.f, 0.f, 0.f, 0.f};
       if (s < Ns) {
-        // CSR row, or row s of a fixed-width table (entries ranked, shadow entries = Nq at the end)
-        const int beg = rev_ptr ? __builtin_amdgcn_readfirstlane(rev_ptr[s]) : s * rev_width;
-        const int end = rev_ptr ? __builtin_amdgcn_readfirstlane(rev_ptr[s + 1]) : beg + rev_width;
+        // CSR row: every entry counts
+        const int beg = __builtin_amdgcn_readfirstlane(rev_ptr[s]);
+        const int end = __builtin_amdgcn_readfirstlane(rev_ptr[s + 1]);
         const float sx = s_pts[3 * (size_t)s + 0], sy = s_pts[3 * (size_t)s + 1], sz = s_pts[3 * (size_t)s + 2];
         const float cx = sx - kx, cy = sy - ky, cz = sz - kz;
-        const RevTest rt = {last_key, sx, sy, sz, (unsigned)s, rev_r2};
         for (int c0 = beg; c0 < end; c0 += 64) {
-          int rem = end - c0;
-          int n = lane < rem ? min(max(rev_ent[(size_t)c0 + lane], 0), Nq) : Nq;
-          if (!rev_ptr) {  // table form: the live prefix of this chunk
-            rem = __popcll(__ballot(n < Nq));
-            if (rem == 0) break;
-            if (rev_r2 > 0.0f && status && ch == 0 && c0 + 64 >= end) {
-              // a full row of the wider search whose last entry is still within r: members may have been cut off
-              const int last = __shfl(n, (end - c0 - 1) & 63, 64);
-              if (last < Nq && lane == 0) {
-                const float d2 = sqdist_exact(q_pts[3 * (size_t)last], q_pts[3 * (size_t)last + 1],
-                                              q_pts[3 * (size_t)last + 2], sx, sy, sz);
-                if (d2 < rev_r2) atomicOr(status, D3F_ST_WIDE_OVERFLOW);
-              }
-            }
-          }
-          const bool live = lane < rem && n < Nq;
-          const int steps = (min(rem, 64) + 15) >> 4;
-          if (steps == 3)
-            dxg_chunk<CV, 3>(n, live, rs_q, rs_nn, rs_g, row_bytes, col_off, cx, cy, cz, inv_extent, lg, nn != nullptr, rt, acc);
-          else if (steps == 1)
-            dxg_chunk<CV, 1>(n, live, rs_q, rs_nn, rs_g, row_bytes, col_off, cx, cy, cz, inv_extent, lg, nn != nullptr, rt, acc);
-          else if (steps == 2)
-            dxg_chunk<CV, 2>(n, live, rs_q, rs_nn, rs_g, row_bytes, col_off, cx, cy, cz, inv_extent, lg, nn != nullptr, rt, acc);
-          else
-            dxg_chunk<CV, 4>(n, live, rs_q, rs_nn, rs_g, row_bytes, col_off, cx, cy, cz, inv_extent, lg, nn != nullptr, rt, acc);
+          const int rem = min(end - c0, 64);
+          const int n = lane < rem ? min(max(rev_ent[(size_t)c0 + lane], 0), Nq) : Nq;
+          // the lane's own reverse neighbor: position and 1/nn (a shadow lane reads zeros and gets weight 0)
+          const float qx = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs_q, (unsigned)n * 12u, 0, 0));
+          const float qy = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs_q, (unsigned)n * 12u + 4u, 0, 0));
+          const float qz = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs_q, (unsigned)n * 12u + 8u, 0, 0));
+          const float nnv = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs_nn, (unsigned)n * 4u, 0, 0));
+          const float inn = (lane < rem && n < Nq) ? (nn ? 1.0f / nnv : 1.0f) : 0.0f;
+          dxg_core_n<CV>((rem + 15) >> 4, n, qx, qy, qz, inn, rs_g, row_bytes, col_off, cx, cy, cz, inv_extent, lg, acc);
         }
       }
       store_wf_tile<CV>(tile + (wave * 4 + i) * RS, li, lg, acc);
@@ -246,7 +334,7 @@ static int launch_dxg(const float* s_pts, const float* q_pts, const int32_t* rev
                       int32_t* status, hipStream_t stream) {
   const int tiles = cdiv(Ns, 16);
   constexpr int CC = 16 * CV;
-  const size_t lds_base = sizeof(float) * (size_t)(16 * (16 * CC + 4));
+  const size_t lds_base = sizeof(float) * (size_t)(16 * (16 * CC + 4) + 5 * 256);  // tile + compaction scratch
   int slab = Cin;  // few rows: split the input channels over workgroups (deterministic; no reduction split)
   while (slab > 64 && (long long)tiles * (Cin / slab) < 512) slab >>= 1;
 #define D3F_DXG(NBW, WK)                                                                                            \

@@ -84,35 +84,44 @@ batch_grid_subsampling = batch_grid_subsampling_kpconv
 
 
 class _Walk:
-    """The reference's block walk (dataloader.py:98-178): which layers convolve, which pool, with what radius."""
+    """Which pyramid levels convolve, which pool, and with what radii -- the schedule the reference derives while it
+    walks ``config.architecture`` (dataloader.py:98-178), here computed up front as one entry per level:
+    ``conv_r`` (None when the level has no convolution), ``pool`` and, for pooling levels, ``dl`` / ``pool_r`` / ``up_r``."""
 
     def __init__(self, config):
-        self.layers = []  # dicts: conv_r (or None), pool (bool), pool_r, dl, up_r
-        r_normal = config.first_subsampling_dl * config.conv_radius
-        layer_blocks = []
-        arch = config.architecture
-        for block_i, block in enumerate(arch):
-            if 'global' in block or 'upsample' in block:
+        self.layers = [self._entry(config, run, closing, level)
+                       for level, (run, closing) in enumerate(self._levels(config.architecture))]
+
+    @staticmethod
+    def _levels(architecture):
+        """[(same-resolution blocks, closing pool / strided block or None)] of the encoder (everything before the first
+        'global' / 'upsample' block)."""
+        levels, run = [], []
+        for name in architecture:
+            if 'global' in name or 'upsample' in name:
                 break
-            if not ('pool' in block or 'strided' in block):
-                layer_blocks += [block]
-                if block_i < len(arch) - 1 and not ('upsample' in arch[block_i + 1]):
-                    continue
-            entry = {'conv_r': None, 'pool': False}
-            if layer_blocks:
-                if np.any(['deformable' in blck for blck in layer_blocks[:-1]]):
-                    entry['conv_r'] = r_normal * config.deform_radius / config.conv_radius
-                else:
-                    entry['conv_r'] = r_normal
-            if 'pool' in block or 'strided' in block:
-                entry['pool'] = True
-                entry['dl'] = 2 * r_normal / config.conv_radius
-                entry['pool_r'] = (r_normal * config.deform_radius / config.conv_radius) if 'deformable' in block \
-                    else r_normal
-                entry['up_r'] = 2 * entry['pool_r']
-            self.layers.append(entry)
-            r_normal *= 2
-            layer_blocks = []
+            if 'pool' in name or 'strided' in name:
+                levels.append((run, name))
+                run = []
+            else:
+                run.append(name)
+        if run:
+            levels.append((run, None))
+        return levels
+
+    @staticmethod
+    def _entry(config, run, closing, level):
+        r_normal = config.first_subsampling_dl * config.conv_radius * 2 ** level
+        r_deform = r_normal * config.deform_radius / config.conv_radius
+        entry = {'conv_r': None, 'pool': closing is not None}
+        if run:
+            # the reference looks at every block of the level but the last one (`layer_blocks[:-1]`, dataloader.py:118)
+            entry['conv_r'] = r_deform if any('deformable' in name for name in run[:-1]) else r_normal
+        if closing is not None:
+            entry['dl'] = 2 * r_normal / config.conv_radius
+            entry['pool_r'] = r_deform if 'deformable' in closing else r_normal
+            entry['up_r'] = 2 * entry['pool_r']
+        return entry
 
 
 def _conv_table(grid_for, pts, lens, level, e, lim, reverse_tables, want_max=False, group=0):

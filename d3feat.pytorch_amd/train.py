@@ -352,6 +352,11 @@ class TrainStep:
                                 inputs=self.flat.params[:self.n_shallow])
         self.flat.gather_grads(0, self.n_shallow)
 
+    def _poison_if_flagged(self, grad, pair_status):
+        """A flagged pair makes its gradient non-finite before the exchange (d3f_poison_gradient_if_status) and parks
+        the flags in the optimizer state: the guard on the REDUCED gradient then skips the step on every rank."""
+        ops.poison_gradient_if_status(grad, pair_status, self.opt.state)
+
     def _exchange_and_step(self, after_deep, after_shallow, pair_status=None):
         """after_deep(): runs/launches stage 1; after_shallow(): stage 2.  The deep bucket's all-reduce is in flight
         while stage 2 executes.  ``pair_status``: this rank's pair status word -- with several ranks a flagged pair
@@ -360,13 +365,7 @@ class TrainStep:
         g = self.flat.grad
         works = []
         if self.world > 1 and pair_status is not None:
-            if g.is_cuda:
-                ops.poison_gradient_if_status(g[self.numel_shallow:], pair_status, self.opt.state)
-            else:   # host tensors (gloo tests of the exchange logic): the same arithmetic in torch
-                bad = pair_status.reshape(-1)[0] != 0
-                g[self.numel_shallow] = torch.where(bad, torch.full((), float('nan')), g[self.numel_shallow])
-                self.opt.state[2] |= pair_status.reshape(-1)[0].to(self.opt.state.dtype)
-                self.opt.state[3] += bad.to(self.opt.state.dtype)
+            self._poison_if_flagged(g[self.numel_shallow:], pair_status)
             pair_status = None
         if self.world > 1:
             deep = g[self.numel_shallow:]

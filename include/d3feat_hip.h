@@ -42,6 +42,10 @@ const char* d3f_version(void);
 int d3f_device_arch_ok(void); /* 1 if the current HIP device is gfx950, 0 otherwise, <0 = -(hipError_t) */
 int d3f_device_arch_name(char* out, int n); /* gcnArchName of the current device */
 void d3f_debug_set_flags(int flags);      /* profiling aid: ablation switches of the fused KPConv kernels (0 = off) */
+/* measurement aid (profiles/gemm_microbench.py): force the decomposition of d3f_gemm (0 = heuristic for each) -- fa =
+ * 1 | 2 fragments per wave along M for a KC-layout A, fb = 2 | 4 along N for a KC-layout B, kw = 1 | 2 | 4 | 8 waves of a
+ * workgroup splitting the reduction of one tile, split >= 1 grid-level slices of the reduction. */
+void d3f_debug_set_gemm_plan(int fa, int fb, int kw, int split);
 /* measurement aid (bench.py roofline leg): HIP events on the launch stream around every launch of ONE kernel
  * (which = 1 fused KPConv forward kernel, 2 scatter-form grad-input kernel, 3 gather-form grad-input kernel; or,
  * negative, minus a bit mask of several: -(1 | 2 | 4)) between begin and end.  end -- after the caller synchronised
@@ -251,7 +255,7 @@ int d3f_closest_pool_backward(const float* grad_out, int ld, const int32_t* idx,
  *   so  y = x W^T (KC,KC),  grad_x = g W (KC,KS),  grad_W = g^T x (KS,KS),  wf W (KC,KS),  g W^T (KC,KC)  need no
  *   transposed copies.  Contiguous extents and leading dimensions must be multiples of 4 floats, bases 16-B aligned.
  *   prologue : a_mask (optional, same shape/layout as A): A' = A * (a_mask > 0 ? 1 : mask_slope) -- the LeakyReLU
- *              backward evaluated on the saved block output while the tile is staged.
+ *              backward evaluated on the saved block output while the operand is loaded.
  *   by-product: rowsum / rowsum2 (optional, [M], KS layout of A only): sum_k A'[m][k] -- the bias gradient when
  *              A' = (masked gradient)^T in the weight-gradient GEMM; both buffers receive the same sums.
  *   epilogue : v = acc (/ row_div[m]) + bias1[n] + add[m*ldadd + n] + bias2[n];  C = v > 0 ? v : slope*v  (slope = 1:
@@ -260,6 +264,7 @@ int d3f_closest_pool_backward(const float* grad_out, int ld, const int32_t* idx,
  *   zero_init (optional, zero_n floats) is cleared on the side (backward accumulators of the caller).
  * Few-row / deep-reduction shapes split the reduction over workgroups; partial tiles are summed in a fixed order by a
  * second launch that applies the epilogue (d3f_gemm_ws_bytes > 0 for those shapes).  Results are bit-reproducible.
+ * With a KS-layout B, C and ldc must be 16-byte / 4-float aligned as well (float4 stores); rowsum buffers likewise.
  * ---------------------------------------------------------------------------------------------- */
 #define D3F_GEMM_KC 0
 #define D3F_GEMM_KS 1

@@ -1,5 +1,5 @@
 """Do two independent small-grid kernels captured on two streams inside ONE hipGraph overlap on replay?
-python profiles/graph_branch_test.py"""
+python profiles/graph_branch_experiment.py"""
 import torch
 dev = torch.device("cuda:0")
 g = torch.randn(159, 512, device=dev)

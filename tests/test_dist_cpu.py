@@ -86,6 +86,15 @@ def _split_worker(rank, world, port, ret):
     eng.opt = GuardedSGD(eng.flat, lr=0.1, momentum=0.9, weight_decay=1e-3)
     eng.opt.grad_scale = 1.0 / world
     eng.numel_shallow = sum(p.numel() for p in model[0].parameters())      # "fine levels" = the first layer
+
+    def host_poison(grad, pair_status):
+        """d3f_poison_gradient_if_status restated on host tensors (the product calls the HIP kernel): first element of
+        the bucket -> NaN when the status word is set, flags OR-ed into state[2], skip count into state[3]."""
+        bad = pair_status.reshape(-1)[0] != 0
+        grad[0] = torch.where(bad, torch.full((), float('nan')), grad[0])
+        eng.opt.state[2] |= pair_status.reshape(-1)[0].to(eng.opt.state.dtype)
+        eng.opt.state[3] += bad.to(eng.opt.state.dtype)
+    eng._poison_if_flagged = host_poison
     ref_opt = torch.optim.SGD(ref.parameters(), lr=0.1, momentum=0.9, weight_decay=1e-3)
     ok = True
     for step in range(4):
@@ -143,3 +152,21 @@ def test_flat_params_views_track_module():
     f.zero_grad()
     assert m.weight.grad is None
     assert float(f.gather_grads().abs().sum()) == 0.0  # parameters without a gradient contribute zeros
+
+
+def test_bench_launched_plainly_with_gpus_2_runs_two_ranks():
+    """`python bench.py --gpus 2` without a launcher must yield n_gpus == 2 (it spawns its ranks through
+    torch.distributed.run) and a rank count that disagrees with --gpus must fail instead of running 1 rank; the
+    rendezvous-only mode does exactly the launch + process-group part, over gloo, without a GPU."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--rendezvous-only"], cwd=REPO, env=env,
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1 and json.loads(lines[0]) == {"n_gpus": 2, "ranks": 2, "rendezvous_only": True}
+    # a launcher that provides a different world size than --gpus asks for is an error, not a silent 1-rank run
+    bad = subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--rendezvous-only"], cwd=REPO,
+                         env=dict(env, WORLD_SIZE="1", RANK="0"), capture_output=True, text=True, timeout=300)
+    assert bad.returncode != 0 and "WORLD_SIZE=1" in (bad.stderr + bad.stdout)

@@ -642,7 +642,8 @@ def test_trainer_consumes_threedmatch_pickles(golden_s0, tmp_path):
 
 
 def test_two_rank_bench_control_flow_on_one_gpu():
-    """bench.py as the driver launches it for N = 2 (torch.distributed.run), both ranks on cuda:0 with gloo standing in
+    """bench.py --gpus 2 launched plainly (it re-launches itself through torch.distributed.run, the driver's command
+    for N = 2), both ranks on cuda:0 with gloo standing in
     for RCCL (which refuses two ranks on one device): rank start-up broadcast, graph capture with a live process
     group, split backward + bucketed exchange, max-over-ranks timing, the single JSON line -- and replicas that stay
     bit-identical."""
@@ -652,15 +653,16 @@ def test_two_rank_bench_control_flow_on_one_gpu():
     import sys
     repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, D3F_BENCH_SHARE_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
-           "127.0.0.1", "--master-port", "29517", "bench.py", "--gpus", "2", "--steps", "4", "--warmup", "2", "--pairs",
-           "2", "--no-cpu-baseline"]
+    env.pop("WORLD_SIZE", None)
+    # launched PLAINLY: bench.py spawns its ranks through torch.distributed.run itself (and refuses to run 1 rank as 2)
+    cmd = [sys.executable, "bench.py", "--gpus", "2", "--steps", "4", "--warmup", "2", "--pairs", "2", "--no-cpu-baseline"]
     r = subprocess.run(cmd, cwd=repo, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith('{"metric"')]
     assert len(lines) == 1, r.stdout[-2000:]
     res = json.loads(lines[0])
     assert res["n_gpus"] == 2 and res["steps"] == 4 and res["scaling"] == "weak" and res["value"] > 0
+    assert abs(res["value_per_gpu"] * 2 - res["value"]) < 0.01 * res["value"]
     cfg = res["config"]
     assert cfg["parallelism"] == "dp2" and cfg["launch"].startswith("hipGraph replay")
     assert cfg["replica_param_checksum_spread"] == 0.0 and cfg["skipped_steps"] == 0

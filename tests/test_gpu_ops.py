@@ -97,6 +97,35 @@ def test_grid_subsample_features_and_labels_bitexact(native, n, n_labels, ldim, 
     assert np.array_equal(c.cpu().numpy(), native.subsample_batch_ex(pts, lens, None, labels[:, :1], sampleDl=dl_)[2])
 
 
+def test_native_module_spelling_of_subsample_batch_with_features_and_classes(native):
+    """grid_subsampling.subsample_batch(points, batches, features=, classes=, sampleDl=) and .subsample(...) -- the
+    reference's CPython module (cpp_subsampling/wrapper.cpp:75-82,316-322,350-356,550-556): NumPy in, NumPy out, all
+    four return shapes, through d3f_grid_subsample_ex."""
+    from d3feat_pytorch_amd.cpp_wrappers.cpp_subsampling import grid_subsampling as gs
+    rng = np.random.default_rng(77)
+    n = [1800, 1100]
+    pts, lens = _cloud(rng, sum(n)), np.array(n, np.int32)
+    feats = rng.normal(size=(sum(n), 3)).astype(np.float32)
+    labels = rng.integers(0, 6, size=(sum(n), 1)).astype(np.int32)
+    ref = native.subsample_batch_ex(pts, lens, feats, labels, sampleDl=0.15)
+    got = gs.subsample_batch(pts, lens, features=feats, classes=labels, sampleDl=0.15)
+    assert len(got) == 4 and all(isinstance(g, np.ndarray) for g in got)
+    for g, r in zip(got, ref):
+        assert g.shape == r.shape and g.dtype == r.dtype and np.array_equal(g.view(np.uint32), r.view(np.uint32))
+    pf = gs.subsample_batch(pts, lens, features=feats, sampleDl=0.15)
+    assert len(pf) == 3 and np.array_equal(pf[2], native.subsample_batch_ex(pts, lens, feats, None, sampleDl=0.15)[2])
+    pc = gs.subsample_batch(pts, lens, classes=labels, sampleDl=0.15)
+    assert len(pc) == 3 and pc[2].dtype == np.int32 and np.array_equal(pc[2], ref[3])
+    # single-cloud form: points alone, or (points, features, classes)
+    one = native.subsample_batch_ex(pts[:n[0]], lens[:1], feats[:n[0]], labels[:n[0]], sampleDl=0.15)
+    p_only = gs.subsample(pts[:n[0]], sampleDl=0.15)
+    assert isinstance(p_only, np.ndarray) and np.array_equal(p_only, one[0])
+    p3 = gs.subsample(pts[:n[0]], features=feats[:n[0]], classes=labels[:n[0]], sampleDl=0.15)
+    assert len(p3) == 3 and np.array_equal(p3[0], one[0]) and np.array_equal(p3[1], one[2]) and np.array_equal(p3[2], one[3])
+    with pytest.raises(RuntimeError):
+        gs.subsample_batch(pts, lens, sampleDl=0.15, method="nonsense")
+
+
 @pytest.mark.parametrize("radius,limit", [(0.12, 40), (0.2, 64), (0.2, 0), (0.35, 130)])
 def test_radius_neighbors_exact(native, radius, limit):
     rng = np.random.default_rng(7)
