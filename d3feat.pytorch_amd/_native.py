@@ -23,6 +23,7 @@ SIGNATURES = {
     "d3f_device_arch_name": (_i, [C.c_char_p, _i]),
     "d3f_debug_set_flags": (None, [_i]),
     "d3f_debug_set_gemm_plan": (None, [_i, _i, _i, _i]),
+    "d3f_debug_set_phase_clock": (None, [_vp]),
     "d3f_debug_kernel_timing_begin": (_i, [_i, _i]),
     "d3f_debug_kernel_timing_end": (_i, [_vp, _vp, _i]),
     "d3f_radius_grid_ws_bytes": (_sz, [_i]),
@@ -56,7 +57,9 @@ SIGNATURES = {
     "d3f_reverse_table_ws_bytes": (_sz, [_i, _i, _i]),
     "d3f_reverse_table_build": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _sz, _vp]),
     "d3f_kpconv_grad_input_gather_supported": (_i, [_i, _i, _i]),
-    "d3f_kpconv_grad_input_gather": (_i, [_vp, _i, _vp, _i, _vp, _vp, _vp, _i, _f, _vp, _i, _vp, _i, _i, _f, _vp, _vp, _vp, _vp, _vp]),
+    "d3f_kpconv_grad_input_gather": (_i, [_vp, _i, _vp, _i, _vp, _vp, _vp, _i, _f, _vp, _vp, _i, _vp, _i, _i, _f, _vp, _vp, _vp,
+                                          _vp, _vp]),
+    "d3f_reverse_table_filter": (_i, [_vp, _i, _vp, _vp, _i, _vp, _i, _f, _vp, _vp, _vp]),
     "d3f_linear_grad_weight_supported": (_i, [_i, _i, _i]),
     "d3f_linear_fused_supported": (_i, [_i, _i, _i]),
     "d3f_linear_bias_act_forward": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp, _f, _vp, _vp, _i, _vp]),

@@ -92,6 +92,43 @@ __device__ __forceinline__ float sqdist_exact(float ax, float ay, float az, floa
 
 __device__ __forceinline__ int lane_id() { return threadIdx.x & (D3F_WAVE - 1); }
 
+// Measurement aid (d3f_debug_set_phase_clock): per-phase shader cycles of a kernel's waves.  `out` (device uint64, null
+// in normal operation): out[0] = number of waves recorded (atomic ticket, taken once per wave at its end), out[1] =
+// record capacity; record r (8 words) starts at out[8 + 8 r] and holds the cycles the wave spent before each lap(i).
+// The laps live in scalar registers until the wave's last instruction: no memory operation of the clock sits inside
+// the measured phases (an atomic per lap would queue behind the kernel's own loads and be waited for by its vmcnt).
+struct PhaseClock {
+  unsigned long long* out;
+  unsigned long long t, acc[6];
+  __device__ __forceinline__ void start(unsigned long long* o) {
+    out = o;
+    if (out) {
+#pragma unroll
+      for (int i = 0; i < 6; ++i) acc[i] = 0;
+      t = __builtin_readcyclecounter();
+    }
+  }
+  __device__ __forceinline__ void lap(int i) {
+    if (out) {
+      const unsigned long long n = __builtin_readcyclecounter();
+#pragma unroll
+      for (int j = 0; j < 6; ++j)
+        if (j == i) acc[j] += n - t;
+      t = n;
+    }
+  }
+  __device__ __forceinline__ void done() {
+    if (out && (threadIdx.x & 63) == 0) {
+      const unsigned long long r = atomicAdd(out, 1ull);
+      if (r < out[1]) {
+#pragma unroll
+        for (int j = 0; j < 6; ++j) out[8 + 8 * r + j] = acc[j];
+      }
+    }
+  }
+};
+unsigned long long* phase_clock_ptr();   // kpconv_fused.hip
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

@@ -429,7 +429,7 @@ static GemmPlan gemm_plan(int M, int N, int K, bool aks, bool bks) {
   pl.split = 1;
   if (pl.kw == 8 && want >= 24) {                       // the second launch has to buy >= 3x the waves
     long long s = want / 8;
-    if (s > 16) s = 16;
+    if (s > 4) s = 4;                                   // (measured: beyond 4 slices the slab round trip eats the gain)
     pl.split = (int)s;
   }
   if (g_force_split >= 1) pl.split = g_force_split > chunks ? chunks : g_force_split;

@@ -605,14 +605,16 @@ int d3f_grid_subsample_ex(const float* points, int N, const int32_t* len, int B,
                                                         L.ncell);
   scatter_kernel<<<d3f::cdiv(N, 256), 256, 0, stream>>>(N, len, B, L.slot_of, L.tfill, L.members);
   cell_sum_kernel<<<d3f::cdiv(L.M, 256), 256, 0, stream>>>(L.M, points, L.tcount, L.tstart, L.members, L.bary);
-  static int lds_cap = -1;   // 80 KB of dynamic LDS needs the opt-in; without it the bucket tables stay in global memory
-  if (lds_cap < 0) {
+  // 80 KB of dynamic LDS needs the opt-in, which is a per-DEVICE function attribute: asked for on every call (it is a
+  // host-side table update, no stream operation; a process may drive several devices and threads).  Without it the
+  // bucket tables stay in global memory.
+  int lds_cap = 0;
+  {
     const size_t want = 4 * sizeof(int32_t) * (size_t)kLdsBuckets;
-    lds_cap = hipFuncSetAttribute((const void*)order_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)want) ==
-                      hipSuccess
-                  ? kLdsBuckets
-                  : 0;
-    (void)hipGetLastError();
+    if (hipFuncSetAttribute((const void*)order_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)want) == hipSuccess)
+      lds_cap = kLdsBuckets;
+    else
+      (void)hipGetLastError();
   }
   order_kernel<<<B, kOrderThreads, 4 * sizeof(int32_t) * (size_t)lds_cap, stream>>>(
       len, B, max_p, order, sched, L.bitmap, L.wprefix, L.slot_of, L.tkey, L.bary, L.ncell, L.seq_key, L.seq_slot,

@@ -265,6 +265,7 @@ using namespace d3f;
 
 namespace d3f {
 void kpconv_set_debug_flags(int f);
+void set_phase_clock(unsigned long long* p);
 int kpconv_timing_begin(int which, int max_launches);
 int kpconv_timing_end(float* ms_out, int* shapes_out, int cap);
 }
@@ -273,6 +274,7 @@ extern "C" {
 
 // profiling aid (not part of the operator contract): run-time ablation switches of the fused forward kernel
 void d3f_debug_set_flags(int flags) { d3f::kpconv_set_debug_flags(flags); }
+void d3f_debug_set_phase_clock(void* counters) { d3f::set_phase_clock((unsigned long long*)counters); }
 
 // measurement aid: HIP events on the launch stream around every launch of one kernel (which = 1: fused KPConv
 // forward kernel, 2: KPConv grad-input kernel) between begin and end; end (after a device synchronisation by the

@@ -113,7 +113,9 @@ __global__ __launch_bounds__(256) void kpconv_dx_gather_kernel(
     const int32_t* __restrict__ rev_ent, const float* __restrict__ gout, const float* __restrict__ nn,
     const float* __restrict__ kp, const float* __restrict__ W, int Ns, int Nq, int Cin, int Cout, int K, float extent,
     float* __restrict__ gx, const uint64_t* __restrict__ last_key, int rev_width, float rev_r2,
-    int32_t* __restrict__ status) {
+    int32_t* __restrict__ status, unsigned long long* __restrict__ clk, const float4* __restrict__ rev_rel) {
+  PhaseClock pc;   // laps: 0 prologue, 1 index + position loads of the 4 rows, 2 rows (membership, gathers, MFMAs),
+  pc.start(clk);   //       3 barrier wait, 4 phase B, 5 second barrier + store
   constexpr int CC = 16 * CV;
   constexpr int WN = 4 / WK;
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -150,11 +152,67 @@ __global__ __launch_bounds__(256) void kpconv_dx_gather_kernel(
 
   const unsigned row_bytes = (unsigned)Cout * 4u;
   const int nchunks = Cout / CC;
+  pc.lap(0);
   for (int ch = 0; ch < nchunks; ++ch) {
     const int cbase = ch * CC;
     const unsigned col_off = (unsigned)(cbase + li * CV) * 4u;
     // ------------------------------------------------------------------ phase A: 4 rows per wave
-    if (last_key) {
+    if (rev_rel) {
+      // exact form (d3f_reverse_table_filter): row s = its true reverse neighbors, compacted, as {q - s, q}: one coalesced
+      // kilobyte per row and a 4-byte gather of 1/nn per entry; the kernel points are seen from s itself (centre = -kp).
+      // (A software-pipelined variant -- row i + 1's gradient-row gathers in flight under row i's MFMAs -- halved the
+      // cycles per wave but needs 204 instead of 160 VGPRs at 32 channels, one occupancy step: 53.1 vs 50.4 us per
+      // launch, profiles/r03_kpconv_phase_clock.txt; the kernel has no saturated unit -- MFMA 0.20, VALU 0.31, LDS 0.35,
+      // TA 0.31 busy -- it is bound by how many dependent phases the resident waves overlap.)
+      const int W = rev_width;
+      float4 eA[4];
+      float nvA[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int s = s0 + wave * 4 + i;
+        // (unconditional load from a clamped address + a select on the VALUE: a conditional load with a constant
+        // alternative becomes a select of pointers into scratch)
+        eA[i] = rev_rel[(size_t)min(s, Ns - 1) * W + min(lane, W - 1)];
+        if (!(s < Ns && lane < W)) eA[i].w = __int_as_float(Nq);
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        nvA[i] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(
+            rs_nn, (unsigned)min(max(__float_as_int(eA[i].w), 0), Nq) * 4u, 0, 0));
+      if (clk) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        pc.lap(1);
+      }
+#pragma unroll 1
+      for (int i = 0; i < 4; ++i) {
+        const int s = s0 + wave * 4 + i;
+        f32x4 acc[CV];
+#pragma unroll
+        for (int r = 0; r < CV; ++r) acc[r] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (s < Ns) {
+          float4 e = eA[0];
+          float nv = nvA[0];
+          for (int c0 = 0; c0 < W; c0 += 64) {
+            if (c0 > 0) {   // rows longer than 64 entries (rare)
+              e = rev_rel[(size_t)s * W + min(c0 + lane, W - 1)];
+              if (c0 + lane >= W) e.w = __int_as_float(Nq);
+              nv = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(
+                  rs_nn, (unsigned)min(max(__float_as_int(e.w), 0), Nq) * 4u, 0, 0));
+            }
+            const int n = min(max(__float_as_int(e.w), 0), Nq);
+            const int cnt = __popcll(__ballot(n < Nq));     // compacted: the live entries are a prefix
+            if (cnt == 0) break;
+            const float inn = n < Nq ? (nn ? 1.0f / nv : 1.0f) : 0.0f;
+            dxg_core_n<CV>((cnt + 15) >> 4, n, e.x, e.y, e.z, inn, rs_g, row_bytes, col_off, -kx, -ky, -kz, inv_extent,
+                           lg, acc);
+            if (cnt < 64) break;
+          }
+        }
+        store_wf_tile<CV>(tile + (wave * 4 + i) * RS, li, lg, acc);
+#pragma unroll
+        for (int j = 0; j < 3; ++j) { eA[j] = eA[j + 1]; nvA[j] = nvA[j + 1]; }
+      }
+    } else if (last_key) {
       // table form.  The index rows of the wave's four supports (two 64-entry chunks each) are fetched together, then
       // position / last key / 1/nn of every first-chunk entry of all four rows: two memory round trips for four rows.
       const int W = rev_width;
@@ -181,6 +239,10 @@ __global__ __launch_bounds__(256) void kpconv_dx_gather_kernel(
         const u32x2v k2 = __builtin_amdgcn_raw_buffer_load_b64(rs_lk, n * 8u, 0, 0);
         lklo[i] = (int)k2[0];
         lkhi[i] = (int)k2[1];
+      }
+      if (clk) {   // (only when measuring: wait for the batched loads so that lap 1 is their latency)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        pc.lap(1);
       }
 #pragma unroll 1
       for (int i = 0; i < 4; ++i) {
@@ -249,7 +311,9 @@ __global__ __launch_bounds__(256) void kpconv_dx_gather_kernel(
       }
       store_wf_tile<CV>(tile + (wave * 4 + i) * RS, li, lg, acc);
     }
+    pc.lap(2);
     __syncthreads();
+    pc.lap(3);
     // ------------------------------------------------------------------ phase B: out[16 x SLAB] += tile @ W^T
     const int steps = (K * CC) >> 4;
     constexpr int BS = NBW >= 8 ? 1 : (NBW == 4 ? 2 : (NBW == 2 ? 4 : 8));
@@ -282,6 +346,7 @@ __global__ __launch_bounds__(256) void kpconv_dx_gather_kernel(
         }
       }
     }
+    pc.lap(4);
     __syncthreads();
   }
   // ------------------------------------------------------------------ store
@@ -319,6 +384,8 @@ __global__ __launch_bounds__(256) void kpconv_dx_gather_kernel(
       if (s0 + rowl < Ns) gx[(size_t)(s0 + rowl) * Cin + col] = red[t];
     }
   }
+  pc.lap(5);
+  pc.done();
 }
 
 bool kpconv_dx_gather_supported(int Cin, int Cout, int K) {
@@ -331,7 +398,7 @@ template <int CV>
 static int launch_dxg(const float* s_pts, const float* q_pts, const int32_t* rev_ptr, const int32_t* rev_ent,
                       const float* gout, const float* nn, const float* kp, const float* W, int Ns, int Nq, int Cin,
                       int Cout, int K, float extent, float* gx, const uint64_t* last_key, int rev_width, float rev_r2,
-                      int32_t* status, hipStream_t stream) {
+                      int32_t* status, const float4* rev_rel, hipStream_t stream) {
   const int tiles = cdiv(Ns, 16);
   constexpr int CC = 16 * CV;
   const size_t lds_base = sizeof(float) * (size_t)(16 * (16 * CC + 4) + 5 * 256);  // tile + compaction scratch
@@ -343,7 +410,8 @@ static int launch_dxg(const float* s_pts, const float* q_pts, const int32_t* rev
     dim3 grid(tiles, Cin / slab);                                                                                   \
     kpconv_dx_gather_kernel<CV, NBW, WK><<<grid, 256, lds, stream>>>(s_pts, q_pts, rev_ptr, rev_ent, gout, nn, kp, W, \
                                                                       Ns, Nq, Cin, Cout, K, extent, gx, last_key,    \
-                                                                      rev_width, rev_r2, status);                    \
+                                                                      rev_width, rev_r2, status, phase_clock_ptr(), \
+                                                                      rev_rel);                                     \
   }
   void* timing = kpconv_timing_open(3, stream, Nq, Ns, 0, Cin, Cout, K);
   switch (slab) {
@@ -371,23 +439,28 @@ int d3f_kpconv_grad_input_gather_supported(int Cin, int Cout, int K) {
 
 int d3f_kpconv_grad_input_gather(const float* q_pts, int Nq, const float* s_pts, int Ns, const int32_t* rev_ptr,
                                  const int32_t* rev_ent, const uint64_t* rev_last_key, int rev_width, float rev_radius,
-                                 const float* kernel_points, int K, const float* weights, int Cin, int Cout,
-                                 float extent, const float* nn, const float* grad_out, float* grad_x, int32_t* status,
-                                 void* stream) {
-  if (!q_pts || !s_pts || !rev_ent || !kernel_points || !weights || !grad_out || !grad_x || Nq < 0 || Ns < 0 ||
+                                 const float* rev_rel, const float* kernel_points, int K, const float* weights, int Cin,
+                                 int Cout, float extent, const float* nn, const float* grad_out, float* grad_x,
+                                 int32_t* status, void* stream) {
+  if (!q_pts || !s_pts || !kernel_points || !weights || !grad_out || !grad_x || Nq < 0 || Ns < 0 ||
       !d3f::kpconv_dx_gather_supported(Cin, Cout, K) || !(extent > 0.0f))
     return D3F_EINVAL;
-  // exactly one of the two forms: CSR (rev_ptr) or fixed-width table with the membership keys
-  if ((rev_ptr != nullptr) == (rev_last_key != nullptr) || (!rev_ptr && rev_width < 1)) return D3F_EINVAL;
+  // exactly one of the three forms: CSR (rev_ptr + rev_ent), search form (rev_ent + rev_last_key), exact form (rev_rel)
+  if (rev_rel) {
+    if (rev_ptr || rev_ent || rev_last_key || rev_width < 1 || ((uintptr_t)rev_rel & 15u)) return D3F_EINVAL;
+  } else {
+    if (!rev_ent || (rev_ptr != nullptr) == (rev_last_key != nullptr) || (!rev_ptr && rev_width < 1)) return D3F_EINVAL;
+  }
   if ((double)Nq * Cout * 4.0 >= 4294967295.0 || (!rev_ptr && (double)Ns * rev_width >= 2147483647.0)) return D3F_EINVAL;
   if (Ns == 0) return D3F_OK;
   hipStream_t st = (hipStream_t)stream;
   const float rev_r2 = rev_radius > 0.0f ? rev_radius * rev_radius : 0.0f;  // float32 product, like the search
+  const float4* rel = (const float4*)rev_rel;
   if (Cout == 16)
-    return d3f::launch_dxg<1>(s_pts, q_pts, rev_ptr, rev_ent, grad_out, nn, kernel_points, weights, Ns, Nq, Cin, Cout, K, extent, grad_x, rev_last_key, rev_width, rev_r2, status, st);
+    return d3f::launch_dxg<1>(s_pts, q_pts, rev_ptr, rev_ent, grad_out, nn, kernel_points, weights, Ns, Nq, Cin, Cout, K, extent, grad_x, rev_last_key, rev_width, rev_r2, status, rel, st);
   if (Cout == 32)
-    return d3f::launch_dxg<2>(s_pts, q_pts, rev_ptr, rev_ent, grad_out, nn, kernel_points, weights, Ns, Nq, Cin, Cout, K, extent, grad_x, rev_last_key, rev_width, rev_r2, status, st);
-  return d3f::launch_dxg<4>(s_pts, q_pts, rev_ptr, rev_ent, grad_out, nn, kernel_points, weights, Ns, Nq, Cin, Cout, K, extent, grad_x, rev_last_key, rev_width, rev_r2, status, st);
+    return d3f::launch_dxg<2>(s_pts, q_pts, rev_ptr, rev_ent, grad_out, nn, kernel_points, weights, Ns, Nq, Cin, Cout, K, extent, grad_x, rev_last_key, rev_width, rev_r2, status, rel, st);
+  return d3f::launch_dxg<4>(s_pts, q_pts, rev_ptr, rev_ent, grad_out, nn, kernel_points, weights, Ns, Nq, Cin, Cout, K, extent, grad_x, rev_last_key, rev_width, rev_r2, status, rel, st);
 }
 
 }  // extern "C"

@@ -39,6 +39,9 @@ namespace d3f {
 // stores; grad-input bit3 skip the scatter atomics, bit4 skip phase 1 (gW tile), bit5 skip phase 2
 static int g_debug_flags = 0;
 void kpconv_set_debug_flags(int f) { g_debug_flags = f; }
+static unsigned long long* g_phase_clock = nullptr;
+unsigned long long* phase_clock_ptr() { return g_phase_clock; }
+void set_phase_clock(unsigned long long* p) { g_phase_clock = p; }
 
 // Measurement aid (bench.py's roofline leg): HIP events recorded on the launch stream right around ONE kernel of
 // this file (1 = fused forward, 2 = grad input), one event pair per launch, read back after a synchronisation.
@@ -124,11 +127,13 @@ __global__ __launch_bounds__(256) void kpconv_fwd_fused_kernel(
     const float* __restrict__ q_pts, const float4* __restrict__ spack, const int32_t* __restrict__ idx,
     const float* __restrict__ x, const float* __restrict__ kp, const float* __restrict__ W, int Nq, int Ns, int H,
     int Cin, int Cout, int K, float extent, float* __restrict__ out, float* __restrict__ nn_out,
-    float* __restrict__ wf_save, int dbg) {
+    float* __restrict__ wf_save, int dbg, unsigned long long* __restrict__ clk) {
   constexpr int CC = 16 * CV;
   constexpr int WN = 4 / WK;
   extern __shared__ __attribute__((aligned(16))) float lds[];
   constexpr int RS = 16 * CC + 4;  // 16 kernel-point rows per query (row 15 is zero padding when K = 15)
+  PhaseClock pc;   // laps: 0 prologue, 1 phase A (4 queries of the wave), 2 barrier wait, 3 wf_save, 4 phase B,
+  pc.start(clk);   //       5 second barrier + epilogue
   float* wf = lds;              // [16][RS]
   float* nn_l = lds + 16 * RS;  // [16]
   float* red = nn_l + 16;       // [16][16*NBW*WN] when WK > 1
@@ -161,6 +166,7 @@ __global__ __launch_bounds__(256) void kpconv_fwd_fused_kernel(
 
   const int nchunks = Cin / CC;
   bool first = true;
+  pc.lap(0);
   for (int ch = blockIdx.z; ch < nchunks; ch += gridDim.z) {
     const int cbase = ch * CC;
     // ------------------------------------------------------------------ phase A
@@ -168,7 +174,9 @@ __global__ __launch_bounds__(256) void kpconv_fwd_fused_kernel(
     aggregate_wave<CV>(q_pts, idx, q0 + wave * 4, Nq, H, Ns, rs_sp, rs_x, Cin, cbase, kx, ky, kz, inv_extent, lane,
                        first ? nn_l + wave * 4 : nullptr,
                        [&](int i, const f32x4(&acc)[CV]) { store_wf_tile<CV>(wf + (wave * 4 + i) * RS, li, lg, acc); });
+    pc.lap(1);
     __syncthreads();
+    pc.lap(2);
     if (first && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x < 16 && q0 + (int)threadIdx.x < Nq)
       nn_out[q0 + threadIdx.x] = nn_l[threadIdx.x];
     first = false;
@@ -183,6 +191,7 @@ __global__ __launch_bounds__(256) void kpconv_fwd_fused_kernel(
               *(const float4*)(wf + ql * RS + k * CC + 4 * v);
       }
     }
+    pc.lap(3);
     // ------------------------------------------------------------------ phase B
     const int steps = (K * CC) >> 4;
     // The W fragments stream from L2 and each 16-row step is only 4*NBW MFMAs, so a step-at-a-time loop pays one
@@ -221,6 +230,7 @@ __global__ __launch_bounds__(256) void kpconv_fwd_fused_kernel(
         }
       }
     }
+    pc.lap(4);
     __syncthreads();
   }
   // ------------------------------------------------------------------ epilogue
@@ -262,6 +272,8 @@ __global__ __launch_bounds__(256) void kpconv_fwd_fused_kernel(
       }
     }
   }
+  pc.lap(5);
+  pc.done();
 }
 
 // ================================================================================================ grad input
@@ -504,7 +516,7 @@ static int launch_fused_cv(const float* q_pts, const float4* spack, const int32_
     dim3 grid(tiles, Cout / slab, zsplit);                                                                      \
     kpconv_fwd_fused_kernel<CV, NBW, WK><<<grid, 256, lds, stream>>>(q_pts, spack, idx, x, kp, W, Nq, Ns, H, Cin, \
                                                                       Cout, K, extent, out, nn_out, wf_save,       \
-                                                                      g_debug_flags);                            \
+                                                                      g_debug_flags, g_phase_clock);             \
   }
   TimingScope timing(1, stream, Nq, Ns, H, Cin, Cout, K);
   switch (slab) {
@@ -608,7 +620,7 @@ int kpconv_aggregate(const float* q_pts, int Nq, const float* s_pts, int Ns, con
   const int dbg = 2 | 4;  // no contraction, no output store
 #define D3F_AGG(CVV)                                                                                                  \
   kpconv_fwd_fused_kernel<CVV, 1, 1><<<grid, 256, lds, stream>>>(q_pts, spack, idx, x, kp, nullptr, Nq, Ns, H, Cin, 64, K, \
-                                                                 extent, nullptr, nn_out, wf_out, dbg)
+                                                                 extent, nullptr, nn_out, wf_out, dbg, nullptr)
   if (CV == 1) D3F_AGG(1);
   else if (CV == 2) D3F_AGG(2);
   else D3F_AGG(4);

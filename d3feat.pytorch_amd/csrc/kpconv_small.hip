@@ -15,11 +15,17 @@ namespace d3f {
 
 template <int CIN, int OPL>  // OPL = output channels per lane (Cout <= 64*OPL)
 struct SmallAgg {
-  // returns wf[k = li][c] (valid on every lane, replicated over lg) and nn
+  // returns wf[k = li][c] (valid on every lane, replicated over lg) and nn.  `rec` = this wave's 64-entry LDS record
+  // (float4 {s.x, s.y, s.z, x[.,0]} per neighbor, + CIN - 1 further feature words in `recx`): every lane publishes the
+  // neighbor it fetched, then lane (k, j) reads neighbor 4 g + j of every group as ONE 16-byte LDS read (4 distinct
+  // addresses per wave: a broadcast) -- the 5 ds_bpermute per group this replaces kept the LDS pipe 0.86 busy
+  // (profiles/r03_pmc_kpconv.txt).  A shadow neighbor reads x = 0 (bounds-checked buffer), so it contributes nothing
+  // whatever its weight.
   __device__ static __forceinline__ void run(const float* __restrict__ q_pts, const int32_t* __restrict__ idx, int q,
                                              int H, int Ns, __amdgpu_buffer_rsrc_t rs_s, __amdgpu_buffer_rsrc_t rs_x,
                                              float kx, float ky, float kz, float inv_extent, int lane,
-                                             float (&wf)[CIN], float& nn) {
+                                             float4* __restrict__ rec, float* __restrict__ recx, float (&wf)[CIN],
+                                             float& nn) {
     const int lg = lane >> 4;
     const int n_own = (int)min((unsigned)(lane < H ? idx[(size_t)q * H + lane] : Ns), (unsigned)Ns);
     // s_pts [Ns,3] and x [Ns,CIN] are read through bounds-checked buffers: the shadow index returns zeros
@@ -33,22 +39,25 @@ struct SmallAgg {
       xo[c] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs_x, ((unsigned)n_own * CIN + c) * 4u, 0, 0));
       rowsum += xo[c];
     }
-    nn = fmaxf(wave_sum(rowsum > 0.0f ? 1.0f : 0.0f), 1.0f);
+    nn = fmaxf((float)__popcll(__ballot(rowsum > 0.0f)), 1.0f);   // (#neighbors with a positive feature sum, blocks.py:377)
+    rec[lane] = make_float4(sx, sy, sz, xo[0]);
+#pragma unroll
+    for (int c = 1; c < CIN; ++c) recx[(c - 1) * 64 + lane] = xo[c];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
     const float cx = q_pts[3 * (size_t)q + 0] + kx, cy = q_pts[3 * (size_t)q + 1] + ky, cz = q_pts[3 * (size_t)q + 2] + kz;
 #pragma unroll
     for (int c = 0; c < CIN; ++c) wf[c] = 0.0f;
     const int ng = (H + 3) >> 2;
     for (int g = 0; g < ng; ++g) {
       const int src = 4 * g + lg;  // < 64
-      float4 sp;
-      sp.x = __shfl(sx, src, 64);
-      sp.y = __shfl(sy, src, 64);
-      sp.z = __shfl(sz, src, 64);
-      const int nsrc = __shfl(n_own, src, 64);
-      const float w = nsrc < Ns ? kp_influence(sp, cx, cy, cz, inv_extent) : 0.0f;
+      const float4 sp = rec[src];
+      const float w = kp_influence(sp, cx, cy, cz, inv_extent);
+      wf[0] = fmaf(w, sp.w, wf[0]);
 #pragma unroll
-      for (int c = 0; c < CIN; ++c) wf[c] = fmaf(w, __shfl(xo[c], src, 64), wf[c]);
+      for (int c = 1; c < CIN; ++c) wf[c] = fmaf(w, recx[(c - 1) * 64 + src], wf[c]);
     }
+    __builtin_amdgcn_wave_barrier();   // (the record is rewritten for the wave's next query)
 #pragma unroll
     for (int c = 0; c < CIN; ++c) {
       wf[c] += __shfl_xor(wf[c], 16, 64);
@@ -76,6 +85,10 @@ __global__ __launch_bounds__(256) void kpconv_small_fwd_kernel(const float* __re
   const __amdgpu_buffer_rsrc_t rs_s = make_rsrc(s_pts, (unsigned)Ns * 12u);
   const __amdgpu_buffer_rsrc_t rs_x = make_rsrc(x, (unsigned)Ns * CIN * 4u);
   const float inv_extent = 1.0f / extent;
+  __shared__ __attribute__((aligned(16))) float4 rec_all[4][64];
+  __shared__ float recx_all[4][CIN > 1 ? (CIN - 1) * 64 : 1];
+  float4* rec = rec_all[threadIdx.x >> 6];
+  float* recx = recx_all[threadIdx.x >> 6];
   float wreg[16][CIN][OPL];  // W[k][c][o = lane + 64*j]
 #pragma unroll
   for (int k = 0; k < 16; ++k)
@@ -88,7 +101,7 @@ __global__ __launch_bounds__(256) void kpconv_small_fwd_kernel(const float* __re
       }
   for (int q = gw; q < Nq; q += nw) {
     float wf[CIN], nn;
-    SmallAgg<CIN, OPL>::run(q_pts, idx, q, H, Ns, rs_s, rs_x, kx, ky, kz, inv_extent, lane, wf, nn);
+    SmallAgg<CIN, OPL>::run(q_pts, idx, q, H, Ns, rs_s, rs_x, kx, ky, kz, inv_extent, lane, rec, recx, wf, nn);
     float acc[OPL];
 #pragma unroll
     for (int j = 0; j < OPL; ++j) acc[j] = 0.0f;
@@ -96,7 +109,8 @@ __global__ __launch_bounds__(256) void kpconv_small_fwd_kernel(const float* __re
     for (int k = 0; k < 16; ++k)
 #pragma unroll
       for (int c = 0; c < CIN; ++c) {
-        const float v = __shfl(wf[c], k, 64);  // wf[k][c] lives on lane k
+        // wf[k][c] lives on lane k: a scalar broadcast (v_readlane), not a trip through the LDS crossbar
+        const float v = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(wf[c]), k));
 #pragma unroll
         for (int j = 0; j < OPL; ++j) acc[j] = fmaf(v, wreg[k][c][j], acc[j]);
       }
@@ -133,6 +147,10 @@ __global__ __launch_bounds__(256) void kpconv_small_dw_kernel(const float* __res
   const __amdgpu_buffer_rsrc_t rs_s = make_rsrc(s_pts, (unsigned)Ns * 12u);
   const __amdgpu_buffer_rsrc_t rs_x = make_rsrc(x, (unsigned)Ns * CIN * 4u);
   const float inv_extent = 1.0f / extent;
+  __shared__ __attribute__((aligned(16))) float4 rec_all[4][64];
+  __shared__ float recx_all[4][CIN > 1 ? (CIN - 1) * 64 : 1];
+  float4* rec = rec_all[threadIdx.x >> 6];
+  float* recx = recx_all[threadIdx.x >> 6];
   float dw[16][CIN][OPL];
 #pragma unroll
   for (int k = 0; k < 16; ++k)
@@ -142,7 +160,7 @@ __global__ __launch_bounds__(256) void kpconv_small_dw_kernel(const float* __res
       for (int j = 0; j < OPL; ++j) dw[k][c][j] = 0.0f;
   for (int q = gw; q < Nq; q += nw) {
     float wf[CIN], nn;
-    SmallAgg<CIN, OPL>::run(q_pts, idx, q, H, Ns, rs_s, rs_x, kx, ky, kz, inv_extent, lane, wf, nn);
+    SmallAgg<CIN, OPL>::run(q_pts, idx, q, H, Ns, rs_s, rs_x, kx, ky, kz, inv_extent, lane, rec, recx, wf, nn);
     float g[OPL];
     const float inv_nn = 1.0f / nn_in[q];
 #pragma unroll

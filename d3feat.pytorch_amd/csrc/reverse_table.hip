@@ -102,9 +102,62 @@ __global__ __launch_bounds__(256) void rev_sort_kernel(const int32_t* __restrict
   }
 }
 
+// Search form -> exact form.  Row s of a search-form transpose lists every query point within the search radius of s,
+// ranked; q really lists s iff key(q, s) = (d2 bits << 32 | s) <= last_key[q] (s survived q's truncation to the table
+// width) and, when the row comes from a search with a larger radius (the 2r upsampling table standing in for the
+// transpose of a pooling table), d2 < r2.  One wave per row evaluates that once, here, in the pyramid build (side
+// stream: hidden under the previous pair's network step), and leaves the surviving entries compacted, in rank order,
+// as float4 {q - s, q's index bits}: the grad-input kernel then reads its neighborhood as ONE coalesced kilobyte per
+// row -- no position / key gathers (5 scattered 4..8-byte requests per entry before), no membership test, no
+// compaction on the training stream.  Rows end with entries whose index is Nq.
+__global__ __launch_bounds__(256) void rev_filter_kernel(const int32_t* __restrict__ ent, int W,
+                                                         const uint64_t* __restrict__ last_key,
+                                                         const float* __restrict__ q_pts, int Nq,
+                                                         const float* __restrict__ s_pts, int Ns, float r2,
+                                                         float4* __restrict__ out, int32_t* __restrict__ status) {
+  const int lane = threadIdx.x & 63;
+  const int s = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (s >= Ns) return;
+  const float sx = s_pts[3 * (size_t)s], sy = s_pts[3 * (size_t)s + 1], sz = s_pts[3 * (size_t)s + 2];
+  const float4 none = make_float4(0.f, 0.f, 0.f, __int_as_float(Nq));
+  int kept = 0;
+  for (int c0 = 0; c0 < W; c0 += 64) {
+    int n = (c0 + lane < W) ? ent[(size_t)s * W + c0 + lane] : Nq;
+    n = min(max(n, 0), Nq);
+    const bool real = n < Nq;
+    if (__ballot(real) == 0ull) break;   // ranked rows: shadow entries come last
+    const int nn = real ? n : 0;
+    const float qx = q_pts[3 * (size_t)nn], qy = q_pts[3 * (size_t)nn + 1], qz = q_pts[3 * (size_t)nn + 2];
+    const float d2 = d3f::sqdist_exact(qx, qy, qz, sx, sy, sz);
+    const uint64_t key = ((uint64_t)__float_as_uint(d2) << 32) | (unsigned)s;
+    const bool member = real && key <= last_key[nn] && (r2 <= 0.0f || d2 < r2);
+    // a full row of the wider search whose LAST entry is still within r: members may have been cut off
+    if (r2 > 0.0f && status && c0 + lane == W - 1 && real && d2 < r2) atomicOr(status, D3F_ST_WIDE_OVERFLOW);
+    const uint64_t m = __ballot(member);
+    const int rank = __popcll(m & ((1ull << lane) - 1ull));
+    if (member) out[(size_t)s * W + kept + rank] = make_float4(qx - sx, qy - sy, qz - sz, __int_as_float(n));
+    kept += __popcll(m);
+  }
+  for (int i = kept + lane; i < W; i += 64) out[(size_t)s * W + i] = none;
+}
+
 }  // namespace
 
 extern "C" {
+
+int d3f_reverse_table_filter(const int32_t* rev_ent, int rev_width, const uint64_t* rev_last_key, const float* q_pts,
+                             int Nq, const float* s_pts, int Ns, float rev_radius, float* rev_rel_out, int32_t* status,
+                             void* stream) {
+  if (!rev_ent || !rev_last_key || !q_pts || !s_pts || !rev_rel_out || rev_width < 1 || Nq < 0 || Ns < 0)
+    return D3F_EINVAL;
+  if ((double)Ns * rev_width * 16.0 >= 4294967295.0 * 4.0) return D3F_EINVAL;
+  if (Ns == 0) return D3F_OK;
+  const float r2 = rev_radius > 0.0f ? rev_radius * rev_radius : 0.0f;  // float32 product, like the search
+  rev_filter_kernel<<<d3f::cdiv(Ns, 4), 256, 0, (hipStream_t)stream>>>(rev_ent, rev_width, rev_last_key, q_pts, Nq, s_pts,
+                                                                       Ns, r2, (float4*)rev_rel_out, status);
+  D3F_LAUNCH_CHECK();
+  return D3F_OK;
+}
 
 size_t d3f_reverse_table_ws_bytes(int Nq, int H, int Ns) {
   if (Nq < 0 || H < 1 || Ns < 0) return 0;

@@ -138,7 +138,11 @@ def _conv_table(grid_for, pts, lens, level, e, lim, reverse_tables, want_max=Fal
     res = grid.query(pts[level], lens[level], lim, want_max=want_max, wide=ops.REV_WIDTH_CONV, want_last_key=True,
                      max_group=group)
     tab, wide, lkey = res[0], res[-2], res[-1]
-    ops.attach_reverse_table(tab, ops.ReverseTable(wide, n, lim, n, last_key=lkey))
+    # ... evaluated once here into the exact form (membership of every entry, compacted {q - s, q} rows): the training
+    # stream then reads each neighborhood as one coalesced run
+    rev = ops.filter_reverse_table(ops.ReverseTable(wide, n, lim, n, last_key=lkey, status=grid.status),
+                                   pts[level], pts[level])
+    ops.attach_reverse_table(tab, rev)
     return (tab, res[1]) if want_max else tab
 
 
@@ -154,8 +158,9 @@ def _pool_tables(grid_for, pts, lens, level, e, lim, reverse_tables, status, gro
         return tab, mx, up
     tab, mx, lkey = grid.query(pts[level + 1], lens[level + 1], lim, want_max=True, want_last_key=True,
                                max_group=group)
-    ops.attach_reverse_table(tab, ops.ReverseTable(up, pts[level + 1].shape[0], lim, ns, last_key=lkey,
-                                                   radius=e['pool_r'], status=status))
+    rev = ops.filter_reverse_table(ops.ReverseTable(up, pts[level + 1].shape[0], lim, ns, last_key=lkey,
+                                                    radius=e['pool_r'], status=status), pts[level + 1], pts[level])
+    ops.attach_reverse_table(tab, rev)
     return tab, mx, up
 
 

@@ -260,29 +260,51 @@ class ReverseTable(object):
       CSR    ``ent[ptr[s] : ptr[s+1]]`` = the queries that list support s, ascending (build_reverse_table);
       search ``ent`` [Ns, width] = every query point within the radius of s, ranked, and ``last_key`` [Nq] = rank key of
              the last entry each table row kept: q lists s iff key(q, s) <= last_key[q] (RadiusGrid.query outputs)."""
-    __slots__ = ("ptr", "ent", "last_key", "width", "Nq", "H", "Ns", "radius", "status")
+    __slots__ = ("ptr", "ent", "last_key", "width", "Nq", "H", "Ns", "radius", "status", "rel")
 
-    def __init__(self, ent, Nq, H, Ns, ptr=None, last_key=None, radius=0.0, status=None):
-        if (ptr is None) == (last_key is None):
+    def __init__(self, ent, Nq, H, Ns, ptr=None, last_key=None, radius=0.0, status=None, rel=None):
+        """``rel`` [Ns, width, 4] float32: the EXACT form (filter_reverse_table) -- row s = its true reverse neighbors
+        compacted as {q - s, bits of q}; ``ent`` / ``ptr`` / ``last_key`` are then None."""
+        if rel is not None:
+            if ent is not None or ptr is not None or last_key is not None:
+                raise ValueError("an exact-form reverse table carries only `rel`")
+        elif (ptr is None) == (last_key is None):
             raise ValueError("a reverse table is either CSR (ptr) or search-form (last_key)")
+        self.rel = rel
         self.ptr, self.ent, self.last_key = ptr, ent, last_key
         # radius > 0: `ent` comes from a search with a larger radius (an upsampling table); only its entries within
         # `radius` count.  status: DeviceStatus that receives D3F_ST_WIDE_OVERFLOW if such a row was cut short.
         self.radius, self.status = float(radius), status
-        self.width = int(ent.shape[1]) if ptr is None else 0
+        self.width = int(rel.shape[1]) if rel is not None else (int(ent.shape[1]) if ptr is None else 0)
         self.Nq, self.H, self.Ns = int(Nq), int(H), int(Ns)
 
     def matches(self, Nq, H, Ns):
         return (self.Nq, self.H, self.Ns) == (int(Nq), int(H), int(Ns))
 
     def tensors(self):
-        return [t for t in (self.ptr, self.ent, self.last_key) if t is not None]
+        return [t for t in (self.ptr, self.ent, self.last_key, self.rel) if t is not None]
 
     def edges(self):
         """Number of (query, support) pairs (one host read-back; measurement only)."""
+        if self.rel is not None:
+            return int((self.rel[:, :, 3].contiguous().view(torch.int32) < self.Nq).sum())
         if self.ptr is not None:
             return int(self.ptr[-1])
-        return int((self.ent < self.Nq).sum())   # (an upper bound when radius > 0)
+        return int((self.ent < self.Nq).sum())   # (search form: an upper bound -- the rows are supersets)
+
+
+def filter_reverse_table(rev, q_pts, s_pts):
+    """Search-form ReverseTable -> exact form (one launch, meant for the pyramid build): the membership test of every
+    entry evaluated once, survivors compacted as {q - s, q}.  The search-form tensors are not kept."""
+    if rev.rel is not None or rev.ptr is not None:
+        return rev
+    q, sp = _f32(q_pts, "q_pts"), _f32(s_pts, "s_pts")
+    rel = torch.empty((rev.Ns, rev.width, 4), dtype=torch.float32, device=sp.device)
+    with _region("reverse_table_filter[Ns=%d,W=%d]" % (rev.Ns, rev.width), 20 * rev.Ns * rev.width):
+        _native.check(_native.lib().d3f_reverse_table_filter(
+            _p(rev.ent), rev.width, _p(rev.last_key), _p(q), rev.Nq, _p(sp), rev.Ns, rev.radius, _p(rel),
+            _p(rev.status.word) if rev.status is not None else None, _stream()), "d3f_reverse_table_filter")
+    return ReverseTable(None, rev.Nq, rev.H, rev.Ns, rel=rel)
 
 
 def attach_reverse_table(neighb_inds, rev):
@@ -325,7 +347,7 @@ def reverse_table_of(neighb_inds, Nq, H, Ns, rev=None):
 # Measured per layer of the S1 pair (profiles/r02b_timeline.txt vs r02a): 38k rows 177 -> 67 us, 8k rows x 64 ch
 # 84 -> 36 us, the 8k -> 2k strided layer 43 -> 29 us; at 2k rows a tie, below that the scatter (few edges, the chip
 # is filled by splitting channels, which the gather form would pay for with repeated aggregation) stays ahead.
-DX_GATHER_MIN_ROWS = 4096
+DX_GATHER_MIN_ROWS = int(__import__('os').environ.get('D3F_DX_GATHER_MIN_ROWS', 4096))   # (env: experiments)
 
 
 # width of the search-form transpose of a conv table (the whole in-radius list of a point; S1: mean 41, max 68 at the
@@ -433,7 +455,7 @@ class _KPConvFn(torch.autograd.Function):
             with _region("kpconv_dx_gather[Ns=%d,Cin=%d,Cout=%d]" % (Ns, Cin, Cout),
                          kpconv_bwd_bytes(Nq, Ns, H, K, Cin, Cout)):
                 _native.check(L.d3f_kpconv_grad_input_gather(_p(q_pts), Nq, _p(s_pts), Ns, _p(rev.ptr), _p(rev.ent),
-                                                             _p(rev.last_key), rev.width, rev.radius,
+                                                             _p(rev.last_key), rev.width, rev.radius, _p(rev.rel),
                                                              _p(kernel_points), K, _p(weights), Cin, Cout, ctx.extent,
                                                              _p(nn), _p(go), _p(gx),
                                                              _p(rev.status.word) if rev.status is not None else None,
@@ -472,6 +494,12 @@ class _KPConvFn(torch.autograd.Function):
         return None, None, None, gx, None, (_adoptable(gw, ctx.gw_slot) if gw is not None else None), None, None, None
 
 
+# few-point KPConv contractions that run on the own GEMM (csrc/gemm.hip) with the /nn + bias + LeakyReLU epilogue fused:
+# at most this many query rows and at least this deep a reduction (K * Cin)
+_OWN_GEMM_MAX_ROWS = 700
+_OWN_GEMM_MIN_DEPTH = 3840
+
+
 class _KPConvGemmBiasActFn(torch.autograd.Function):
     """act(KPConv(x) + bias) for the few-point / wide layers (bottom of the U-Net), as
         aggregation kernel -> wf [Nq, K*Cin], nn      library GEMM  raw = wf @ W       epilogue  act(raw/nn + bias)
@@ -508,13 +536,20 @@ class _KPConvGemmBiasActFn(torch.autograd.Function):
                                                  SPACK_READY if use_ready else _p(gx_buf), _p(ws), nbytes, _stream()),
                           "d3f_kpconv_aggregate")
         ctx.keep, ctx.gx_buf = keep, gx_buf
-        raw = torch.mm(wf, weights.view(K * Cin, Cout))
-        out = torch.empty_like(raw)
         want_b = bias is not None and ctx.needs_input_grad[6]
         gbuf = torch.empty((1, Cout), dtype=torch.float32, device=dev) if want_b else None
-        _native.check(L.d3f_bias_act_forward(_p(raw), _p(bias), None, None, float(slope), Nq, Cout, _p(out), _p(gbuf),
-                                             Cout if want_b else 0, _p(nn), None, 0, 0, _stream()),
-                      "d3f_bias_act_forward")
+        if Nq <= _OWN_GEMM_MAX_ROWS and K * Cin >= _OWN_GEMM_MIN_DEPTH and Cout % 4 == 0:
+            # few rows x deep reduction (levels 3-4: 159..640 rows x 3840..7680): act((wf @ W) / nn + bias) in ONE launch
+            # of the own split-reduction GEMM (profiles/r03_gemm_sweep.txt: 12.0 / 23.1 / 24.9 us against 16.4 / 24.1 /
+            # 28.6 us for library GEMM + epilogue launch); the bias-gradient accumulators are cleared on the side
+            out = gemm(wf, weights.view(K * Cin, Cout), b_ks=True, row_div=nn, bias1=bias, slope=float(slope),
+                       zero_init=gbuf)
+        else:
+            raw = torch.mm(wf, weights.view(K * Cin, Cout))
+            out = torch.empty_like(raw)
+            _native.check(L.d3f_bias_act_forward(_p(raw), _p(bias), None, None, float(slope), Nq, Cout, _p(out), _p(gbuf),
+                                                 Cout if want_b else 0, _p(nn), None, 0, 0, _stream()),
+                          "d3f_bias_act_forward")
         ctx.save_for_backward(q_pts, s_pts, idx, x, kernel_points, weights, nn, wf, out)
         ctx.gbuf, ctx.extent, ctx.slope, ctx.want_b = gbuf, float(extent), float(slope), want_b
         ctx.gw_slot = _grad_slot(weights)
@@ -547,7 +582,7 @@ class _KPConvGemmBiasActFn(torch.autograd.Function):
             with _region("kpconv_dx_gather[Ns=%d,Cin=%d,Cout=%d]" % (Ns, Cin, Cout),
                          kpconv_bwd_bytes(Nq, Ns, H, K, Cin, Cout)):
                 _native.check(L.d3f_kpconv_grad_input_gather(_p(q_pts), Nq, _p(s_pts), Ns, _p(rev.ptr), _p(rev.ent),
-                                                             _p(rev.last_key), rev.width, rev.radius,
+                                                             _p(rev.last_key), rev.width, rev.radius, _p(rev.rel),
                                                              _p(kernel_points), K, _p(weights), Cin, Cout, ctx.extent,
                                                              None, _p(gon), _p(gx),
                                                              _p(rev.status.word) if rev.status is not None else None,

@@ -272,8 +272,12 @@ class TrainStep:
         pend = getattr(self, '_eager_status', None)
         if pend is None:
             pend = self._eager_status = []
-        pend.append(batch.pop('_status'))
+        status = batch.pop('_status')
+        pend.append(status)
         del pend[:-64]
+        # ... and the word itself rides with the batch: the eager step gates its update on it exactly like the graph step
+        # does on its set's word (a truncated search-form transpose must not reach the parameters)
+        batch['_pair_status'] = status.word
         return batch
 
     def _loss_from_raw(self, x, scores, batch):
@@ -414,8 +418,17 @@ class TrainStep:
             self.batch = None     # persistent pyramid tensors (filled by the side branch of the OTHER graph)
             self.status = None
             self.loaded = None    # the item whose pyramid `batch` holds
+            # host mirror of the status word after the pair's network step (async copy queued behind the step) and the
+            # pair it belongs to: a pair whose update the optimizer skipped (capacity overflow) can be re-run eagerly
+            self.status_host = torch.zeros(1, dtype=torch.int32).pin_memory() if torch.device(dev).type == 'cuda' else None
+            self.status_item = None
 
     def enable_graph(self, capacities, num_corr):
+        if getattr(self.config, 'use_batch_norm', False) and self.model.training:
+            # capacity-shaped levels carry ~10 % zero rows: batch statistics over them are not the reference's
+            # BatchNorm1d over the live points (the blocks do not hand the live row count to the normalisation)
+            raise RuntimeError("use_batch_norm=True trains on the eager path only: the captured graphs run on "
+                               "capacity-padded levels, which would bias the batch statistics")
         dev = self.device
         self.caps = [int(c) for c in capacities]
         self.sets = [TrainStep._Set(self.caps, num_corr, dev) for _ in range(self.NSETS)]
@@ -424,6 +437,60 @@ class TrainStep:
             st.feat = torch.ones((self.caps[0], fdim), dtype=torch.float32, device=dev)   # self_augment)
         self.graphs = None
         self.cur = 0
+
+    NO_PREFETCH = object()   # step_graph(item, NO_PREFETCH): do not build any pyramid for the following step
+
+    def clone_for_capacities(self, capacities, num_corr):
+        """A second engine over the SAME model, flat buffers, optimizer and streams with its own static buffer sets and
+        graphs for other level capacities -- one per size class of the dataset (trainer.Trainer): real 3DMatch pairs
+        vary several-fold in size, and a single capacity set makes every small pair pay for the largest."""
+        import copy
+        if getattr(self, '_side', None) is None:
+            self._side = torch.cuda.Stream(device=self.device)
+        if getattr(self, '_h2d', None) is None and self.device.type == 'cuda':
+            self._h2d = torch.cuda.Stream(device=self.device)
+        other = copy.copy(self)
+        for name in ('sets', 'graphs', 'g_net', 'g_net_b', 'g_pyr', '_graph_out', '_graph_dist', 'ev_net', 'ev_pyr',
+                     '_pending', '_cuts', 'caps', 'cur', '_overflowed'):
+            other.__dict__.pop(name, None)
+        other.enable_graph(capacities, num_corr)
+        return other
+
+    def _collect_status(self, i):
+        """Set i is about to be reused (the caller has waited for its last network step): if that pair was flagged --
+        the optimizer then skipped its update -- remember it for take_overflowed()."""
+        st = self.sets[i]
+        item = getattr(st, 'status_item', None)
+        if item is not None and st.status_host is not None and getattr(self, 'opt', None) is not None:
+            flags = int(st.status_host[0])
+            if flags:
+                self.__dict__.setdefault('_overflowed', []).append((item, flags))
+        st.status_item = None
+
+    def take_overflowed(self, drain=False):
+        """[(item, flags)] of pairs whose graph step was skipped because a level outgrew its capacity (or a search
+        overflowed), oldest first; ``drain`` also waits for and checks the sets still in flight (end of an epoch)."""
+        if drain and getattr(self, 'ev_net', None) is not None:
+            for i in range(len(self.sets)):
+                self.ev_net[i].synchronize()
+                self._collect_status(i)
+        out, self._overflowed = self.__dict__.get('_overflowed', []), []
+        return out
+
+    def preload(self, item):
+        """Build ``item``'s pyramid on the side stream into the set this engine trains on next (used when the previous
+        pair belonged to another size class, whose step_graph cannot prefetch into this engine's sets)."""
+        i = self.cur
+        st = self.sets[i]
+        if st.loaded is item:
+            return
+        self.ev_net[i].synchronize()
+        self._collect_status(i)
+        with torch.cuda.stream(self._side):
+            self._load_inputs(st, item)
+            self.g_pyr[i].replay()
+            self.ev_pyr[i].record(self._side)
+        st.loaded = item
 
     def fits(self, item):
         """Whether the pair can go through the captured graphs (level-0 capacity and correspondence count; deeper
@@ -584,19 +651,28 @@ class TrainStep:
         main = torch.cuda.current_stream(self.device)
         if st.loaded is not item:
             self.ev_net[i].synchronize()
+            self._collect_status(i)
             with torch.cuda.stream(self._side):
                 self._load_inputs(st, item)
                 self.g_pyr[i].replay()
                 self.ev_pyr[i].record(self._side)
             st.loaded = item
         nxt = item if next_item is None else next_item
-        self.ev_net[n].synchronize()
-        with torch.cuda.stream(self._side):
-            self._load_inputs(nx, nxt)
-            self.g_pyr[n].replay()
-            self.ev_pyr[n].record(self._side)
-        nx.loaded = nxt
+        if nxt is not TrainStep.NO_PREFETCH:
+            self.ev_net[n].synchronize()
+            self._collect_status(n)
+            with torch.cuda.stream(self._side):
+                self._load_inputs(nx, nxt)
+                self.g_pyr[n].replay()
+                self.ev_pyr[n].record(self._side)
+            nx.loaded = nxt
         self.ev_pyr[i].synchronize()
+
+        def done():   # queued behind the pair's network step: host mirror of its status word, then the set's event
+            if st.status_host is not None and st.status is not None:
+                st.status_host.copy_(st.status.word, non_blocking=True)
+                st.status_item = item
+            self.ev_net[i].record(main)
         if self.split_backward:
             def stage1():
                 self.g_net[i].replay()
@@ -604,11 +680,11 @@ class TrainStep:
 
             def stage2():
                 self.g_net_b[i].replay()
-                self.ev_net[i].record(main)
+                done()
             self._exchange_and_step(stage1, stage2, pair_status=st.status.word)
         else:
             self.g_net[i].replay()
-            self.ev_net[i].record(main)
+            done()
         self.cur = n
         self.last_distances = self._graph_dist[i]
         return self._graph_out[i]
@@ -662,20 +738,29 @@ class TrainStep:
             batch, ev = pending
             self._pending = None
             torch.cuda.current_stream(self.device).wait_event(ev)
+            cur = torch.cuda.current_stream(self.device)
             for v in batch.values():  # tensors produced on the side stream are consumed on this one
                 for t in (v if isinstance(v, list) else [v]):
                     if isinstance(t, torch.Tensor):
-                        t.record_stream(torch.cuda.current_stream(self.device))
+                        t.record_stream(cur)
+                        rev = getattr(t, '_d3f_rev', None)     # the table's transpose is read by the backward pass
+                        for r in (rev.tensors() if rev is not None else ()):
+                            r.record_stream(cur)
         else:
             batch = self.build_batch(item)
             batch['n0'] = int(item[0].shape[0])
         if next_item is not None:
             self.prefetch(next_item)
+        pair_status = batch.get('_pair_status')
         if self.split_backward:
-            return self._exchange_and_step(lambda: self._backward_deep(batch), self._backward_shallow)
+            return self._exchange_and_step(lambda: self._backward_deep(batch), self._backward_shallow,
+                                           pair_status=pair_status)
         self.flat.zero_grad()
         loss, desc, det, acc = self.forward_loss(batch)
         torch.autograd.backward(loss, self._seed(loss))
+        if self.world > 1 and pair_status is not None:
+            self._poison_if_flagged(self.flat.gather_grads(), pair_status)
+            pair_status = None
         allreduce_mean_(self.flat.gather_grads(), self.world, average=False)   # the mean is opt.grad_scale
-        self.opt.step(want_ok=False)
+        self.opt.step(want_ok=False, pair_status=pair_status)
         return loss.detach(), desc.detach(), det.detach(), acc.detach()

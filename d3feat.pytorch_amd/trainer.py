@@ -123,25 +123,51 @@ class Trainer(object):
         self.scheduler = ExponentialLR(self.optimizer, gamma=args.scheduler_gamma)
         self.writer = _get(args, 'writer', None) or ScalarLog(_get(args, 'tboard_dir', None) if self.rank == 0 else None)
         self.use_graph = bool(_get(args, 'graph', self.device.type == 'cuda'))
+        if self.use_graph and _get(args, 'use_batch_norm', False):
+            # batch statistics must run over the live points: the capacity-padded graph path is not used with BatchNorm
+            if self.rank == 0:
+                print("note: use_batch_norm=True -> eager training path (no hipGraph replay)")
+            self.use_graph = False
         self._captured = False
         if _get(args, 'pretrain', ''):
             self._load_pretrain(args.pretrain)
 
     # ---------------------------------------------------------------------------------------------------------
-    def _capacities(self, dataset, samples=32, slack=1.10):
-        """Static per-level row capacities for the captured graphs: level sizes of up to ``samples`` pairs spread over
-        the dataset, with head-room.  A pair whose level 0 does not fit runs on the eager path; an overflow at a deeper
-        level is flagged on the device (D3F_ST_CAPACITY), the optimizer skips that pair's update and the epoch report
-        counts it -- pass ``graph_capacities`` to size the levels by hand."""
+    def _capacity_classes(self, dataset, samples=32, slack=1.10, classes=3):
+        """[(capacities, dataset index of a member)] ascending by level-0 capacity: the level sizes of up to ``samples``
+        pairs spread over the dataset, sorted by their level-0 size and cut into up to ``classes`` groups of equal
+        count, each with its own head-room -- real 3DMatch pairs (reference datasets/ThreeDMatch.py:93-149) vary
+        several-fold in size, and ONE capacity set would make every small pair pay the largest pair's kernels.  Groups
+        whose level-0 capacities end up within 20 % of each other are merged (a class costs three buffer sets and six
+        graphs).  ``graph_capacities`` in the config (one list, or a list of lists) overrides the sampling."""
         caps = _get(self.config, 'graph_capacities', None)
-        if caps is not None:
-            return [int(c) for c in caps]
-        sizes = []
         n = len(dataset)
-        for i in sorted(set(int(round(k * (n - 1) / max(1, min(samples, n) - 1))) for k in range(min(samples, n)))):
+        picks = sorted(set(int(round(k * (n - 1) / max(1, min(samples, n) - 1))) for k in range(min(samples, n))))
+        sized = []
+        for i in picks:
             b = self.engine.build_batch(self._fetch(dataset, i))
-            sizes.append([int(t.shape[0]) for t in b['points']])
-        return TrainStep.capacities_for(sizes, slack=slack)
+            sized.append(([int(t.shape[0]) for t in b['points']], i))
+        sized.sort(key=lambda t: t[0][0])
+        if caps is not None:
+            lists = [list(map(int, c)) for c in caps] if isinstance(caps[0], (list, tuple)) else [list(map(int, caps))]
+            out = []
+            for c in sorted(lists, key=lambda c: c[0]):
+                fit = [i for sz, i in sized if all(a <= b for a, b in zip(sz, c))]
+                if not fit:
+                    raise ValueError("no sampled pair fits graph_capacities %s" % (c,))
+                out.append((c, fit[-1]))
+            return out
+        k = max(1, min(int(classes), len(sized)))
+        groups = [sized[len(sized) * g // k: len(sized) * (g + 1) // k] for g in range(k)]
+        out = []
+        for grp in (g for g in groups if g):
+            c = TrainStep.capacities_for([sz for sz, _ in grp], slack=slack)
+            if out and c[0] <= 1.2 * out[-1][0][0]:
+                merged = [max(a, b) for a, b in zip(out[-1][0], c)]
+                out[-1] = (merged, grp[-1][1])
+            else:
+                out.append((c, grp[-1][1]))
+        return out
 
     def _shuffles(self, loader):
         """Whether the loader asks for a random order: our ``_PairLoader.shuffle``, or a ``torch.utils.data.DataLoader``
@@ -150,7 +176,11 @@ class Trainer(object):
         if hasattr(loader, 'shuffle'):
             return bool(loader.shuffle)
         sampler = getattr(loader, 'sampler', None)
-        return sampler is not None and type(sampler).__name__ in ('RandomSampler', 'DistributedSampler')
+        if sampler is None:
+            return False
+        if type(sampler).__name__ == 'DistributedSampler':
+            return bool(getattr(sampler, 'shuffle', True))     # DistributedSampler(shuffle=False) keeps the order
+        return type(sampler).__name__ == 'RandomSampler'
 
     def _order(self, loader, epoch):
         n = len(loader.dataset)
@@ -159,8 +189,16 @@ class Trainer(object):
         return np.arange(n)
 
     def _report_skipped(self):
+        self._rerun_overflowed(drain=True)
         flags, count = self.engine.check_status(raise_on_skip=False)
-        if count and self.rank == 0:
+        rerun = getattr(self, 'rerun_pairs', 0) - getattr(self, '_rerun_reported', 0)
+        self._rerun_reported = getattr(self, 'rerun_pairs', 0)
+        if rerun and self.rank == 0:
+            print("note: %d pair(s) outgrew their capacity class and were trained on the eager path instead" % rerun)
+        count = max(0, count - rerun)
+        if rerun and not count:
+            flags = 0
+        if (count or flags) and self.rank == 0:
             from . import _native
             print("warning: %d pair(s) skipped -- %s" % (count, _native.status_message(flags) or ("status %d" % flags)))
         self.skipped_pairs = getattr(self, 'skipped_pairs', 0) + count
@@ -169,20 +207,57 @@ class Trainer(object):
     def _fetch(self, dataset, i):
         return self.engine.upload(dataset[int(i)])
 
+    def _capture_classes(self, item):
+        """One graph engine per size class (TrainStep.clone_for_capacities), each captured on a member of its class.
+        capture() warms the step up by running it: parameters, momentum and counters are put back afterwards."""
+        eng = self.engine
+        ds = self.train_loader.dataset
+        self._engines = []
+        keep = (eng.flat.data.clone(), eng.opt.buf.clone(), eng.opt.state.clone())
+        for caps, member in self._capacity_classes(ds, classes=int(_get(self.config, 'capacity_classes', 3))):
+            if not self._engines:     # the first class lives in the engine itself, the others in clones of it
+                e = eng
+                e.enable_graph(caps, num_corr=int(item[4].shape[0]))
+            else:
+                e = eng.clone_for_capacities(caps, num_corr=int(item[4].shape[0]))
+            e.capture(self._fetch(ds, member))
+            self._engines.append(e)
+        for dst, src in zip((eng.flat.data, eng.opt.buf, eng.opt.state), keep):
+            dst.copy_(src)
+        self._captured = True
+
+    def _class_of(self, item):
+        for e in self._engines:       # ascending capacities: the smallest class the pair fits
+            if e.fits(item):
+                return e
+        return None
+
+    def _rerun_overflowed(self, drain=False):
+        """Pairs whose graph step the optimizer skipped because a deeper level outgrew its class capacity are trained
+        on the eager path (exact shapes) a few steps late instead of being dropped -- the reference trains on every
+        pair (trainer.py:89-111)."""
+        for e in getattr(self, '_engines', []):
+            for item, flags in e.take_overflowed(drain=drain):
+                self.engine.step(item)
+                self.rerun_pairs = getattr(self, 'rerun_pairs', 0) + 1
+
     def _one_step(self, item, next_item):
         eng = self.engine
         if self.use_graph:
             if not self._captured:
-                eng.enable_graph(self._capacities(self.train_loader.dataset), num_corr=int(item[4].shape[0]))
-                # capture() warms the step up by running it: put parameters, momentum and counters back afterwards
-                keep = (eng.flat.data.clone(), eng.opt.buf.clone(), eng.opt.state.clone())
-                eng.capture(item)
-                for dst, src in zip((eng.flat.data, eng.opt.buf, eng.opt.state), keep):
-                    dst.copy_(src)
-                self._captured = True
-            if eng.fits(item):
-                nxt = next_item if (next_item is not None and eng.fits(next_item)) else None
-                return eng.step_graph(item, nxt)
+                self._capture_classes(item)
+            e = self._class_of(item)
+            if e is not None:
+                nxt_e = self._class_of(next_item) if next_item is not None else None
+                if nxt_e is e:
+                    out = e.step_graph(item, next_item)
+                else:
+                    if nxt_e is not None:
+                        nxt_e.preload(next_item)       # the next pair belongs to another class: its sets, its graph
+                    out = e.step_graph(item, TrainStep.NO_PREFETCH)
+                eng.last_distances = e.last_distances
+                self._rerun_overflowed()
+                return out
         return eng.step(item)
 
     def train(self):

@@ -42,6 +42,10 @@ const char* d3f_version(void);
 int d3f_device_arch_ok(void); /* 1 if the current HIP device is gfx950, 0 otherwise, <0 = -(hipError_t) */
 int d3f_device_arch_name(char* out, int n); /* gcnArchName of the current device */
 void d3f_debug_set_flags(int flags);      /* profiling aid: ablation switches of the fused KPConv kernels (0 = off) */
+/* measurement aid (profiles/phase_clock.py): `counters` = device uint64 buffer (or NULL to switch it off): [0] = waves
+ * recorded (cleared by the caller), [1] = record capacity, record r at [8 + 8 r .. +5] = shader cycles one wave of the
+ * fused KPConv forward / gather-form grad-input kernel spent in each of its phases (see the kernels). */
+void d3f_debug_set_phase_clock(void* counters);
 /* measurement aid (profiles/gemm_microbench.py): force the decomposition of d3f_gemm (0 = heuristic for each) -- fa =
  * 1 | 2 fragments per wave along M for a KC-layout A, fb = 2 | 4 along N for a KC-layout B, kw = 1 | 2 | 4 | 8 waves of a
  * workgroup splitting the reduction of one tile, split >= 1 grid-level slices of the reduction. */
@@ -162,7 +166,8 @@ int d3f_kpconv_backward(const float* q_pts, int Nq, const float* s_pts, int Ns, 
  *   Deterministic.  Built once per table (next to the radius search) and reused by every layer on that table.
  * d3f_kpconv_grad_input_gather: grad_x [Ns,Cin] = sum_k (sum_{q in rev(s)} w(q,s,k) grad_out[q,:]/nn[q]) @ W[k]^T
  *   (OVERWRITTEN; no atomics, bit-reproducible).  nn may be NULL (grad_out already divided).  rev(s) comes in one of
- *   two forms: CSR (rev_ptr + rev_ent, rev_last_key NULL) or the search's own output (rev_ptr NULL): rev_ent =
+ *   three forms: the exact form rev_rel (below), CSR (rev_ptr + rev_ent, rev_last_key NULL) or the search's own output
+ *   (rev_ptr NULL): rev_ent =
  *   out_wide [Ns, rev_width] of a d3f_radius_query_ex of the SUPPORT points over the QUERY cloud with the table's
  *   radius, rev_last_key = out_last_key [Nq] of the query that produced the table -- no transposition pass at all.
  *   rev_radius > 0: rev_ent comes from a search with a LARGER radius (a pooling table's transpose is the prefix, within
@@ -175,9 +180,17 @@ int d3f_reverse_table_build(const int32_t* idx, int Nq, int H, int Ns, int32_t* 
 int d3f_kpconv_grad_input_gather_supported(int Cin, int Cout, int K);
 int d3f_kpconv_grad_input_gather(const float* q_pts, int Nq, const float* s_pts, int Ns, const int32_t* rev_ptr,
                                  const int32_t* rev_ent, const uint64_t* rev_last_key, int rev_width, float rev_radius,
-                                 const float* kernel_points, int K, const float* weights, int Cin, int Cout,
-                                 float extent, const float* nn, const float* grad_out, float* grad_x, int32_t* status,
-                                 void* stream);
+                                 const float* rev_rel, const float* kernel_points, int K, const float* weights, int Cin,
+                                 int Cout, float extent, const float* nn, const float* grad_out, float* grad_x,
+                                 int32_t* status, void* stream);
+/* d3f_reverse_table_filter: search form -> EXACT form, once per table in the pyramid build: rev_rel_out [Ns, rev_width]
+ * float4 {q - s, bits of q} = the entries of row s that pass the membership test (key <= rev_last_key[q], and d2 <
+ * rev_radius^2 when rev_radius > 0), compacted in rank order, rows padded with index Nq.  d3f_kpconv_grad_input_gather
+ * with rev_rel (rev_ptr / rev_ent / rev_last_key NULL) then reads each neighborhood as one coalesced run: no position
+ * or key gathers, no membership test on the training stream. */
+int d3f_reverse_table_filter(const int32_t* rev_ent, int rev_width, const uint64_t* rev_last_key, const float* q_pts,
+                             int Nq, const float* s_pts, int Ns, float rev_radius, float* rev_rel_out, int32_t* status,
+                             void* stream);
 
 /* grad_x alone, from gwf = (grad_out / nn) @ W^T  [Nq, K*Cin] computed by the caller (an ordinary GEMM: the right
  * tool for the few-point / 256..512-channel layers at the bottom of the U-Net, where the fused kernel's own gW tile

@@ -6,7 +6,7 @@ mkdir -p gpurun_out
 (timeout 1200 python profiles/gemm_microbench.py --json gpurun_out/gemm_sweep.json 2>&1 | tail -60) > gpurun_out/c1_gemm_sweep.log
 export TMPDIR=/tmp
 (timeout 600 rocprofv3 --kernel-trace -d gpurun_out/tl -o tl -- python profiles/step_timeline.py 12 2>&1 | tail -5) > gpurun_out/c1_tl.log
-(python profiles/timeline_rocpd.py gpurun_out/tl/*/*.db 2>&1) > gpurun_out/c1_step_timeline.txt
+(python profiles/timeline_rocpd.py $(find gpurun_out/tl -name "*.db" | head -1) 2>&1) > gpurun_out/c1_step_timeline.txt
 rm -rf gpurun_out/tl
 (timeout 600 python bench.py --steps 20 --warmup 5 2>gpurun_out/c1_bench.err | tail -3) > gpurun_out/c1_bench.json
 echo done

@@ -1,0 +1,14 @@
+set -x
+cd $GRAFT_REPO_ROOT
+mkdir -p gpurun_out
+export TMPDIR=/tmp
+T=${1:-c13}
+rm -f gpurun_out/${T}_pmc.txt
+i=0
+for set in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE" "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_VMEM" "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum" "TCP_TCC_READ_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum TA_BUSY_avr TA_TA_BUSY_sum" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_LDS_ADDR_CONFLICT SQ_INSTS_VMEM_WR"; do
+  i=$((i+1))
+  (timeout 300 rocprofv3 --kernel-trace --pmc $set -d gpurun_out/kp$i -o kp -- python profiles/net_step_only.py 5 2>&1 | tail -2) > gpurun_out/${T}_pmc$i.log
+  (echo "## --pmc $set"; python profiles/pmc_table.py $(find gpurun_out/kp$i -name "*.db" | head -1) '%kpconv%') >> gpurun_out/${T}_pmc.txt 2>&1
+  rm -rf gpurun_out/kp$i
+done
+echo done

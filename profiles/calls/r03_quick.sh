@@ -1,0 +1,8 @@
+set -x
+cd $GRAFT_REPO_ROOT
+mkdir -p gpurun_out
+T=${1:-cq}
+(timeout 900 python -m pytest tests -m gpu -x -q 2>&1 | tail -25) > gpurun_out/${T}_tests.log
+(timeout 600 python profiles/phase_clock.py 2>&1 | tail -20) > gpurun_out/${T}_phase.log
+(timeout 900 python bench.py --steps 20 --warmup 5 --no-cpu-baseline 2>gpurun_out/${T}_bench.err | tail -3) > gpurun_out/${T}_bench.json
+echo done

@@ -226,6 +226,17 @@ def test_reverse_table_is_the_sorted_transpose(nq, h, ns):
     assert torch.equal(again.ent[:int(ptr[-1])], rev.ent[:int(ptr[-1])])
 
 
+def _rev_sets_exact(rev):
+    """[set of queries per support] of an exact-form reverse table (rows = float4 {q - s, bits of q}, padded with Nq)."""
+    q = rev.rel[:, :, 3].contiguous().view(torch.int32).cpu().numpy()
+    out = []
+    for row in q:
+        live = row[row < rev.Nq]
+        assert (row[:live.size] < rev.Nq).all()          # compacted: the live entries lead
+        out.append(set(int(v) for v in live))
+    return out
+
+
 def _rev_sets_csr(rev):
     ptr, ent = rev.ptr.cpu().numpy(), rev.ent.cpu().numpy()
     return [set(ent[ptr[s]:ptr[s + 1]].tolist()) for s in range(rev.Ns)]
@@ -279,12 +290,17 @@ def test_search_form_transpose_equals_the_csr_transpose(n0, n1, r, lim):
     wp = cu((rng.normal(size=(15, 32, 32)) / 20).astype(np.float32))
     kpp = cu((rng.normal(size=(15, 3)) * r / 3).astype(np.float32))
     gop = cu(rng.normal(size=(coarse.shape[0], 32)).astype(np.float32))
+    # the exact form (d3f_reverse_table_filter: membership evaluated once, rows compacted as {q - s, q}) holds the same edges
+    exu, exp_ = ops.filter_reverse_table(revu, coarse, cu(fine)), ops.filter_reverse_table(revp, coarse, cu(fine))
+    assert exu.edges() == exp_.edges() == csrp.edges() == int((tabp < n0 + n1).sum())
+    assert _rev_sets_exact(exu) == _rev_sets_csr(csrp) and _rev_sets_exact(exp_) == _rev_sets_csr(csrp)
     gp = []
-    for rv in (revu, revp, csrp):
+    for rv in (revu, revp, csrp, exu, exp_):
         gx = xf.clone().requires_grad_(True)
         ops.kpconv(coarse, cu(fine), tabp, gx, kpp, wp, r * 0.8, rev=rv).backward(gop)
         gp.append(gx.grad)
-    assert rel_err(gp[0].cpu().numpy(), gp[2].cpu().numpy()) < 1e-5 and rel_err(gp[1].cpu().numpy(), gp[2].cpu().numpy()) < 1e-5
+    for gpi in gp[:2] + gp[3:]:
+        assert rel_err(gpi.cpu().numpy(), gp[2].cpu().numpy()) < 1e-5
     g_fine.status.raise_if_set()
     g_coarse.status.raise_if_set()
     # and the two forms give the same gradient, bit for bit up to summation order inside a row
@@ -293,11 +309,19 @@ def test_search_form_transpose_equals_the_csr_transpose(n0, n1, r, lim):
     kp = cu((rng.normal(size=(15, 3)) * r / 3).astype(np.float32))
     go = cu(rng.normal(size=(n0 + n1, 32)).astype(np.float32))
     grads = []
-    for rv in (rev, csr):
+    ex = ops.filter_reverse_table(rev, cu(fine), cu(fine))
+    assert ex.edges() == csr.edges() and _rev_sets_exact(ex) == _rev_sets_csr(csr)
+    for rv in (rev, csr, ex):
         gx = x.clone().requires_grad_(True)
         ops.kpconv(cu(fine), cu(fine), tab, gx, kp, w, r * 0.8, rev=rv).backward(go)
         grads.append(gx.grad)
     assert rel_err(grads[0].cpu().numpy(), grads[1].cpu().numpy()) < 1e-5
+    assert rel_err(grads[2].cpu().numpy(), grads[1].cpu().numpy()) < 1e-5
+    # the gather form (taken from ops.DX_GATHER_MIN_ROWS support rows) is deterministic: same bits on a second backward
+    if n0 + n1 >= ops.DX_GATHER_MIN_ROWS:
+        gx = x.clone().requires_grad_(True)
+        ops.kpconv(cu(fine), cu(fine), tab, gx, kp, w, r * 0.8, rev=ex).backward(go)
+        assert torch.equal(gx.grad, grads[2])
 
 
 @pytest.mark.parametrize("nq,ns,h,cin,cout", [(1000, 1000, 42, 32, 32), (333, 1000, 37, 64, 64), (4500, 4500, 42, 64, 64),

@@ -173,3 +173,8 @@ def test_trainer_reads_the_loaders_shuffle_request():
     class L:
         shuffle = True
     assert Trainer._shuffles(None, L()) is True
+    # a DistributedSampler shuffles only when it was built to (reference-style loaders with shuffle=False keep the order)
+    from torch.utils.data.distributed import DistributedSampler
+    for flag in (True, False):
+        smp = DistributedSampler(ds, num_replicas=2, rank=0, shuffle=flag)
+        assert Trainer._shuffles(None, tud.DataLoader(ds, sampler=smp)) is flag

@@ -75,3 +75,43 @@ def grad_mismatch(a, b, elem_tol=5e-3):
 
 class Cfg:
     pass
+
+
+def gate_margins(x, idx):
+    """Per point: max_c ( x[n,c] - max over the OTHER entries of row n of x'[idx[n,h], c] ), x' = x with the zero shadow
+    row (index == N) -- the eval-mode detector keeps a point iff this is >= 0, i.e. iff some channel of the point is
+    the maximum of its neighborhood (architectures.py:361-366: `features == max_h features[idx]`, self included).
+    x: [N,C] float tensor / array (the normalisation by a positive global maximum does not move the comparison),
+    idx: [N,H] integer table whose entries >= N are shadow."""
+    import torch
+    x = torch.as_tensor(x).double().cpu()
+    idx = torch.as_tensor(idx).long().cpu().clamp(max=x.shape[0])
+    n = x.shape[0]
+    pad = torch.cat([x, torch.zeros((1, x.shape[1]), dtype=x.dtype)], 0)
+    out = torch.empty(n, dtype=torch.float64)
+    rows = torch.arange(n)
+    for a in range(0, n, 4096):   # chunked: [4096, H, C] at a time
+        b = min(n, a + 4096)
+        nb = pad[idx[a:b]]                                              # [b-a, H, C]
+        others = idx[a:b] != rows[a:b, None]
+        nb = torch.where(others[:, :, None], nb, torch.full_like(nb, -float('inf')))
+        out[a:b] = (x[a:b] - nb.max(dim=1).values).max(dim=1).values
+    return out.numpy()
+
+
+def assert_gate_flips_are_ties(got_scores, ref_scores, x_raw, idx, rel_tol=2e-4, max_share=1e-3):
+    """Eval-mode scores against the reference's: the zero / non-zero pattern may differ only at points whose gate is a
+    floating-point tie -- the margin by which the point is (or misses being) a channel-wise local maximum is within
+    `rel_tol` of the feature scale, i.e. inside the 1e-4 descriptor tolerance -- and such points are rare."""
+    import numpy as np
+    got = np.asarray(got_scores).reshape(-1)
+    ref = np.asarray(ref_scores).reshape(-1)
+    flips = np.nonzero((got != 0) != (ref != 0))[0]
+    assert flips.size <= max_share * got.size, (flips.size, got.size)
+    if flips.size:
+        import torch
+        xr = torch.as_tensor(x_raw).double().cpu()
+        scale = float(xr.abs().max())
+        m = gate_margins(xr, idx)
+        assert np.abs(m[flips]).max() <= rel_tol * scale, (np.abs(m[flips]).max(), scale, flips[:10])
+    return int(flips.size)
