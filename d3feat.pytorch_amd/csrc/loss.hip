@@ -256,6 +256,200 @@ __global__ __launch_bounds__(kThreads) void loss_bwd_kernel(
   }
 }
 
+// ---- tiled variants (M <= 128, C <= 64: the training / validation shapes) ------------------------------------------
+// The one-workgroup kernels above spend 71 + 55 us per step on ONE of 256 CUs (16k distances x 32 channels through
+// LDS, then 256 wave-serial line statistics).  Here the matrix is cut into strips of kLossStrip lines: workgroup g owns
+// rows [g L, (g+1) L) AND columns [g L, (g+1) L) -- it computes its row strip and its column strip of D itself (the
+// same expression in the same order, so both copies of an element are bit-identical), takes the row statistics from
+// the one and the column statistics from the other, and never needs another workgroup's data.  Forward: the scalar
+// sums over all lines are left to a second, tiny launch (loss_finalize_kernel) -- a dependent launch costs 1.7 us here
+// (profiles/r03_launch_floor.txt), an in-kernel rendezvous of 8 workgroups more.  Backward: ga needs row strips of G, gp
+// column strips: no cross-workgroup dependency at all.
+constexpr int kLossStrip = 8;
+
+__host__ __device__ inline size_t tiled_lds_bytes(int M, int C) {
+  // a, p [M][C+1]; row strip [L][M+1]; column strip [M][L+1]; mask bytes of both strips
+  return sizeof(float) * ((size_t)2 * M * (C + 1) + (size_t)kLossStrip * (M + 1) + (size_t)M * (kLossStrip + 1)) +
+         (size_t)2 * kLossStrip * M;
+}
+
+__global__ __launch_bounds__(256) void loss_fwd_tile_kernel(const float* __restrict__ a, const float* __restrict__ p,
+                                                            int M, int C, const uint8_t* __restrict__ negm, LossParams P,
+                                                            float* __restrict__ D, float* __restrict__ fp_out,
+                                                            float* __restrict__ avgneg_out, float* __restrict__ stats) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  constexpr int L = kLossStrip;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int CS = C + 1, RS = M + 1, KS = L + 1;
+  float* al = lds;
+  float* pl = al + (size_t)M * CS;
+  float* Dr = pl + (size_t)M * CS;            // [L][RS]  rows l0 .. l0+L-1
+  float* Dc = Dr + (size_t)L * RS;            // [M][KS]  columns l0 .. l0+L-1
+  uint8_t* mr = (uint8_t*)(Dc + (size_t)M * KS);   // [L][M]
+  uint8_t* mc = mr + (size_t)L * M;                // [M][L]
+  const int l0 = blockIdx.x * L, nl = min(L, M - l0);
+  for (int t = tid; t < M * C; t += 256) {
+    al[(t / C) * CS + t % C] = a[t];
+    pl[(t / C) * CS + t % C] = p[t];
+  }
+  for (int t = tid; t < nl * M; t += 256) {
+    mr[t] = negm[(size_t)(l0 + t / M) * M + t % M];
+    const int i = t / nl, c = t % nl;
+    mc[i * L + c] = negm[(size_t)i * M + l0 + c];
+  }
+  __syncthreads();
+  for (int t = tid; t < nl * M; t += 256) {
+    {  // row strip
+      const int r = t / M, j = t % M;
+      float acc = 0.0f;
+      for (int c = 0; c < C; ++c) {
+        const float df = al[(l0 + r) * CS + c] - pl[j * CS + c];
+        acc += df * df;
+      }
+      const float d = sqrtf(acc + 1e-12f);
+      Dr[r * RS + j] = d;
+      D[(size_t)(l0 + r) * M + j] = d;
+    }
+    {  // column strip
+      const int i = t / nl, cc = t % nl;
+      float acc = 0.0f;
+      for (int c = 0; c < C; ++c) {
+        const float df = al[i * CS + c] - pl[(l0 + cc) * CS + c];
+        acc += df * df;
+      }
+      Dc[i * KS + cc] = sqrtf(acc + 1e-12f);
+    }
+  }
+  __syncthreads();
+  for (int r = wave; r < nl; r += 4) {
+    const int i = l0 + r;
+    float lp, ln, sd, cm; int ca;
+    line_stats(Dr, (long)r * RS, 1, mr, (long)r * M, 1, M, i, P, lp, ln, sd, cm, ca);
+    if (lane == 0) {
+      stats[i] = lp;
+      stats[M + i] = ln;
+      stats[4 * M + i] = cm;
+      ((int*)stats)[5 * M + i] = ca;
+      const float fp = Dr[r * RS + i];  // max_j D*I = D_ii (D > 0)
+      fp_out[i] = fp;
+      avgneg_out[i] = (sd - fp) / (float)(M - 1);
+    }
+  }
+  for (int cc = wave; cc < nl; cc += 4) {
+    const int j = l0 + cc;
+    float lp, ln, sd, cm; int ca;
+    line_stats(Dc, (long)cc, KS, mc, (long)cc, L, M, j, P, lp, ln, sd, cm, ca);
+    if (lane == 0) {
+      stats[2 * M + j] = lp;
+      stats[3 * M + j] = ln;
+    }
+  }
+}
+
+// scalars of the loss from the per-line statistics (second launch of the tiled forward)
+__global__ __launch_bounds__(256) void loss_finalize_kernel(int M, const float* __restrict__ sa, const float* __restrict__ sp,
+                                                            LossParams P, const float* __restrict__ fp_out,
+                                                            const float* __restrict__ avgneg_out,
+                                                            const float* __restrict__ stats, float* __restrict__ scalars) {
+  __shared__ float sh[16];
+  const int tid = threadIdx.x;
+  float l = 0.0f, dt = 0.0f, ac = 0.0f, fps = 0.0f, ans = 0.0f;
+  for (int i = tid; i < M; i += blockDim.x) {
+    l += softplus_t(stats[i] + stats[M + i]) / P.s + softplus_t(stats[2 * M + i] + stats[3 * M + i]) / P.s;
+    const float diff = fp_out[i] - stats[4 * M + i];
+    dt += diff * (sa[i] + sp[i]);
+    ac += diff < 0.0f ? 1.0f : 0.0f;
+    fps += fp_out[i];
+    ans += avgneg_out[i];
+  }
+  l = block_sum(l, sh);
+  dt = block_sum(dt, sh);
+  ac = block_sum(ac, sh);
+  fps = block_sum(fps, sh);
+  ans = block_sum(ans, sh);
+  if (tid == 0) {
+    scalars[0] = l / (float)M;
+    scalars[1] = dt / (float)M;
+    scalars[2] = ac * 100.0f / (float)M;
+    scalars[3] = fps / (float)M;
+    scalars[4] = ans / (float)M;
+    scalars[5] = l / (float)M + dt / (float)M;  // desc + det: the step's loss with unit weights (trainer.py:98)
+  }
+}
+
+__device__ __forceinline__ float loss_grad_entry(float d, bool negm, int i, int j, int M, const LossParams& P,
+                                                 const float* __restrict__ stats, float gdM, float w) {
+  float tp, pw, tn, nw;
+  terms(d, negm, P, tp, pw, tn, nw);
+  const float sr = sigmoid_sp(stats[i] + stats[M + i]);
+  const float sc = sigmoid_sp(stats[2 * M + j] + stats[3 * M + j]);
+  float g = gdM * (sr * (expf(tp - stats[i]) * pw - expf(tn - stats[M + i]) * nw) +
+                   sc * (expf(tp - stats[2 * M + j]) * pw - expf(tn - stats[3 * M + j]) * nw));
+  if (j == i) g += w;
+  if (j == ((const int*)stats)[5 * M + i]) g -= w;
+  return g / d;
+}
+
+__global__ __launch_bounds__(256) void loss_bwd_tile_kernel(const float* __restrict__ a, const float* __restrict__ p,
+                                                            int M, int C, const uint8_t* __restrict__ negm,
+                                                            const float* __restrict__ sa, const float* __restrict__ sp,
+                                                            LossParams P, const float* __restrict__ D,
+                                                            const float* __restrict__ stats,
+                                                            const float* __restrict__ g_desc, const float* __restrict__ g_det,
+                                                            float* __restrict__ ga, float* __restrict__ gp,
+                                                            float* __restrict__ gsa, float* __restrict__ gsp) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  constexpr int L = kLossStrip;
+  const int tid = threadIdx.x;
+  const int CS = C + 1, RS = M + 1, KS = L + 1;
+  float* al = lds;
+  float* pl = al + (size_t)M * CS;
+  float* Gr = pl + (size_t)M * CS;            // [L][RS]  rows of G = dL/dD / D
+  float* Gc = Gr + (size_t)L * RS;            // [M][KS]  columns of G
+  const int l0 = blockIdx.x * L, nl = min(L, M - l0);
+  const float gd = g_desc ? *g_desc : 0.0f, gt = g_det ? *g_det : 0.0f;
+  const float invM = 1.0f / (float)M;
+  for (int t = tid; t < M * C; t += 256) {
+    al[(t / C) * CS + t % C] = a[t];
+    pl[(t / C) * CS + t % C] = p[t];
+  }
+  for (int t = tid; t < nl * M; t += 256) {
+    {
+      const int r = t / M, j = t % M, i = l0 + r;
+      const size_t e = (size_t)i * M + j;
+      Gr[r * RS + j] = loss_grad_entry(D[e], negm[e] != 0, i, j, M, P, stats, gd * invM, gt * invM * (sa[i] + sp[i]));
+    }
+    {
+      const int i = t / nl, cc = t % nl, j = l0 + cc;
+      const size_t e = (size_t)i * M + j;
+      Gc[i * KS + cc] = loss_grad_entry(D[e], negm[e] != 0, i, j, M, P, stats, gd * invM, gt * invM * (sa[i] + sp[i]));
+    }
+  }
+  __syncthreads();
+  for (int t = tid; t < nl * C; t += 256) {
+    {
+      const int r = t / C, c = t % C, i = l0 + r;
+      const float ai = al[i * CS + c];
+      float acc = 0.0f;
+      for (int j = 0; j < M; ++j) acc += Gr[r * RS + j] * (ai - pl[j * CS + c]);
+      ga[(size_t)i * C + c] = acc;
+    }
+    {
+      const int cc = t / C, c = t % C, j = l0 + cc;
+      const float pj = pl[j * CS + c];
+      float acc = 0.0f;
+      for (int i = 0; i < M; ++i) acc += Gc[i * KS + cc] * (pj - al[i * CS + c]);
+      gp[(size_t)j * C + c] = acc;
+    }
+  }
+  for (int r = tid; r < nl; r += 256) {
+    const int i = l0 + r;
+    const float v = gt * invM * (D[(size_t)i * M + i] - stats[4 * M + i]);
+    if (gsa) gsa[i] = v;
+    if (gsp) gsp[i] = v;
+  }
+}
+
 // ---- keypoint selection + L2 normalisation of the selected descriptors -------------------------------------------
 // The reference normalises ALL N descriptors (architectures.py:318, F.normalize) and then indexes the M sampled
 // correspondences out of them and out of the scores (trainer.py:91-94): ~10 PyTorch launches forward and ~15 backward
@@ -344,11 +538,12 @@ int d3f_circle_det_loss_forward(const float* anchor, const float* positive, int 
       !average_negative || !out_scalars || !stats || M < 2 || M > kMaxM || C < 1)
     return D3F_EINVAL;
   LossParams P = {log_scale, safe_radius, pos_margin, neg_margin};
-  if (cache_ok(M, C))
-    loss_fwd_kernel<true><<<1, kThreads, cached_lds_bytes(M, C), (hipStream_t)stream>>>(
-        anchor, positive, M, C, neg_mask, anc_score, pos_score, P, dists, furthest_positive, average_negative,
-        out_scalars, stats);
-  else
+  if (cache_ok(M, C)) {
+    loss_fwd_tile_kernel<<<d3f::cdiv(M, kLossStrip), 256, tiled_lds_bytes(M, C), (hipStream_t)stream>>>(
+        anchor, positive, M, C, neg_mask, P, dists, furthest_positive, average_negative, stats);
+    loss_finalize_kernel<<<1, 256, 0, (hipStream_t)stream>>>(M, anc_score, pos_score, P, furthest_positive,
+                                                             average_negative, stats, out_scalars);
+  } else
     loss_fwd_kernel<false><<<1, kThreads, 0, (hipStream_t)stream>>>(anchor, positive, M, C, neg_mask, anc_score,
                                                                      pos_score, P, dists, furthest_positive,
                                                                      average_negative, out_scalars, stats);
@@ -368,9 +563,9 @@ int d3f_circle_det_loss_backward(const float* anchor, const float* positive, int
   if (ws_bytes < d3f_circle_det_loss_ws_bytes(M)) return D3F_EWORKSPACE;
   LossParams P = {log_scale, safe_radius, pos_margin, neg_margin};
   if (cache_ok(M, C))
-    loss_bwd_kernel<true><<<1, kThreads, cached_lds_bytes(M, C), (hipStream_t)stream>>>(
-        anchor, positive, M, C, neg_mask, anc_score, pos_score, P, dists, stats, grad_desc, grad_det, (float*)ws,
-        grad_anchor, grad_positive, grad_anc_score, grad_pos_score);
+    loss_bwd_tile_kernel<<<d3f::cdiv(M, kLossStrip), 256, tiled_lds_bytes(M, C), (hipStream_t)stream>>>(
+        anchor, positive, M, C, neg_mask, anc_score, pos_score, P, dists, stats, grad_desc, grad_det, grad_anchor,
+        grad_positive, grad_anc_score, grad_pos_score);
   else
     loss_bwd_kernel<false><<<1, kThreads, 0, (hipStream_t)stream>>>(anchor, positive, M, C, neg_mask, anc_score,
                                                                      pos_score, P, dists, stats, grad_desc, grad_det,

@@ -345,9 +345,12 @@ def reverse_table_of(neighb_inds, Nq, H, Ns, rev=None):
 
 # KPConv layers whose grad-input runs as a gather over the reverse table: those with at least this many SUPPORT rows.
 # Measured per layer of the S1 pair (profiles/r02b_timeline.txt vs r02a): 38k rows 177 -> 67 us, 8k rows x 64 ch
-# 84 -> 36 us, the 8k -> 2k strided layer 43 -> 29 us; at 2k rows a tie, below that the scatter (few edges, the chip
-# is filled by splitting channels, which the gather form would pay for with repeated aggregation) stays ahead.
-DX_GATHER_MIN_ROWS = int(__import__('os').environ.get('D3F_DX_GATHER_MIN_ROWS', 4096))   # (env: experiments)
+# 84 -> 36 us, the 8k -> 2k strided layer 43 -> 29 us.  Round 3 (exact-form tables, profiles/r03_dx_gather_threshold.txt):
+# at the 2k-point level the two forms tie (4.096 vs 4.098 ms per step) -- the gather form is taken there too, it has no
+# atomics and is bit-reproducible; below that (581 / 159 points x 256 / 512 channels) the scatter stays ahead (4.25 ms
+# with the gather form at 581 points, 4.57 ms at 159: the chip is filled by splitting channels, which the gather form
+# pays for with repeated aggregation).
+DX_GATHER_MIN_ROWS = int(__import__('os').environ.get('D3F_DX_GATHER_MIN_ROWS', 2000))   # (env: experiments)
 
 
 # width of the search-form transpose of a conv table (the whole in-radius list of a point; S1: mean 41, max 68 at the
@@ -732,10 +735,13 @@ class _KPConvDeformAggFn(torch.autograd.Function):
         ctx.save_for_backward(q_pts, s_pts, idx, x, kp_def)
         ctx.extent, ctx.extent_sq, ctx.mode = extent, extent_sq, mode
         ctx.mark_non_differentiable(nn_, min_idx)
+        ctx.set_materialize_grads(False)
         return wf, nn_, min_idx
 
     @staticmethod
     def backward(ctx, gwf, _gnn, _gidx):
+        if gwf is None:
+            return (None,) * 8
         q_pts, s_pts, idx, x, kp_def = ctx.saved_tensors
         L = _native.lib()
         Nq, Ns, H = int(q_pts.shape[0]), int(s_pts.shape[0]), int(idx.shape[1])
@@ -1297,6 +1303,9 @@ class _BiasActFn(torch.autograd.Function):
             ctx.mark_non_differentiable(spack)
             if gx_clear is not None:
                 ctx.mark_non_differentiable(gx_clear)
+            # (without this autograd hands backward zero-FILLED gradients for the two by-products: two fill launches
+            # per packed layer and step, visible in the step timeline as FillFunctor pairs)
+            ctx.set_materialize_grads(False)
             return out, spack, gx_clear
         # the backward's bias-gradient accumulators [2, C] are cleared by the forward kernel on the side: no fill
         # launch in backward, and the two bias parameters get separate buffers (autograd would clone a shared one)
@@ -1315,6 +1324,8 @@ class _BiasActFn(torch.autograd.Function):
     def backward(ctx, grad_out, *_unused):
         (out,) = ctx.saved_tensors
         N, C = int(out.shape[0]), int(out.shape[1])
+        if grad_out is None:     # (only by-products were used: possible with set_materialize_grads(False))
+            return None, None, None, None, None, None
         go = grad_out.contiguous()
         need_gx = ctx.needs_input_grad[0] or (ctx.has[1] and ctx.needs_input_grad[2])
         want1 = ctx.has[0] and ctx.needs_input_grad[1]
@@ -1388,10 +1399,13 @@ class _BatchNormFn(torch.autograd.Function):
         ctx.save_for_backward(x, weight, bias, mean, invstd)
         ctx.n_live, ctx.slope, ctx.training = n_live, float(slope), bool(training)
         ctx.mark_non_differentiable(mean, invstd)
+        ctx.set_materialize_grads(False)
         return y, mean, invstd
 
     @staticmethod
     def backward(ctx, gy, _gm, _gi):
+        if gy is None:
+            return (None,) * 10
         x, weight, bias, mean, invstd = ctx.saved_tensors
         N, C = int(x.shape[0]), int(x.shape[1])
         L = _native.lib()
@@ -1528,10 +1542,13 @@ class _CircleDetFn(torch.autograd.Function):
         ctx.save_for_backward(anchor, positive, neg_mask, anc_score, pos_score, dists, stats)
         ctx.params = (float(log_scale), float(safe_radius), float(pos_margin), float(neg_margin))
         ctx.mark_non_differentiable(dists, fp, an)
+        ctx.set_materialize_grads(False)
         return scalars, dists, fp, an
 
     @staticmethod
     def backward(ctx, g_scalars, g_dists, g_fp, g_an):
+        if g_scalars is None:
+            return (None,) * 9
         anchor, positive, neg_mask, anc_score, pos_score, dists, stats = ctx.saved_tensors
         L = _native.lib()
         M, C = int(anchor.shape[0]), int(anchor.shape[1])
@@ -1658,10 +1675,13 @@ class _TrainLossFn(torch.autograd.Function):
                               sp, dists, stats, gw)
         ctx.meta = (stride, p_offset is not None, params, weights == (1.0, 1.0))
         ctx.mark_non_differentiable(scalars, dists, fp, an)
+        ctx.set_materialize_grads(False)   # (else four zero-fill launches per step for the by-products' gradients)
         return total, scalars, dists, fp, an
 
     @staticmethod
     def backward(ctx, g_total, g_scalars, g_dists, g_fp, g_an):
+        if g_total is None:
+            return (None,) * 8
         x, ia, ip, p_off, neg_mask, oa, op, sa, sp, dists, stats, gw = ctx.saved_tensors
         stride, has_off, (s, sr, pm, nm), unit = ctx.meta
         L = _native.lib()
