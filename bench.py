@@ -421,6 +421,64 @@ def main():
                 "ms_per_step": round((th1 - th0) / args.steps * 1e3, 3),
                 "note": "same step, every pair uploaded from pageable host arrays (points, correspondences, keypoint "
                         "distances: ~0.6 MB) inside the timed region"}
+    # What a USER of trainer.Trainer gets: capacities sampled with 10 % head-room instead of sized to the
+    # exact pairs, and a stream of pairs of different sizes through capacity classes (one graph engine per class,
+    # the next pair's pyramid prefetched into its own class's sets).  Reported next to `value`, never as `value`.
+    trainer_path = None
+    if world == 1 and use_graph:
+        try:
+            keep = (ts.flat.data.clone(), ts.opt.buf.clone(), ts.opt.state.clone())
+            eng110 = ts.clone_for_capacities(TrainStep.capacities_for(sizes, slack=1.10), num_corr=int(items[0][4].shape[0]))
+            eng110.capture(items[0])
+            for k in range(3):
+                eng110.step_graph(items[k % len(items)], items[(k + 1) % len(items)])
+            torch.cuda.synchronize()
+            tt0 = time.perf_counter()
+            for k in range(args.steps):
+                eng110.step_graph(items[(3 + k) % len(items)], items[(4 + k) % len(items)])
+            torch.cuda.synchronize()
+            tt1 = time.perf_counter()
+            trainer_path = {"capacity_slack_1.10": {"value": round(args.steps / (tt1 - tt0), 3), "unit": "fragment-pairs/s",
+                                                     "capacities": eng110.caps}}
+            del eng110
+            # mixed sizes: the S1-class pairs alternating with pairs a quarter of their size, two capacity classes
+            small_items = []
+            for i in range(2):
+                it = synthetic.make_pair(900 + 2 * i, 901 + 2 * i, gpu_subsample, n_raw=80000, scale=0.31)
+                small_items.append(tuple(torch.from_numpy(np.ascontiguousarray(a)).to(dev) for a in it))
+            ssz = [[int(t.shape[0]) for t in ts.build_batch(it)['points']] for it in small_items]
+            eng_s = ts.clone_for_capacities(TrainStep.capacities_for(ssz, slack=1.10), num_corr=int(items[0][4].shape[0]))
+            eng_s.capture(small_items[0])
+            stream_items = [items[0], small_items[0], items[1], small_items[1]]
+
+            def cls(it):
+                return eng_s if eng_s.fits(it) else ts
+
+            def mixed(k):
+                cur, nxt = stream_items[k % 4], stream_items[(k + 1) % 4]
+                e, ne = cls(cur), cls(nxt)
+                if ne is e:
+                    return e.step_graph(cur, nxt)
+                ne.preload(nxt)
+                return e.step_graph(cur, TrainStep.NO_PREFETCH)
+            for k in range(4):
+                mixed(k)
+            torch.cuda.synchronize()
+            tm0 = time.perf_counter()
+            for k in range(args.steps):
+                mixed(4 + k)
+            torch.cuda.synchronize()
+            tm1 = time.perf_counter()
+            pts_mix = [int(it[0].shape[0] + it[1].shape[0]) for it in stream_items]
+            trainer_path["mixed_sizes_two_classes"] = {
+                "value": round(args.steps / (tm1 - tm0), 3), "unit": "fragment-pairs/s", "points_per_pair": pts_mix,
+                "capacities": [eng_s.caps, ts.caps],
+                "skipped_or_rerun": len(eng_s.take_overflowed(drain=True)) + len(ts.take_overflowed(drain=True))}
+            del eng_s
+            for dst, src in zip((ts.flat.data, ts.opt.buf, ts.opt.state), keep):
+                dst.copy_(src)
+        except Exception as e:  # pragma: no cover - the headline number must not depend on this leg
+            trainer_path = {"error": "%s: %s" % (type(e).__name__, e)}
     # N > 1: how much of the gradient exchange hides under the backward of the fine levels.  Three legs of the same K
     # steps: (a) the timed region above; (b) the steps with the all-reduces left out (ranks drift apart: run LAST, after
     # the replica check below would be too late, so parameters are saved and restored); (c) the all-reduces alone.
@@ -746,6 +804,7 @@ def main():
                                  "(static level capacities %s)" % ts.caps
                                  if use_graph else "eager launches, pyramid on a side stream"},
             "pcie_inclusive": pcie,
+            "trainer_path": trainer_path,
             "exchange": exchange,
             "roofline": roofline,
             "matching": matching,
