@@ -21,6 +21,8 @@ import time
 REPO = os.path.dirname(os.path.abspath(__file__))
 if REPO not in sys.path:
     sys.path.insert(0, REPO)
+# one hardware queue per busy stream (see d3feat.pytorch_amd/__init__.py); before the HIP runtime starts
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
@@ -247,6 +249,10 @@ def main():
     ap.add_argument("--no-tuned-gemm", action="store_true", help="library-default GEMM kernels instead of the shipped "
                                                                  "TunableOp table (d3feat.pytorch_amd/tuned/)")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
+    ap.add_argument("--lanes", type=int, default=2,
+                    help="fragment pairs in flight per GPU (train.PairLanes): each on streams and graphs of its own, one "
+                         "optimizer step on the mean of their gradients per step.  1 = the reference's one pair per "
+                         "optimizer step (also measured and reported when this is > 1)")
     ap.add_argument("--cpu-budget", type=float, default=90.0)
     ap.add_argument("--blocks", type=int, default=5, help="extra timed blocks of --steps steps after the contract region "
                                                          "(median / min / max reported next to `value`)")
@@ -362,12 +368,28 @@ def main():
                   file=sys.stderr)
             use_graph = False
 
-    def run(k):
+    def run_one(k):
         # the pyramid of pair k+1 is built on a side stream / side branch of the graph meanwhile
         nxt = items[(k + 1) % len(items)] if k + 1 < n_total else None
         if use_graph:
             return ts.step_graph(items[k % len(items)], nxt)
         return ts.step(items[k % len(items)], next_item=nxt)
+
+    # several pairs in flight (graph mode only): lane j of step k trains on pair P*k + j of the rank's cycle
+    P = max(1, args.lanes) if use_graph else 1
+    lanes = None
+    if P > 1:
+        from d3feat_pytorch_amd.train import PairLanes
+        lanes = PairLanes(ts, P)
+        lanes.enable_graph(ts.caps, num_corr=int(items[0][4].shape[0]))
+        lanes.capture(items[0])
+
+    def run(k):
+        if lanes is None:
+            return run_one(k)
+        cur = [items[(P * k + j) % len(items)] for j in range(P)]
+        nxt = [items[(P * (k + 1) + j) % len(items)] for j in range(P)]
+        return lanes.step_graph(cur, nxt)[0]
 
     for w in range(args.warmup):
         run(w)
@@ -396,9 +418,33 @@ def main():
             for k in range(args.steps):
                 run(args.warmup + k)
             torch.cuda.synchronize()
-            block_rates.append(args.steps / (time.perf_counter() - tb0))
+            block_rates.append(P * args.steps / (time.perf_counter() - tb0))
         if use_graph:
             ts.check_status()
+    # the reference's schedule -- ONE pair per optimizer step -- on the same engine, same K steps
+    one_in_flight = None
+    if lanes is not None:
+        torch.cuda.synchronize()
+        ts.opt.grad_scale = 1.0 / max(1, world)
+        for k in range(3):
+            run_one(k)
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        to0 = time.perf_counter()
+        for k in range(args.steps):
+            run_one(3 + k)
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        dt1 = torch.tensor([time.perf_counter() - to0], dtype=torch.float64, device=dev)
+        if world > 1:
+            dist.all_reduce(dt1, op=dist.ReduceOp.MAX)
+        one_in_flight = {"value": round(world * args.steps / float(dt1.item()), 3), "unit": "fragment-pairs/s",
+                         "ms_per_step": round(float(dt1.item()) / args.steps * 1e3, 3),
+                         "note": "one pair per optimizer step (dataloader.py:73 batch size 1), one network graph in "
+                                 "flight per GPU: the schedule of rounds 1-2"}
+        ts.check_status()
     # The reference's boundary hands HOST arrays to the step (dataset item -> collate).  Same K steps again with every
     # pair uploaded from pageable NumPy memory inside the timed region (TrainStep.upload); reported next to `value`,
     # never as `value`.
@@ -504,6 +550,10 @@ def main():
             step = (deep.numel() + 2) // 3
 
             def exchange_only():
+                if lanes is not None:   # the join of the lanes: the summed gradient in four buckets
+                    from d3feat_pytorch_amd.train import allreduce_mean_
+                    allreduce_mean_(g, world, average=False)
+                    return
                 works = [dist.all_reduce(deep[b * step:min(deep.numel(), (b + 1) * step)], op=dist.ReduceOp.SUM,
                                          async_op=True) for b in range(3)]
                 works.append(dist.all_reduce(g[:ts.numel_shallow], op=dist.ReduceOp.SUM, async_op=True))
@@ -521,7 +571,8 @@ def main():
             t_step = (t1 - t0) / args.steps
             exposed = max(0.0, t_step - t_noex)
             exchange = {"rccl_ranks": world, "backend": dist.get_backend(), "bytes_per_step": int(g.numel() * 4),
-                        "buckets": "3 deep chunks (overlapped with the stage-2 backward graph) + 1 shallow",
+                        "buckets": "4 chunks of the lanes' summed gradient at the join (not overlapped)" if lanes is not None
+                        else "3 deep chunks (overlapped with the stage-2 backward graph) + 1 shallow",
                         "step_ms": round(t_step * 1e3, 3), "step_without_exchange_ms": round(t_noex * 1e3, 3),
                         "exchange_alone_ms": round(t_comm * 1e3, 3), "exposed_ms": round(exposed * 1e3, 3),
                         "overlap_frac": round(1.0 - exposed / t_comm, 3) if t_comm > 0 else None}
@@ -779,12 +830,14 @@ def main():
                             "most time per training step"}
         res = {
             "metric": "fragment-pairs/sec (fwd+bwd) on 3DMatch-shaped pairs",
-            "value": round(args.steps * world / elapsed, 3),
+            "value": round(P * args.steps * world / elapsed, 3),
             "unit": "fragment-pairs/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 3),
+            "pairs_per_step": P * world,
             # whole-job value / ranks: what one GPU of this run sustains (cross-check against the N = 1 line)
-            "value_per_gpu": round(args.steps / elapsed, 3),
+            "value_per_gpu": round(P * args.steps / elapsed, 3),
+            "one_pair_in_flight": one_in_flight,
             "value_blocks": None if not block_rates else {
                 "blocks": len(block_rates), "median": round(float(np.median(block_rates)), 3),
                 "min": round(min(block_rates), 3), "max": round(max(block_rates), 3),
@@ -792,16 +845,23 @@ def main():
             "host_enqueue_ms_per_step": round((t_enq - t0) / args.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "configs[2]: full D3Feat KPFCNN fwd+bwd on one fragment pair per step "
+            "config": {"workload": "configs[2]: full D3Feat KPFCNN fwd+bwd on fragment pairs "
                                    "(%d stacked points avg, 128 correspondences, 32-d descriptors, circle+detector loss, "
-                                   "on-device radius search + grid subsample, SGD step)" % int(np.mean(n_pts)),
+                                   "on-device radius search + grid subsample, SGD step); %s" % (int(np.mean(n_pts)), (
+                                       "%d pairs in flight per GPU, each a whole forward + loss + backward on streams and "
+                                       "graphs of its own, ONE guarded SGD step per %d pairs on the mean of their gradients "
+                                       "(the update a %d-rank data-parallel step makes); one_pair_in_flight = one pair per "
+                                       "optimizer step" % (P, P * world, P * world)) if P > 1 else
+                                       "one pair per optimizer step"),
                        "points_per_pair": n_pts, "neighbor_limits": limits, "pairs_per_rank": len(items),
-                       "parallelism": "dp%d" % world, "final_loss": round(loss_val, 5),
+                       "pairs_in_flight_per_gpu": P,
+                       "parallelism": "dp%d" % world if P == 1 else "dp%d x %d lanes" % (world, P),
+                       "final_loss": round(loss_val, 5),
                        "replica_param_checksum_spread": replica_spread,
                        "skipped_steps": int(ts.opt.skipped),
                        "library_gemms": "TunableOp table tuned/tunableop_gfx950.csv" if tuned else "library default",
-                       "launch": "hipGraph replay: network step on the training stream, next pair's pyramid graph on a side stream "
-                                 "(static level capacities %s)" % ts.caps
+                       "launch": "hipGraph replay: network step on the %s, next pair's pyramid graph on a side stream "
+                                 "(static level capacities %s)" % ("training stream" if P == 1 else "lane's stream", ts.caps)
                                  if use_graph else "eager launches, pyramid on a side stream"},
             "pcie_inclusive": pcie,
             "trainer_path": trainer_path,

@@ -11,7 +11,16 @@ Layout mirrors the reference's module paths so its callers keep working:
 ``install_reference_aliases()`` registers those names in ``sys.modules`` so the reference's own
 ``models/architectures.py`` (``from models.blocks import *``) runs on top of this package unchanged.
 """
-from . import _native  # noqa: F401
+import os as _os
+
+# The training step keeps several HIP streams busy at once (a training stream and a pyramid side stream per pair in
+# flight, train.PairLanes).  The HIP runtime multiplexes streams onto GPU_MAX_HW_QUEUES hardware queues (default 4) and
+# streams that share a queue run back to back -- measured: two pairs in flight 244 pairs/s on 4 queues, 302 on 16
+# (profiles/r03_queue_pipes.txt).  Read when the runtime initialises (first HIP call), so it is set at import; a value
+# the user exported wins.
+_os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+
+from . import _native  # noqa: F401,E402
 
 __version__ = "0.1.0"
 

@@ -96,6 +96,7 @@ SIGNATURES = {
     "d3f_mutual_nn_batched": (_i, [_vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _sz, _vp]),
     "d3f_topk_scores": (_i, [_vp, _i, _vp, _i, _i, _vp, _vp]),
     "d3f_sgd_guarded_step": (_i, [_vp, _vp, _vp, _sz, _f, _f, _f, _vp, _vp, _vp, _vp]),
+    "d3f_sgd_guarded_step_lanes": (_i, [_vp, _i, _vp, _vp, _sz, _f, _f, _f, _vp, _vp, _vp, _vp]),
     "d3f_poison_gradient_if_status": (_i, [_vp, _vp, _vp, _vp]),
 }
 

@@ -1793,10 +1793,15 @@ def topk_scores(scores, seg, k):
 # ---------------------------------------------------------------------------------------------------------------
 def sgd_guarded_step(grad, params, momentum_buf, lr, momentum, weight_decay, state, hyper=None, pair_status=None):
     """In place: params/momentum_buf updated unless grad holds a non-finite value (then state[1] += 1).
-    ``hyper``: optional fp32[4] device tensor {lr, momentum, weight_decay, grad_scale} read by the kernel when it
+    ``grad``: the gradient buffer, or a list of up to four of them (one per pair in flight on this GPU,
+    train.PairLanes): the step then uses their sum (d3f_sgd_guarded_step_lanes).  ``hyper``: optional fp32[4] device tensor {lr, momentum, weight_decay, grad_scale} read by the kernel when it
     runs.  ``pair_status``: optional device int32[1], the status word of the pair the gradient came from: non-zero
     skips the update too (state[2] |= flags, state[3] += 1)."""
-    for t, name in ((grad, "grad"), (params, "params"), (momentum_buf, "momentum_buf")):
+    lanes = list(grad) if isinstance(grad, (list, tuple)) else [grad]
+    if not 1 <= len(lanes) <= 4:
+        raise ValueError("1..4 gradient buffers, got %d" % len(lanes))
+    grad = lanes[0]
+    for t, name in [(g, "grad") for g in lanes] + [(params, "params"), (momentum_buf, "momentum_buf")]:
         if not (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous() and t.numel() == grad.numel()):
             raise ValueError("%s must be a contiguous fp32 device tensor of %d elements" % (name, grad.numel()))
     if not (state.is_cuda and state.dtype == torch.int32 and state.numel() >= 4):
@@ -1804,11 +1809,19 @@ def sgd_guarded_step(grad, params, momentum_buf, lr, momentum, weight_decay, sta
     if hyper is not None and not (hyper.is_cuda and hyper.dtype == torch.float32 and hyper.numel() == 4
                                   and hyper.is_contiguous()):
         raise ValueError("hyper must be a contiguous fp32[4] device tensor")
-    with _region("sgd", 20 * grad.numel()):
-        _native.check(_native.lib().d3f_sgd_guarded_step(_p(grad), _p(params), _p(momentum_buf), grad.numel(),
-                                                         float(lr), float(momentum), float(weight_decay),
-                                                         _p(hyper) if hyper is not None else None, _p(state),
-                                                         _p(pair_status), _stream()), "d3f_sgd_guarded_step")
+    with _region("sgd", (12 + 8 * len(lanes)) * grad.numel()):
+        if len(lanes) == 1:
+            _native.check(_native.lib().d3f_sgd_guarded_step(_p(grad), _p(params), _p(momentum_buf), grad.numel(),
+                                                             float(lr), float(momentum), float(weight_decay),
+                                                             _p(hyper) if hyper is not None else None, _p(state),
+                                                             _p(pair_status), _stream()), "d3f_sgd_guarded_step")
+        else:
+            import ctypes
+            ptrs = (ctypes.c_void_p * len(lanes))(*[g.data_ptr() for g in lanes])
+            _native.check(_native.lib().d3f_sgd_guarded_step_lanes(
+                ctypes.cast(ptrs, ctypes.c_void_p), len(lanes), _p(params), _p(momentum_buf), grad.numel(), float(lr),
+                float(momentum), float(weight_decay), _p(hyper) if hyper is not None else None, _p(state),
+                _p(pair_status), _stream()), "d3f_sgd_guarded_step_lanes")
 
 
 def poison_gradient_if_status(grad, pair_status, state):

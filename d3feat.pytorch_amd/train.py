@@ -60,6 +60,25 @@ class FlatParams:
                 p._d3f_grad_slot = slot
             off += k
         self.numel = n
+        self.lanes = [(self.grad, self.slots)]
+
+    def add_lane(self):
+        """A further gradient buffer over the same parameters: one per pair in flight on this GPU (PairLanes).  Returns
+        its index for ``bind``."""
+        grad = torch.zeros_like(self.grad)
+        slots, off = [], 0
+        for p in self.params:
+            slots.append(grad[off:off + p.numel()].view_as(p.data))
+            off += p.numel()
+        self.lanes.append((grad, slots))
+        return len(self.lanes) - 1
+
+    def bind(self, lane):
+        """Backward passes run (or captured) from here on leave their gradients in buffer ``lane``."""
+        self.grad, self.slots = self.lanes[lane]
+        for p, slot in zip(self.params, self.slots):
+            if hasattr(p, '_d3f_grad_slot'):
+                p._d3f_grad_slot = slot
 
     def zero_grad(self):
         for p in self.params:
@@ -173,13 +192,20 @@ class GuardedSGD:
         return self.state[1]
 
     @torch.no_grad()
-    def step(self, want_ok=True, pair_status=None):
+    def step(self, want_ok=True, pair_status=None, grads=None):
         """Returns a 0-dim bool tensor: True when the update was applied (None with want_ok=False: the training
-        step only consults the skipped-step counter).  ``pair_status``: device status word (int32[1]) of the pair the
+        step only consults the skipped-step counter).  ``grads``: the gradient buffers of several pairs in flight
+        (PairLanes) -- the step uses their sum.  ``pair_status``: device status word (int32[1]) of the pair the
         gradient came from; when it is set the update is skipped like for a non-finite gradient (a pyramid that
         outgrew a graph capacity, say, never reaches the parameters) and the flags are kept in ``state[2:4]``."""
-        g = self.flat.grad
-        if g.is_cuda:
+        g = self.flat.grad if grads is None else list(grads)
+        on_gpu = (g if grads is None else g[0]).is_cuda
+        if grads is not None and not on_gpu:    # host tensors (gloo tests): the same fixed-order sum
+            total = g[0].clone()
+            for other in g[1:]:
+                total += other
+            g = total
+        if on_gpu:
             before = self.state[1].clone() if want_ok else None
             ops.sgd_guarded_step(g, self.flat.data, self.buf, self.lr, self.momentum, self.weight_decay, self.state,
                                  hyper=self.hyper, pair_status=pair_status)
@@ -198,6 +224,24 @@ class GuardedSGD:
         self.flat.data.sub_(torch.where(ok, new_buf, torch.zeros_like(new_buf)), alpha=self.lr)
         self.state[1] += (~ok).to(torch.int32)
         return ok
+
+
+def fresh_streams(n, device):
+    """``n`` HIP streams whose hardware queues are created HERE, one after the other.
+
+    Streams that are busy at the same time must not share a compute pipe of the GPU: the four pipes of an XCD's
+    dispatcher each work through the queues mapped to them one dispatch at a time, and the driver deals queues to pipes
+    round-robin in the order the queues come into existence -- which for a HIP stream is its first use, not its
+    creation.  Measured (profiles/r03_queue_pipes.txt): two pairs in flight run at 361 pairs/s when the two training
+    streams and the two pyramid streams sit on four different pipes and at 290-304 when a pyramid stream shares a pipe
+    with a training stream; which of the two a process got depended on how many other streams had been used before.
+    Touching the streams back to back gives them consecutive queues, hence different pipes for any four of them."""
+    streams = [torch.cuda.Stream(device=device) for _ in range(n)]
+    for s in streams:
+        with torch.cuda.stream(s):
+            torch.zeros(1, device=device).add_(1)       # the first launch on the stream brings its queue to life
+        s.synchronize()
+    return streams
 
 
 class TrainStep:
@@ -456,6 +500,26 @@ class TrainStep:
         other.enable_graph(capacities, num_corr)
         return other
 
+    def clone_for_lane(self, lane, stream=None, side=None):
+        """An engine over the SAME model, parameters and optimizer whose network step leaves its gradient in buffer
+        ``lane`` of the flat parameters and does NOT step the optimizer, with streams, static buffer sets and graphs of
+        its own: one of the pairs in flight of ``PairLanes``."""
+        import copy
+        other = copy.copy(self)
+        for name in ('sets', 'graphs', 'g_net', 'g_net_b', 'g_pyr', '_graph_out', '_graph_dist', 'ev_net', 'ev_pyr',
+                     '_pending', '_cuts', 'caps', 'cur', '_overflowed', '_eager_status'):
+            other.__dict__.pop(name, None)
+        while len(self.flat.lanes) <= lane:
+            self.flat.add_lane()
+        other.lane = int(lane)
+        other.split_backward = False     # the exchange between ranks happens at the join, on the summed gradient
+        if stream is None or side is None:
+            stream, side = fresh_streams(2, self.device)
+        other.stream, other._side = stream, side
+        if getattr(self, '_h2d', None) is None and self.device.type == 'cuda':
+            self._h2d = torch.cuda.Stream(device=self.device)    # uploads: shared by the lanes (copy engines)
+        return other
+
     def _collect_status(self, i):
         """Set i is about to be reused (the caller has waited for its last network step): if that pair was flagged --
         the optimizer then skipped its update -- remember it for take_overflowed()."""
@@ -554,11 +618,21 @@ class TrainStep:
 
     def _net_step(self, st):
         batch = self._set_batch(st)
-        self.flat.zero_grad()
-        loss, desc, det, acc = self.forward_loss(batch)
-        torch.autograd.backward(loss, self._seed(loss))
-        self.flat.gather_grads()
-        self.opt.step(want_ok=False, pair_status=st.status.word)
+        lane = getattr(self, 'lane', None)
+        if lane is not None:      # one of several pairs in flight (PairLanes): gradient into the lane's own buffer,
+            self.flat.bind(lane)  # the optimizer step belongs to the join
+        try:
+            self.flat.zero_grad()
+            loss, desc, det, acc = self.forward_loss(batch)
+            torch.autograd.backward(loss, self._seed(loss))
+            grad = self.flat.gather_grads()
+            if lane is None:
+                self.opt.step(want_ok=False, pair_status=st.status.word)
+            else:   # a flagged pair turns its lane non-finite: the guard of the joint step then skips the update
+                self._poison_if_flagged(grad, st.status.word)
+        finally:
+            if lane is not None:
+                self.flat.bind(0)
         return loss.detach(), desc.detach(), det.detach(), acc.detach()
 
     def _static_step(self, item):
@@ -645,10 +719,15 @@ class TrainStep:
         least one step earlier, so the host stays a step ahead of the GPU and the training stream never idles:
           * the pyramid of pair k+1 overwrites the set last read by the network step of pair k-2,
           * the network step of pair k needs the pyramid launched during step k-1."""
+        self._ensure_loaded(item)
+        self._prefetch_next(item if next_item is None else next_item)
+        return self._launch_net(item)
+
+    # step_graph in three host phases (PairLanes interleaves them over its lanes: every network graph is launched before
+    # any lane spends host time on the following pair's pyramid)
+    def _ensure_loaded(self, item):
         i = self.cur
-        n = (i + 1) % self.NSETS
-        st, nx = self.sets[i], self.sets[n]
-        main = torch.cuda.current_stream(self.device)
+        st = self.sets[i]
         if st.loaded is not item:
             self.ev_net[i].synchronize()
             self._collect_status(i)
@@ -657,15 +736,25 @@ class TrainStep:
                 self.g_pyr[i].replay()
                 self.ev_pyr[i].record(self._side)
             st.loaded = item
-        nxt = item if next_item is None else next_item
-        if nxt is not TrainStep.NO_PREFETCH:
-            self.ev_net[n].synchronize()
-            self._collect_status(n)
-            with torch.cuda.stream(self._side):
-                self._load_inputs(nx, nxt)
-                self.g_pyr[n].replay()
-                self.ev_pyr[n].record(self._side)
-            nx.loaded = nxt
+
+    def _prefetch_next(self, nxt, n=None):
+        """Pyramid of the following pair into set ``n`` (default: the one after the current) on the side stream."""
+        if nxt is TrainStep.NO_PREFETCH:
+            return
+        n = (self.cur + 1) % self.NSETS if n is None else n
+        nx = self.sets[n]
+        self.ev_net[n].synchronize()
+        self._collect_status(n)
+        with torch.cuda.stream(self._side):
+            self._load_inputs(nx, nxt)
+            self.g_pyr[n].replay()
+            self.ev_pyr[n].record(self._side)
+        nx.loaded = nxt
+
+    def _launch_net(self, item):
+        i = self.cur
+        st = self.sets[i]
+        main = torch.cuda.current_stream(self.device)
         self.ev_pyr[i].synchronize()
 
         def done():   # queued behind the pair's network step: host mirror of its status word, then the set's event
@@ -685,7 +774,7 @@ class TrainStep:
         else:
             self.g_net[i].replay()
             done()
-        self.cur = n
+        self.cur = (i + 1) % self.NSETS
         self.last_distances = self._graph_dist[i]
         return self._graph_out[i]
 
@@ -764,3 +853,113 @@ class TrainStep:
         allreduce_mean_(self.flat.gather_grads(), self.world, average=False)   # the mean is opt.grad_scale
         self.opt.step(want_ok=False, pair_status=pair_status)
         return loss.detach(), desc.detach(), det.detach(), acc.detach()
+
+
+class PairLanes:
+    """Several fragment pairs IN FLIGHT on one GPU, meeting at one optimizer step.
+
+    One pair's network step leaves most of an MI355X idle: the kernels of the coarse levels launch 50-200 workgroups on
+    256 CUs, and the fine-level KPConv kernels saturate no unit (profiles/r03_pmc_kpconv.txt) -- they wait on gather
+    latency.  Two independent steps replayed on two streams fill those holes (1.43x the pairs/s of one,
+    profiles/r03_queue_pipes.txt).  ``lanes`` engines share the model, the flat parameter buffer and the optimizer;
+    each has its own training stream, side stream, static buffer sets, graphs and GRADIENT buffer (FlatParams.add_lane).
+    A step trains on ``lanes`` pairs at once: every lane replays forward + loss + backward of its pair, then the join
+    (on lane 0's stream) applies ONE guarded SGD step on the sum of the lane gradients scaled by 1/(lanes * world) --
+    exactly the update a data-parallel step over that many ranks makes (d3f_sgd_guarded_step_lanes forms the sum inside
+    the update kernel).  With several ranks the summed gradient is all-reduced at the join.
+    The reference trains one pair per optimizer step (dataloader.py:73); ``lanes=1`` keeps that."""
+
+    def __init__(self, ts, lanes=2):
+        if not 1 <= int(lanes) <= 4:
+            raise ValueError("1..4 pairs in flight, got %r" % (lanes,))
+        self.ts, self.P = ts, int(lanes)
+        streams = fresh_streams(2 * self.P, ts.device)       # lanes' training streams, then their side streams
+        self.engines = [ts.clone_for_lane(k, streams[k], streams[self.P + k]) for k in range(self.P)]
+        ts.opt.grad_scale = 1.0 / (self.P * max(1, ts.world))
+        self.ev_lane = [torch.cuda.Event() for _ in range(self.P)]
+        self.ev_step = torch.cuda.Event()
+        self._stepped = False
+        self._groups = {}
+
+    def enable_graph(self, capacities, num_corr):
+        for eng in self.engines:
+            eng.enable_graph(capacities, num_corr)
+
+    def capture(self, item):
+        out = None
+        for eng in self.engines:
+            eng.stream.wait_stream(torch.cuda.current_stream(self.ts.device))
+            with torch.cuda.stream(eng.stream):
+                out = eng.capture(item)
+            eng.stream.synchronize()
+        return out
+
+    def fits(self, item):
+        return self.engines[0].fits(item)
+
+    def step_graph(self, items, next_items=None):
+        """Train on ``items`` (one pair per lane); ``next_items`` (default: the same again) are the pairs of the
+        following call, whose pyramids are built on the lanes' side streams meanwhile.  Returns the lanes' (loss,
+        desc_loss, det_loss, accuracy) device scalars; they are complete after ``synchronize()``."""
+        if len(items) != self.P:
+            raise ValueError("%d pairs for %d lanes" % (len(items), self.P))
+        nxt = [items[k] if next_items is None else next_items[k] for k in range(self.P)]
+        outs = []
+        host_join = os.environ.get("D3F_LANES_JOIN", "stream") == "host"     # measurement knob (DESIGN.md, round 3)
+        for k, eng in enumerate(self.engines):
+            eng._ensure_loaded(items[k])
+        for k, eng in enumerate(self.engines):     # every network graph first ...
+            with torch.cuda.stream(eng.stream):
+                if k > 0 and self._stepped:      # the parameters of the previous joint update
+                    if host_join:
+                        self.ev_step.synchronize()
+                    else:
+                        eng.stream.wait_event(self.ev_step)
+                outs.append(eng._launch_net(items[k]))
+                self.ev_lane[k].record(eng.stream)
+        for k, eng in enumerate(self.engines):     # ... then the following pairs' pyramids, under the running networks
+            eng._prefetch_next(nxt[k], n=eng.cur)
+        s0 = self.engines[0].stream
+        flat, opt = self.ts.flat, self.ts.opt
+        with torch.cuda.stream(s0):
+            for k in range(1, self.P):
+                if host_join:
+                    self.ev_lane[k].synchronize()
+                else:
+                    s0.wait_event(self.ev_lane[k])
+            grads = [flat.lanes[k][0] for k in range(self.P)]
+            if self.ts.world > 1:
+                for g in grads[1:]:
+                    grads[0].add_(g)
+                allreduce_mean_(grads[0], self.ts.world, average=False)    # the mean is opt.grad_scale
+                grads = grads[:1]
+            opt.step(want_ok=False, grads=grads)
+            self.ev_step.record(s0)
+        self._stepped = True
+        group = tuple(items)
+        for it in group:
+            self._groups[id(it)] = group
+        while len(self._groups) > 16 * self.P:
+            self._groups.pop(next(iter(self._groups)))
+        return outs
+
+    def synchronize(self):
+        for eng in self.engines:
+            eng.stream.synchronize()
+
+    def check_status(self, raise_on_skip=True):
+        return self.engines[0].check_status(raise_on_skip)
+
+    def take_overflowed(self, drain=False):
+        """[(item, flags)]: pairs whose joint update the optimizer skipped -- the flagged pair AND the pairs that shared
+        its step (flags 0), for the caller to run again."""
+        flagged = []
+        for eng in self.engines:
+            flagged += eng.take_overflowed(drain)
+        out, seen = [], set()
+        for item, flags in flagged:
+            for mate in self._groups.get(id(item), (item,)):
+                if id(mate) not in seen:
+                    seen.add(id(mate))
+                    out.append((mate, flags if mate is item else 0))
+        return out

@@ -510,6 +510,13 @@ int d3f_kpconv_grad_input_modes(const float* q_pts, int Nq, const float* s_pts, 
 int d3f_sgd_guarded_step(const float* grad, float* params, float* momentum_buf, size_t n, float lr, float momentum,
                          float weight_decay, const float* hyper_device, int32_t* state, const int32_t* pair_status,
                          void* stream);
+/* The same step on the SUM of n_grads (1..4) gradient buffers -- `grads` is a host array of device pointers, one buffer
+ * per pair in flight on this GPU (train.PairLanes: several network steps run concurrently on streams of their own and
+ * meet at one optimizer step, the update a data-parallel step over as many ranks makes).  Every buffer is tested for
+ * non-finite values on its own; the sum is formed inside the update kernel (no pass of its own). */
+int d3f_sgd_guarded_step_lanes(const float* const* grads, int n_grads, float* params, float* momentum_buf, size_t n,
+                               float lr, float momentum, float weight_decay, const float* hyper_device, int32_t* state,
+                               const int32_t* pair_status, void* stream);
 /* data-parallel form of the pair-status gate: poisons grad[0] with NaN before the exchange when the flag is set */
 int d3f_poison_gradient_if_status(float* grad, const int32_t* pair_status, int32_t* state, void* stream);
 

@@ -154,6 +154,34 @@ def test_flat_params_views_track_module():
     assert float(f.gather_grads().abs().sum()) == 0.0  # parameters without a gradient contribute zeros
 
 
+def test_gradient_lanes_on_host_tensors():
+    """FlatParams.add_lane / bind and GuardedSGD.step(grads=[...]) on host tensors: the step uses the fixed-order sum of
+    the lane buffers (the arithmetic d3f_sgd_guarded_step_lanes does on the device)."""
+    sys.path.insert(0, REPO)
+    from d3feat_pytorch_amd.train import FlatParams, GuardedSGD
+    torch.manual_seed(0)
+    m, twin = torch.nn.Linear(5, 3), torch.nn.Linear(5, 3)
+    twin.load_state_dict(m.state_dict())
+    f, tf = FlatParams(m), FlatParams(twin)
+    o, to = GuardedSGD(f, lr=0.1, momentum=0.9, weight_decay=1e-3), GuardedSGD(tf, lr=0.1, momentum=0.9, weight_decay=1e-3)
+    o.grad_scale = to.grad_scale = 0.5
+    assert f.add_lane() == 1 and len(f.lanes) == 2 and f.lanes[1][0].shape == f.grad.shape
+    f.bind(1)
+    assert f.grad is f.lanes[1][0] and f.slots[0].data_ptr() == f.lanes[1][0].data_ptr()
+    f.bind(0)
+    assert f.grad is f.lanes[0][0]
+    for step in range(3):
+        a, b = torch.randn(f.numel), torch.randn(f.numel)
+        f.lanes[0][0].copy_(a)
+        f.lanes[1][0].copy_(b)
+        tf.grad.copy_(a + b)
+        assert bool(o.step(grads=[f.lanes[0][0], f.lanes[1][0]])) and bool(to.step())
+        assert torch.equal(f.data, tf.data) and torch.equal(o.buf, to.buf)
+    f.lanes[1][0][2] = float('nan')
+    before = f.data.clone()
+    assert not bool(o.step(grads=[f.lanes[0][0], f.lanes[1][0]])) and torch.equal(before, f.data)
+
+
 def test_bench_launched_plainly_with_gpus_2_runs_two_ranks():
     """`python bench.py --gpus 2` without a launcher must yield n_gpus == 2 (it spawns its ranks through
     torch.distributed.run) and a rank count that disagrees with --gpus must fail instead of running 1 rank; the

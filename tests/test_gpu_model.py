@@ -494,6 +494,89 @@ def test_every_graph_replay_reproduces_the_eager_gradient(golden_s0):
             assert float((t.flat.data - pe).abs().max()) < 1e-6, (gi, name)
 
 
+def test_pair_lanes_make_the_update_of_a_two_rank_step(golden_s0):
+    """Two pairs in flight on one GPU (train.PairLanes: a network graph per lane on streams of their own, gradient
+    buffers of their own, ONE guarded SGD step at the join) == the update of the mean of the two pairs' eager gradients,
+    step after step; every lane's loss is the eager loss of its pair at the parameters of that step; a pair that outgrows
+    a capacity costs BOTH pairs of its step their update and both come back from take_overflowed()."""
+    from d3feat_pytorch_amd.train import PairLanes, TrainStep
+    g = golden_s0
+    cfg = cfgmod.default_config(first_features_dim=16, num_node=64)
+    limits = [int(x) for x in g['limits']]
+    item = tuple(torch.from_numpy(np.ascontiguousarray(a)).to(DEV) for a in _item(g))
+    swapped = (item[1], item[0], item[3], item[2], item[4].flip(1).contiguous(), item[5].t().contiguous())
+    sizes = [[int(g['batch.points.%d' % l].shape[0]) for l in range(5)]]
+
+    def fresh():
+        np.random.seed(0)
+        torch.manual_seed(0)
+        return TrainStep(cfg, limits, torch.device(DEV), seed=0)
+    ts = fresh()
+    lanes = PairLanes(ts, 2)
+    assert ts.opt.grad_scale == 0.5 and len(ts.flat.lanes) == 2
+    lanes.enable_graph(TrainStep.capacities_for(sizes, slack=1.3), num_corr=item[4].shape[0])
+    lanes.capture(item)               # lane engines never step the optimizer on their own: parameters untouched
+    torch.cuda.synchronize()
+    ref = fresh()
+    assert torch.equal(ts.flat.data, ref.flat.data)
+    lr, mom, wd = ref.opt.lr, ref.opt.momentum, ref.opt.weight_decay
+    buf = torch.zeros_like(ref.flat.data)
+    steps = [(item, swapped), (swapped, item), (item, item)]
+    for k, pair in enumerate(steps):
+        nxt = steps[k + 1] if k + 1 < len(steps) else None
+        outs = lanes.step_graph(list(pair), list(nxt) if nxt else None)
+        lanes.synchronize()
+        grads, losses = [], []
+        for it in pair:               # the eager gradient of each pair at the SAME parameters
+            batch = ref.build_batch(it)
+            batch['n0'] = int(it[0].shape[0])
+            ref.flat.zero_grad()
+            loss = ref.forward_loss(batch)[0]
+            torch.autograd.backward(loss, ref._seed(loss))
+            grads.append(ref.flat.gather_grads().clone())
+            losses.append(float(loss.detach()))
+        for o, le in zip(outs, losses):
+            assert abs(float(o[0]) - le) < 2e-3 * max(1.0, abs(le)), (k, float(o[0]), le)
+        gsum = (grads[0] + grads[1]) * 0.5
+        for lane in range(2):         # each lane's buffer holds ITS pair's gradient
+            gl = ts.flat.lanes[lane][0]
+            assert float((gl - grads[lane]).abs().max()) < 1e-4 * float(grads[lane].abs().max()), (k, lane)
+        d = gsum + wd * ref.flat.data
+        buf = buf * mom + d
+        ref.flat.data.sub_(lr * buf)
+        assert float((ts.flat.data - ref.flat.data).abs().max()) < 1e-6 + 1e-4 * lr * float(buf.abs().max()), k
+    assert lanes.check_status() == (0, 0) and int(ts.opt.skipped) == 0 and lanes.take_overflowed(drain=True) == []
+    # the plain engine still trains one pair per step on buffer 0 after the lanes were captured
+    ts.opt.grad_scale = 1.0
+    before = ts.flat.data.clone()
+    ts.step(item)
+    torch.cuda.synchronize()
+    assert not torch.equal(before, ts.flat.data) and torch.isfinite(ts.flat.data).all()
+    # capacity overflow in ONE lane: the joint update is skipped, both pairs are handed back.  Capacities: level 0
+    # holds `item`, the deeper levels are sized for a pair a fraction of its size (the one the graphs are captured on)
+    tiny = synthetic.make_pair(5, 6, _gpu_subsample, n_raw=20000, scale=0.12, num_node=int(item[4].shape[0]))
+    tiny = tuple(torch.from_numpy(np.ascontiguousarray(a)).to(DEV) for a in tiny)
+    small = fresh()
+    tsz = [int(t.shape[0]) for t in small.build_batch(tiny)['points']]
+    caps = [lanes.engines[0].caps[0]] + TrainStep.capacities_for([tsz], slack=1.1)[1:]
+    assert tsz[0] < sizes[0][0] and caps[1] < sizes[0][1], (tsz, sizes, caps)
+    tight = PairLanes(small, 2)
+    tight.enable_graph(caps, num_corr=item[4].shape[0])
+    tight.capture(tiny)
+    before = small.flat.data.clone()
+    tight.step_graph([tiny, tiny])
+    tight.synchronize()
+    assert not torch.equal(before, small.flat.data) and tight.take_overflowed(drain=True) == []
+    before = small.flat.data.clone()
+    tight.step_graph([tiny, item])
+    tight.synchronize()
+    again = tight.take_overflowed(drain=True)
+    assert torch.equal(before, small.flat.data) and int(small.opt.skipped) == 1
+    assert len(again) == 2 and {id(a[0]) for a in again} == {id(tiny), id(item)}
+    assert [f for it, f in again if it is item][0] != 0 and [f for it, f in again if it is tiny][0] == 0
+    assert tight.check_status(raise_on_skip=False)[1] == 1
+
+
 def test_split_backward_matches_single_backward(golden_s0):
     """The data-parallel mode cuts the autograd graph at encoder block CUT (deep gradient bucket is exchanged while the
     fine levels are still in backward).  Same gradients / same trajectory as the single backward, eager and as graphs."""
@@ -731,7 +814,7 @@ def test_two_rank_bench_control_flow_on_one_gpu():
     assert res["n_gpus"] == 2 and res["steps"] == 4 and res["scaling"] == "weak" and res["value"] > 0
     assert abs(res["value_per_gpu"] * 2 - res["value"]) < 0.01 * res["value"]
     cfg = res["config"]
-    assert cfg["parallelism"] == "dp2" and cfg["launch"].startswith("hipGraph replay")
+    assert cfg["parallelism"] == "dp2 x 2 lanes" and res["pairs_per_step"] == 4 and cfg["launch"].startswith("hipGraph replay")
     assert cfg["replica_param_checksum_spread"] == 0.0 and cfg["skipped_steps"] == 0
     assert np.isfinite(cfg["final_loss"]) and "cpu_baseline" not in res
     ex = res["exchange"]     # the overlap leg: step with / without the exchange, the exchange alone

@@ -810,6 +810,48 @@ def test_guarded_sgd_step_matches_torch_sgd_and_skips_on_nonfinite():
     assert int(opt.skipped) == 1
 
 
+def test_guarded_sgd_on_gradient_lanes_steps_on_their_sum():
+    """d3f_sgd_guarded_step_lanes: the update uses lane 0 + lane 1 (+ ...) in that order, bit-identical to the
+    single-buffer step on the pre-added sum; a non-finite value in ANY lane skips it -- also Inf and -Inf at the same
+    place in two lanes, which a test of the sum alone would let through as NaN only by luck of the arithmetic."""
+    from d3feat_pytorch_amd.train import FlatParams, GuardedSGD
+    torch.manual_seed(0)
+    model = torch.nn.Sequential(torch.nn.Linear(41, 29), torch.nn.Linear(29, 6)).to(DEV)   # 1398 floats: scalar tail
+    twin = torch.nn.Sequential(torch.nn.Linear(41, 29), torch.nn.Linear(29, 6)).to(DEV)
+    twin.load_state_dict(model.state_dict())
+    flat, tflat = FlatParams(model), FlatParams(twin)
+    assert flat.numel % 4 != 0
+    opt, topt = GuardedSGD(flat, lr=0.01, momentum=0.9, weight_decay=1e-4), GuardedSGD(tflat, lr=0.01, momentum=0.9, weight_decay=1e-4)
+    opt.grad_scale = topt.grad_scale = 1.0 / 3
+    for k in (1, 2):
+        assert flat.add_lane() == k
+    gen = torch.Generator(device=DEV).manual_seed(2)
+    for step in range(4):
+        gs = [torch.randn(flat.numel, generator=gen, device=DEV) for _ in range(3)]
+        for (buf, _), g in zip(flat.lanes, gs):
+            buf.copy_(g)
+        tflat.grad.copy_((gs[0] + gs[1]) + gs[2])
+        opt.step(want_ok=False, grads=[l[0] for l in flat.lanes])
+        topt.step(want_ok=False)
+        assert torch.equal(flat.data, tflat.data) and torch.equal(opt.buf, topt.buf), step
+    before = flat.data.clone()
+    flat.lanes[1][0][7] = float('inf')
+    flat.lanes[2][0][7] = float('-inf')
+    assert not bool(opt.step(grads=[l[0] for l in flat.lanes])) and torch.equal(before, flat.data)
+    flat.lanes[1][0][7] = 0.0
+    flat.lanes[2][0][7] = 0.0
+    flat.lanes[2][0][flat.numel - 1] = float('nan')          # in the scalar tail
+    assert not bool(opt.step(grads=[l[0] for l in flat.lanes])) and int(opt.skipped) == 2
+    with pytest.raises(ValueError):
+        ops.sgd_guarded_step([flat.grad] * 5, flat.data, opt.buf, 0.1, 0.9, 0.0, opt.state)
+    # bind(): weight-gradient slots follow the lane
+    w = model[0].weight
+    flat.bind(2)
+    assert w._d3f_grad_slot.data_ptr() == flat.lanes[2][1][0].data_ptr() and flat.grad.data_ptr() == flat.lanes[2][0].data_ptr()
+    flat.bind(0)
+    assert w._d3f_grad_slot.data_ptr() == flat.lanes[0][1][0].data_ptr()
+
+
 # ------------------------------------------------------------------------------------------------ full-size matching
 def _golden_s1_match():
     import os
