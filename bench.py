@@ -22,7 +22,7 @@ REPO = os.path.dirname(os.path.abspath(__file__))
 if REPO not in sys.path:
     sys.path.insert(0, REPO)
 # one hardware queue per busy stream (see d3feat.pytorch_amd/__init__.py); before the HIP runtime starts
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "32")
 
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
@@ -244,12 +244,12 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--pairs", type=int, default=4, help="distinct synthetic pairs per rank (cycled)")
+    ap.add_argument("--pairs", type=int, default=6, help="distinct synthetic pairs per rank (cycled)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-tuned-gemm", action="store_true", help="library-default GEMM kernels instead of the shipped "
                                                                  "TunableOp table (d3feat.pytorch_amd/tuned/)")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
-    ap.add_argument("--lanes", type=int, default=2,
+    ap.add_argument("--lanes", type=int, default=3,
                     help="fragment pairs in flight per GPU (train.PairLanes): each on streams and graphs of its own, one "
                          "optimizer step on the mean of their gradients per step.  1 = the reference's one pair per "
                          "optimizer step (also measured and reported when this is > 1)")
@@ -855,6 +855,7 @@ def main():
                                        "one pair per optimizer step"),
                        "points_per_pair": n_pts, "neighbor_limits": limits, "pairs_per_rank": len(items),
                        "pairs_in_flight_per_gpu": P,
+                       "side_stream_probe_ms": getattr(ts, "_side_probe", None),
                        "parallelism": "dp%d" % world if P == 1 else "dp%d x %d lanes" % (world, P),
                        "final_loss": round(loss_val, 5),
                        "replica_param_checksum_spread": replica_spread,

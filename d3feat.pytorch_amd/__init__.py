@@ -15,10 +15,10 @@ import os as _os
 
 # The training step keeps several HIP streams busy at once (a training stream and a pyramid side stream per pair in
 # flight, train.PairLanes).  The HIP runtime multiplexes streams onto GPU_MAX_HW_QUEUES hardware queues (default 4) and
-# streams that share a queue run back to back -- measured: two pairs in flight 244 pairs/s on 4 queues, 302 on 16
+# streams that share a queue run back to back -- measured: two pairs in flight 244 pairs/s on 4 queues, 302 on 16 or more
 # (profiles/r03_queue_pipes.txt).  Read when the runtime initialises (first HIP call), so it is set at import; a value
 # the user exported wins.
-_os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+_os.environ.setdefault("GPU_MAX_HW_QUEUES", "32")
 
 from . import _native  # noqa: F401,E402
 

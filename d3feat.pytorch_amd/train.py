@@ -226,6 +226,17 @@ class GuardedSGD:
         return ok
 
 
+_WARM = {}
+
+
+def _warm_stream(device):
+    """One warm-up stream per device for every capture of the process (each used stream holds a hardware queue)."""
+    key = str(device)
+    if key not in _WARM:
+        _WARM[key] = torch.cuda.Stream(device=device)
+    return _WARM[key]
+
+
 def fresh_streams(n, device):
     """``n`` HIP streams whose hardware queues are created HERE, one after the other.
 
@@ -652,7 +663,7 @@ class TrainStep:
             self._load_inputs(st, item)
             self._build_set(st)
             st.loaded = item
-        warm = torch.cuda.Stream(device=dev)
+        warm = _warm_stream(dev)
         warm.wait_stream(main)
         with torch.cuda.stream(warm):
             for k in range(3):
@@ -684,6 +695,7 @@ class TrainStep:
         for g in self.g_pyr:    # a capture records, it does not run: fill the adopted tensors (inputs are loaded)
             g.replay()
         torch.cuda.synchronize(dev)
+        self._choose_side_stream()
         for i in range(self.NSETS):
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g, pool=self.g_net[0].pool() if self.g_net else None, capture_error_mode=_CAPTURE_MODE):
@@ -706,6 +718,40 @@ class TrainStep:
             self.ev_pyr[i].record(main)
         self.cur = 0
         return out
+
+    def _choose_side_stream(self):
+        """The pyramid stream must not sit on the compute pipe of the stream the network graphs replay on
+        (fresh_streams; measured: 251 pairs/s against 188-218 when they share one).  The training stream is the
+        caller's, so its pipe is not ours to pick: four candidates with consecutive queues cover all four pipes, and a
+        probe -- two pyramid graphs at once, one on the training stream, one on the candidate -- tells which to avoid.
+        The lanes of PairLanes bring their own streams (consecutive queues by construction)."""
+        if getattr(self, 'lane', None) is not None or self.__dict__.get('_side_probe') is not None:
+            return
+        import time
+        dev = self.device
+
+        def timed(stream):
+            best = float('inf')
+            for _ in range(4):
+                torch.cuda.synchronize(dev)
+                t0 = time.perf_counter()
+                self.g_pyr[0].replay()
+                with torch.cuda.stream(stream):
+                    self.g_pyr[1].replay()
+                torch.cuda.synchronize(dev)
+                best = min(best, time.perf_counter() - t0)
+            return best
+        serial = timed(torch.cuda.current_stream(dev))     # both on the training stream: what sharing a pipe costs
+        probe, chosen = [], None
+        for _ in range(4):          # consecutive queues: at most one of four shares the training stream's pipe
+            cand = fresh_streams(1, dev)[0]
+            probe.append(timed(cand))
+            if chosen is None or probe[-1] < chosen[0]:
+                chosen = (probe[-1], cand)
+            if probe[-1] < 0.8 * serial:
+                break
+        self._side = chosen[1]
+        self._side_probe = {'serial_ms': round(serial * 1e3, 4), 'candidates_ms': [round(t * 1e3, 4) for t in probe]}
 
     def step_graph(self, item, next_item=None):
         """Train on ``item``; the pyramid of ``next_item`` (default: ``item`` again) is built on the side stream
@@ -870,16 +916,40 @@ class PairLanes:
     The reference trains one pair per optimizer step (dataloader.py:73); ``lanes=1`` keeps that."""
 
     def __init__(self, ts, lanes=2):
-        if not 1 <= int(lanes) <= 4:
-            raise ValueError("1..4 pairs in flight, got %r" % (lanes,))
+        if not 1 <= int(lanes) <= 3:
+            raise ValueError("1..3 pairs in flight (four compute pipes: one per training stream + one for the pyramid "
+                             "streams; a fourth lane sharing a pipe measured 308 pairs/s against 409 for three), got %r"
+                             % (lanes,))
         self.ts, self.P = ts, int(lanes)
-        streams = fresh_streams(2 * self.P, ts.device)       # lanes' training streams, then their side streams
-        self.engines = [ts.clone_for_lane(k, streams[k], streams[self.P + k]) for k in range(self.P)]
+        # lanes' training streams on different compute pipes, the pyramid stream(s) on the remaining one(s): two lanes
+        # have a pyramid stream each, three share one (their 0.6 ms builds run back to back under a 7 ms step) -- four
+        # streams either way, and no more: every stream that has run a kernel keeps a hardware queue, and a process
+        # with more queues than the GPU has slots for gets them time-sliced
+        streams = fresh_streams(min(2 * self.P, 4), ts.device)
+        nets = streams[:self.P]
+        sides = streams[self.P:] if 2 * self.P <= 4 else [streams[3]] * self.P
+        self.engines = [ts.clone_for_lane(k, nets[k], sides[k]) for k in range(self.P)]
         ts.opt.grad_scale = 1.0 / (self.P * max(1, ts.world))
         self.ev_lane = [torch.cuda.Event() for _ in range(self.P)]
-        self.ev_step = torch.cuda.Event()
-        self._stepped = False
+        # the last joint update -- shared with the clones for other capacity classes (they step the same parameters)
+        self._join = {'ev_step': torch.cuda.Event(), 'stepped': False}
         self._groups = {}
+
+    caps = property(lambda self: self.engines[0].caps)
+
+    def clone_for_capacities(self, capacities, num_corr):
+        """The same lanes (streams, gradient buffers, join) with buffer sets and graphs for other level capacities: one
+        per size class of the dataset (TrainStep.clone_for_capacities)."""
+        import copy
+        other = copy.copy(self)
+        other.engines = [e.clone_for_capacities(capacities, num_corr) for e in self.engines]
+        other._groups = {}
+        return other
+
+    def preload(self, items):
+        """Pyramids of the lanes' next pairs into the sets they train on next (the previous step ran on another class)."""
+        for eng, item in zip(self.engines, items):
+            eng.preload(item)
 
     def enable_graph(self, capacities, num_corr):
         for eng in self.engines:
@@ -903,18 +973,21 @@ class PairLanes:
         desc_loss, det_loss, accuracy) device scalars; they are complete after ``synchronize()``."""
         if len(items) != self.P:
             raise ValueError("%d pairs for %d lanes" % (len(items), self.P))
-        nxt = [items[k] if next_items is None else next_items[k] for k in range(self.P)]
+        if next_items is TrainStep.NO_PREFETCH:
+            nxt = [TrainStep.NO_PREFETCH] * self.P
+        else:
+            nxt = [items[k] if next_items is None else next_items[k] for k in range(self.P)]
         outs = []
         host_join = os.environ.get("D3F_LANES_JOIN", "stream") == "host"     # measurement knob (DESIGN.md, round 3)
         for k, eng in enumerate(self.engines):
             eng._ensure_loaded(items[k])
         for k, eng in enumerate(self.engines):     # every network graph first ...
             with torch.cuda.stream(eng.stream):
-                if k > 0 and self._stepped:      # the parameters of the previous joint update
+                if k > 0 and self._join['stepped']:      # the parameters of the previous joint update
                     if host_join:
-                        self.ev_step.synchronize()
+                        self._join['ev_step'].synchronize()
                     else:
-                        eng.stream.wait_event(self.ev_step)
+                        eng.stream.wait_event(self._join['ev_step'])
                 outs.append(eng._launch_net(items[k]))
                 self.ev_lane[k].record(eng.stream)
         for k, eng in enumerate(self.engines):     # ... then the following pairs' pyramids, under the running networks
@@ -934,8 +1007,8 @@ class PairLanes:
                 allreduce_mean_(grads[0], self.ts.world, average=False)    # the mean is opt.grad_scale
                 grads = grads[:1]
             opt.step(want_ok=False, grads=grads)
-            self.ev_step.record(s0)
-        self._stepped = True
+            self._join['ev_step'].record(s0)
+        self._join['stepped'] = True
         group = tuple(items)
         for it in group:
             self._groups[id(it)] = group
@@ -946,6 +1019,20 @@ class PairLanes:
     def synchronize(self):
         for eng in self.engines:
             eng.stream.synchronize()
+
+    def resync(self):
+        """After the parameters were updated OUTSIDE the lanes (an eager step on the current stream; the caller has
+        ``synchronize()``d the lanes before it): the lanes' next graphs wait for that update."""
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(self.ts.device))
+        for eng in self.engines:
+            eng.stream.wait_event(ev)
+
+    def make_visible(self, stream=None):
+        """The lanes' latest outputs (losses, distances) become readable on ``stream`` (default: the current one)."""
+        stream = torch.cuda.current_stream(self.ts.device) if stream is None else stream
+        for ev in self.ev_lane:
+            stream.wait_event(ev)
 
     def check_status(self, raise_on_skip=True):
         return self.engines[0].check_status(raise_on_skip)

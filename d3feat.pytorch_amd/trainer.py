@@ -14,6 +14,10 @@ every ``log_interval`` iterations (the reference reads five scalars back per ste
 any object with ``add_scalar(tag, value, step)`` (``args.writer``; tensorboardX is not a dependency), by default a
 JSON-lines file under ``args.tboard_dir``.  With ``world_size > 1`` every rank walks the same shuffled order and takes
 every ``world_size``-th pair; rank 0 writes snapshots and logs.
+
+``args.pairs_in_flight`` (default 1 = the reference's one pair per optimizer step, dataloader.py:73) > 1 trains on that
+many pairs AT ONCE per GPU (train.PairLanes: a network graph per pair on streams of their own, one SGD step on the mean
+of their gradients -- the update a data-parallel step over as many more ranks makes); graph mode only.
 """
 import json
 import os
@@ -22,7 +26,7 @@ import numpy as np
 import torch
 import torch.distributed as dist
 
-from .train import TrainStep
+from .train import PairLanes, TrainStep
 
 
 class ExponentialLR:
@@ -129,6 +133,11 @@ class Trainer(object):
                 print("note: use_batch_norm=True -> eager training path (no hipGraph replay)")
             self.use_graph = False
         self._captured = False
+        self.lanes = max(1, int(_get(args, 'pairs_in_flight', 1)))
+        if self.lanes > 1 and not self.use_graph:
+            if self.rank == 0:
+                print("note: pairs_in_flight=%d needs the hipGraph path; training one pair per step" % self.lanes)
+            self.lanes = 1
         if _get(args, 'pretrain', ''):
             self._load_pretrain(args.pretrain)
 
@@ -215,7 +224,13 @@ class Trainer(object):
         self._engines = []
         keep = (eng.flat.data.clone(), eng.opt.buf.clone(), eng.opt.state.clone())
         for caps, member in self._capacity_classes(ds, classes=int(_get(self.config, 'capacity_classes', 3))):
-            if not self._engines:     # the first class lives in the engine itself, the others in clones of it
+            if self.lanes > 1:        # several pairs in flight: the lanes of every class share streams and the join
+                if not self._engines:
+                    e = PairLanes(eng, self.lanes)
+                    e.enable_graph(caps, num_corr=int(item[4].shape[0]))
+                else:
+                    e = self._engines[0].clone_for_capacities(caps, num_corr=int(item[4].shape[0]))
+            elif not self._engines:   # the first class lives in the engine itself, the others in clones of it
                 e = eng
                 e.enable_graph(caps, num_corr=int(item[4].shape[0]))
             else:
@@ -236,10 +251,56 @@ class Trainer(object):
         """Pairs whose graph step the optimizer skipped because a deeper level outgrew its class capacity are trained
         on the eager path (exact shapes) a few steps late instead of being dropped -- the reference trains on every
         pair (trainer.py:89-111)."""
-        for e in getattr(self, '_engines', []):
-            for item, flags in e.take_overflowed(drain=drain):
-                self.engine.step(item)
-                self.rerun_pairs = getattr(self, 'rerun_pairs', 0) + 1
+        again = [x for e in getattr(self, '_engines', []) for x in e.take_overflowed(drain=drain)]
+        if again:
+            self._eager_steps([item for item, _ in again])
+            self.rerun_pairs = getattr(self, 'rerun_pairs', 0) + len(again)
+
+    def _eager_steps(self, items):
+        """Eager steps on the current stream.  With pairs in flight the lanes are drained first and wait for these
+        updates afterwards (their graphs run on streams of their own)."""
+        lanes = self._engines[0] if self.lanes > 1 and getattr(self, '_engines', None) else None
+        if lanes is not None:
+            lanes.synchronize()
+        res = []
+        for it in items:
+            _, desc, det, acc = self.engine.step(it)
+            fp, an = self.engine.last_distances
+            res.append((desc, det, acc, fp.mean(), an.mean()))
+        if lanes is not None:
+            lanes.resync()
+        return res
+
+    def _lanes_step(self, items, next_items):
+        """One joint step on ``pairs_in_flight`` pairs: the smallest capacity class that holds all of them (pairs that
+        fit no class -- or a group the graphs cannot take -- go through the eager step one by one).  Returns
+        [(desc, det, acc, d_pos, d_neg)] per pair, readable on the current stream."""
+        if not self._captured:
+            self._capture_classes(items[0])
+
+        def cls(group):
+            if group is None:
+                return None
+            for e in self._engines:
+                if all(e.fits(it) for it in group):
+                    return e
+            return None
+        e, res = cls(items), []
+        if e is None:
+            return self._eager_steps(items)
+        nxt_e = cls(next_items)
+        if nxt_e is e:
+            outs = e.step_graph(items, next_items)
+        else:
+            if nxt_e is not None:
+                nxt_e.preload(next_items)
+            outs = e.step_graph(items, TrainStep.NO_PREFETCH)
+        e.make_visible()
+        for lane, out in zip(e.engines, outs):
+            fp, an = lane.last_distances
+            res.append((out[1], out[2], out[3], fp.mean(), an.mean()))
+        self._rerun_overflowed()      # a flagged pair and the pairs that shared its (skipped) step: eager, one by one
+        return res
 
     def _one_step(self, item, next_item):
         eng = self.engine
@@ -283,15 +344,24 @@ class Trainer(object):
     def train_epoch(self, epoch):
         ds = self.train_loader.dataset
         order = self._order(self.train_loader, epoch)
-        num_iter = min(self.training_max_iter, len(ds) // max(1, getattr(self.train_loader, 'batch_size', 1)) // self.world)
+        P = self.lanes
+        num_iter = min(self.training_max_iter,
+                       len(ds) // max(1, getattr(self.train_loader, 'batch_size', 1)) // self.world // P)
         meters = _Meters(self.device)
-        item = self._fetch(ds, order[self.rank]) if num_iter else None
+
+        def group(it):      # lane k of step `it` on this rank (pairs_in_flight = 1: the reference's one pair per step)
+            return [self._fetch(ds, order[(it * P + k) * self.world + self.rank]) for k in range(P)]
+        items = group(0) if num_iter else None
         for it in range(num_iter):
-            nxt = self._fetch(ds, order[(it + 1) * self.world + self.rank]) if it + 1 < num_iter else None
-            _, desc, det, acc = self._one_step(item, nxt)
-            fp, an = self.engine.last_distances
-            meters.update(desc, det, acc, fp.mean(), an.mean())
-            item = nxt
+            nxt = group(it + 1) if it + 1 < num_iter else None
+            if P == 1:
+                _, desc, det, acc = self._one_step(items[0], nxt[0] if nxt else None)
+                fp, an = self.engine.last_distances
+                meters.update(desc, det, acc, fp.mean(), an.mean())
+            else:
+                for stats in self._lanes_step(items, nxt):
+                    meters.update(*stats)
+            items = nxt
             if (it + 1) % self.log_interval == 0 and self.verbose:
                 avg = meters.averages()
                 self._report_skipped()
@@ -306,6 +376,8 @@ class Trainer(object):
                                                           self._get_lr(), int(self.optimizer.skipped)))
         avg = meters.averages()
         self._report_skipped()
+        if self.lanes > 1 and self.device.type == 'cuda':
+            torch.cuda.synchronize(self.device)      # the lanes' last joint update, before evaluation / snapshots
         if self.rank == 0:
             print("Epoch %d: Desc Loss: %.2f, Det Loss : %.2f, Accuracy: %.2f, D_pos: %.2f, D_neg: %.2f" % (
                 epoch, avg['desc_loss'], avg['det_loss'], avg['accuracy'], avg['d_pos'], avg['d_neg']))

@@ -751,6 +751,55 @@ def test_trainer_size_classes_train_every_pair_like_the_eager_trainer():
     assert torch.isfinite(tr2.engine.flat.data).all() and not torch.equal(before, tr2.engine.flat.data)
 
 
+def test_trainer_with_two_pairs_in_flight_trains_on_the_mean_gradient_of_each_group():
+    """Trainer(pairs_in_flight=2) over a mix of ~5k- and ~30k-point pairs with two capacity classes: every step trains on
+    two pairs at once (train.PairLanes; the lanes of both classes share streams, gradient buffers and the join), a mixed
+    group goes to the class that holds both pairs, and after the epoch the parameters equal eager training on the mean
+    gradient of each group of two."""
+    from d3feat_pytorch_amd.train import PairLanes, TrainStep
+    from d3feat_pytorch_amd.trainer import Trainer
+    small = [synthetic.make_pair(31 + 2 * i, 32 + 2 * i, _gpu_subsample, n_raw=60000, scale=0.22, num_node=64) for i in range(2)]
+    big = [synthetic.make_pair(41 + 2 * i, 42 + 2 * i, _gpu_subsample, n_raw=300000, scale=0.55, num_node=64) for i in range(2)]
+    order = [small[0], small[1], big[0], big[1], big[0], small[0], small[1], small[0]]
+
+    class _Loader:
+        dataset, batch_size, shuffle = order, 1, False
+
+    cfg = cfgmod.default_config(first_features_dim=32, num_node=64)
+    cfg.max_epoch, cfg.save_dir, cfg.tboard_dir, cfg.device = 1, None, None, DEV
+    cfg.train_loader, cfg.val_max_iter, cfg.verbose, cfg.seed = _Loader(), 1, False, 3
+    cfg.neighborhood_limits = [40, 40, 40, 40, 30]
+    cfg.graph, cfg.capacity_classes, cfg.pairs_in_flight = True, 2, 2
+    tr = Trainer(cfg)
+    avg = tr.train_epoch(1)
+    torch.cuda.synchronize()
+    assert tr.lanes == 2 and len(tr._engines) == 2 and all(isinstance(e, PairLanes) for e in tr._engines)
+    assert tr._engines[0].engines[0].stream is tr._engines[1].engines[0].stream      # the classes share the lanes
+    assert tr._engines[0].caps[0] < 0.5 * tr._engines[1].caps[0]
+    assert tr._report_skipped() == 0 and getattr(tr, 'rerun_pairs', 0) == 0 and int(tr.optimizer.skipped) == 0
+    assert np.isfinite(avg['desc_loss']) and 0.0 <= avg['accuracy'] <= 100.0
+    ref = TrainStep(cfg, cfg.neighborhood_limits, torch.device(DEV), seed=3)
+    start = ref.flat.data.clone()
+    ref.flat.add_lane()
+    ref.opt.grad_scale = 0.5
+    for g in range(len(order) // 2):
+        for k in range(2):
+            it = ref.upload(order[2 * g + k])
+            batch = ref.build_batch(it)
+            batch['n0'] = int(it[0].shape[0])
+            ref.flat.bind(k)
+            ref.flat.zero_grad()
+            loss = ref.forward_loss(batch)[0]
+            torch.autograd.backward(loss, ref._seed(loss))
+            ref.flat.gather_grads()
+        ref.flat.bind(0)
+        ref.opt.step(want_ok=False, grads=[ref.flat.lanes[0][0], ref.flat.lanes[1][0]])
+    torch.cuda.synchronize()
+    a, b = tr.engine.flat.data, ref.flat.data
+    moved = float((b - start).abs().max())
+    assert moved > 0 and float((a - b).abs().max()) < 2e-3 * moved, (float((a - b).abs().max()), moved)
+
+
 def test_trainer_consumes_threedmatch_pickles(golden_s0, tmp_path):
     """Host items of the dataset front-end (float64 points, fresh objects every draw) through the pipelined step."""
     import pickle
@@ -805,7 +854,7 @@ def test_two_rank_bench_control_flow_on_one_gpu():
     env = dict(os.environ, D3F_BENCH_SHARE_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
     env.pop("WORLD_SIZE", None)
     # launched PLAINLY: bench.py spawns its ranks through torch.distributed.run itself (and refuses to run 1 rank as 2)
-    cmd = [sys.executable, "bench.py", "--gpus", "2", "--steps", "4", "--warmup", "2", "--pairs", "2", "--no-cpu-baseline"]
+    cmd = [sys.executable, "bench.py", "--gpus", "2", "--steps", "4", "--warmup", "2", "--pairs", "2", "--lanes", "2", "--no-cpu-baseline"]
     r = subprocess.run(cmd, cwd=repo, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith('{"metric"')]
