@@ -244,12 +244,12 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--pairs", type=int, default=6, help="distinct synthetic pairs per rank (cycled)")
+    ap.add_argument("--pairs", type=int, default=8, help="distinct synthetic pairs per rank (cycled)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-tuned-gemm", action="store_true", help="library-default GEMM kernels instead of the shipped "
                                                                  "TunableOp table (d3feat.pytorch_amd/tuned/)")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
-    ap.add_argument("--lanes", type=int, default=3,
+    ap.add_argument("--lanes", type=int, default=4,
                     help="fragment pairs in flight per GPU (train.PairLanes): each on streams and graphs of its own, one "
                          "optimizer step on the mean of their gradients per step.  1 = the reference's one pair per "
                          "optimizer step (also measured and reported when this is > 1)")
@@ -861,8 +861,11 @@ def main():
                        "replica_param_checksum_spread": replica_spread,
                        "skipped_steps": int(ts.opt.skipped),
                        "library_gemms": "TunableOp table tuned/tunableop_gfx950.csv" if tuned else "library default",
-                       "launch": "hipGraph replay: network step on the %s, next pair's pyramid graph on a side stream "
-                                 "(static level capacities %s)" % ("training stream" if P == 1 else "lane's stream", ts.caps)
+                       "launch": "hipGraph replay: network step on the %s, next pair's pyramid graph %s "
+                                 "(static level capacities %s)" % (
+                                     "training stream" if P == 1 else "lane's stream",
+                                     "on a side stream" if P <= 2 else "on a pyramid stream the lanes share" if P == 3
+                                     else "on the lane's own stream behind it (all four compute pipes train)", ts.caps)
                                  if use_graph else "eager launches, pyramid on a side stream"},
             "pcie_inclusive": pcie,
             "trainer_path": trainer_path,

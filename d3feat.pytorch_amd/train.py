@@ -916,18 +916,20 @@ class PairLanes:
     The reference trains one pair per optimizer step (dataloader.py:73); ``lanes=1`` keeps that."""
 
     def __init__(self, ts, lanes=2):
-        if not 1 <= int(lanes) <= 3:
-            raise ValueError("1..3 pairs in flight (four compute pipes: one per training stream + one for the pyramid "
-                             "streams; a fourth lane sharing a pipe measured 308 pairs/s against 409 for three), got %r"
-                             % (lanes,))
+        if not 1 <= int(lanes) <= 4:
+            raise ValueError("1..4 pairs in flight (the dispatcher has four compute pipes: one per training stream), "
+                             "got %r" % (lanes,))
         self.ts, self.P = ts, int(lanes)
-        # lanes' training streams on different compute pipes, the pyramid stream(s) on the remaining one(s): two lanes
-        # have a pyramid stream each, three share one (their 0.6 ms builds run back to back under a 7 ms step) -- four
-        # streams either way, and no more: every stream that has run a kernel keeps a hardware queue, and a process
-        # with more queues than the GPU has slots for gets them time-sliced
+        # The lanes' training streams sit on different compute pipes (fresh_streams); what is left of the four pipes
+        # goes to the pyramid builds: two lanes have a pyramid stream each (361 pairs/s), three share one (their 0.6-ms
+        # builds run back to back under a 7-ms step: 414), and with four lanes every pipe trains and each lane builds
+        # its next pyramid on its OWN stream, behind its network graph (434) -- a stream that SHARES a pipe with another
+        # busy stream is far worse than either (a fifth stream for the pyramids: 256).  Never more streams than that:
+        # every stream that has run a kernel keeps a hardware queue, and a process with more queues than the GPU has
+        # slots for gets them time-sliced.
         streams = fresh_streams(min(2 * self.P, 4), ts.device)
         nets = streams[:self.P]
-        sides = streams[self.P:] if 2 * self.P <= 4 else [streams[3]] * self.P
+        sides = streams[self.P:] if self.P <= 2 else [streams[3]] * self.P if self.P == 3 else nets
         self.engines = [ts.clone_for_lane(k, nets[k], sides[k]) for k in range(self.P)]
         ts.opt.grad_scale = 1.0 / (self.P * max(1, ts.world))
         self.ev_lane = [torch.cuda.Event() for _ in range(self.P)]

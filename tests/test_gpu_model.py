@@ -494,8 +494,9 @@ def test_every_graph_replay_reproduces_the_eager_gradient(golden_s0):
             assert float((t.flat.data - pe).abs().max()) < 1e-6, (gi, name)
 
 
-def test_pair_lanes_make_the_update_of_a_two_rank_step(golden_s0):
-    """Two pairs in flight on one GPU (train.PairLanes: a network graph per lane on streams of their own, gradient
+@pytest.mark.parametrize("n_lanes", [2, 4])
+def test_pair_lanes_make_the_update_of_a_two_rank_step(golden_s0, n_lanes):
+    """Two (four) pairs in flight on one GPU (train.PairLanes: a network graph per lane on streams of their own, gradient
     buffers of their own, ONE guarded SGD step at the join) == the update of the mean of the two pairs' eager gradients,
     step after step; every lane's loss is the eager loss of its pair at the parameters of that step; a pair that outgrows
     a capacity costs BOTH pairs of its step their update and both come back from take_overflowed()."""
@@ -512,8 +513,8 @@ def test_pair_lanes_make_the_update_of_a_two_rank_step(golden_s0):
         torch.manual_seed(0)
         return TrainStep(cfg, limits, torch.device(DEV), seed=0)
     ts = fresh()
-    lanes = PairLanes(ts, 2)
-    assert ts.opt.grad_scale == 0.5 and len(ts.flat.lanes) == 2
+    lanes = PairLanes(ts, n_lanes)
+    assert ts.opt.grad_scale == 1.0 / n_lanes and len(ts.flat.lanes) == n_lanes
     lanes.enable_graph(TrainStep.capacities_for(sizes, slack=1.3), num_corr=item[4].shape[0])
     lanes.capture(item)               # lane engines never step the optimizer on their own: parameters untouched
     torch.cuda.synchronize()
@@ -522,6 +523,8 @@ def test_pair_lanes_make_the_update_of_a_two_rank_step(golden_s0):
     lr, mom, wd = ref.opt.lr, ref.opt.momentum, ref.opt.weight_decay
     buf = torch.zeros_like(ref.flat.data)
     steps = [(item, swapped), (swapped, item), (item, item)]
+    if n_lanes == 4:
+        steps = [(item, swapped, swapped, item), (swapped, item, item, item), (item, item, swapped, swapped)]
     for k, pair in enumerate(steps):
         nxt = steps[k + 1] if k + 1 < len(steps) else None
         outs = lanes.step_graph(list(pair), list(nxt) if nxt else None)
@@ -537,8 +540,11 @@ def test_pair_lanes_make_the_update_of_a_two_rank_step(golden_s0):
             losses.append(float(loss.detach()))
         for o, le in zip(outs, losses):
             assert abs(float(o[0]) - le) < 2e-3 * max(1.0, abs(le)), (k, float(o[0]), le)
-        gsum = (grads[0] + grads[1]) * 0.5
-        for lane in range(2):         # each lane's buffer holds ITS pair's gradient
+        gsum = grads[0].clone()
+        for other_g in grads[1:]:
+            gsum += other_g
+        gsum *= 1.0 / n_lanes
+        for lane in range(n_lanes):   # each lane's buffer holds ITS pair's gradient
             gl = ts.flat.lanes[lane][0]
             assert float((gl - grads[lane]).abs().max()) < 1e-4 * float(grads[lane].abs().max()), (k, lane)
         d = gsum + wd * ref.flat.data
@@ -546,6 +552,17 @@ def test_pair_lanes_make_the_update_of_a_two_rank_step(golden_s0):
         ref.flat.data.sub_(lr * buf)
         assert float((ts.flat.data - ref.flat.data).abs().max()) < 1e-6 + 1e-4 * lr * float(buf.abs().max()), k
     assert lanes.check_status() == (0, 0) and int(ts.opt.skipped) == 0 and lanes.take_overflowed(drain=True) == []
+    if n_lanes != 2:
+        return
+    # stream layouts: 2 lanes = a pyramid stream each; 3 = one shared; 4 = each lane's own stream; never more than 4
+    for p_, n_side in ((3, 1), (4, 4)):
+        other = PairLanes(fresh(), p_)
+        nets = [e.stream for e in other.engines]
+        sides = [e._side for e in other.engines]
+        assert len({s.cuda_stream for s in nets}) == p_ and len({s.cuda_stream for s in sides}) == n_side
+        assert (p_ == 4) == all(a is b for a, b in zip(nets, sides))
+    with pytest.raises(ValueError):
+        PairLanes(fresh(), 5)
     # the plain engine still trains one pair per step on buffer 0 after the lanes were captured
     ts.opt.grad_scale = 1.0
     before = ts.flat.data.clone()
