@@ -451,10 +451,17 @@ def main():
     pcie = None
     if world == 1:
         def run_host(k):
+            if lanes is not None:     # P pairs per step, each uploaded inside the timed region
+                cur = run_host.cur if run_host.cur is not None else [
+                    ts.upload(host_items[(P * k + j) % len(host_items)]) for j in range(P)]
+                run_host.cur = [ts.upload(host_items[(P * (k + 1) + j) % len(host_items)]) for j in range(P)]
+                return lanes.step_graph(cur, run_host.cur)[0]
             cur = run_host.cur if run_host.cur is not None else ts.upload(host_items[k % len(host_items)])
             run_host.cur = ts.upload(host_items[(k + 1) % len(host_items)])
             return ts.step_graph(cur, run_host.cur) if use_graph else ts.step(cur, next_item=run_host.cur)
         run_host.cur = None
+        if lanes is not None:
+            ts.opt.grad_scale = 1.0 / (P * world)
         for k in range(2):
             run_host(k)
         torch.cuda.synchronize()
@@ -463,7 +470,9 @@ def main():
             run_host(2 + k)
         torch.cuda.synchronize()
         th1 = time.perf_counter()
-        pcie = {"value": round(args.steps / (th1 - th0), 3), "unit": "fragment-pairs/s",
+        if lanes is not None:
+            ts.opt.grad_scale = 1.0 / max(1, world)
+        pcie = {"value": round(P * args.steps / (th1 - th0), 3), "unit": "fragment-pairs/s",
                 "ms_per_step": round((th1 - th0) / args.steps * 1e3, 3),
                 "note": "same step, every pair uploaded from pageable host arrays (points, correspondences, keypoint "
                         "distances: ~0.6 MB) inside the timed region"}
@@ -520,6 +529,34 @@ def main():
                 "value": round(args.steps / (tm1 - tm0), 3), "unit": "fragment-pairs/s", "points_per_pair": pts_mix,
                 "capacities": [eng_s.caps, ts.caps],
                 "skipped_or_rerun": len(eng_s.take_overflowed(drain=True)) + len(ts.take_overflowed(drain=True))}
+            if lanes is not None:
+                # the same two classes with pairs in flight (Trainer(pairs_in_flight=P)): groups of P large pairs
+                # alternating with groups of P small ones -- every step changes class, so every group's pyramids are
+                # preloaded into the other class's sets instead of prefetched by the running step
+                lanes_s = lanes.clone_for_capacities(eng_s.caps, num_corr=int(items[0][4].shape[0]))
+                lanes_s.capture(small_items[0])
+                groups = [[items[j % len(items)] for j in range(P)], [small_items[j % 2] for j in range(P)],
+                          [items[(P + j) % len(items)] for j in range(P)], [small_items[(j + 1) % 2] for j in range(P)]]
+                ts.opt.grad_scale = 1.0 / (P * world)
+
+                def mixed_lanes(k):
+                    e, ne = (lanes, lanes_s)[k % 2], (lanes, lanes_s)[(k + 1) % 2]
+                    ne.preload(groups[(k + 1) % 4])
+                    return e.step_graph(groups[k % 4], TrainStep.NO_PREFETCH)
+                for k in range(4):
+                    mixed_lanes(k)
+                torch.cuda.synchronize()
+                tl0 = time.perf_counter()
+                for k in range(args.steps):
+                    mixed_lanes(4 + k)
+                torch.cuda.synchronize()
+                tl1 = time.perf_counter()
+                ts.opt.grad_scale = 1.0 / max(1, world)
+                trainer_path["mixed_sizes_two_classes_pairs_in_flight"] = {
+                    "value": round(P * args.steps / (tl1 - tl0), 3), "unit": "fragment-pairs/s", "pairs_in_flight": P,
+                    "groups": "P large pairs / P small pairs alternating (a class change every step)",
+                    "skipped_or_rerun": len(lanes.take_overflowed(drain=True)) + len(lanes_s.take_overflowed(drain=True))}
+                del lanes_s
             del eng_s
             for dst, src in zip((ts.flat.data, ts.opt.buf, ts.opt.state), keep):
                 dst.copy_(src)
