@@ -255,6 +255,25 @@ def fresh_streams(n, device):
     return streams
 
 
+def lane_streams(lanes, device):
+    """(network streams, pyramid streams) for ``lanes`` pairs in flight on one GPU.
+
+    The lanes' network streams sit on different compute pipes (fresh_streams); what is left of the four pipes goes to
+    the pyramid builds: two lanes have a pyramid stream each (361 pairs/s in training), three share one (their 0.6-ms
+    builds run back to back under a 7-ms step: 414), and with four lanes every pipe runs a network and each lane builds
+    its next pyramid on its OWN stream, behind its network graph (434) -- a stream that SHARES a pipe with another busy
+    stream is far worse than either (a fifth stream for the pyramids: 256).  Never more streams than that: every stream
+    that has run a kernel keeps a hardware queue, and a process with more queues than the GPU has slots for gets them
+    time-sliced (profiles/r03_queue_pipes.txt)."""
+    if not 1 <= int(lanes) <= 4:
+        raise ValueError("1..4 pairs in flight (the dispatcher has four compute pipes: one per network stream), got %r"
+                         % (lanes,))
+    streams = fresh_streams(min(2 * lanes, 4), device)
+    nets = streams[:lanes]
+    sides = streams[lanes:] if lanes <= 2 else [streams[3]] * lanes if lanes == 3 else nets
+    return nets, sides
+
+
 class TrainStep:
     """Owns model + optimizer state for one rank and runs fragment pairs through the whole hot path."""
 
@@ -916,20 +935,8 @@ class PairLanes:
     The reference trains one pair per optimizer step (dataloader.py:73); ``lanes=1`` keeps that."""
 
     def __init__(self, ts, lanes=2):
-        if not 1 <= int(lanes) <= 4:
-            raise ValueError("1..4 pairs in flight (the dispatcher has four compute pipes: one per training stream), "
-                             "got %r" % (lanes,))
         self.ts, self.P = ts, int(lanes)
-        # The lanes' training streams sit on different compute pipes (fresh_streams); what is left of the four pipes
-        # goes to the pyramid builds: two lanes have a pyramid stream each (361 pairs/s), three share one (their 0.6-ms
-        # builds run back to back under a 7-ms step: 414), and with four lanes every pipe trains and each lane builds
-        # its next pyramid on its OWN stream, behind its network graph (434) -- a stream that SHARES a pipe with another
-        # busy stream is far worse than either (a fifth stream for the pyramids: 256).  Never more streams than that:
-        # every stream that has run a kernel keeps a hardware queue, and a process with more queues than the GPU has
-        # slots for gets them time-sliced.
-        streams = fresh_streams(min(2 * self.P, 4), ts.device)
-        nets = streams[:self.P]
-        sides = streams[self.P:] if self.P <= 2 else [streams[3]] * self.P if self.P == 3 else nets
+        nets, sides = lane_streams(self.P, ts.device)
         self.engines = [ts.clone_for_lane(k, nets[k], sides[k]) for k in range(self.P)]
         ts.opt.grad_scale = 1.0 / (self.P * max(1, ts.world))
         self.ev_lane = [torch.cuda.Event() for _ in range(self.P)]
