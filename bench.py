@@ -495,6 +495,26 @@ def main():
             tt1 = time.perf_counter()
             trainer_path = {"capacity_slack_1.10": {"value": round(args.steps / (tt1 - tt0), 3), "unit": "fragment-pairs/s",
                                                      "capacities": eng110.caps}}
+            if lanes is not None:      # the same head-room with pairs in flight (Trainer(pairs_in_flight=P))
+                lanes110 = lanes.clone_for_capacities(eng110.caps, num_corr=int(items[0][4].shape[0]))
+                lanes110.capture(items[0])
+                ts.opt.grad_scale = 1.0 / (P * world)
+
+                def run110(k):
+                    return lanes110.step_graph([items[(P * k + j) % len(items)] for j in range(P)],
+                                               [items[(P * (k + 1) + j) % len(items)] for j in range(P)])
+                for k in range(3):
+                    run110(k)
+                torch.cuda.synchronize()
+                tt0 = time.perf_counter()
+                for k in range(args.steps):
+                    run110(3 + k)
+                torch.cuda.synchronize()
+                tt1 = time.perf_counter()
+                ts.opt.grad_scale = 1.0 / max(1, world)
+                trainer_path["capacity_slack_1.10_pairs_in_flight"] = {
+                    "value": round(P * args.steps / (tt1 - tt0), 3), "unit": "fragment-pairs/s", "pairs_in_flight": P}
+                del lanes110
             del eng110
             # mixed sizes: the S1-class pairs alternating with pairs a quarter of their size, two capacity classes
             small_items = []
