@@ -934,6 +934,18 @@ def main():
                             "total_ms": round(v["total_ms"], 3)} for k, v in
                         sorted(summary.items(), key=lambda kv: -kv[1]["total_ms"])[:12]},
         }
+        # the step as a whole against the matrix peak: SURVEY 8d's algorithmic FLOPs of one S1-class pair (KPConv 16.56
+        # + Linear 19.78 GFLOP forward; x3 for forward + the two backward products) times the measured pairs/s per GPU
+        if roofline is not None:
+            fl_pair = 3.0 * (16.56e9 + 19.78e9)
+            per_gpu = res["value"] / world
+            roofline["whole_step"] = {
+                "flops_per_pair": int(fl_pair), "achieved_TFLOPs": round(per_gpu * fl_pair / 1e12, 2),
+                "mfma_f32_frac": round(per_gpu * fl_pair / 1e12 / F32_MFMA_PEAK_TFLOPS, 4),
+                "one_pair_in_flight_frac": None if one_in_flight is None else round(
+                    one_in_flight["value"] / world * fl_pair / 1e12 / F32_MFMA_PEAK_TFLOPS, 4),
+                "note": "SURVEY 8d algorithmic FLOPs (forward KPConv + Linear, x3) x pairs/s per GPU; `frac` above is the "
+                        "dominant hand-written kernel running alone"}
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(host_items[0], cfg, limits, budget_s=args.cpu_budget)
         print(json.dumps(res))
