@@ -62,3 +62,4 @@ run("enc1  L0 conv 32->32", pts[0], pts[0], nb[0], 32, 32, ext(0))
 run("enc2  L0->L1 strided 32->32", pts[1], pts[0], pools[0], 32, 32, ext(0))
 run("enc3  L1 conv 64->64", pts[1], pts[1], nb[1], 64, 64, ext(1))
 run("enc5  L1->L2 strided 64->64", pts[2], pts[1], pools[1], 64, 64, ext(1))
+run("enc6  L2 conv 128->128", pts[2], pts[2], nb[2], 128, 128, ext(2))
