@@ -912,6 +912,7 @@ def main():
                                        "one pair per optimizer step"),
                        "points_per_pair": n_pts, "neighbor_limits": limits, "pairs_per_rank": len(items),
                        "pairs_in_flight_per_gpu": P,
+                       "peak_hbm_allocated_gb": round(torch.cuda.max_memory_allocated(dev) / 2 ** 30, 2),
                        "side_stream_probe_ms": getattr(ts, "_side_probe", None),
                        "parallelism": "dp%d" % world if P == 1 else "dp%d x %d lanes" % (world, P),
                        "final_loss": round(loss_val, 5),
