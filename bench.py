@@ -380,9 +380,16 @@ def main():
     lanes = None
     if P > 1:
         from d3feat_pytorch_amd.train import PairLanes
-        lanes = PairLanes(ts, P)
-        lanes.enable_graph(ts.caps, num_corr=int(items[0][4].shape[0]))
-        lanes.capture(items[0])
+        try:
+            lanes = PairLanes(ts, P)
+            lanes.enable_graph(ts.caps, num_corr=int(items[0][4].shape[0]))
+            lanes.capture(items[0])
+        except Exception as e:  # pragma: no cover - keep the benchmark alive: one pair in flight, as in rounds 1-2
+            print("pairs in flight unavailable (%s: %s); running one pair per step" % (type(e).__name__, e),
+                  file=sys.stderr)
+            lanes, P = None, 1
+            ts.opt.grad_scale = 1.0 / max(1, world)
+            ts.flat.bind(0)
 
     def run(k):
         if lanes is None:
