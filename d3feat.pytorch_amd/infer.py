@@ -115,78 +115,3 @@ class InferStep(TrainStep):
         row, col, mutual = ops.mutual_nn_batched(desc, desc, pair, k, k)
         return row.view(2 * P, k)[0::2], mutual.view(2 * P, k)[0::2], sel
 
-
-class InferLanes:
-    """Several inputs IN FLIGHT on one GPU: ``lanes`` InferStep engines over the same model, each with its own network
-    stream, buffer sets and graphs, on streams laid out over the dispatcher's compute pipes like the training lanes
-    (train.lane_streams).  One input's forward graph leaves most of an MI355X idle (the coarse levels launch 50-200
-    workgroups); independent forwards side by side fill it.  Unlike training there is no join: lane k's outputs are
-    complete when ITS stream is."""
-
-    def __init__(self, model, config, neighborhood_limits, device, clouds=1, group=0, lanes=3):
-        from .train import lane_streams
-        self.device = torch.device(device)
-        nets, sides = lane_streams(int(lanes), self.device)
-        self.engines = []
-        for k in range(int(lanes)):
-            eng = InferStep(model, config, neighborhood_limits, self.device, clouds=clouds, group=group)
-            eng.lane, eng.stream, eng._side = k, nets[k], sides[k]     # (a lane brings its streams: no side-stream probe)
-            self.engines.append(eng)
-        self.P = int(lanes)
-        self.ev = [torch.cuda.Event() for _ in range(self.P)]
-
-    caps = property(lambda self: self.engines[0].caps)
-
-    def enable_graph(self, capacities):
-        for eng in self.engines:
-            eng.enable_graph(capacities)
-
-    def fits(self, item):
-        return self.engines[0].fits(item)
-
-    def capture(self, item):
-        for eng in self.engines:
-            eng.stream.wait_stream(torch.cuda.current_stream(self.device))
-            with torch.cuda.stream(eng.stream):
-                eng.capture(item)
-            eng.stream.synchronize()
-
-    def describe(self, items, next_items=None, post=None):
-        """``items``: one input per lane (fewer is fine: the remaining lanes idle).  Returns per input ``(descriptors,
-        scores)`` of its live rows -- views of the lane's static outputs, valid until that lane's buffer set comes round
-        again (two calls later) -- or, with ``post``, whatever ``post(lane, item, descriptors, scores)`` returned: it
-        runs on the lane's stream right behind the network graph (keypoint selection, matching), so the lanes' follow-up
-        work overlaps too.  Results are ordered on the CURRENT stream when this returns (stream waits, no host sync)."""
-        if len(items) > self.P:
-            raise ValueError("%d inputs for %d lanes" % (len(items), self.P))
-        if self.engines[0].g_net is None:
-            self.capture(items[0])
-        nxt = list(next_items) if next_items is not None else list(items)
-        pairs = list(zip(self.engines, items))
-        for eng, item in pairs:
-            eng._ensure_loaded(item)
-        outs = []
-        for k, (eng, item) in enumerate(pairs):       # every network graph first ...
-            with torch.cuda.stream(eng.stream):
-                feats, scores = eng._launch_net(item)
-                n = sum(int(p.shape[0]) for p in item)
-                res = (feats[:n], scores[:n])
-                outs.append(post(k, item, *res) if post is not None else res)
-                self.ev[k].record(eng.stream)
-        for k, (eng, item) in enumerate(pairs):       # ... then the following inputs' pyramids, under the running networks
-            if k < len(nxt) and nxt[k] is not None:
-                eng._prefetch_next(nxt[k], n=eng.cur)
-        cur = torch.cuda.current_stream(self.device)
-        for k in range(len(pairs)):
-            cur.wait_event(self.ev[k])
-        return outs
-
-    def synchronize(self):
-        for eng in self.engines:
-            eng.stream.synchronize()
-
-    def check_status(self, raise_on_skip=True):
-        flags = 0
-        for eng in self.engines:
-            flags |= eng.check_status(raise_on_skip)[0]
-        return flags, 0

@@ -960,25 +960,6 @@ def test_inference_pipeline_matches_eager_eval_forward(golden_s0, tmp_path):
     pair.check_status()
     with pytest.raises(RuntimeError):
         pair.describe((p0,))
-    # three inputs in flight (InferLanes: an engine per lane on streams of their own): the same results, lane by lane,
-    # round after round; a follow-up on the lane's stream (post=); fewer inputs than lanes
-    from d3feat_pytorch_amd.infer import InferLanes
-    il = InferLanes(model, cfg, limits, torch.device(DEV), clouds=2, lanes=3)
-    il.enable_graph(caps)
-    inputs = [(p0, p1), (p1, p0), (p0.clone(), p1.clone())]
-    want = [eager(list(item)) for item in inputs]
-    for rnd in range(3):
-        outs = il.describe(inputs, inputs)
-        assert len(outs) == 3
-        for (f, s), (fe, se) in zip(outs, want):
-            assert f.shape == fe.shape and float((f - fe).abs().max()) < 1e-5 and float((s - se).abs().max()) < 1e-5, rnd
-    outs = il.describe(inputs[1:], None, post=lambda k, item, f, s: (k, f.abs().sum(), s.sum()))
-    assert [o[0] for o in outs] == [0, 1]
-    for (k, fa, ss), (fe, se) in zip(outs, want[1:]):
-        assert abs(float(fa) - float(fe.abs().sum())) < 1e-2 and abs(float(ss) - float(se.sum())) < 1e-2
-    il.check_status()
-    with pytest.raises(ValueError):
-        il.describe(inputs + inputs)
 
     # single fragments through generate_features.  The graph engine keeps every neighbor table at the calibrated width,
     # the eager reference path trims to min(limit, max_count); pts1's coarse levels never reach the limit, so its
