@@ -72,3 +72,32 @@ def enable_tuned_gemms(path=None, tune_missing=False):
     except Exception:  # pragma: no cover - an unreadable table must not take the training step down
         tunable.enable(False)
         return False
+
+
+import contextlib as _contextlib
+
+
+@_contextlib.contextmanager
+def tuning_missing_gemms(max_ms=10, max_iterations=20):
+    """While active, library-GEMM shapes that are NOT in the loaded TunableOp table are tuned at their first call (a few
+    solutions' worth of milliseconds each) instead of running on the library's default pick.  ``TrainStep.capture``
+    wraps its warm-up steps in this: the shipped table holds the shapes of S1-class pairs at exact capacities, and any
+    other capacity set (a trainer's size classes, head-room) changes every row count -- measured at 10 % head-room:
+    221.9 pairs/s on the default picks, 238.6 after 18 s of tuning 85 shapes during the capture
+    (profiles/tune_on_capture_experiment.py).  No effect (yields False) unless ``enable_tuned_gemms`` is on."""
+    import torch
+    tunable = torch.cuda.tunable
+    if not (torch.cuda.is_available() and tunable.is_enabled()):
+        yield False
+        return
+    prev = (tunable.tuning_is_enabled(), tunable.get_max_tuning_duration(), tunable.get_max_tuning_iterations())
+    tunable.set_max_tuning_duration(int(max_ms))
+    tunable.set_max_tuning_iterations(int(max_iterations))
+    tunable.tuning_enable(True)
+    try:
+        yield True
+    finally:
+        tunable.tuning_enable(prev[0])
+        tunable.set_max_tuning_duration(prev[1])
+        tunable.set_max_tuning_iterations(prev[2])
+

@@ -684,7 +684,9 @@ class TrainStep:
             st.loaded = item
         warm = _warm_stream(dev)
         warm.wait_stream(main)
-        with torch.cuda.stream(warm):
+        from . import tuning_missing_gemms
+        # (library-GEMM shapes of THESE capacities that the loaded TunableOp table lacks are tuned by the warm-up steps)
+        with torch.cuda.stream(warm), tuning_missing_gemms():
             for k in range(3):
                 self._build_set(self.sets[(k + 1) % self.NSETS])
                 if self.split_backward:

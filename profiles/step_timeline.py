@@ -26,7 +26,8 @@ item = tuple(torch.from_numpy(np.ascontiguousarray(a)).to(dev) for a in it)
 ts = TrainStep(cfg, [42] * 5, dev, seed=0)
 b = ts.build_batch(item)
 sizes = [[int(t.shape[0]) for t in b['points']]]
-ts.enable_graph(TrainStep.capacities_for(sizes, slack=1.0), num_corr=int(item[4].shape[0]))
+slack = float(sys.argv[2]) if len(sys.argv) > 2 else 1.0     # capacity head-room (trainer default 1.10)
+ts.enable_graph(TrainStep.capacities_for(sizes, slack=slack), num_corr=int(item[4].shape[0]))
 ts.capture(item)
 torch.cuda.synchronize()
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
