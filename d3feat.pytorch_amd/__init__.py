@@ -58,8 +58,9 @@ def enable_tuned_gemms(path=None, tune_missing=False):
     import os
     import torch
     tunable = torch.cuda.tunable
-    if path is None:
-        path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tuned", "tunableop_gfx950.csv")
+    if path is None:     # (D3F_TUNABLEOP_TABLE: another table, e.g. one produced by profiles/tune_under_load_experiment.py)
+        path = os.environ.get("D3F_TUNABLEOP_TABLE") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "tuned",
+                                                                     "tunableop_gfx950.csv")
     if not os.path.exists(path):
         return False
     tunable.enable(True)
