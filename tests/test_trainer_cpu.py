@@ -178,3 +178,34 @@ def test_trainer_reads_the_loaders_shuffle_request():
     for flag in (True, False):
         smp = DistributedSampler(ds, num_replicas=2, rank=0, shuffle=flag)
         assert Trainer._shuffles(None, tud.DataLoader(ds, sampler=smp)) is flag
+
+
+def test_pairs_in_flight_needs_the_graph_path_and_groups_the_epoch(tmp_path, capsys):
+    """``pairs_in_flight`` > 1 (several pairs per optimizer step, train.PairLanes) is a property of the hipGraph path:
+    without it the trainer says so and trains one pair per step; with it an epoch is cut into groups of that many pairs
+    per rank (the tail that does not fill a group is left out, like a DataLoader's drop_last)."""
+    from d3feat_pytorch_amd.trainer import Trainer
+    tr = Trainer(_args(tmp_path, model=_small_model(), pairs_in_flight=3))
+    assert tr.lanes == 1 and "pairs_in_flight=3 needs the hipGraph path" in capsys.readouterr().out
+    assert Trainer(_args(tmp_path, model=_small_model())).lanes == 1          # the reference's one pair per step
+
+    class _Probe(Trainer):       # the epoch loop's grouping, without a device: record what each step is handed
+        def __init__(self, n, lanes):
+            self.lanes, self.world, self.rank, self.training_max_iter = lanes, 1, 0, 10 ** 9
+            self.train_loader = type('L', (), {'dataset': list(range(n)), 'batch_size': 1, 'shuffle': False})()
+            self.config, self.device, self.verbose, self.log_interval = type('C', (), {})(), torch.device('cpu'), False, 100
+            self.steps = []
+
+        def _fetch(self, ds, i):
+            return int(i)
+
+        def _lanes_step(self, items, nxt):
+            self.steps.append((list(items), None if nxt is None else list(nxt)))
+            z = torch.zeros(())
+            return [(z, z, z, z, z) for _ in items]
+
+        def _report_skipped(self):
+            return 0
+    p = _Probe(11, 4)
+    p.train_epoch(1)
+    assert [s[0] for s in p.steps] == [[0, 1, 2, 3], [4, 5, 6, 7]] and p.steps[0][1] == [4, 5, 6, 7] and p.steps[1][1] is None
