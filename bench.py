@@ -253,6 +253,11 @@ def main():
                     help="fragment pairs in flight per GPU (train.PairLanes): each on streams and graphs of its own, one "
                          "optimizer step on the mean of their gradients per step.  1 = the reference's one pair per "
                          "optimizer step (also measured and reported when this is > 1)")
+    ap.add_argument("--stack", type=int, default=1,
+                    help="fragment pairs STACKED into one pyramid + one network graph per lane (TrainStep stack): a step "
+                         "trains on lanes x stack pairs, one optimizer step on the mean of their gradients")
+    ap.add_argument("--quick", action="store_true", help="headline legs only (value, blocks, one_pair_in_flight): no "
+                                                         "trainer-path / evaluation / matching / roofline / CPU legs")
     ap.add_argument("--cpu-budget", type=float, default=90.0)
     ap.add_argument("--blocks", type=int, default=5, help="extra timed blocks of --steps steps after the contract region "
                                                          "(median / min / max reported next to `value`)")
@@ -376,19 +381,26 @@ def main():
         return ts.step(items[k % len(items)], next_item=nxt)
 
     # several pairs in flight (graph mode only): lane j of step k trains on pair P*k + j of the rank's cycle
-    P = max(1, args.lanes) if use_graph else 1
+    L = max(1, args.lanes) if use_graph else 1      # lanes: network graphs in flight
+    Q = max(1, args.stack) if use_graph else 1      # pairs stacked into each of them
+    P = L * Q                                       # pairs per step and GPU
     lanes = None
+
+    def stacked_caps(slack):
+        """Capacities of a stack of Q pairs: Q times the largest level sizes seen (any Q of the cycled pairs fit)."""
+        if Q == 1:
+            return TrainStep.capacities_for(sizes, slack=slack)
+        return TrainStep.capacities_for([[Q * max(sz[l] for sz in sizes) for l in range(len(sizes[0]))]], slack=slack)
     if P > 1:
         from d3feat_pytorch_amd.train import PairLanes
         try:
-            lanes = PairLanes(ts, P)
-            lanes.enable_graph(ts.caps, num_corr=int(items[0][4].shape[0]))
-            lanes.capture(items[0])
+            lanes = PairLanes(ts, L, stack=Q)
+            lanes.enable_graph(stacked_caps(1.0), num_corr=int(items[0][4].shape[0]))
+            lanes.capture(tuple(items[j % len(items)] for j in range(P)))
         except Exception as e:  # pragma: no cover - keep the benchmark alive: one pair in flight, as in rounds 1-2
             print("pairs in flight unavailable (%s: %s); running one pair per step" % (type(e).__name__, e),
                   file=sys.stderr)
-            lanes, P = None, 1
-            ts.opt.grad_scale = 1.0 / max(1, world)
+            lanes, P, L, Q = None, 1, 1, 1
             ts.flat.bind(0)
 
     def run(k):
@@ -413,7 +425,7 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     t1 = time.perf_counter()
-    loss_val = float(out[0].item())
+    loss_val = float(out[0].item()) / Q      # (a stacked lane reports the sum over its stack)
     if use_graph:
         ts.check_status()
     # run-to-run spread: the same K steps a few more times (single shots of 90 ms differ by ~1 %)
@@ -432,7 +444,6 @@ def main():
     one_in_flight = None
     if lanes is not None:
         torch.cuda.synchronize()
-        ts.opt.grad_scale = 1.0 / max(1, world)
         for k in range(3):
             run_one(k)
         torch.cuda.synchronize()
@@ -456,7 +467,7 @@ def main():
     # pair uploaded from pageable NumPy memory inside the timed region (TrainStep.upload); reported next to `value`,
     # never as `value`.
     pcie = None
-    if world == 1:
+    if world == 1 and not args.quick:
         def run_host(k):
             if lanes is not None:     # P pairs per step, each uploaded inside the timed region
                 cur = run_host.cur if run_host.cur is not None else [
@@ -467,8 +478,6 @@ def main():
             run_host.cur = ts.upload(host_items[(k + 1) % len(host_items)])
             return ts.step_graph(cur, run_host.cur) if use_graph else ts.step(cur, next_item=run_host.cur)
         run_host.cur = None
-        if lanes is not None:
-            ts.opt.grad_scale = 1.0 / (P * world)
         for k in range(2):
             run_host(k)
         torch.cuda.synchronize()
@@ -477,8 +486,6 @@ def main():
             run_host(2 + k)
         torch.cuda.synchronize()
         th1 = time.perf_counter()
-        if lanes is not None:
-            ts.opt.grad_scale = 1.0 / max(1, world)
         pcie = {"value": round(P * args.steps / (th1 - th0), 3), "unit": "fragment-pairs/s",
                 "ms_per_step": round((th1 - th0) / args.steps * 1e3, 3),
                 "note": "same step, every pair uploaded from pageable host arrays (points, correspondences, keypoint "
@@ -487,7 +494,7 @@ def main():
     # exact pairs, and a stream of pairs of different sizes through capacity classes (one graph engine per class,
     # the next pair's pyramid prefetched into its own class's sets).  Reported next to `value`, never as `value`.
     trainer_path = None
-    if world == 1 and use_graph:
+    if world == 1 and use_graph and not args.quick:
         try:
             keep = (ts.flat.data.clone(), ts.opt.buf.clone(), ts.opt.state.clone())
             eng110 = ts.clone_for_capacities(TrainStep.capacities_for(sizes, slack=1.10), num_corr=int(items[0][4].shape[0]))
@@ -503,9 +510,8 @@ def main():
             trainer_path = {"capacity_slack_1.10": {"value": round(args.steps / (tt1 - tt0), 3), "unit": "fragment-pairs/s",
                                                      "capacities": eng110.caps}}
             if lanes is not None:      # the same head-room with pairs in flight (Trainer(pairs_in_flight=P))
-                lanes110 = lanes.clone_for_capacities(eng110.caps, num_corr=int(items[0][4].shape[0]))
-                lanes110.capture(items[0])
-                ts.opt.grad_scale = 1.0 / (P * world)
+                lanes110 = lanes.clone_for_capacities(stacked_caps(1.10), num_corr=int(items[0][4].shape[0]))
+                lanes110.capture(tuple(items[j % len(items)] for j in range(P)))
 
                 def run110(k):
                     return lanes110.step_graph([items[(P * k + j) % len(items)] for j in range(P)],
@@ -518,9 +524,9 @@ def main():
                     run110(3 + k)
                 torch.cuda.synchronize()
                 tt1 = time.perf_counter()
-                ts.opt.grad_scale = 1.0 / max(1, world)
                 trainer_path["capacity_slack_1.10_pairs_in_flight"] = {
-                    "value": round(P * args.steps / (tt1 - tt0), 3), "unit": "fragment-pairs/s", "pairs_in_flight": P}
+                    "value": round(P * args.steps / (tt1 - tt0), 3), "unit": "fragment-pairs/s", "pairs_in_flight": P,
+                    "lanes": L, "stacked_pairs_per_lane": Q}
                 del lanes110
             del eng110
             # mixed sizes: the S1-class pairs alternating with pairs a quarter of their size, two capacity classes
@@ -560,11 +566,12 @@ def main():
                 # the same two classes with pairs in flight (Trainer(pairs_in_flight=P)): groups of P large pairs
                 # alternating with groups of P small ones -- every step changes class, so every group's pyramids are
                 # preloaded into the other class's sets instead of prefetched by the running step
-                lanes_s = lanes.clone_for_capacities(eng_s.caps, num_corr=int(items[0][4].shape[0]))
+                lanes_s = lanes.clone_for_capacities(
+                    TrainStep.capacities_for([[Q * max(sz[l] for sz in ssz) for l in range(len(ssz[0]))]], slack=1.10),
+                    num_corr=int(items[0][4].shape[0]))
                 lanes_s.capture(small_items[0])
                 groups = [[items[j % len(items)] for j in range(P)], [small_items[j % 2] for j in range(P)],
                           [items[(P + j) % len(items)] for j in range(P)], [small_items[(j + 1) % 2] for j in range(P)]]
-                ts.opt.grad_scale = 1.0 / (P * world)
 
                 def mixed_lanes(k):
                     e, ne = (lanes, lanes_s)[k % 2], (lanes, lanes_s)[(k + 1) % 2]
@@ -578,7 +585,6 @@ def main():
                     mixed_lanes(4 + k)
                 torch.cuda.synchronize()
                 tl1 = time.perf_counter()
-                ts.opt.grad_scale = 1.0 / max(1, world)
                 trainer_path["mixed_sizes_two_classes_pairs_in_flight"] = {
                     "value": round(P * args.steps / (tl1 - tl0), 3), "unit": "fragment-pairs/s", "pairs_in_flight": P,
                     "groups": "P large pairs / P small pairs alternating (a class change every step)",
@@ -652,12 +658,13 @@ def main():
         replica_spread = float((hi - lo).item())
     # Per-operator HIP-event timing (events on the launch stream around every C-ABI call).  Events cannot be recorded
     # inside a replayed graph, so the same steps are run eagerly right after the timed region, same process and data.
-    ops.set_profiler(prof)
-    ts._pending = None
-    for k in range(3):
-        ts.step(items[k % len(items)])
-    torch.cuda.synchronize()
-    ops.set_profiler(None)
+    if not args.quick:
+        ops.set_profiler(prof)
+        ts._pending = None
+        for k in range(3):
+            ts.step(items[k % len(items)])
+        torch.cuda.synchronize()
+        ops.set_profiler(None)
     prof_steps = 3
     elapsed = torch.tensor([t1 - t0], dtype=torch.float64, device=dev)
     if world > 1:
@@ -672,7 +679,7 @@ def main():
         for k in range(3):
             ts.step(items[k % len(items)])
     edges, widths = {}, {}
-    for k in range(min(3, len(items))):   # TRUE edges of the transposed tables = valid entries of the forward tables
+    for k in range(0 if args.quick else min(3, len(items))):   # TRUE edges of the transposed tables = valid entries of the forward tables
         b_k = ts.build_batch(items[k])
         for tabs in (b_k['neighbors'], b_k['pools']):
             for t in tabs:
@@ -680,15 +687,15 @@ def main():
                 if r is not None:
                     edges[(r.Nq, r.Ns)] = int((t < r.Ns).sum())
                     widths[(r.Nq, r.Ns)] = int(r.width)
-    kt = timed_kernels(_native.lib(), _three_steps,
-                       {1: fwd_kernel_cost, 2: dx_kernel_cost, 3: gather_kernel_cost(edges, widths)}, 3)
+    kt = {} if args.quick else timed_kernels(
+        _native.lib(), _three_steps, {1: fwd_kernel_cost, 2: dx_kernel_cost, 3: gather_kernel_cost(edges, widths)}, 3)
     dom = max(kt, key=lambda w: kt[w]["us_per_step"]) if kt else None
     dx_t = kt.get(dom)
 
     # dense mutual-NN matching of the pair's descriptors (19k x 19k x 32, the distance matrix is
     # never materialised) -- the one MFMA-bound kernel of the path; timed with HIP events on the current stream.
     matching = None
-    if rank == 0:
+    if rank == 0 and not args.quick:
         n0m, n1m = int(items[0][0].shape[0]), int(items[0][1].shape[0])
         gen = torch.Generator(device=dev).manual_seed(0)
         da = torch.nn.functional.normalize(torch.randn(n0m, 32, device=dev, generator=gen), dim=1)
@@ -713,7 +720,7 @@ def main():
     # evaluation pass of one pair -- pyramid + eval-mode forward (descriptors, gated scores), top-k
     # keypoints by score, mutual-NN matching of the selected descriptors (build_correspondence); eager launches.
     evaluation = None
-    if rank == 0:
+    if rank == 0 and not args.quick:
         from d3feat_pytorch_amd.geometric_registration.common import build_correspondence, select_keypoints
         ts.model.eval()
         ev_item = items[0]
@@ -912,16 +919,17 @@ def main():
             "config": {"workload": "configs[2]: full D3Feat KPFCNN fwd+bwd on fragment pairs "
                                    "(%d stacked points avg, 128 correspondences, 32-d descriptors, circle+detector loss, "
                                    "on-device radius search + grid subsample, SGD step); %s" % (int(np.mean(n_pts)), (
-                                       "%d pairs in flight per GPU, each a whole forward + loss + backward on streams and "
-                                       "graphs of its own, ONE guarded SGD step per %d pairs on the mean of their gradients "
-                                       "(the update a %d-rank data-parallel step makes); one_pair_in_flight = one pair per "
-                                       "optimizer step" % (P, P * world, P * world)) if P > 1 else
+                                       "%d pairs per step and GPU = %d network graph(s) in flight x %d pairs stacked into "
+                                       "each (one pyramid, one forward + loss + backward for the stack), every pair a whole "
+                                       "forward + loss + backward, ONE guarded SGD step per %d pairs on the mean of their "
+                                       "gradients (the update a %d-rank data-parallel step makes); one_pair_in_flight = one "
+                                       "pair per optimizer step" % (P, L, Q, P * world, P * world)) if P > 1 else
                                        "one pair per optimizer step"),
                        "points_per_pair": n_pts, "neighbor_limits": limits, "pairs_per_rank": len(items),
-                       "pairs_in_flight_per_gpu": P,
+                       "pairs_in_flight_per_gpu": P, "lanes": L, "stacked_pairs_per_lane": Q,
                        "peak_hbm_allocated_gb": round(torch.cuda.max_memory_allocated(dev) / 2 ** 30, 2),
                        "side_stream_probe_ms": getattr(ts, "_side_probe", None),
-                       "parallelism": "dp%d" % world if P == 1 else "dp%d x %d lanes" % (world, P),
+                       "parallelism": "dp%d" % world if P == 1 else "dp%d x %d lanes x %d stacked" % (world, L, Q),
                        "final_loss": round(loss_val, 5),
                        "replica_param_checksum_spread": replica_spread,
                        "skipped_steps": int(ts.opt.skipped),
@@ -929,8 +937,9 @@ def main():
                        "launch": "hipGraph replay: network step on the %s, next pair's pyramid graph %s "
                                  "(static level capacities %s)" % (
                                      "training stream" if P == 1 else "lane's stream",
-                                     "on a side stream" if P <= 2 else "on a pyramid stream the lanes share" if P == 3
-                                     else "on the lane's own stream behind it (all four compute pipes train)", ts.caps)
+                                     "on a side stream" if L <= 2 else "on a pyramid stream the lanes share" if L == 3
+                                     else "on the lane's own stream behind it (all four compute pipes train)",
+                                     lanes.caps if lanes is not None else ts.caps)
                                  if use_graph else "eager launches, pyramid on a side stream"},
             "pcie_inclusive": pcie,
             "trainer_path": trainer_path,
@@ -954,7 +963,7 @@ def main():
                     one_in_flight["value"] / world * fl_pair / 1e12 / F32_MFMA_PEAK_TFLOPS, 4),
                 "note": "SURVEY 8d algorithmic FLOPs (forward KPConv + Linear, x3) x pairs/s per GPU; `frac` above is the "
                         "dominant hand-written kernel running alone"}
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and not args.quick:
             res["cpu_baseline"] = cpu_baseline(host_items[0], cfg, limits, budget_s=args.cpu_budget)
         print(json.dumps(res))
     if world > 1:

@@ -82,6 +82,13 @@ SIGNATURES = {
     "d3f_detection_scores_forward": (_i, [_vp, _i, _i, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _i, _i, _vp]),
     "d3f_detection_scores_ws_bytes": (_sz, [_i, _i]),
     "d3f_detection_scores_backward": (_i, [_vp, _i, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "d3f_detection_scores_backward_groups": (_i, [_vp, _i, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _sz, _vp]),
+    "d3f_circle_det_loss_forward_pairs": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp, _f, _f, _f, _f, _f, _f, _vp, _vp, _vp,
+                                               _vp, _vp, _vp, _vp]),
+    "d3f_circle_det_loss_backward_pairs": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp, _f, _f, _f, _f, _f, _f, _vp, _vp,
+                                                _vp, _vp, _vp, _vp, _vp, _vp]),
+    "d3f_select_normalize_forward_pairs": (_i, [_vp, _vp, _i, _i, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "d3f_select_normalize_backward_pairs": (_i, [_vp, _i, _i, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "d3f_circle_det_loss_stats_floats": (_sz, [_i]),
     "d3f_circle_det_loss_ws_bytes": (_sz, [_i]),
     "d3f_circle_det_loss_forward": (_i, [_vp, _vp, _i, _i, _vp, _vp, _vp, _f, _f, _f, _f, _vp, _vp, _vp, _vp, _vp,

@@ -100,11 +100,13 @@ template <int CP>
 __global__ __launch_bounds__(256) void det_bwd_kernel(const float* __restrict__ feat, int N, int C,
                                                       const int32_t* __restrict__ idx, int H,
                                                       const float* __restrict__ fmax,
-                                                      const float* __restrict__ gscore, float* __restrict__ df) {
+                                                      const float* __restrict__ gscore, float* __restrict__ df,
+                                                      d3f::RowGroups rg) {
   const int lane = threadIdx.x & 63;
   const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (n >= N) return;
   const int c = lane % CP, g = lane / CP;
+  fmax += d3f::group_of_row(rg, n);
   const float denom = fmaxf(*fmax, 0.0f) + 1e-6f;
   const int32_t* row = idx + (size_t)n * H;
   PointStats s = point_stats<CP>(feat, N, C, row, H, denom, c, g);
@@ -321,13 +323,28 @@ __global__ void gmax_final_kernel(const uint32_t* __restrict__ enc, float* __res
   if (i < n) out[i] = ord2f(enc[i]);
 }
 
-// S = sum(df * f), ties = #{feat == fmax}
+// Element range of group blockIdx.y (all rows when there are no groups; the last group also owns the padding rows of a
+// capacity-shaped batch, whose gradient is zero)
+__device__ __forceinline__ void group_range(const d3f::RowGroups& rg, int cap_rows, int C, size_t& beg, size_t& end) {
+  if (!rg.len || rg.group <= 0) { beg = 0; end = (size_t)cap_rows * C; return; }
+  const int b0 = blockIdx.y * rg.group, b1 = min(rg.B, b0 + rg.group);
+  const int r0 = min(cap_rows, d3f::batch_offset(rg.len, b0));
+  const int r1 = (b1 >= rg.B) ? cap_rows : min(cap_rows, d3f::batch_offset(rg.len, b1));
+  beg = (size_t)r0 * C;
+  end = (size_t)r1 * C;
+}
+
+// S = sum(df * f), ties = #{feat == fmax}; per group of clouds (blockIdx.y): acc[2 g], acc[2 g + 1]
 __global__ __launch_bounds__(256) void det_reduce_kernel(const float* __restrict__ feat, const float* __restrict__ df,
-                                                         size_t n, const float* __restrict__ fmax,
-                                                         float* __restrict__ acc /*[2]*/) {
+                                                         int cap_rows, int C, const float* __restrict__ fmax,
+                                                         float* __restrict__ acc /*[2 G]*/, d3f::RowGroups rg) {
+  size_t beg, n;
+  group_range(rg, cap_rows, C, beg, n);
+  fmax += blockIdx.y;
+  acc += 2 * blockIdx.y;
   const float mx = fmaxf(*fmax, 0.0f), denom = mx + 1e-6f;
   float s = 0.0f, t = (blockIdx.x == 0 && threadIdx.x == 0 && mx == 0.0f) ? 1.0f : 0.0f;  // the zero shadow row ties at 0
-  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+  for (size_t i = beg + (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
     const float v = feat[i];
     s += df[i] * (v / denom);
     t += v == mx ? 1.0f : 0.0f;
@@ -347,14 +364,19 @@ __global__ __launch_bounds__(256) void det_reduce_kernel(const float* __restrict
 }
 
 // grad_feat = df / g  +  [feat == max] * ( -S / g ) / ties        (g = max + 1e-6; d g / d feat flows to the arg-max)
-__global__ void det_finalize_kernel(const float* __restrict__ feat, size_t n, const float* __restrict__ fmax,
-                                    const float* __restrict__ acc, float* __restrict__ gfeat) {
-  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
+__global__ void det_finalize_kernel(const float* __restrict__ feat, int cap_rows, int C, const float* __restrict__ fmax,
+                                    const float* __restrict__ acc, float* __restrict__ gfeat, d3f::RowGroups rg) {
+  size_t beg, n;
+  group_range(rg, cap_rows, C, beg, n);
+  fmax += blockIdx.y;
+  acc += 2 * blockIdx.y;
   const float mx = fmaxf(*fmax, 0.0f), denom = mx + 1e-6f;
-  float gval = gfeat[i] / denom;
-  if (feat[i] == mx) gval += (-acc[0] / denom) / fmaxf(acc[1], 1.0f);
-  gfeat[i] = gval;
+  const float tie_term = (-acc[0] / denom) / fmaxf(acc[1], 1.0f);
+  for (size_t i = beg + (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    float gval = gfeat[i] / denom;
+    if (feat[i] == mx) gval += tie_term;
+    gfeat[i] = gval;
+  }
 }
 
 }  // namespace
@@ -402,7 +424,7 @@ int d3f_detection_scores_forward(const float* feat, int N, int C, const int32_t*
                                  int training, float* scores, float* aux, const int32_t* width, const int32_t* len,
                                  int B, int group, void* stream_) {
   if (!feat || !idx || !feat_max || !scores || N < 0 || C < 1 || C > 64 || H < 1) return D3F_EINVAL;
-  if (len && (B < 1 || B > D3F_MAX_BATCH || group < 1 || aux)) return D3F_EINVAL;   // grouped form: forward only
+  if (len && (B < 1 || B > D3F_MAX_BATCH || group < 1)) return D3F_EINVAL;
   const d3f::RowGroups rg = {len, B, group};
   if (aux && (!training || !d3f_detection_scores_aux_floats(C) || H > 64)) return D3F_EINVAL;
   if (N == 0) return D3F_OK;
@@ -424,28 +446,50 @@ int d3f_detection_scores_forward(const float* feat, int N, int C, const int32_t*
 
 size_t d3f_detection_scores_ws_bytes(int N, int C) { (void)N; (void)C; return 256; }
 
-int d3f_detection_scores_backward(const float* feat, int N, int C, const int32_t* idx, int H, const float* feat_max,
-                                  const float* grad_scores, const float* aux, float* grad_feat, void* ws,
-                                  size_t ws_bytes, void* stream_) {
-  if (!feat || !idx || !feat_max || !grad_scores || !grad_feat || !ws || ws_bytes < 8 || N < 0 || C < 1 || C > 64 ||
-      H < 1)
+static int det_backward_impl(const float* feat, int N, int C, const int32_t* idx, int H, const float* feat_max,
+                             const float* grad_scores, const float* aux, float* grad_feat, const int32_t* len, int B,
+                             int group, void* ws, size_t ws_bytes, void* stream_) {
+  if (!feat || !idx || !feat_max || !grad_scores || !grad_feat || !ws || N < 0 || C < 1 || C > 64 || H < 1)
     return D3F_EINVAL;
+  if (len && (B < 1 || B > D3F_MAX_BATCH || group < 1)) return D3F_EINVAL;
+  const int G = len ? d3f::cdiv(B, group) : 1;
+  if (ws_bytes < 8 * (size_t)G) return D3F_EWORKSPACE;
   if (N == 0) return D3F_OK;
+  const d3f::RowGroups rg = {len, B, group};
   hipStream_t stream = (hipStream_t)stream_;
   const size_t n = (size_t)N * C;
   if (d3f::zero_async(grad_feat, sizeof(float) * n, stream) != hipSuccess) return D3F_ELAUNCH;
-  if (d3f::zero_async(ws, 8, stream) != hipSuccess) return D3F_ELAUNCH;
+  if (d3f::zero_async(ws, 8 * (size_t)G, stream) != hipSuccess) return D3F_ELAUNCH;
   const int grid = d3f::cdiv(N, 4);
   if (aux) det_bwd_aux_kernel<<<d3f::cdiv((long long)N * H, 256), 256, 0, stream>>>(aux, N, C, idx, H, grad_scores, grad_feat);
-  else if (C <= 16) det_bwd_kernel<16><<<grid, 256, 0, stream>>>(feat, N, C, idx, H, feat_max, grad_scores, grad_feat);
-  else if (C <= 32) det_bwd_kernel<32><<<grid, 256, 0, stream>>>(feat, N, C, idx, H, feat_max, grad_scores, grad_feat);
-  else det_bwd_kernel<64><<<grid, 256, 0, stream>>>(feat, N, C, idx, H, feat_max, grad_scores, grad_feat);
-  int blocks = d3f::cdiv((long long)n, 256 * 8);
+  else if (C <= 16) det_bwd_kernel<16><<<grid, 256, 0, stream>>>(feat, N, C, idx, H, feat_max, grad_scores, grad_feat, rg);
+  else if (C <= 32) det_bwd_kernel<32><<<grid, 256, 0, stream>>>(feat, N, C, idx, H, feat_max, grad_scores, grad_feat, rg);
+  else det_bwd_kernel<64><<<grid, 256, 0, stream>>>(feat, N, C, idx, H, feat_max, grad_scores, grad_feat, rg);
+  int blocks = d3f::cdiv((long long)n, 256 * 8 * G);
   if (blocks > 128) blocks = 128;
-  det_reduce_kernel<<<blocks, 256, 0, stream>>>(feat, grad_feat, n, feat_max, (float*)ws);
-  det_finalize_kernel<<<d3f::cdiv((long long)n, 256), 256, 0, stream>>>(feat, n, feat_max, (const float*)ws, grad_feat);
+  if (blocks < 1) blocks = 1;
+  det_reduce_kernel<<<dim3(blocks, G), 256, 0, stream>>>(feat, grad_feat, N, C, feat_max, (float*)ws, rg);
+  int fblocks = d3f::cdiv((long long)n, 256 * G);
+  if (fblocks < 1) fblocks = 1;
+  det_finalize_kernel<<<dim3(fblocks, G), 256, 0, stream>>>(feat, N, C, feat_max, (const float*)ws, grad_feat, rg);
   D3F_LAUNCH_CHECK();
   return D3F_OK;
+}
+
+int d3f_detection_scores_backward(const float* feat, int N, int C, const int32_t* idx, int H, const float* feat_max,
+                                  const float* grad_scores, const float* aux, float* grad_feat, void* ws,
+                                  size_t ws_bytes, void* stream_) {
+  return det_backward_impl(feat, N, C, idx, H, feat_max, grad_scores, aux, grad_feat, nullptr, 0, 0, ws, ws_bytes,
+                           stream_);
+}
+
+int d3f_detection_scores_backward_groups(const float* feat, int N, int C, const int32_t* idx, int H,
+                                         const float* feat_max, const float* grad_scores, const float* aux,
+                                         float* grad_feat, const int32_t* len, int B, int group, void* ws,
+                                         size_t ws_bytes, void* stream_) {
+  if (!len) return D3F_EINVAL;
+  return det_backward_impl(feat, N, C, idx, H, feat_max, grad_scores, aux, grad_feat, len, B, group, ws, ws_bytes,
+                           stream_);
 }
 
 }  // extern "C"

@@ -288,6 +288,11 @@ __global__ __launch_bounds__(256) void loss_fwd_tile_kernel(const float* __restr
   uint8_t* mr = (uint8_t*)(Dc + (size_t)M * KS);   // [L][M]
   uint8_t* mc = mr + (size_t)L * M;                // [M][L]
   const int l0 = blockIdx.x * L, nl = min(L, M - l0);
+  {  // blockIdx.y = fragment pair of a stacked batch (d3f_circle_det_loss_forward_pairs): its own M x M problem
+    const size_t pr = blockIdx.y;
+    a += pr * M * C; p += pr * M * C; negm += pr * M * M; D += pr * M * M;
+    fp_out += pr * M; avgneg_out += pr * M; stats += pr * 6 * M;
+  }
   for (int t = tid; t < M * C; t += 256) {
     al[(t / C) * CS + t % C] = a[t];
     pl[(t / C) * CS + t % C] = p[t];
@@ -346,35 +351,44 @@ __global__ __launch_bounds__(256) void loss_fwd_tile_kernel(const float* __restr
   }
 }
 
-// scalars of the loss from the per-line statistics (second launch of the tiled forward)
+// scalars of the loss from the per-line statistics (second launch of the tiled forward).  One workgroup walks the
+// `pairs` problems of a stacked batch one after the other (pairs <= 32, M <= 128: nothing to spread) and leaves
+// total = sum_p (w_desc desc_p + w_det det_p) -- the step's loss, whose gradient is the SUM of the pairs' gradients.
 __global__ __launch_bounds__(256) void loss_finalize_kernel(int M, const float* __restrict__ sa, const float* __restrict__ sp,
                                                             LossParams P, const float* __restrict__ fp_out,
                                                             const float* __restrict__ avgneg_out,
-                                                            const float* __restrict__ stats, float* __restrict__ scalars) {
+                                                            const float* __restrict__ stats, float* __restrict__ scalars,
+                                                            int pairs, float w_desc, float w_det,
+                                                            float* __restrict__ total) {
   __shared__ float sh[16];
   const int tid = threadIdx.x;
-  float l = 0.0f, dt = 0.0f, ac = 0.0f, fps = 0.0f, ans = 0.0f;
-  for (int i = tid; i < M; i += blockDim.x) {
-    l += softplus_t(stats[i] + stats[M + i]) / P.s + softplus_t(stats[2 * M + i] + stats[3 * M + i]) / P.s;
-    const float diff = fp_out[i] - stats[4 * M + i];
-    dt += diff * (sa[i] + sp[i]);
-    ac += diff < 0.0f ? 1.0f : 0.0f;
-    fps += fp_out[i];
-    ans += avgneg_out[i];
+  float tot = 0.0f;
+  for (int pr = 0; pr < pairs; ++pr, sa += M, sp += M, fp_out += M, avgneg_out += M, stats += 6 * M, scalars += 6) {
+    float l = 0.0f, dt = 0.0f, ac = 0.0f, fps = 0.0f, ans = 0.0f;
+    for (int i = tid; i < M; i += blockDim.x) {
+      l += softplus_t(stats[i] + stats[M + i]) / P.s + softplus_t(stats[2 * M + i] + stats[3 * M + i]) / P.s;
+      const float diff = fp_out[i] - stats[4 * M + i];
+      dt += diff * (sa[i] + sp[i]);
+      ac += diff < 0.0f ? 1.0f : 0.0f;
+      fps += fp_out[i];
+      ans += avgneg_out[i];
+    }
+    l = block_sum(l, sh);
+    dt = block_sum(dt, sh);
+    ac = block_sum(ac, sh);
+    fps = block_sum(fps, sh);
+    ans = block_sum(ans, sh);
+    if (tid == 0) {
+      scalars[0] = l / (float)M;
+      scalars[1] = dt / (float)M;
+      scalars[2] = ac * 100.0f / (float)M;
+      scalars[3] = fps / (float)M;
+      scalars[4] = ans / (float)M;
+      scalars[5] = l / (float)M + dt / (float)M;  // desc + det: the step's loss with unit weights (trainer.py:98)
+    }
+    tot += w_desc * (l / (float)M) + w_det * (dt / (float)M);
   }
-  l = block_sum(l, sh);
-  dt = block_sum(dt, sh);
-  ac = block_sum(ac, sh);
-  fps = block_sum(fps, sh);
-  ans = block_sum(ans, sh);
-  if (tid == 0) {
-    scalars[0] = l / (float)M;
-    scalars[1] = dt / (float)M;
-    scalars[2] = ac * 100.0f / (float)M;
-    scalars[3] = fps / (float)M;
-    scalars[4] = ans / (float)M;
-    scalars[5] = l / (float)M + dt / (float)M;  // desc + det: the step's loss with unit weights (trainer.py:98)
-  }
+  if (tid == 0 && total) *total = tot;
 }
 
 __device__ __forceinline__ float loss_grad_entry(float d, bool negm, int i, int j, int M, const LossParams& P,
@@ -397,7 +411,8 @@ __global__ __launch_bounds__(256) void loss_bwd_tile_kernel(const float* __restr
                                                             const float* __restrict__ stats,
                                                             const float* __restrict__ g_desc, const float* __restrict__ g_det,
                                                             float* __restrict__ ga, float* __restrict__ gp,
-                                                            float* __restrict__ gsa, float* __restrict__ gsp) {
+                                                            float* __restrict__ gsa, float* __restrict__ gsp,
+                                                            float w_desc, float w_det) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   constexpr int L = kLossStrip;
   const int tid = threadIdx.x;
@@ -407,7 +422,14 @@ __global__ __launch_bounds__(256) void loss_bwd_tile_kernel(const float* __restr
   float* Gr = pl + (size_t)M * CS;            // [L][RS]  rows of G = dL/dD / D
   float* Gc = Gr + (size_t)L * RS;            // [M][KS]  columns of G
   const int l0 = blockIdx.x * L, nl = min(L, M - l0);
-  const float gd = g_desc ? *g_desc : 0.0f, gt = g_det ? *g_det : 0.0f;
+  {  // blockIdx.y = fragment pair of a stacked batch
+    const size_t pr = blockIdx.y;
+    a += pr * M * C; p += pr * M * C; negm += pr * M * M; D += pr * M * M; stats += pr * 6 * M;
+    sa += pr * M; sp += pr * M; ga += pr * M * C; gp += pr * M * C;
+    if (gsa) gsa += pr * M;
+    if (gsp) gsp += pr * M;
+  }
+  const float gd = (g_desc ? *g_desc : 0.0f) * w_desc, gt = (g_det ? *g_det : 0.0f) * w_det;
   const float invM = 1.0f / (float)M;
   for (int t = tid; t < M * C; t += 256) {
     al[(t / C) * CS + t % C] = a[t];
@@ -463,13 +485,18 @@ __global__ __launch_bounds__(256) void select_normalize_fwd_kernel(const float* 
                                                                    const int32_t* __restrict__ p_offset,
                                                                    float* __restrict__ out_a, float* __restrict__ out_p,
                                                                    float* __restrict__ sa, float* __restrict__ sp,
-                                                                   int idx_stride) {
+                                                                   int idx_stride, const int32_t* __restrict__ pair_len,
+                                                                   int M_pair) {
   const int lane = threadIdx.x & 63;
   const int m2 = blockIdx.x * 4 + (threadIdx.x >> 6);  // 0..2M-1: anchors then positives
   if (m2 >= 2 * M) return;
   const bool pos = m2 >= M;
   const int m = pos ? m2 - M : m2;
   long row = pos ? idx_p[(size_t)m * idx_stride] + (p_offset ? (long)*p_offset : 0) : idx_a[(size_t)m * idx_stride];
+  if (pair_len) {  // stacked pairs: rows of pair m / M_pair are local to its own two clouds (2p, 2p + 1 of the stack)
+    const int pr = m / M_pair;
+    row += d3f::batch_offset(pair_len, 2 * pr + (pos ? 1 : 0));
+  }
   row = row < 0 ? 0 : (row >= N ? N - 1 : row);
   float ss = 0.0f;
   for (int c = lane; c < C; c += 64) {
@@ -493,13 +520,18 @@ __global__ __launch_bounds__(256) void select_normalize_bwd_kernel(const float* 
                                                                    const float* __restrict__ g_sa,
                                                                    const float* __restrict__ g_sp,
                                                                    float* __restrict__ grad_x,
-                                                                   float* __restrict__ grad_s, int idx_stride) {
+                                                                   float* __restrict__ grad_s, int idx_stride,
+                                                                   const int32_t* __restrict__ pair_len, int M_pair) {
   const int lane = threadIdx.x & 63;
   const int m2 = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (m2 >= 2 * M) return;
   const bool pos = m2 >= M;
   const int m = pos ? m2 - M : m2;
   long row = pos ? idx_p[(size_t)m * idx_stride] + (p_offset ? (long)*p_offset : 0) : idx_a[(size_t)m * idx_stride];
+  if (pair_len) {  // stacked pairs: rows of pair m / M_pair are local to its own two clouds (2p, 2p + 1 of the stack)
+    const int pr = m / M_pair;
+    row += d3f::batch_offset(pair_len, 2 * pr + (pos ? 1 : 0));
+  }
   row = row < 0 ? 0 : (row >= N ? N - 1 : row);
   const float* g = (pos ? g_p : g_a) + (size_t)m * C;
   float ss = 0.0f, dot = 0.0f;
@@ -530,25 +562,48 @@ extern "C" {
 size_t d3f_circle_det_loss_stats_floats(int M) { return 6 * (size_t)(M > 0 ? M : 1); }
 size_t d3f_circle_det_loss_ws_bytes(int M) { return sizeof(float) * (size_t)(M > 0 ? M : 1) * (size_t)(M > 0 ? M : 1); }
 
+static int loss_forward_impl(const float* anchor, const float* positive, int M, int C, int pairs, const uint8_t* neg_mask,
+                             const float* anc_score, const float* pos_score, LossParams P, float w_desc, float w_det,
+                             float* dists, float* furthest_positive, float* average_negative, float* out_scalars,
+                             float* out_total, float* stats, void* stream) {
+  if (!anchor || !positive || !neg_mask || !anc_score || !pos_score || !dists || !furthest_positive ||
+      !average_negative || !out_scalars || !stats || M < 2 || M > kMaxM || C < 1 || pairs < 1 || pairs > 32)
+    return D3F_EINVAL;
+  if (cache_ok(M, C)) {
+    loss_fwd_tile_kernel<<<dim3(d3f::cdiv(M, kLossStrip), pairs), 256, tiled_lds_bytes(M, C), (hipStream_t)stream>>>(
+        anchor, positive, M, C, neg_mask, P, dists, furthest_positive, average_negative, stats);
+    loss_finalize_kernel<<<1, 256, 0, (hipStream_t)stream>>>(M, anc_score, pos_score, P, furthest_positive,
+                                                             average_negative, stats, out_scalars, pairs, w_desc, w_det,
+                                                             out_total);
+  } else {
+    if (pairs != 1 || out_total) return D3F_EINVAL;   // the one-workgroup form (M > 128) serves a single pair
+    loss_fwd_kernel<false><<<1, kThreads, 0, (hipStream_t)stream>>>(anchor, positive, M, C, neg_mask, anc_score,
+                                                                     pos_score, P, dists, furthest_positive,
+                                                                     average_negative, out_scalars, stats);
+  }
+  D3F_LAUNCH_CHECK();
+  return D3F_OK;
+}
+
 int d3f_circle_det_loss_forward(const float* anchor, const float* positive, int M, int C, const uint8_t* neg_mask,
                                 const float* anc_score, const float* pos_score, float log_scale, float safe_radius,
                                 float pos_margin, float neg_margin, float* dists, float* furthest_positive,
                                 float* average_negative, float* out_scalars, float* stats, void* stream) {
-  if (!anchor || !positive || !neg_mask || !anc_score || !pos_score || !dists || !furthest_positive ||
-      !average_negative || !out_scalars || !stats || M < 2 || M > kMaxM || C < 1)
-    return D3F_EINVAL;
   LossParams P = {log_scale, safe_radius, pos_margin, neg_margin};
-  if (cache_ok(M, C)) {
-    loss_fwd_tile_kernel<<<d3f::cdiv(M, kLossStrip), 256, tiled_lds_bytes(M, C), (hipStream_t)stream>>>(
-        anchor, positive, M, C, neg_mask, P, dists, furthest_positive, average_negative, stats);
-    loss_finalize_kernel<<<1, 256, 0, (hipStream_t)stream>>>(M, anc_score, pos_score, P, furthest_positive,
-                                                             average_negative, stats, out_scalars);
-  } else
-    loss_fwd_kernel<false><<<1, kThreads, 0, (hipStream_t)stream>>>(anchor, positive, M, C, neg_mask, anc_score,
-                                                                     pos_score, P, dists, furthest_positive,
-                                                                     average_negative, out_scalars, stats);
-  D3F_LAUNCH_CHECK();
-  return D3F_OK;
+  return loss_forward_impl(anchor, positive, M, C, 1, neg_mask, anc_score, pos_score, P, 1.0f, 1.0f, dists,
+                           furthest_positive, average_negative, out_scalars, nullptr, stats, stream);
+}
+
+int d3f_circle_det_loss_forward_pairs(const float* anchor, const float* positive, int M, int C, int pairs,
+                                      const uint8_t* neg_mask, const float* anc_score, const float* pos_score,
+                                      float log_scale, float safe_radius, float pos_margin, float neg_margin,
+                                      float w_desc, float w_det, float* dists, float* furthest_positive,
+                                      float* average_negative, float* out_scalars, float* out_total, float* stats,
+                                      void* stream) {
+  if (!out_total || !cache_ok(M, C)) return D3F_EINVAL;
+  LossParams P = {log_scale, safe_radius, pos_margin, neg_margin};
+  return loss_forward_impl(anchor, positive, M, C, pairs, neg_mask, anc_score, pos_score, P, w_desc, w_det, dists,
+                           furthest_positive, average_negative, out_scalars, out_total, stats, stream);
 }
 
 int d3f_circle_det_loss_backward(const float* anchor, const float* positive, int M, int C, const uint8_t* neg_mask,
@@ -565,12 +620,29 @@ int d3f_circle_det_loss_backward(const float* anchor, const float* positive, int
   if (cache_ok(M, C))
     loss_bwd_tile_kernel<<<d3f::cdiv(M, kLossStrip), 256, tiled_lds_bytes(M, C), (hipStream_t)stream>>>(
         anchor, positive, M, C, neg_mask, anc_score, pos_score, P, dists, stats, grad_desc, grad_det, grad_anchor,
-        grad_positive, grad_anc_score, grad_pos_score);
+        grad_positive, grad_anc_score, grad_pos_score, 1.0f, 1.0f);
   else
     loss_bwd_kernel<false><<<1, kThreads, 0, (hipStream_t)stream>>>(anchor, positive, M, C, neg_mask, anc_score,
                                                                      pos_score, P, dists, stats, grad_desc, grad_det,
                                                                      (float*)ws, grad_anchor, grad_positive,
                                                                      grad_anc_score, grad_pos_score);
+  D3F_LAUNCH_CHECK();
+  return D3F_OK;
+}
+
+int d3f_circle_det_loss_backward_pairs(const float* anchor, const float* positive, int M, int C, int pairs,
+                                       const uint8_t* neg_mask, const float* anc_score, const float* pos_score,
+                                       float log_scale, float safe_radius, float pos_margin, float neg_margin,
+                                       float w_desc, float w_det, const float* dists, const float* stats,
+                                       const float* grad_total, float* grad_anchor, float* grad_positive,
+                                       float* grad_anc_score, float* grad_pos_score, void* stream) {
+  if (!anchor || !positive || !neg_mask || !anc_score || !pos_score || !dists || !stats || !grad_total || !grad_anchor ||
+      !grad_positive || M < 2 || C < 1 || pairs < 1 || pairs > 32 || !cache_ok(M, C))
+    return D3F_EINVAL;
+  LossParams P = {log_scale, safe_radius, pos_margin, neg_margin};
+  loss_bwd_tile_kernel<<<dim3(d3f::cdiv(M, kLossStrip), pairs), 256, tiled_lds_bytes(M, C), (hipStream_t)stream>>>(
+      anchor, positive, M, C, neg_mask, anc_score, pos_score, P, dists, stats, grad_total, grad_total, grad_anchor,
+      grad_positive, grad_anc_score, grad_pos_score, w_desc, w_det);
   D3F_LAUNCH_CHECK();
   return D3F_OK;
 }
@@ -587,7 +659,7 @@ int d3f_select_normalize_forward(const float* x, const float* scores, int N, int
     return D3F_EINVAL;
   select_normalize_fwd_kernel<<<d3f::cdiv(2 * M, 4), 256, 0, (hipStream_t)stream>>>(x, scores, N, C, idx_a, idx_p, M,
                                                                                       p_offset, out_a, out_p, sa, sp,
-                                                                                      idx_stride);
+                                                                                      idx_stride, nullptr, 1);
   D3F_LAUNCH_CHECK();
   return D3F_OK;
 }
@@ -605,7 +677,40 @@ int d3f_select_normalize_backward(const float* x, int N, int C, const int64_t* i
     return D3F_ELAUNCH;
   select_normalize_bwd_kernel<<<d3f::cdiv(2 * M, 4), 256, 0, (hipStream_t)stream>>>(x, N, C, idx_a, idx_p, M, p_offset,
                                                                                       g_a, g_p, g_sa, g_sp, grad_x,
-                                                                                      grad_scores, idx_stride);
+                                                                                      grad_scores, idx_stride, nullptr, 1);
+  D3F_LAUNCH_CHECK();
+  return D3F_OK;
+}
+
+/* The same for `pairs` fragment pairs stacked into one batch (clouds 2p, 2p+1 of the stack = pair p; len [2 pairs] the
+ * level-0 stack lengths on the device): corr [pairs*M, 2] int64 holds every pair's own table (cloud-local rows, as the
+ * dataset yields them, trainer.py:91-94), outputs are [pairs*M, ...]. */
+int d3f_select_normalize_forward_pairs(const float* x, const float* scores, int N, int C, const int64_t* corr, int M,
+                                       int pairs, const int32_t* len, float* out_a, float* out_p, float* sa, float* sp,
+                                       void* stream) {
+  if (!x || !scores || !corr || !len || !out_a || !out_p || !sa || !sp || N < 1 || C < 1 || M < 1 || pairs < 1 ||
+      2 * pairs > D3F_MAX_BATCH)
+    return D3F_EINVAL;
+  const int T = pairs * M;
+  select_normalize_fwd_kernel<<<d3f::cdiv(2 * T, 4), 256, 0, (hipStream_t)stream>>>(x, scores, N, C, corr, corr + 1, T,
+                                                                                      nullptr, out_a, out_p, sa, sp, 2,
+                                                                                      len, M);
+  D3F_LAUNCH_CHECK();
+  return D3F_OK;
+}
+
+int d3f_select_normalize_backward_pairs(const float* x, int N, int C, const int64_t* corr, int M, int pairs,
+                                        const int32_t* len, const float* g_a, const float* g_p, const float* g_sa,
+                                        const float* g_sp, float* grad_x, float* grad_scores, void* stream) {
+  if (!x || !corr || !len || !grad_x || !grad_scores || N < 1 || C < 1 || M < 1 || pairs < 1 ||
+      2 * pairs > D3F_MAX_BATCH || grad_scores != grad_x + (size_t)N * C)
+    return D3F_EINVAL;
+  if (d3f::zero_async(grad_x, sizeof(float) * (size_t)N * (C + 1), (hipStream_t)stream) != hipSuccess)
+    return D3F_ELAUNCH;
+  const int T = pairs * M;
+  select_normalize_bwd_kernel<<<d3f::cdiv(2 * T, 4), 256, 0, (hipStream_t)stream>>>(x, N, C, corr, corr + 1, T, nullptr,
+                                                                                      g_a, g_p, g_sa, g_sp, grad_x,
+                                                                                      grad_scores, 2, len, M);
   D3F_LAUNCH_CHECK();
   return D3F_OK;
 }

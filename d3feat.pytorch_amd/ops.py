@@ -1472,8 +1472,8 @@ class _DetScoreFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, feat, idx, training, lens=None, width=None, group=0):
         N, C, H = int(feat.shape[0]), int(feat.shape[1]), int(idx.shape[1])
-        if group and (lens is None or ctx.needs_input_grad[0]):
-            raise RuntimeError("detection_scores: the grouped form needs stack lengths and is forward-only")
+        if group and lens is None:
+            raise RuntimeError("detection_scores: the grouped form needs the stack lengths")
         fmax = global_max(feat, lens, group)
         scores = torch.empty((N, 1), dtype=torch.float32, device=feat.device)
         na = _native.lib().d3f_detection_scores_aux_floats(C) if (training and ctx.needs_input_grad[0] and H <= 64) else 0
@@ -1487,6 +1487,7 @@ class _DetScoreFn(torch.autograd.Function):
         ctx.aux = aux
         ctx.save_for_backward(feat, idx, fmax)
         ctx.training = bool(training)
+        ctx.groups = (lens, int(group)) if group else None
         return scores
 
     @staticmethod
@@ -1499,9 +1500,15 @@ class _DetScoreFn(torch.autograd.Function):
         gf = torch.empty_like(feat)
         ws = _ws(256, feat.device)
         with _region("detection_bwd[N=%d]" % N, 4 * N * H + 4 * N * H * C + 12 * N * C + 4 * N):
-            _native.check(_native.lib().d3f_detection_scores_backward(_p(feat), N, C, _p(idx), H, _p(fmax), _p(gs),
-                                                                      _p(ctx.aux), _p(gf), _p(ws), 256, _stream()),
-                          "d3f_detection_scores_backward")
+            if ctx.groups is not None:   # stacked pairs: the normaliser's gradient stays inside each pair
+                lens, group = ctx.groups
+                _native.check(_native.lib().d3f_detection_scores_backward_groups(
+                    _p(feat), N, C, _p(idx), H, _p(fmax), _p(gs), _p(ctx.aux), _p(gf), _p(lens), int(lens.numel()),
+                    group, _p(ws), 256, _stream()), "d3f_detection_scores_backward_groups")
+            else:
+                _native.check(_native.lib().d3f_detection_scores_backward(_p(feat), N, C, _p(idx), H, _p(fmax), _p(gs),
+                                                                          _p(ctx.aux), _p(gf), _p(ws), 256, _stream()),
+                              "d3f_detection_scores_backward")
         return gf, None, None, None, None, None
 
 
@@ -1511,7 +1518,7 @@ def detection_scores(features, neighbors, training=True, lens=None, width=None, 
     int32[1], the table's max neighbor count) makes a table kept at the full limit behave like the reference's
     min(limit, max_count)-column table in the eval-mode local-maximum gate (as for max_pool).  ``group`` > 0: the batch
     stacks several reference batches of that many clouds (8 pairs: 2); the normaliser (architectures.py:342 takes the
-    maximum of ONE pair) and ``width`` are then per group (forward only)."""
+    maximum of ONE pair) and ``width`` are then per group, in forward and backward."""
     _check_groups(width, (lens, group) if group else None, "detection_scores")
     return _DetScoreFn.apply(_f32(features, "features"), _i32(neighbors, "neighbors"), bool(training), lens, width,
                              int(group))
@@ -1731,6 +1738,99 @@ def train_loss(x, scores, corr, p_offset, dist_keypts, log_scale=10.0, safe_radi
         (float(log_scale), float(safe_radius), float(pos_margin), float(neg_margin)), (float(w_desc), float(w_det)),
         _gw_cache[key])
     return total, scalars[0], scalars[1], scalars[2], fp, an
+
+
+class _TrainLossPairsFn(torch.autograd.Function):
+    """_TrainLossFn for P fragment pairs stacked into one batch: x [N,C], scores [N,1], corr [P*M,2] (every pair's own
+    cloud-local table), lens int32 [2P] (level-0 stack lengths on the device), neg_mask [P,M,M] -> (total, scalars
+    [P,6], dists [P,M,M], furthest_positive [P*M], average_negative [P*M]) with total = sum_p (w_desc desc_p + w_det
+    det_p).  Three launches forward (select + normalise, strips of all pairs, finalize), two backward."""
+
+    @staticmethod
+    def forward(ctx, x, scores, corr, lens, neg_mask, params, weights):
+        L = _native.lib()
+        P, M = int(neg_mask.shape[0]), int(neg_mask.shape[1])
+        N, C = int(x.shape[0]), int(x.shape[1])
+        dev = x.device
+        T = P * M
+        oa = torch.empty((T, C), dtype=torch.float32, device=dev)
+        op = torch.empty((T, C), dtype=torch.float32, device=dev)
+        sa = torch.empty(T, dtype=torch.float32, device=dev)
+        sp = torch.empty(T, dtype=torch.float32, device=dev)
+        _native.check(L.d3f_select_normalize_forward_pairs(_p(x), _p(scores), N, C, _p(corr), M, P, _p(lens), _p(oa),
+                                                           _p(op), _p(sa), _p(sp), _stream()),
+                      "d3f_select_normalize_forward_pairs")
+        dists = torch.empty((P, M, M), dtype=torch.float32, device=dev)
+        fp = torch.empty(T, dtype=torch.float32, device=dev)
+        an = torch.empty(T, dtype=torch.float32, device=dev)
+        scalars = torch.empty((P, 6), dtype=torch.float32, device=dev)
+        total = torch.empty((), dtype=torch.float32, device=dev)
+        stats = torch.empty(P * L.d3f_circle_det_loss_stats_floats(M), dtype=torch.float32, device=dev)
+        s, sr, pm, nm = params
+        _native.check(L.d3f_circle_det_loss_forward_pairs(_p(oa), _p(op), M, C, P, _p(neg_mask), _p(sa), _p(sp), s, sr,
+                                                          pm, nm, weights[0], weights[1], _p(dists), _p(fp), _p(an),
+                                                          _p(scalars), _p(total), _p(stats), _stream()),
+                      "d3f_circle_det_loss_forward_pairs")
+        ctx.save_for_backward(x, corr, lens, neg_mask, oa, op, sa, sp, dists, stats)
+        ctx.meta = (params, weights)
+        ctx.mark_non_differentiable(scalars, dists, fp, an)
+        ctx.set_materialize_grads(False)
+        return total, scalars, dists, fp, an
+
+    @staticmethod
+    def backward(ctx, g_total, g_scalars, g_dists, g_fp, g_an):
+        if g_total is None:
+            return (None,) * 7
+        x, corr, lens, neg_mask, oa, op, sa, sp, dists, stats = ctx.saved_tensors
+        (s, sr, pm, nm), weights = ctx.meta
+        L = _native.lib()
+        P, M = int(neg_mask.shape[0]), int(neg_mask.shape[1])
+        N, C = int(x.shape[0]), int(x.shape[1])
+        g = g_total.contiguous().float().reshape(1)
+        ga, gp = torch.empty_like(oa), torch.empty_like(op)
+        gsa, gsp = torch.empty_like(sa), torch.empty_like(sp)
+        _native.check(L.d3f_circle_det_loss_backward_pairs(_p(oa), _p(op), M, C, P, _p(neg_mask), _p(sa), _p(sp), s, sr,
+                                                           pm, nm, weights[0], weights[1], _p(dists), _p(stats), _p(g),
+                                                           _p(ga), _p(gp), _p(gsa), _p(gsp), _stream()),
+                      "d3f_circle_det_loss_backward_pairs")
+        buf = torch.empty(N * (C + 1), dtype=torch.float32, device=x.device)
+        gx, gs = buf[:N * C].view(N, C), buf[N * C:].view(N, 1)
+        _native.check(L.d3f_select_normalize_backward_pairs(_p(x), N, C, _p(corr), M, P, _p(lens), _p(ga), _p(gp),
+                                                            _p(gsa), _p(gsp), _p(gx), _p(gs), _stream()),
+                      "d3f_select_normalize_backward_pairs")
+        return gx, gs, None, None, None, None, None
+
+
+def train_loss_pairs(x, scores, corr, lens, dist_keypts=None, log_scale=10.0, safe_radius=0.1, pos_margin=0.1,
+                     neg_margin=1.4, w_desc=1.0, w_det=1.0, neg_mask=None):
+    """Loss of one training step on P fragment pairs STACKED into one batch (clouds 2p, 2p+1 = pair p): per pair the
+    reference's ``CircleLoss`` + ``DetLoss`` on its own M sampled correspondences (trainer.py:91-98; the reference
+    trains one pair per step, dataloader.py:73), ``total`` = their sum -- its gradient is the sum of the pairs'
+    gradients, the optimizer's gradient scale makes the mean.  ``corr`` int64 [P,M,2] / [P*M,2] cloud-local rows as the
+    dataset yields them, ``lens`` device int32 [2P] (level-0 stack lengths), ``dist_keypts`` [P,M,M] or ``neg_mask``
+    uint8 [P,M,M] = dist_keypts > safe_radius.
+    Returns (total, desc [P], det [P], accuracy [P], furthest_positive [P,M], average_negative [P,M])."""
+    x = _f32(x, "x")
+    sc = _f32(scores, "scores").reshape(-1, 1)
+    if neg_mask is None:
+        if dist_keypts is None or not dist_keypts.is_cuda:
+            raise RuntimeError("dist_keypts must be a CUDA/HIP tensor")
+        neg_mask = (dist_keypts > safe_radius).to(torch.uint8).contiguous()   # evaluated in the caller's dtype (f64)
+    if not (neg_mask.is_cuda and neg_mask.dtype == torch.uint8 and neg_mask.is_contiguous() and neg_mask.dim() == 3
+            and neg_mask.shape[1] == neg_mask.shape[2]):
+        raise ValueError("neg_mask must be a contiguous uint8 [P,M,M] device tensor (dist_keypts > safe_radius)")
+    P, M = int(neg_mask.shape[0]), int(neg_mask.shape[1])
+    if not (corr.is_cuda and corr.dtype == torch.int64 and corr.numel() == 2 * P * M and corr.shape[-1] == 2):
+        raise ValueError("corr must be an int64 [P,M,2] device tensor (P = %d, M = %d)" % (P, M))
+    corr = corr.contiguous().view(P * M, 2)
+    if not (isinstance(lens, torch.Tensor) and lens.is_cuda and lens.dtype == torch.int32 and lens.numel() == 2 * P):
+        raise ValueError("lens must hold the 2P level-0 stack lengths as device int32")
+    if M > 128 or int(x.shape[1]) > 64 or P > 32:
+        raise ValueError("stacked loss: M <= 128 correspondences, C <= 64 channels, P <= 32 pairs")
+    total, scalars, dists, fp, an = _TrainLossPairsFn.apply(
+        x, sc, corr, lens.contiguous(), neg_mask,
+        (float(log_scale), float(safe_radius), float(pos_margin), float(neg_margin)), (float(w_desc), float(w_det)))
+    return total, scalars[:, 0], scalars[:, 1], scalars[:, 2], fp.view(P, M), an.view(P, M)
 
 
 # ---------------------------------------------------------------------------------------------------------------

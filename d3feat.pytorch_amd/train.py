@@ -147,6 +147,22 @@ class GuardedSGD:
     # the gradient is multiplied by this first: 1/world_size makes the mean out of an all-reduced SUM inside the step
     grad_scale = property(lambda self: self._hyper[3], lambda self, v: self._set(3, v))
 
+    def use_grad_scale(self, v):
+        """Make ``v`` the gradient scale of the steps launched from here on: 1 / (pairs whose gradients are summed into
+        one update, over all lanes, stacked pairs and ranks).  Every engine asks for ITS scale before it launches a step,
+        so engines with different pair counts (a stacked graph engine, the eager single-pair fallback) can share one
+        optimizer.  The value lives on the device and is read by the update kernel when it runs: a change first drains
+        the device (an update still in flight on another stream must see the old value) -- rare, engines alternate only
+        when a pair leaves the graph path."""
+        v = float(v)
+        if self._hyper[3] == v:
+            return
+        if self.hyper.is_cuda:
+            torch.cuda.synchronize(self.hyper.device)
+        self.grad_scale = v
+        if self.hyper.is_cuda:
+            torch.cuda.current_stream(self.hyper.device).synchronize()
+
     @property
     def param_groups(self):
         """Read-only view in torch.optim's shape (the reference reads ``param_groups[0]['lr']``, trainer.py:224)."""
@@ -274,8 +290,32 @@ def lane_streams(lanes, device):
     return nets, sides
 
 
+def is_stack(item):
+    """A stack of pairs (tuple of dataset items) rather than one dataset item (tuple of arrays)."""
+    return isinstance(item, (tuple, list)) and len(item) > 0 and isinstance(item[0], (tuple, list))
+
+
+def same_item(a, b):
+    """Identity of a step's input: the same item object, or stacks of the same item objects in the same order."""
+    if a is b:
+        return True
+    if a is None or b is None or not (is_stack(a) and is_stack(b)) or len(a) != len(b):
+        return False
+    return all(x is y for x, y in zip(a, b))
+
+
 class TrainStep:
-    """Owns model + optimizer state for one rank and runs fragment pairs through the whole hot path."""
+    """Owns model + optimizer state for one rank and runs fragment pairs through the whole hot path.
+
+    ``stack`` (``enable_graph(..., stack=Q)``) > 1: the static-shape step trains on Q fragment pairs STACKED into one
+    batch of 2Q clouds -- one pyramid, one network forward / backward, one loss launch sequence for all of them, the
+    gradient is the sum of the pairs' gradients and the optimizer's gradient scale 1 / (Q * ranks) makes their mean:
+    the update a data-parallel step over Q times as many ranks makes.  The reference refuses batches of more than one
+    pair (datasets/dataloader.py:73); what a reference batch of ONE pair shares stays per pair: the neighbor-table widths
+    (dataloader.py:64-66), the detector's feature normaliser (architectures.py:342), the loss's M x M problem
+    (trainer.py:91-98).  A stacked step's input is a tuple of Q dataset items."""
+
+    stack = 1
 
     def __init__(self, config, neighborhood_limits, device, world_size=1, seed=0, model=None):
         self.config, self.limits, self.device, self.world = config, [int(x) for x in neighborhood_limits], device, world_size
@@ -357,8 +397,15 @@ class TrainStep:
     def _loss_from_raw(self, x, scores, batch):
         """Reference trainer.py:91-98 on the un-normalised descriptors: the 2M sampled rows are gathered and
         normalised by one launch (the other rows never enter the loss)."""
-        n0 = batch['n0'] if 'n0' in batch else batch['stack_lengths'][0][:1]  # host int, or a device scalar (no sync)
         c = self.circle
+        if batch.get('_pairs', 1) > 1:     # stacked pairs: every pair's own M x M problem, total = their sum
+            total, desc, det, acc, fp, an = ops.train_loss_pairs(
+                x, scores, batch['corr'], batch['stack_lengths'][0], None, c.log_scale, c.safe_radius, c.pos_margin,
+                c.neg_margin, self.w_desc, self.w_det, neg_mask=batch['neg_mask'])
+            self.last_distances = (fp, an)                     # [Q, M] each
+            self.last_pair_losses = (desc, det, acc)           # [Q] each
+            return total, desc, det, acc
+        n0 = batch['n0'] if 'n0' in batch else batch['stack_lengths'][0][:1]  # host int, or a device scalar (no sync)
         loss, desc, det, acc, fp, an = ops.train_loss(x, scores, batch['corr'], n0, batch['dist_keypts'], c.log_scale,
                                                       c.safe_radius, c.pos_margin, c.neg_margin, self.w_desc, self.w_det,
                                                       neg_mask=batch.get('neg_mask'))
@@ -482,13 +529,14 @@ class TrainStep:
     class _Set:
         """Inputs of one pair (static addresses) + its capacity-shaped pyramid."""
 
-        def __init__(self, caps, num_corr, dev):
+        def __init__(self, caps, num_corr, dev, stack=1):
             self.pts = torch.zeros((caps[0], 3), dtype=torch.float32, device=dev)
             self.feat = None      # [caps[0], in_features_dim]: the pair's input features (set by enable_graph)
-            self.lens = torch.zeros(2, dtype=torch.int32, device=dev)
-            self.corr = torch.zeros((num_corr, 2), dtype=torch.int64, device=dev)
-            self.dk = torch.zeros((num_corr, num_corr), dtype=torch.float64, device=dev)
-            self.mask = torch.zeros((num_corr, num_corr), dtype=torch.uint8, device=dev)   # dk > safe_radius
+            self.lens = torch.zeros(2 * stack, dtype=torch.int32, device=dev)
+            lead = (stack,) if stack > 1 else ()      # stacked pairs: every pair's own table / matrix
+            self.corr = torch.zeros(lead + (num_corr, 2), dtype=torch.int64, device=dev)
+            self.dk = torch.zeros(lead + (num_corr, num_corr), dtype=torch.float64, device=dev)
+            self.mask = torch.zeros(lead + (num_corr, num_corr), dtype=torch.uint8, device=dev)   # dk > safe_radius
             self.batch = None     # persistent pyramid tensors (filled by the side branch of the OTHER graph)
             self.status = None
             self.loaded = None    # the item whose pyramid `batch` holds
@@ -497,7 +545,13 @@ class TrainStep:
             self.status_host = torch.zeros(1, dtype=torch.int32).pin_memory() if torch.device(dev).type == 'cuda' else None
             self.status_item = None
 
-    def enable_graph(self, capacities, num_corr):
+    def enable_graph(self, capacities, num_corr, stack=None):
+        """Static shapes for the captured step: per-level row capacities (of the whole stack), correspondences per
+        pair, and ``stack`` = fragment pairs per step (default: as before, 1 unless set)."""
+        if stack is not None:
+            if not 1 <= int(stack) <= 16:
+                raise ValueError("1..16 stacked pairs per step, got %r" % (stack,))
+            self.stack = int(stack)
         if getattr(self.config, 'use_batch_norm', False) and self.model.training:
             # capacity-shaped levels carry ~10 % zero rows: batch statistics over them are not the reference's
             # BatchNorm1d over the live points (the blocks do not hand the live row count to the normalisation)
@@ -505,7 +559,7 @@ class TrainStep:
                                "capacity-padded levels, which would bias the batch statistics")
         dev = self.device
         self.caps = [int(c) for c in capacities]
-        self.sets = [TrainStep._Set(self.caps, num_corr, dev) for _ in range(self.NSETS)]
+        self.sets = [TrainStep._Set(self.caps, num_corr, dev, self.stack) for _ in range(self.NSETS)]
         fdim = int(getattr(self.config, 'in_features_dim', 1))
         for st in self.sets:    # input features at static addresses (the reference feeds ones, or zeros under
             st.feat = torch.ones((self.caps[0], fdim), dtype=torch.float32, device=dev)   # self_augment)
@@ -514,10 +568,11 @@ class TrainStep:
 
     NO_PREFETCH = object()   # step_graph(item, NO_PREFETCH): do not build any pyramid for the following step
 
-    def clone_for_capacities(self, capacities, num_corr):
+    def clone_for_capacities(self, capacities, num_corr, stack=None):
         """A second engine over the SAME model, flat buffers, optimizer and streams with its own static buffer sets and
         graphs for other level capacities -- one per size class of the dataset (trainer.Trainer): real 3DMatch pairs
-        vary several-fold in size, and a single capacity set makes every small pair pay for the largest."""
+        vary several-fold in size, and a single capacity set makes every small pair pay for the largest.  ``stack``:
+        pairs per step of the clone (default: this engine's)."""
         import copy
         if getattr(self, '_side', None) is None:
             self._side = torch.cuda.Stream(device=self.device)
@@ -527,7 +582,7 @@ class TrainStep:
         for name in ('sets', 'graphs', 'g_net', 'g_net_b', 'g_pyr', '_graph_out', '_graph_dist', 'ev_net', 'ev_pyr',
                      '_pending', '_cuts', 'caps', 'cur', '_overflowed'):
             other.__dict__.pop(name, None)
-        other.enable_graph(capacities, num_corr)
+        other.enable_graph(capacities, num_corr, stack=stack)
         return other
 
     def clone_for_lane(self, lane, stream=None, side=None):
@@ -571,12 +626,17 @@ class TrainStep:
         out, self._overflowed = self.__dict__.get('_overflowed', []), []
         return out
 
+    @staticmethod
+    def pairs_of(item):
+        """The dataset items of a step's input (a stack's members, or the one pair)."""
+        return list(item) if is_stack(item) else [item]
+
     def preload(self, item):
         """Build ``item``'s pyramid on the side stream into the set this engine trains on next (used when the previous
         pair belonged to another size class, whose step_graph cannot prefetch into this engine's sets)."""
         i = self.cur
         st = self.sets[i]
-        if st.loaded is item:
+        if same_item(st.loaded, item):
             return
         self.ev_net[i].synchronize()
         self._collect_status(i)
@@ -587,26 +647,47 @@ class TrainStep:
         st.loaded = item
 
     def fits(self, item):
-        """Whether the pair can go through the captured graphs (level-0 capacity and correspondence count; deeper
-        levels are checked on the device, D3F_ST_CAPACITY -> check_status)."""
-        return (int(item[0].shape[0]) + int(item[1].shape[0]) <= self.caps[0]
-                and tuple(item[4].shape) == tuple(self.sets[0].corr.shape))
+        """Whether the pair (the stack of pairs) can go through the captured graphs (level-0 capacity and correspondence
+        count; deeper levels are checked on the device, D3F_ST_CAPACITY -> check_status)."""
+        pairs = self.pairs_of(item)
+        if len(pairs) != self.stack or is_stack(item) != (self.stack > 1):
+            return False
+        m = tuple(self.sets[0].corr.shape[-2:])
+        return (sum(int(it[0].shape[0]) + int(it[1].shape[0]) for it in pairs) <= self.caps[0]
+                and all(tuple(it[4].shape) == m for it in pairs))
 
     def _load_inputs(self, st, item):
-        p0, p1, _, _, corr, dk = item
-        n0, n1 = int(p0.shape[0]), int(p1.shape[0])
         if not self.fits(item):
-            raise RuntimeError("pair does not fit the captured shapes (%d + %d points, capacity %d; corr %s)" % (
-                n0, n1, self.caps[0], tuple(corr.shape)))
-        st.pts[:n0].copy_(p0, non_blocking=True)
-        st.pts[n0:n0 + n1].copy_(p1, non_blocking=True)
-        if len(item) >= 6 and item[2] is not None and item[3] is not None:   # (feat0, feat1) of the dataset item
-            st.feat[:n0].copy_(item[2].reshape(n0, -1), non_blocking=True)
-            st.feat[n0:n0 + n1].copy_(item[3].reshape(n1, -1), non_blocking=True)
-        st.lens[0] = n0
-        st.lens[1] = n1
-        st.corr.copy_(corr, non_blocking=True)
-        st.dk.copy_(dk, non_blocking=True)
+            pairs = self.pairs_of(item)
+            raise RuntimeError("input does not fit the captured shapes (%d pair(s), %d points, corr %s; the graphs take "
+                               "%d pair(s), capacity %d, corr %s)" % (
+                                   len(pairs), sum(int(it[0].shape[0]) + int(it[1].shape[0]) for it in pairs),
+                                   tuple(pairs[0][4].shape), self.stack, self.caps[0], tuple(self.sets[0].corr.shape[-2:])))
+        if self.stack == 1:
+            p0, p1, _, _, corr, dk = item
+            n0, n1 = int(p0.shape[0]), int(p1.shape[0])
+            st.pts[:n0].copy_(p0, non_blocking=True)
+            st.pts[n0:n0 + n1].copy_(p1, non_blocking=True)
+            if len(item) >= 6 and item[2] is not None and item[3] is not None:   # (feat0, feat1) of the dataset item
+                st.feat[:n0].copy_(item[2].reshape(n0, -1), non_blocking=True)
+                st.feat[n0:n0 + n1].copy_(item[3].reshape(n1, -1), non_blocking=True)
+            st.lens[0] = n0
+            st.lens[1] = n1
+            st.corr.copy_(corr, non_blocking=True)
+            st.dk.copy_(dk, non_blocking=True)
+        else:       # clouds 2q, 2q + 1 of the stack = pair q
+            off, lens = 0, []
+            for q, it in enumerate(item):
+                for p, f in ((it[0], it[2]), (it[1], it[3])):
+                    n = int(p.shape[0])
+                    st.pts[off:off + n].copy_(p, non_blocking=True)
+                    if f is not None:
+                        st.feat[off:off + n].copy_(f.reshape(n, -1), non_blocking=True)
+                    off += n
+                    lens.append(n)
+                st.corr[q].copy_(it[4], non_blocking=True)
+                st.dk[q].copy_(it[5], non_blocking=True)
+            st.lens.copy_(torch.tensor(lens, dtype=torch.int32))   # one small copy, not 2Q fills
         st.mask.copy_(st.dk > self.circle.safe_radius)   # with the upload, off the training stream (utils/loss.py:119)
 
     def _build_set(self, st, adopt=False):
@@ -622,7 +703,7 @@ class TrainStep:
         batch = dl.build_pyramid_static(st.pts, st.lens, self.config, self.limits, self.caps,
                                         reverse_tables=self.reverse_tables, status=st.status,
                                         conv_widths=not self.reverse_tables,   # (the eval-mode gate's input: inference)
-                                        group=getattr(self, 'group', 0))
+                                        group=2 if self.stack > 1 else getattr(self, 'group', 0))
         batch.pop('_status')
         if st.batch is None or adopt:
             st.batch = batch
@@ -644,9 +725,18 @@ class TrainStep:
         batch = dict(st.batch)
         batch['features'], batch['corr'], batch['dist_keypts'] = st.feat, st.corr, st.dk
         batch['neg_mask'] = st.mask
+        if self.stack > 1:
+            batch['_pairs'] = self.stack
         return batch
 
+    def _use_scale(self):
+        """The optimizer's gradient scale for THIS engine's steps (lanes: the join sets it)."""
+        if getattr(self, 'lane', None) is None:
+            self.opt.use_grad_scale(1.0 / (self.stack * max(1, self.world)))
+
     def _net_step(self, st):
+        """Forward + loss + backward (+ guarded update) on the set's pair(s).  Returns (loss, desc, det, accuracy) device
+        scalars; with stacked pairs ``loss`` is the sum over the stack and the other three are per pair [Q]."""
         batch = self._set_batch(st)
         lane = getattr(self, 'lane', None)
         if lane is not None:      # one of several pairs in flight (PairLanes): gradient into the lane's own buffer,
@@ -668,6 +758,7 @@ class TrainStep:
     def _static_step(self, item):
         """One step on static shapes without a graph (pyramid, then network, on the current stream)."""
         st = self.sets[0]
+        self._use_scale()
         self._load_inputs(st, item)
         self._build_set(st)
         st.loaded = item
@@ -678,6 +769,7 @@ class TrainStep:
         per buffer set.  Network graphs replay on the training stream, pyramid graphs on a side stream."""
         dev = self.device
         main = torch.cuda.current_stream(dev)
+        self._use_scale()
         for st in self.sets:
             self._load_inputs(st, item)
             self._build_set(st)
@@ -795,7 +887,7 @@ class TrainStep:
     def _ensure_loaded(self, item):
         i = self.cur
         st = self.sets[i]
-        if st.loaded is not item:
+        if not same_item(st.loaded, item):
             self.ev_net[i].synchronize()
             self._collect_status(i)
             with torch.cuda.stream(self._side):
@@ -822,6 +914,7 @@ class TrainStep:
         i = self.cur
         st = self.sets[i]
         main = torch.cuda.current_stream(self.device)
+        self._use_scale()
         self.ev_pyr[i].synchronize()
 
         def done():   # queued behind the pair's network step: host mirror of its status word, then the set's event
@@ -889,6 +982,7 @@ class TrainStep:
     def step(self, item=None, next_item=None):
         """item = (pts0, pts1, feat0, feat1, sel_corr, dist_keypts), host arrays or device tensors.  With
         ``next_item`` the following pair's pyramid is started on the side stream before this step's network runs."""
+        self.opt.use_grad_scale(1.0 / max(1, self.world))      # one pair per eager step
         pending = getattr(self, '_pending', None)
         if pending is not None:
             batch, ev = pending
@@ -936,17 +1030,19 @@ class PairLanes:
     the update kernel).  With several ranks the summed gradient is all-reduced at the join.
     The reference trains one pair per optimizer step (dataloader.py:73); ``lanes=1`` keeps that."""
 
-    def __init__(self, ts, lanes=2):
-        self.ts, self.P = ts, int(lanes)
+    def __init__(self, ts, lanes=2, stack=1):
+        self.ts, self.P, self.Q = ts, int(lanes), int(stack)
         nets, sides = lane_streams(self.P, ts.device)
         self.engines = [ts.clone_for_lane(k, nets[k], sides[k]) for k in range(self.P)]
-        ts.opt.grad_scale = 1.0 / (self.P * max(1, ts.world))
+        for eng in self.engines:
+            eng.stack = self.Q
         self.ev_lane = [torch.cuda.Event() for _ in range(self.P)]
         # the last joint update -- shared with the clones for other capacity classes (they step the same parameters)
         self._join = {'ev_step': torch.cuda.Event(), 'stepped': False}
         self._groups = {}
 
     caps = property(lambda self: self.engines[0].caps)
+    pairs_per_step = property(lambda self: self.P * self.Q)
 
     def clone_for_capacities(self, capacities, num_corr):
         """The same lanes (streams, gradient buffers, join) with buffer sets and graphs for other level capacities: one
@@ -957,37 +1053,57 @@ class PairLanes:
         other._groups = {}
         return other
 
+    def deal(self, items):
+        """The step's ``lanes * stack`` pairs as one input per lane: the pair itself, or a stack of ``stack`` pairs."""
+        if len(items) != self.P * self.Q:
+            raise ValueError("%d pairs for %d lanes x %d stacked pairs" % (len(items), self.P, self.Q))
+        if self.Q == 1:
+            return list(items)
+        return [tuple(items[k * self.Q:(k + 1) * self.Q]) for k in range(self.P)]
+
     def preload(self, items):
         """Pyramids of the lanes' next pairs into the sets they train on next (the previous step ran on another class)."""
-        for eng, item in zip(self.engines, items):
+        for eng, item in zip(self.engines, self.deal(items)):
             eng.preload(item)
 
     def enable_graph(self, capacities, num_corr):
         for eng in self.engines:
-            eng.enable_graph(capacities, num_corr)
+            eng.enable_graph(capacities, num_corr, stack=self.Q)
+
+    def fits(self, item):
+        """Whether one pair fits a lane's share of the captured capacities (a lane's stack holds ``stack`` of them)."""
+        eng = self.engines[0]
+        m = tuple(eng.sets[0].corr.shape[-2:])
+        return (self.Q * (int(item[0].shape[0]) + int(item[1].shape[0])) <= eng.caps[0]
+                and tuple(item[4].shape) == m) if self.Q > 1 else eng.fits(item)
+
+    def fits_group(self, items):
+        """Whether the ``lanes * stack`` pairs of a step fit the captured shapes as dealt."""
+        return len(items) == self.P * self.Q and all(e.fits(it) for e, it in zip(self.engines, self.deal(items)))
 
     def capture(self, item):
+        """``item``: one pair (repeated to fill every stack) or the ``lanes * stack`` pairs of a step."""
+        per_lane = self.deal(item) if is_stack(item) and len(item) == self.P * self.Q and self.P * self.Q > 1 else [
+            (tuple([item] * self.Q) if self.Q > 1 else item)] * self.P
         out = None
-        for eng in self.engines:
+        for eng, it in zip(self.engines, per_lane):
             eng.stream.wait_stream(torch.cuda.current_stream(self.ts.device))
             with torch.cuda.stream(eng.stream):
-                out = eng.capture(item)
+                out = eng.capture(it)
             eng.stream.synchronize()
         return out
 
-    def fits(self, item):
-        return self.engines[0].fits(item)
-
     def step_graph(self, items, next_items=None):
-        """Train on ``items`` (one pair per lane); ``next_items`` (default: the same again) are the pairs of the
-        following call, whose pyramids are built on the lanes' side streams meanwhile.  Returns the lanes' (loss,
-        desc_loss, det_loss, accuracy) device scalars; they are complete after ``synchronize()``."""
-        if len(items) != self.P:
-            raise ValueError("%d pairs for %d lanes" % (len(items), self.P))
+        """Train on ``items`` (``lanes * stack`` pairs: lane k takes items[k*stack:(k+1)*stack]); ``next_items``
+        (default: the same again) are the pairs of the following call, whose pyramids are built on the lanes' side
+        streams meanwhile.  Returns the lanes' (loss, desc_loss, det_loss, accuracy) device scalars (stacked lanes: see
+        TrainStep._net_step); they are complete after ``synchronize()``."""
+        items = self.deal(items)
         if next_items is TrainStep.NO_PREFETCH:
             nxt = [TrainStep.NO_PREFETCH] * self.P
         else:
-            nxt = [items[k] if next_items is None else next_items[k] for k in range(self.P)]
+            nxt = items if next_items is None else self.deal(next_items)
+        self.ts.opt.use_grad_scale(1.0 / (self.P * self.Q * max(1, self.ts.world)))
         outs = []
         host_join = os.environ.get("D3F_LANES_JOIN", "stream") == "host"     # measurement knob (DESIGN.md, round 3)
         for k, eng in enumerate(self.engines):
@@ -1057,7 +1173,8 @@ class PairLanes:
         out, seen = [], set()
         for item, flags in flagged:
             for mate in self._groups.get(id(item), (item,)):
-                if id(mate) not in seen:
-                    seen.add(id(mate))
-                    out.append((mate, flags if mate is item else 0))
+                for pair in TrainStep.pairs_of(mate):
+                    if id(pair) not in seen:
+                        seen.add(id(pair))
+                        out.append((pair, flags if mate is item else 0))
         return out

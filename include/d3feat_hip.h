@@ -395,7 +395,7 @@ int d3f_detection_scores_aux_floats(int C); /* 8 for C in {16, 32, 64}, 0 (aux u
  * build it (min(limit, max_count) columns, dataloader.py:64-66): the extra all-shadow columns are then ignored -- they
  * would give the eval-mode local-maximum gate a zero candidate the reference does not have.
  * len (optional, [B]) + group: stacked reference batches (see d3f_max_pool_forward): feat_max and width are arrays with
- * one entry per group (d3f_global_max_groups; d3f_radius_query_ex max_count_group); forward only (aux must be NULL). */
+ * one entry per group (d3f_global_max_groups; d3f_radius_query_ex max_count_group). */
 int d3f_detection_scores_forward(const float* feat, int N, int C, const int32_t* idx, int H, const float* feat_max,
                                  int training, float* scores, float* aux, const int32_t* width, const int32_t* len,
                                  int B, int group, void* stream);
@@ -404,6 +404,13 @@ int d3f_detection_scores_forward(const float* feat, int N, int C, const int32_t*
 int d3f_detection_scores_backward(const float* feat, int N, int C, const int32_t* idx, int H, const float* feat_max,
                                   const float* grad_scores, const float* aux, float* grad_feat, void* ws,
                                   size_t ws_bytes, void* stream);
+/* the same for stacked reference batches (len [B] + group as in the forward; feat_max [ceil(B/group)]): the gradient
+ * through the normaliser stays inside each group -- P fragment pairs stacked into one TRAINING batch keep the
+ * per-pair maximum of architectures.py:342 and its arg-max gradient.  ws >= 8 bytes per group. */
+int d3f_detection_scores_backward_groups(const float* feat, int N, int C, const int32_t* idx, int H,
+                                         const float* feat_max, const float* grad_scores, const float* aux,
+                                         float* grad_feat, const int32_t* len, int B, int group, void* ws,
+                                         size_t ws_bytes, void* stream);
 size_t d3f_detection_scores_ws_bytes(int N, int C);
 
 /* ------------------------------------------------------------------------------------------------
@@ -431,6 +438,25 @@ int d3f_circle_det_loss_backward(const float* anchor, const float* positive, int
                                  float* grad_positive, float* grad_anc_score, float* grad_pos_score, void* ws,
                                  size_t ws_bytes, void* stream);
 
+/* `pairs` fragment pairs stacked into one training batch (the reference trains on one pair per step,
+ * datasets/dataloader.py:73; stacking P of them into one launch sequence is this build's batching): every array above
+ * gains a leading pair dimension (anchor/positive [pairs*M,C], neg_mask [pairs,M,M], scores [pairs*M], dists
+ * [pairs,M,M], out_scalars [pairs,6], stats [pairs * d3f_circle_det_loss_stats_floats(M)]); every pair is its own
+ * M x M problem.  out_total [1] = sum_p (w_desc desc_p + w_det det_p): its gradient is the SUM of the pairs' gradients
+ * (the caller's optimizer scale makes the mean).  M <= 128, C <= 64, pairs <= 32.  backward: grad_total device scalar. */
+int d3f_circle_det_loss_forward_pairs(const float* anchor, const float* positive, int M, int C, int pairs,
+                                      const uint8_t* neg_mask, const float* anc_score, const float* pos_score,
+                                      float log_scale, float safe_radius, float pos_margin, float neg_margin,
+                                      float w_desc, float w_det, float* dists, float* furthest_positive,
+                                      float* average_negative, float* out_scalars, float* out_total, float* stats,
+                                      void* stream);
+int d3f_circle_det_loss_backward_pairs(const float* anchor, const float* positive, int M, int C, int pairs,
+                                       const uint8_t* neg_mask, const float* anc_score, const float* pos_score,
+                                       float log_scale, float safe_radius, float pos_margin, float neg_margin,
+                                       float w_desc, float w_det, const float* dists, const float* stats,
+                                       const float* grad_total, float* grad_anchor, float* grad_positive,
+                                       float* grad_anc_score, float* grad_pos_score, void* stream);
+
 /* Sampled-correspondence front end of the loss -- replaces F.normalize over all N descriptors
  * (models/architectures.py:318) + the four index selections of trainer.py:91-94 and their backward:
  *   out[m,:] = x[idx[m],:] / max(||x[idx[m],:]||, 1e-12),  s[m] = scores[idx[m]].
@@ -445,6 +471,15 @@ int d3f_select_normalize_backward(const float* x, int N, int C, const int64_t* i
                                   int idx_stride, int M, const int32_t* p_offset, const float* g_a, const float* g_p,
                                   const float* g_sa, const float* g_sp, float* grad_x, float* grad_scores,
                                   void* stream);
+/* stacked pairs: clouds 2p, 2p+1 of the stack are pair p (len [2 pairs]: level-0 stack lengths on the device); corr
+ * [pairs*M,2] int64 holds every pair's own table with cloud-local rows (trainer.py:91-94 adds len(first cloud) to the
+ * second column; here each column is offset by the start of its cloud in the stack); outputs [pairs*M, ...]. */
+int d3f_select_normalize_forward_pairs(const float* x, const float* scores, int N, int C, const int64_t* corr, int M,
+                                       int pairs, const int32_t* len, float* out_a, float* out_p, float* sa, float* sp,
+                                       void* stream);
+int d3f_select_normalize_backward_pairs(const float* x, int N, int C, const int64_t* corr, int M, int pairs,
+                                        const int32_t* len, const float* g_a, const float* g_p, const float* g_sa,
+                                        const float* g_sp, float* grad_x, float* grad_scores, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Dense matching -- replaces build_correspondence (geometric_registration/common.py:5-21): the

@@ -514,7 +514,7 @@ def test_pair_lanes_make_the_update_of_a_two_rank_step(golden_s0, n_lanes):
         return TrainStep(cfg, limits, torch.device(DEV), seed=0)
     ts = fresh()
     lanes = PairLanes(ts, n_lanes)
-    assert ts.opt.grad_scale == 1.0 / n_lanes and len(ts.flat.lanes) == n_lanes
+    assert len(ts.flat.lanes) == n_lanes
     lanes.enable_graph(TrainStep.capacities_for(sizes, slack=1.3), num_corr=item[4].shape[0])
     lanes.capture(item)               # lane engines never step the optimizer on their own: parameters untouched
     torch.cuda.synchronize()
@@ -552,6 +552,7 @@ def test_pair_lanes_make_the_update_of_a_two_rank_step(golden_s0, n_lanes):
         ref.flat.data.sub_(lr * buf)
         assert float((ts.flat.data - ref.flat.data).abs().max()) < 1e-6 + 1e-4 * lr * float(buf.abs().max()), k
     assert lanes.check_status() == (0, 0) and int(ts.opt.skipped) == 0 and lanes.take_overflowed(drain=True) == []
+    assert ts.opt.grad_scale == 1.0 / n_lanes      # set by the joint step itself (GuardedSGD.use_grad_scale)
     if n_lanes != 2:
         return
     # stream layouts: 2 lanes = a pyramid stream each; 3 = one shared; 4 = each lane's own stream; never more than 4
@@ -563,11 +564,11 @@ def test_pair_lanes_make_the_update_of_a_two_rank_step(golden_s0, n_lanes):
         assert (p_ == 4) == all(a is b for a, b in zip(nets, sides))
     with pytest.raises(ValueError):
         PairLanes(fresh(), 5)
-    # the plain engine still trains one pair per step on buffer 0 after the lanes were captured
-    ts.opt.grad_scale = 1.0
+    # the plain engine still trains one pair per step on buffer 0 after the lanes were captured -- at ITS gradient scale
     before = ts.flat.data.clone()
     ts.step(item)
     torch.cuda.synchronize()
+    assert ts.opt.grad_scale == 1.0
     assert not torch.equal(before, ts.flat.data) and torch.isfinite(ts.flat.data).all()
     # capacity overflow in ONE lane: the joint update is skipped, both pairs are handed back.  Capacities: level 0
     # holds `item`, the deeper levels are sized for a pair a fraction of its size (the one the graphs are captured on)
@@ -592,6 +593,102 @@ def test_pair_lanes_make_the_update_of_a_two_rank_step(golden_s0, n_lanes):
     assert len(again) == 2 and {id(a[0]) for a in again} == {id(tiny), id(item)}
     assert [f for it, f in again if it is item][0] != 0 and [f for it, f in again if it is tiny][0] == 0
     assert tight.check_status(raise_on_skip=False)[1] == 1
+
+
+@pytest.mark.parametrize("stack,n_lanes", [(2, 1), (3, 1), (2, 2)])
+def test_stacked_pairs_train_on_the_sum_of_their_eager_gradients(golden_s0, stack, n_lanes):
+    """``stack`` fragment pairs stacked into ONE pyramid + ONE network graph (TrainStep.enable_graph(stack=Q)), alone or
+    as the lanes of PairLanes: every pair's losses are the eager losses of that pair at the step's parameters, the
+    flat gradient is the SUM of the pairs' eager gradients, and the parameters follow the eager mean-gradient SGD step
+    after step.  The pairs of a stack differ in size and in the widths of their neighbor tables; what a reference batch
+    of one pair shares (table widths dataloader.py:64-66, detector normaliser architectures.py:342, the M x M loss
+    trainer.py:91-98) stays per pair."""
+    from d3feat_pytorch_amd.train import PairLanes, TrainStep
+    g = golden_s0
+    cfg = cfgmod.default_config(first_features_dim=16, num_node=64)
+    limits = [int(x) for x in g['limits']]
+    item = tuple(torch.from_numpy(np.ascontiguousarray(a)).to(DEV) for a in _item(g))
+    swapped = (item[1], item[0], item[3], item[2], item[4].flip(1).contiguous(), item[5].t().contiguous())
+    tiny = synthetic.make_pair(5, 6, _gpu_subsample, n_raw=20000, scale=0.12, num_node=int(item[4].shape[0]))
+    tiny = tuple(torch.from_numpy(np.ascontiguousarray(a)).to(DEV) for a in tiny)
+    pool = [item, swapped, tiny]
+    n = stack * n_lanes
+
+    def fresh():
+        np.random.seed(0)
+        torch.manual_seed(0)
+        return TrainStep(cfg, limits, torch.device(DEV), seed=0)
+    ts, ref = fresh(), fresh()
+    sizes = {id(it): [int(t.shape[0]) for t in ref.build_batch(it)['points']] for it in pool}
+    biggest = [stack * max(sizes[id(it)][l] for it in pool) for l in range(5)]
+    caps = TrainStep.capacities_for([biggest], slack=1.1)
+    steps = [[pool[(k + j) % 3] for j in range(n)] for k in range(3)]
+    if n_lanes == 1:
+        eng = ts
+        ts.enable_graph(caps, num_corr=item[4].shape[0], stack=stack)
+        ts.capture(tuple(steps[0]))        # (applies its warm-up steps to the parameters)
+        torch.cuda.synchronize()
+        ref.flat.data.copy_(ts.flat.data)
+        buf = ts.opt.buf.clone()
+    else:
+        eng = PairLanes(ts, n_lanes, stack=stack)
+        eng.enable_graph(caps, num_corr=item[4].shape[0])
+        eng.capture(tuple(steps[0]))
+        torch.cuda.synchronize()
+        assert torch.equal(ts.flat.data, ref.flat.data)
+        buf = torch.zeros_like(ref.flat.data)
+    lr, mom, wd = ref.opt.lr, ref.opt.momentum, ref.opt.weight_decay
+    for k, pairs in enumerate(steps):
+        nxt = steps[k + 1] if k + 1 < len(steps) else None
+        if n_lanes == 1:
+            outs = [ts.step_graph(tuple(pairs), tuple(nxt) if nxt else None)]
+        else:
+            outs = eng.step_graph(pairs, nxt)
+            eng.synchronize()
+        torch.cuda.synchronize()
+        grads, descs, dets = [], [], []
+        for it in pairs:                  # the eager losses / gradient of each pair at the SAME parameters
+            batch = ref.build_batch(it)
+            batch['n0'] = int(it[0].shape[0])
+            ref.flat.zero_grad()
+            loss, desc, det, _ = ref.forward_loss(batch)
+            torch.autograd.backward(loss, ref._seed(loss))
+            grads.append(ref.flat.gather_grads().clone())
+            descs.append(float(desc))
+            dets.append(float(det))
+        got_desc = torch.cat([o[1].reshape(-1) for o in outs]).tolist()
+        got_det = torch.cat([o[2].reshape(-1) for o in outs]).tolist()
+        for q in range(n):
+            assert abs(got_desc[q] - descs[q]) < 1e-4 * max(1.0, abs(descs[q])), (k, q, got_desc[q], descs[q])
+            assert abs(got_det[q] - dets[q]) < 1e-4 * max(1.0, abs(dets[q])), (k, q, got_det[q], dets[q])
+        for lane in range(n_lanes):        # each lane's buffer = the sum over ITS stack
+            gsum = sum(grads[lane * stack + 1:(lane + 1) * stack], grads[lane * stack].clone())
+            gl = ts.flat.lanes[lane][0]
+            assert float((gl - gsum).abs().max()) < 1e-3 * float(gsum.abs().max()), (k, lane)
+        gmean = sum(grads[1:], grads[0].clone()) * (1.0 / n)
+        d = gmean + wd * ref.flat.data
+        buf = buf * mom + d
+        ref.flat.data.sub_(lr * buf)
+        assert float((ts.flat.data - ref.flat.data).abs().max()) < 1e-6 + 1e-4 * lr * float(buf.abs().max()), k
+    assert eng.check_status() == (0, 0) and int(ts.opt.skipped) == 0 and eng.take_overflowed(drain=True) == []
+    assert ts.opt.grad_scale == 1.0 / n
+    # one stack outgrows the capacities: the whole (joint) update is skipped and every pair of the step comes back
+    big = synthetic.make_pair(7, 8, _gpu_subsample, n_raw=60000, scale=0.2, num_node=int(item[4].shape[0]))
+    big = tuple(torch.from_numpy(np.ascontiguousarray(a)).to(DEV) for a in big)
+    bsz = [int(t.shape[0]) for t in ref.build_batch(big)['points']]
+    if bsz[0] + (stack - 1) * sizes[id(tiny)][0] <= caps[0] and bsz[1] + (stack - 1) * sizes[id(tiny)][1] > caps[1]:
+        before = ts.flat.data.clone()
+        group = [big] + [tiny] * (n - 1)
+        if n_lanes == 1:
+            ts.step_graph(tuple(group), TrainStep.NO_PREFETCH)
+        else:
+            eng.step_graph(group, TrainStep.NO_PREFETCH)
+            eng.synchronize()
+        torch.cuda.synchronize()
+        again = eng.take_overflowed(drain=True)
+        assert torch.equal(before, ts.flat.data) and int(ts.opt.skipped) == 1
+        back = [p for entry, _ in again for p in TrainStep.pairs_of(entry)]
+        assert {id(p) for p in back} == {id(big), id(tiny)}
 
 
 def test_split_backward_matches_single_backward(golden_s0):
