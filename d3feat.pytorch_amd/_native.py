@@ -11,7 +11,7 @@ _PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 _REPO = os.path.dirname(_PKG_DIR)
 LIB_PATH = os.path.join(_PKG_DIR, "libd3feat_hip.so")
 CSRC = os.path.join(_PKG_DIR, "csrc")
-SOURCES = ["radius_neighbors.hip", "grid_subsample.hip", "kpconv.hip", "kpconv_fused.hip", "kpconv_small.hip", "kpconv_deform.hip", "pool.hip", "detection.hip", "loss.hip",
+SOURCES = ["radius_neighbors.hip", "grid_subsample.hip", "kpconv.hip", "kpconv_fused.hip", "kpconv_aggregate.hip", "kpconv_small.hip", "kpconv_deform.hip", "pool.hip", "detection.hip", "loss.hip",
            "reverse_table.hip", "kpconv_dx_gather.hip", "matching.hip", "elementwise.hip", "batchnorm.hip", "linear.hip", "gemm.hip", "optimizer.hip", "misc.hip"]
 
 _vp, _i, _f, _sz = C.c_void_p, C.c_int, C.c_float, C.c_size_t
@@ -54,6 +54,8 @@ SIGNATURES = {
     "d3f_kpconv_aggregate_modes": (_i, [_vp, _i, _vp, _i, _vp, _i, _vp, _i, _vp, _i, _f, _i, _vp, _vp, _vp]),
     "d3f_kpconv_grad_input_modes": (_i, [_vp, _i, _vp, _i, _vp, _i, _i, _vp, _i, _f, _i, _vp, _vp, _vp]),
     "d3f_kpconv_grad_input": (_i, [_vp, _i, _vp, _i, _vp, _i, _vp, _i, _vp, _i, _f, _vp, _vp, _i, _vp, _vp, _sz, _vp]),
+    "d3f_kpconv_aggregate_transposed_supported": (_i, [_i, _i]),
+    "d3f_kpconv_aggregate_transposed": (_i, [_vp, _i, _i, _i, _vp, _i, _f, _vp, _vp, _i, _vp, _vp]),
     "d3f_reverse_table_ws_bytes": (_sz, [_i, _i, _i]),
     "d3f_reverse_table_build": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _sz, _vp]),
     "d3f_kpconv_grad_input_gather_supported": (_i, [_i, _i, _i]),

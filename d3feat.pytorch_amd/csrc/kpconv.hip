@@ -248,6 +248,9 @@ int kpconv_grad_input_from_gw(const float* q_pts, int Nq, const float* s_pts, in
 int kpconv_aggregate(const float* q_pts, int Nq, const float* s_pts, int Ns, const int32_t* idx, int H, const float* x,
                      int Cin, const float* kp, int K, float extent, float* wf_out, float* nn_out, void* spack_keep,
                      float* grad_x_clear, void* ws, hipStream_t stream);
+int kpconv_aggregate_direct(const float* q_pts, int Nq, const float* s_pts, int Ns, const int32_t* idx, int H,
+                            const float* x, int Cin, const float* kp, int K, float extent, float* wf_out, float* nn_out,
+                            void* spack_keep, float* grad_x_clear, void* ws, hipStream_t stream);   // kpconv_aggregate.hip
 // kpconv_small.hip
 bool kpconv_small_supported(int Cin, int Cout, int K, int H);
 int kpconv_small_dispatch(bool fwd, const float* q_pts, const float* s_pts, const int32_t* idx, const float* x,
@@ -426,6 +429,12 @@ int d3f_kpconv_aggregate(const float* q_pts, int Nq, const float* s_pts, int Ns,
       !(extent > 0.0f) || !kpconv_fused_supported(Cin, 64, K, H, Ns))
     return D3F_EINVAL;
   if (ws_bytes < d3f_kpconv_ws_bytes(Nq, Ns, H, K, Cin, 64)) return D3F_EWORKSPACE;
+  // registers -> HBM (kpconv_aggregate.hip); D3F_AGG_LDS=1 keeps the round-1 form (phase A of the fused kernel, through
+  // its LDS tile) for A/B measurements
+  static const bool through_lds = getenv("D3F_AGG_LDS") != nullptr;
+  if (!through_lds)
+    return kpconv_aggregate_direct(q_pts, Nq, s_pts, Ns, idx, H, x, Cin, kernel_points, K, extent, wf_out, nn_out,
+                                   spack_keep, grad_x_clear, ws, (hipStream_t)stream_);
   return kpconv_aggregate(q_pts, Nq, s_pts, Ns, idx, H, x, Cin, kernel_points, K, extent, wf_out, nn_out, spack_keep,
                           grad_x_clear, ws, (hipStream_t)stream_);
 }

@@ -493,6 +493,11 @@ static int pack_supports(const float* s_pts, const float* x, int Ns, int Cin, fl
   return D3F_OK;
 }
 
+int kpconv_pack_supports(const float* s_pts, const float* x, int Ns, int Cin, float4* spack, hipStream_t stream,
+                         float* zero_rows) {   // kpconv_aggregate.hip
+  return pack_supports(s_pts, x, Ns, Cin, spack, stream, zero_rows);
+}
+
 template <int CV>
 static int launch_fused_cv(const float* q_pts, const float4* spack, const int32_t* idx, const float* x,
                            const float* kp, const float* W, int Nq, int Ns, int H, int Cin, int Cout, int K,

@@ -133,16 +133,12 @@ __device__ __forceinline__ void aggregate_wave_n(const int (&nall)[4], const flo
   }
 }
 
-template <int CV, typename Flush>
-__device__ __forceinline__ void aggregate_wave(const float* __restrict__ q_pts, const int32_t* __restrict__ idx,
-                                               int q_first, int Nq, int H, int Ns, __amdgpu_buffer_rsrc_t rs_sp,
-                                               __amdgpu_buffer_rsrc_t rs_x, int Cin, int cbase, float kx, float ky,
-                                               float kz, float inv_extent, int lane, float* nn_lds, Flush&& flush) {
-  const int li = lane & 15, lg = lane >> 4;
-  const unsigned row_bytes = (unsigned)Cin * 4u;
-  const unsigned col_off = (unsigned)(cbase + li * CV) * 4u;
-  int nall[4];
-  float cqx[4], cqy[4], cqz[4];  // query + kernel point, per query
+// (query + kernel point, clamped index row) of the wave's four queries
+template <int DUMMY = 0>
+__device__ __forceinline__ void load_wave_queries(const float* __restrict__ q_pts, const int32_t* __restrict__ idx,
+                                                  int q_first, int Nq, int H, int Ns, float kx, float ky, float kz,
+                                                  int lane, int (&nall)[4], float (&cqx)[4], float (&cqy)[4],
+                                                  float (&cqz)[4]) {
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int q = q_first + i;
@@ -154,6 +150,19 @@ __device__ __forceinline__ void aggregate_wave(const float* __restrict__ q_pts, 
     cqy[i] = q_pts[3 * (size_t)qs + 1] + ky;
     cqz[i] = q_pts[3 * (size_t)qs + 2] + kz;
   }
+}
+
+template <int CV, typename Flush>
+__device__ __forceinline__ void aggregate_wave(const float* __restrict__ q_pts, const int32_t* __restrict__ idx,
+                                               int q_first, int Nq, int H, int Ns, __amdgpu_buffer_rsrc_t rs_sp,
+                                               __amdgpu_buffer_rsrc_t rs_x, int Cin, int cbase, float kx, float ky,
+                                               float kz, float inv_extent, int lane, float* nn_lds, Flush&& flush) {
+  const int li = lane & 15, lg = lane >> 4;
+  const unsigned row_bytes = (unsigned)Cin * 4u;
+  const unsigned col_off = (unsigned)(cbase + li * CV) * 4u;
+  int nall[4];
+  float cqx[4], cqy[4], cqz[4];  // query + kernel point, per query
+  load_wave_queries(q_pts, idx, q_first, Nq, H, Ns, kx, ky, kz, lane, nall, cqx, cqy, cqz);
   // straight-line bodies per step count (H <= 64 -> 1..4 steps of 16 neighbors)
   const int nsteps = (H + 15) >> 4;
   if (nsteps == 3)
@@ -164,6 +173,21 @@ __device__ __forceinline__ void aggregate_wave(const float* __restrict__ q_pts, 
     aggregate_wave_n<CV, 4>(nall, cqx, cqy, cqz, rs_sp, rs_x, row_bytes, col_off, inv_extent, lg, lane, nn_lds, flush);
   else
     aggregate_wave_n<CV, 1>(nall, cqx, cqy, cqz, rs_sp, rs_x, row_bytes, col_off, inv_extent, lg, lane, nn_lds, flush);
+}
+
+// the same with the step count fixed at compile time (the launcher picks the instantiation from H): the registers of
+// the widest body (16 gathers in flight per lane) are not reserved for tables that never need them
+template <int CV, int NSTEPS, typename Flush>
+__device__ __forceinline__ void aggregate_wave_steps(const float* __restrict__ q_pts, const int32_t* __restrict__ idx,
+                                                     int q_first, int Nq, int H, int Ns, __amdgpu_buffer_rsrc_t rs_sp,
+                                                     __amdgpu_buffer_rsrc_t rs_x, int Cin, int cbase, float kx, float ky,
+                                                     float kz, float inv_extent, int lane, float* nn_lds, Flush&& flush) {
+  const int li = lane & 15, lg = lane >> 4;
+  int nall[4];
+  float cqx[4], cqy[4], cqz[4];
+  load_wave_queries(q_pts, idx, q_first, Nq, H, Ns, kx, ky, kz, lane, nall, cqx, cqy, cqz);
+  aggregate_wave_n<CV, NSTEPS>(nall, cqx, cqy, cqz, rs_sp, rs_x, (unsigned)Cin * 4u, (unsigned)(cbase + li * CV) * 4u,
+                               inv_extent, lg, lane, nn_lds, flush);
 }
 
 // store one query's D tile (rows k = 4*lg + i, column li -> channels li*CV + r) into a [16][CC] LDS row block.

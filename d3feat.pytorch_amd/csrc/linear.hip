@@ -130,7 +130,12 @@ static int atb_partitions(int R, int M, int N) {
   const long long nblocks = (long long)(M / (16 * tile_width(M))) * (N / (16 * tile_width(N)));
   // one workgroup per CU is enough unless the operands are long AND wide (profiles/atb_microbench.py: 512 partitions'
   // worth of slabs cost the small outputs 3 us each in the reduce pass; the 38k x 480 x 32 KPConv gradient wants them)
-  const int target = forced ? forced : ((R >= 30000 && nblocks >= 8) ? D3F_ATB_TARGET_WGS : 256);
+  int target = forced ? forced : ((R >= 30000 && nblocks >= 8) ? D3F_ATB_TARGET_WGS : 256);
+  // the counts above were measured on one S1-class pair (<= 38k rows); several pairs stacked into one batch (round 4)
+  // multiply the rows: keep the ROWS per workgroup where they were instead of the workgroup count (stacked x 4, 153k rows
+  // x 480 x 32: 198 us on 525 workgroups, profiles/r04_step_timeline_stack4.txt)
+  static const int scale_rows = atb_tunable("D3F_ATB_SCALE_ROWS", 40000);
+  if (!forced && scale_rows > 0 && R > scale_rows) target = (int)((long long)target * R / scale_rows);
   long long wgs = (target + nblocks - 1) / nblocks;  // workgroups over the whole launch (256 CUs)
   const long long max_by_rows = (R + 63) / 64;            // >= 16 rows (4 MFMA k-steps) per wave
   if (wgs > max_by_rows) wgs = max_by_rows;

@@ -387,6 +387,17 @@ _SPLITK_MIN_ROWS = 4096
 # below this many query points KPConv goes through library GEMMs (aggregate + wf@W forward; gW = (g/nn) W^T + scatter
 # backward): measured better than the fused kernels up to the 2k-point level, not at 8k points
 _GEMM_DX_MAX_ROWS = 4096
+# ... and, whatever the row count, from this many input channels up (round 4): the contraction with W is then 60 % and
+# more of a KPConv's arithmetic, and inside the fused kernels it runs on 16-row tiles against weights streamed from L2
+# (0.15 - 0.2 of the f32 matrix rate, profiles/r04_step_timeline_stack4.txt); as aggregation kernel (registers -> HBM,
+# csrc/kpconv_aggregate.hip) + tall GEMMs every contraction gets 128-row tiles.  Same split for the grad-input over
+# the exact-form reverse table (transposed aggregation + GEMM with the permuted weights).
+_GEMM_PATH_MIN_CIN = int(__import__('os').environ.get('D3F_GEMM_PATH_MIN_CIN', 64))           # (env: experiments)
+_GEMM_DX_AGG_MIN_COUT = int(__import__('os').environ.get('D3F_GEMM_DX_AGG_MIN_COUT', 64))     # (env: experiments)
+
+
+def _takes_gemm_path(Nq, Cin):
+    return 0 < Nq < _GEMM_DX_MAX_ROWS or (Nq > 0 and Cin >= _GEMM_PATH_MIN_CIN)
 
 
 class _KPConvFn(torch.autograd.Function):
@@ -578,9 +589,29 @@ class _KPConvGemmBiasActFn(torch.autograd.Function):
         gx = gw = None
         if ctx.needs_input_grad[5]:
             gw = ctx.gw_slot if ctx.gw_slot is not None else torch.empty_like(weights)
-            torch.mm(wf.t(), gon, out=gw.view(K * Cin, Cout))
-        if ctx.needs_input_grad[3] and ctx.rev is not None:
-            rev = ctx.rev   # gather form: one launch instead of the gW GEMM + atomic scatter (gon is already / nn)
+            if Nq >= _SPLITK_MIN_ROWS and L.d3f_linear_grad_weight_supported(Nq, Cout, K * Cin):
+                # many rows: the reduction over the points is what has to be spread over the chip (csrc/linear.hip)
+                nbytes = L.d3f_linear_grad_weight_ws_bytes(Nq, Cout, K * Cin)
+                ws = _ws(nbytes, x.device)
+                with _region("kpconv_dw_atb[Nq=%d,Cin=%d,Cout=%d]" % (Nq, Cin, Cout), 4 * Nq * (K * Cin + Cout)):
+                    _native.check(L.d3f_linear_grad_weight(_p(gon), _p(wf), Nq, Cout, K * Cin, _p(gw), _p(ws), nbytes,
+                                                           _stream()), "d3f_linear_grad_weight")
+            else:
+                torch.mm(wf.t(), gon, out=gw.view(K * Cin, Cout))
+        rev = ctx.rev
+        if ctx.needs_input_grad[3] and rev is not None and rev.rel is not None and Cout >= _GEMM_DX_AGG_MIN_COUT \
+                and L.d3f_kpconv_aggregate_transposed_supported(Cout, K):
+            # transposed aggregation (registers -> HBM) + one tall GEMM with the permuted weights W'[k, o, c] = W[k, c, o]:
+            # every row of grad_x written once, no atomics (gon is already / nn)
+            agg = torch.empty((Ns, K * Cout), dtype=torch.float32, device=x.device)
+            with _region("kpconv_agg_transposed[Ns=%d,Cout=%d]" % (Ns, Cout), 4 * Ns * K * Cout + 16 * Ns * rev.width):
+                _native.check(L.d3f_kpconv_aggregate_transposed(_p(rev.rel), rev.width, Ns, Nq, _p(kernel_points), K,
+                                                                ctx.extent, None, _p(gon), Cout, _p(agg), _stream()),
+                              "d3f_kpconv_aggregate_transposed")
+            wp = weights.permute(0, 2, 1).contiguous().view(K * Cout, Cin)
+            gx = torch.mm(agg, wp)
+        elif ctx.needs_input_grad[3] and rev is not None:
+            # gather form: one launch instead of the gW GEMM + atomic scatter (gon is already / nn)
             gx = torch.empty_like(x)
             with _region("kpconv_dx_gather[Ns=%d,Cin=%d,Cout=%d]" % (Ns, Cin, Cout),
                          kpconv_bwd_bytes(Nq, Ns, H, K, Cin, Cout)):
@@ -623,7 +654,7 @@ def kpconv_bias_act(q_pts, s_pts, neighb_inds, x, kernel_points, weights, extent
     q_pts, s_pts, x = _f32(q_pts, "q_pts"), _f32(s_pts, "s_pts"), _f32(x, "x")
     Nq, H = int(q_pts.shape[0]), int(neighb_inds.shape[1])
     K, Cin = int(weights.shape[0]), int(weights.shape[1])
-    if 0 < Nq < _GEMM_DX_MAX_ROWS and s_pts.shape[0] > 0 and \
+    if _takes_gemm_path(Nq, Cin) and s_pts.shape[0] > 0 and \
             _native.lib().d3f_kpconv_grad_input_supported(Cin, K, H, int(s_pts.shape[0])):
         idx = _i32(neighb_inds, "neighb_inds")
         kp, w = _f32(kernel_points, "kernel_points"), _f32(weights, "weights")

@@ -207,6 +207,18 @@ int d3f_kpconv_grad_input(const float* q_pts, int Nq, const float* s_pts, int Ns
                           const float* x, int Cin, const float* kernel_points, int K, float extent, const float* gwf,
                           const void* spack_kept, int grad_x_precleared, float* grad_x, void* ws, size_t ws_bytes,
                           void* stream);
+/* The aggregation of d3f_kpconv_aggregate on the TRANSPOSED graph (autograd of models/blocks.py:359-380 with the sums
+ * over queries and over (kernel point, output channel) exchanged):
+ *   agg_out [Ns, K*Cout],  agg_out[s, k, o] = sum_{q lists s} w(q, s, k) * grad_out[q, o] (/ nn[q] when nn != NULL)
+ * over the exact-form reverse table of d3f_reverse_table_filter (rev_rel [Ns, rev_width, 4]); the caller's GEMM
+ *   grad_x [Ns, Cin] = agg_out @ W',  W'[k*Cout + o, c] = weights[k, c, o]
+ * finishes the grad-input without atomics (every row written once, bit-reproducible).  Registers -> HBM, no LDS tile:
+ * the wide layers (>= 64 channels), whose contraction dominates, run it as a tall library GEMM instead of inside the
+ * fused gather kernel.  Every row of agg_out is written (rows without reverse neighbors get zeros). */
+int d3f_kpconv_aggregate_transposed_supported(int Cout, int K);
+int d3f_kpconv_aggregate_transposed(const float* rev_rel, int rev_width, int Ns, int Nq, const float* kernel_points,
+                                    int K, float extent, const float* nn, const float* grad_out, int Cout,
+                                    float* agg_out, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Weight gradient of the 1x1 "unary" convolutions -- replaces autograd's grad_out^T @ x for nn.Linear in

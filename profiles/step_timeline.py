@@ -1,5 +1,6 @@
-"""Network step of one pair as a hipGraph replay, N times, for a per-dispatch timeline:
-    rocprofv3 --kernel-trace -d gpurun_out/tl -o tl -- python profiles/step_timeline.py 12
+"""Network step of one pair (or of a stack of Q pairs: third argument) as a hipGraph replay, N times, for a per-dispatch
+timeline:
+    rocprofv3 --kernel-trace -d gpurun_out/tl -o tl -- python profiles/step_timeline.py 12 [slack [stack]]
     python profiles/timeline_rocpd.py gpurun_out/tl/*/*.db   -> kernels of the last replay in order, duration + gap"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -27,8 +28,17 @@ ts = TrainStep(cfg, [42] * 5, dev, seed=0)
 b = ts.build_batch(item)
 sizes = [[int(t.shape[0]) for t in b['points']]]
 slack = float(sys.argv[2]) if len(sys.argv) > 2 else 1.0     # capacity head-room (trainer default 1.10)
-ts.enable_graph(TrainStep.capacities_for(sizes, slack=slack), num_corr=int(item[4].shape[0]))
-ts.capture(item)
+Q = int(sys.argv[3]) if len(sys.argv) > 3 else 1             # pairs stacked into the one network graph
+if Q > 1:
+    others = [tuple(torch.from_numpy(np.ascontiguousarray(a)).to(dev) for a in synthetic.make_pair(2 * q + 1, 2 * q + 2, sub))
+              for q in range(1, Q)]
+    stack = (item,) + tuple(others)
+    sizes = [[sum(int(t.shape[0]) for t in [ts.build_batch(it)['points'][l] for it in stack]) for l in range(5)]]
+    ts.enable_graph(TrainStep.capacities_for(sizes, slack=slack), num_corr=int(item[4].shape[0]), stack=Q)
+    ts.capture(stack)
+else:
+    ts.enable_graph(TrainStep.capacities_for(sizes, slack=slack), num_corr=int(item[4].shape[0]))
+    ts.capture(item)
 torch.cuda.synchronize()
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 torch.cuda._sleep(2000000)   # marker kernel: the timeline tool keeps what follows it
@@ -37,4 +47,4 @@ for _ in range(n):
     ts.g_net[0].replay()
 e1.record()
 torch.cuda.synchronize()
-print("replays:", n, "ms/replay: %.3f" % (e0.elapsed_time(e1) / n))
+print("replays:", n, "pairs per replay:", Q, "ms/replay: %.3f" % (e0.elapsed_time(e1) / n))

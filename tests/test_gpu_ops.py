@@ -366,6 +366,62 @@ def test_kpconv_grad_input_as_a_gather_over_the_reverse_table(nq, ns, h, cin, co
         ops.kpconv(cu(q)[:-1], cu(s), tab[:-1], cu(x).requires_grad_(True), cu(kp), cu(w), ext, rev=rev)
 
 
+@pytest.mark.parametrize("n0,n1,r,lim,cin,cout", [(2600, 1900, 0.11, 42, 64, 64), (1500, 900, 0.2, 24, 128, 128),
+                                                  (3000, 1, 0.07, 8, 64, 128), (2300, 2100, 0.11, 48, 32, 64)])
+def test_kpconv_as_aggregation_kernels_plus_gemms(n0, n1, r, lim, cin, cout, monkeypatch):
+    """Wide layers (round 4): LeakyReLU(KPConv(x) + b) as  direct aggregation kernel (registers -> HBM) + tall GEMM +
+    row-divided epilogue, its grad-input as  TRANSPOSED aggregation over the exact-form reverse table + GEMM with the
+    permuted weights, its weight gradient through the reduction-parallel A^T B kernel -- against the oracle's autograd
+    (blocks.py:359-380) and against the fused kernels, conv tables (a cloud against itself) and pooling tables (coarse
+    queries over fine supports); grad_x bit-identical on a second backward (no atomics anywhere)."""
+    rng = np.random.default_rng(n0 + cin)
+    lens = np.array([n0, n1], np.int32)
+    fine = _cloud(rng, n0 + n1)
+    ns = n0 + n1
+    g_fine = ops.RadiusGrid(cu(fine), cu(lens), r)
+    tab, wide, lk = g_fine.query(cu(fine), cu(lens), lim, wide=ops.REV_WIDTH_CONV * 2, want_last_key=True)
+    ex = ops.filter_reverse_table(ops.ReverseTable(wide, ns, lim, ns, last_key=lk, status=g_fine.status), cu(fine), cu(fine))
+    coarse, clen = dl.batch_grid_subsampling_kpconv(cu(fine), cu(lens), sampleDl=r * 0.8)
+    nc = int(coarse.shape[0])
+    tabp, lkp = g_fine.query(coarse, clen, lim, want_last_key=True)
+    g_coarse = ops.RadiusGrid(coarse, clen, 2 * r)
+    up = g_coarse.query(cu(fine), cu(lens), 42)
+    exp_ = ops.filter_reverse_table(ops.ReverseTable(up, nc, lim, ns, last_key=lkp, radius=r, status=g_coarse.status),
+                                    coarse, cu(fine))
+    x = np.abs(rng.normal(size=(ns, cin))).astype(np.float32) * (rng.random((ns, 1)) > 0.05)   # some all-zero rows: nn
+    w = (rng.normal(size=(15, cin, cout)) / np.sqrt(15 * cin)).astype(np.float32)
+    kp = (rng.normal(size=(15, 3)) * r / 3).astype(np.float32)
+    b = rng.normal(size=cout).astype(np.float32)
+    ext = r * 0.8
+    for q_np, q_t, table, rev in ((fine, cu(fine), tab, ex), (coarse.cpu().numpy(), coarse, tabp, exp_)):
+        nq = int(q_t.shape[0])
+        go = rng.normal(size=(nq, cout)).astype(np.float32)
+        tx, tw = torch.from_numpy(x).requires_grad_(True), torch.from_numpy(w).requires_grad_(True)
+        idx64 = table.cpu().long()
+        ref = torch.nn.functional.leaky_relu(
+            ops_ref.kpconv(torch.from_numpy(q_np), torch.from_numpy(fine), idx64, tx, torch.from_numpy(kp), tw, ext)
+            + torch.from_numpy(b), 0.1)
+        ref.backward(torch.from_numpy(go))
+        res = []
+        for split in (True, False, True):
+            monkeypatch.setattr(ops, "_GEMM_PATH_MIN_CIN", 16 if split else 1 << 30)
+            monkeypatch.setattr(ops, "_GEMM_DX_AGG_MIN_COUT", 16 if split else 1 << 30)
+            monkeypatch.setattr(ops, "_GEMM_DX_MAX_ROWS", 0)
+            monkeypatch.setattr(ops, "DX_GATHER_MIN_ROWS", 0)
+            gx, gw, gb = cu(x).requires_grad_(True), cu(w).requires_grad_(True), cu(b).requires_grad_(True)
+            y = ops.kpconv_bias_act(q_t, cu(fine), table, gx, cu(kp), gw, ext, gb, slope=0.1, rev=rev)
+            y.backward(cu(go))
+            res.append([t.detach().cpu().numpy() for t in (y, gx.grad, gw.grad, gb.grad)])
+        assert rel_err(res[0][0], ref.detach().numpy()) < FWD_TOL
+        assert rel_err(res[0][1], tx.grad.numpy()) < BWD_TOL
+        assert rel_err(res[0][2], tw.grad.numpy()) < BWD_TOL
+        for a, c in zip(res[0], res[1]):                 # split == fused
+            assert rel_err(a, c) < 2e-5
+        assert np.array_equal(res[0][1], res[2][1])      # deterministic grad_x
+    g_fine.status.raise_if_set()
+    g_coarse.status.raise_if_set()
+
+
 @pytest.mark.parametrize("nq,ns,h,cin,cout", [(1000, 1000, 42, 32, 32), (97, 154, 23, 512, 512), (300, 400, 42, 16, 16),
                                               (150, 160, 42, 256, 128), (200, 260, 42, 24, 40)])
 @pytest.mark.parametrize("min_rows", [1, 1 << 30])  # reduction-parallel kernel / library GEMM for grad_W
@@ -1115,6 +1171,52 @@ def test_grouped_max_pool_and_detection_equal_per_group_calls():
             sub = np.where(tab[s0:s1] >= ns, s1 - s0, tab[s0:s1] - s0).astype(np.int32)
             want = ops.detection_scores(cu(f[s0:s1]), cu(sub), training=training, width=cu(widths[g:g + 1]))
             assert torch.equal(got[s0:s1], want), (training, g)
+    # training: the gradient through every group's own normaliser (its arg-max row) stays inside the group
+    gs = rng.normal(size=(ns, 1)).astype(np.float32)
+    ff = cu(f).requires_grad_(True)
+    ops.detection_scores(ff, cu(tab), training=True, lens=cu(lens_s), width=cu(widths), group=2).backward(cu(gs))
+    for g in range(3):
+        s0, s1 = so[2 * g], so[2 * g + 2]
+        sub = np.where(tab[s0:s1] >= ns, s1 - s0, tab[s0:s1] - s0).astype(np.int32)
+        fg = cu(f[s0:s1]).requires_grad_(True)
+        ops.detection_scores(fg, cu(sub), training=True, width=cu(widths[g:g + 1])).backward(cu(gs[s0:s1]))
+        assert rel_err(ff.grad[s0:s1].cpu().numpy(), fg.grad.cpu().numpy()) < 1e-5, g
+
+
+def test_train_loss_of_stacked_pairs_equals_the_per_pair_losses():
+    """ops.train_loss_pairs (P pairs stacked: clouds 2p, 2p+1; every pair its own M x M circle + detector problem,
+    trainer.py:91-98) == ops.train_loss on each pair alone: losses, statistics and the gradient wrt descriptors / scores
+    (total = sum over the pairs, so gradients add)."""
+    rng = np.random.default_rng(11)
+    P, M, C = 3, 64, 32
+    lens = np.array([700, 650, 300, 420, 510, 90], np.int32)
+    off = np.concatenate([[0], np.cumsum(lens)])
+    N = int(off[-1]) + 37                                       # capacity rows past the live ones
+    x = rng.normal(size=(N, C)).astype(np.float32)
+    sc = rng.random((N, 1)).astype(np.float32)
+    corr = np.stack([np.stack([rng.integers(0, lens[2 * p], M), rng.integers(0, lens[2 * p + 1], M)], 1) for p in range(P)])
+    dk = rng.random((P, M, M)) * 0.3
+    for w_desc, w_det in ((1.0, 1.0), (0.7, 1.3)):
+        tx, ts = cu(x).requires_grad_(True), cu(sc).requires_grad_(True)
+        tot, desc, det, acc, fp, an = ops.train_loss_pairs(tx, ts, cu(corr), cu(lens), cu(dk), w_desc=w_desc, w_det=w_det)
+        tot.backward()
+        gx, gs = torch.zeros_like(tx), torch.zeros_like(ts)
+        want = 0.0
+        for p in range(P):
+            a0, a1 = int(off[2 * p]), int(off[2 * p + 2])
+            px, ps = cu(x[a0:a1]).requires_grad_(True), cu(sc[a0:a1]).requires_grad_(True)
+            t1, d1, e1, c1, f1, n1 = ops.train_loss(px, ps, cu(corr[p]), int(lens[2 * p]), cu(dk[p]), w_desc=w_desc,
+                                                    w_det=w_det)
+            t1.backward()
+            gx[a0:a1] += px.grad
+            gs[a0:a1] += ps.grad
+            want += float(t1)
+            assert abs(float(desc[p]) - float(d1)) < 1e-6 and abs(float(det[p]) - float(e1)) < 1e-6
+            assert abs(float(acc[p]) - float(c1)) < 1e-4
+            assert torch.equal(fp[p], f1) and torch.equal(an[p], n1)
+        assert abs(float(tot) - want) < 1e-5 * max(1.0, abs(want))
+        assert float((tx.grad - gx).abs().max()) <= 1e-6 * float(gx.abs().max()) + 1e-9
+        assert float((ts.grad - gs).abs().max()) <= 1e-6 * float(gs.abs().max()) + 1e-9
 
 
 @pytest.mark.parametrize("ns,nq,cin", [(700, 500, 64), (700, 700, 512), (5000, 5000, 128), (4500, 1200, 32)])
