@@ -265,6 +265,16 @@ def main():
                     help="launch / rendezvous check only (no GPU work): every rank joins the process group and rank 0 "
                          "prints {n_gpus, ranks}; what tests/test_dist_cpu.py runs on a GPU-less host")
     args = ap.parse_args()
+    # D3F_BENCH_WATCHDOG=<seconds>: dump every thread's Python stack and exit if the run is still going by then (a hung
+    # capture / tuning pass on a rented GPU box costs the whole call's budget otherwise); D3F_BENCH_LOG=1: stage stamps
+    if os.environ.get("D3F_BENCH_WATCHDOG"):
+        import faulthandler
+        faulthandler.dump_traceback_later(float(os.environ["D3F_BENCH_WATCHDOG"]), exit=True)
+    t_begin = time.time()
+
+    def stage(msg):
+        if os.environ.get("D3F_BENCH_LOG"):
+            print("[bench %7.1fs] %s" % (time.time() - t_begin, msg), file=sys.stderr, flush=True)
 
     # `python bench.py --gpus N` launched plainly (no WORLD_SIZE in the environment): spawn the N ranks ourselves, exactly
     # as the documented command does, instead of silently running one rank
@@ -352,6 +362,7 @@ def main():
             return host_items[0]
     limits = [int(x) for x in dl.calibrate_neighbors(_DS(), cfg, samples_threshold=10 ** 9)]
 
+    stage("items + limits ready")
     ts = TrainStep(cfg, limits, dev, world_size=world, seed=0)
     prof = ops.EventProfiler()
     n_total = args.warmup + args.steps
@@ -367,7 +378,9 @@ def main():
         # (a real data loader calibrates them like neighborhood_limits; overflow is detected, D3F_ST_CAPACITY)
         ts.enable_graph(TrainStep.capacities_for(sizes, slack=1.0), num_corr=int(items[0][4].shape[0]))
         try:
+            stage("capturing the one-pair engine, capacities %s" % (ts.caps,))
             ts.capture(items[0])
+            stage("captured")
         except Exception as e:  # pragma: no cover - keep the benchmark alive on a capture problem
             print("hipGraph capture failed (%s: %s); falling back to eager launches" % (type(e).__name__, e),
                   file=sys.stderr)
@@ -396,7 +409,9 @@ def main():
         try:
             lanes = PairLanes(ts, L, stack=Q)
             lanes.enable_graph(stacked_caps(1.0), num_corr=int(items[0][4].shape[0]))
+            stage("capturing %d lanes x %d stacked pairs, capacities %s" % (L, Q, lanes.caps))
             lanes.capture(tuple(items[j % len(items)] for j in range(P)))
+            stage("captured")
         except Exception as e:  # pragma: no cover - keep the benchmark alive: one pair in flight, as in rounds 1-2
             print("pairs in flight unavailable (%s: %s); running one pair per step" % (type(e).__name__, e),
                   file=sys.stderr)
@@ -413,6 +428,7 @@ def main():
     for w in range(args.warmup):
         run(w)
     torch.cuda.synchronize()
+    stage("warm-up done")
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -425,6 +441,7 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     t1 = time.perf_counter()
+    stage("timed region done")
     loss_val = float(out[0].item()) / Q      # (a stacked lane reports the sum over its stack)
     if use_graph:
         ts.check_status()
@@ -929,7 +946,8 @@ def main():
                        "pairs_in_flight_per_gpu": P, "lanes": L, "stacked_pairs_per_lane": Q,
                        "peak_hbm_allocated_gb": round(torch.cuda.max_memory_allocated(dev) / 2 ** 30, 2),
                        "side_stream_probe_ms": getattr(ts, "_side_probe", None),
-                       "parallelism": "dp%d" % world if P == 1 else "dp%d x %d lanes x %d stacked" % (world, L, Q),
+                       "parallelism": "dp%d" % world if P == 1 else ("dp%d x %d lanes" % (world, L)) + (
+                           " x %d stacked" % Q if Q > 1 else ""),
                        "final_loss": round(loss_val, 5),
                        "replica_param_checksum_spread": replica_spread,
                        "skipped_steps": int(ts.opt.skipped),

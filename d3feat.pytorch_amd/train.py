@@ -533,6 +533,12 @@ class TrainStep:
             self.pts = torch.zeros((caps[0], 3), dtype=torch.float32, device=dev)
             self.feat = None      # [caps[0], in_features_dim]: the pair's input features (set by enable_graph)
             self.lens = torch.zeros(2 * stack, dtype=torch.int32, device=dev)
+            # stack lengths travel through pinned memory: a copy from pageable memory blocks the host until everything
+            # queued on the stream before it has run -- with four lanes that stream holds the lane's network graph
+            # (measured: the step stalled for good, profiles/r04_notes.txt)
+            self.lens_host = torch.zeros(2 * stack, dtype=torch.int32).pin_memory() \
+                if (stack > 1 and torch.device(dev).type == 'cuda') else None
+            self.lens_ev = None
             lead = (stack,) if stack > 1 else ()      # stacked pairs: every pair's own table / matrix
             self.corr = torch.zeros(lead + (num_corr, 2), dtype=torch.int64, device=dev)
             self.dk = torch.zeros(lead + (num_corr, num_corr), dtype=torch.float64, device=dev)
@@ -687,7 +693,15 @@ class TrainStep:
                     lens.append(n)
                 st.corr[q].copy_(it[4], non_blocking=True)
                 st.dk[q].copy_(it[5], non_blocking=True)
-            st.lens.copy_(torch.tensor(lens, dtype=torch.int32))   # one small copy, not 2Q fills
+            if st.lens_host is not None:
+                if st.lens_ev is not None:     # the set's previous load (three steps ago in the pipelined loop) has read it
+                    st.lens_ev.synchronize()
+                st.lens_host.copy_(torch.tensor(lens, dtype=torch.int32))
+                st.lens.copy_(st.lens_host, non_blocking=True)          # one small copy, not 2Q fills
+                st.lens_ev = st.lens_ev or torch.cuda.Event()
+                st.lens_ev.record(torch.cuda.current_stream(self.device))
+            else:
+                st.lens.copy_(torch.tensor(lens, dtype=torch.int32))
         st.mask.copy_(st.dk > self.circle.safe_radius)   # with the upload, off the training stream (utils/loss.py:119)
 
     def _build_set(self, st, adopt=False):
