@@ -19,6 +19,17 @@ import os as _os
 # (profiles/r03_queue_pipes.txt).  Read when the runtime initialises (first HIP call), so it is set at import; a value
 # the user exported wins.
 _os.environ.setdefault("GPU_MAX_HW_QUEUES", "32")
+# Library-GEMM selection (enable_tuned_gemms / tuning_missing_gemms below) considers rocBLAS solutions only.  Round 4,
+# measured: with hipBLASLt candidates in the race, shapes tuned during a capture (stacked pairs: 4160- and 8256-row
+# operands) sometimes got a hipBLASLt winner whose kernel never finished on the SECOND replay of the captured graph --
+# the training stream stalled for good (profiles/r04_notes.txt: `4 lanes x 2 stacked` hung in 2 of 3 processes, never
+# with PYTORCH_TUNABLEOP_HIPBLASLT_ENABLED=0 or without tuning; the same family of finding as the memset nodes of
+# DESIGN.md section 5 that are not re-executed on replay).  368 of the 375 rows of the shipped table were rocBLAS
+# winners anyway.  Read by PyTorch when TunableOp first runs; a value the user exported wins.
+_os.environ.setdefault("PYTORCH_TUNABLEOP_HIPBLASLT_ENABLED", "0")
+# set when the HIP runtime was already up at import (GPU_MAX_HW_QUEUES is then ignored: train.PairLanes warns)
+import sys as _sys
+HIP_WAS_INITIALISED_AT_IMPORT = bool('torch' in _sys.modules and _sys.modules['torch'].cuda.is_initialized())
 
 from . import _native  # noqa: F401,E402
 

@@ -14,7 +14,11 @@
 //   correctly rounded sqrt is taken only when a candidate beats the incumbent (a handful of times per row), so two
 //   different v that round to the same distance keep the earlier column as numpy does.  A negative v (NaN after the
 //   reference's sqrt) wins like NaN does in np.argmin.
-// The column arg-min is the same kernel with S and T swapped.
+// Row AND column arg-min come out of ONE sweep over the S x T tiles (round 4; the reference forms S T^T once,
+// common.py:9-13): the products a wave holds for its 32 rows x 16 columns also give, per column, the best of those rows;
+// the workgroup's 128 rows meet in an LDS table of (distance bits << 32 | row) keys over its column chunk (ds_min_u64),
+// and after the sweep every column of the chunk costs one global 64-bit atomicMin.  The dot product of a (row, column)
+// pair is the same bit pattern whichever side asks for it, so both arg-mins see identical distances.
 #include "common.hpp"
 
 namespace {
@@ -33,26 +37,24 @@ __global__ void fill_u64_kernel(unsigned long long* __restrict__ p, int n, unsig
   if (i < n) p[i] = v;
 }
 
-__global__ void unpack_arg_kernel(const unsigned long long* __restrict__ best, int n, int32_t* __restrict__ out) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) out[i] = (int32_t)(best[i] & 0xffffffffull);
-}
-
 // seg != nullptr: blockIdx.z = pair; {S rows, T rows} of the pair are segments of the stacked matrices (seg [P,4] =
-// {src_off, src_len, tgt_off, tgt_len}; swap = 1 exchanges the roles for the column pass); `best` is indexed by the row
-// of the stacked source matrix, the winning column stays pair-local.
+// {src_off, src_len, tgt_off, tgt_len}); `best` / `best_col` are indexed by the row of the stacked source / target
+// matrix, the winning column / row stays pair-local.
 template <int C, int RT, bool PF>
 __global__ __launch_bounds__(256) void row_argmin_kernel(const float* __restrict__ S, int Ns,
                                                          const float* __restrict__ T, int Nt, int cols_per_chunk,
                                                          unsigned long long* __restrict__ best,
-                                                         const int32_t* __restrict__ seg = nullptr, int swap = 0) {
+                                                         unsigned long long* __restrict__ best_col,
+                                                         const int32_t* __restrict__ seg = nullptr) {
   static_assert(C % 16 == 0, "descriptor width must be a multiple of 16");
+  extern __shared__ unsigned long long colbest[];   // [cols_per_chunk]: best (distance, row) key of this workgroup's rows
   if (seg) {
     const int32_t* e = seg + 4 * blockIdx.z;
-    const int so = e[swap ? 2 : 0], sn = e[swap ? 3 : 1], to = e[swap ? 0 : 2], tn = e[swap ? 1 : 3];
+    const int so = e[0], sn = e[1], to = e[2], tn = e[3];
     S += (size_t)so * C;
     T += (size_t)to * C;
     best += so;
+    best_col += to;
     Ns = sn;
     Nt = tn;
     if (Ns < 1 || Nt < 1) return;
@@ -61,8 +63,11 @@ __global__ __launch_bounds__(256) void row_argmin_kernel(const float* __restrict
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int li = lane & 15, lk = lane >> 4;
   const int row0 = (blockIdx.x * 4 + wave) * (16 * RT);
-  if (row0 >= Ns) return;
   const int cbeg = blockIdx.y * cols_per_chunk, cend = min(Nt, cbeg + cols_per_chunk);
+  if (blockIdx.x * 4 * (16 * RT) >= Ns || cbeg >= cend) return;   // (whole workgroup: no barrier is left waiting)
+  for (int t = threadIdx.x; t < cend - cbeg; t += 256) colbest[t] = ~0ull;
+  __syncthreads();
+  const bool live_wave = row0 < Ns;   // a wave past the last row still takes part in the barriers
   // A fragments: A[i = li][kk = lk] for step (u,t) of row tile rt is S[row0 + 16rt + li][16u + 4lk + t]
   float4 afrag[RT][KS];
 #pragma unroll
@@ -97,7 +102,7 @@ __global__ __launch_bounds__(256) void row_argmin_kernel(const float* __restrict
     }
   };
   if (PF && cbeg < cend) load_tile(cbeg);
-  for (int col0 = cbeg; col0 < cend; col0 += kColsPerTile) {
+  for (int col0 = cbeg; live_wave && col0 < cend; col0 += kColsPerTile) {
     float4 bfrag[4][KS];
     if (!PF) load_tile(col0);
 #pragma unroll
@@ -124,6 +129,45 @@ __global__ __launch_bounds__(256) void row_argmin_kernel(const float* __restrict
       // D layout: col = li (target col0 + 16nb + li), row = 4*lk + r of row tile rt.  Columns arrive in ascending
       // order within a lane, so a strict "<" keeps the earliest column among equals.
       const int j = col0 + 16 * nb + li;
+      if (j < cend) {
+        // column side: best of this lane's 4*RT rows for column j.  Rows past Ns are copies of row Ns - 1 (clamped
+        // loads) with a LARGER index: they tie with the real row and lose to it.  `near` counts products within
+        // rounding reach of the maximum: only then can a lower row with a smaller product share its rounded distance.
+        float m = -INFINITY;
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) m = fmaxf(m, acc[rt][r]);
+        const float mthr = m - 4e-7f;
+        int ri = 0, near = 0;
+#pragma unroll
+        for (int rt = RT - 1; rt >= 0; --rt)
+#pragma unroll
+          for (int r = 3; r >= 0; --r) {
+            if (acc[rt][r] == m) ri = 16 * rt + r;
+            near += acc[rt][r] > mthr ? 1 : 0;
+          }
+        unsigned long long ckey;
+        if (near > 1 || !(m == m)) {   // (rare; NaN products: every candidate is looked at)
+          ckey = ~0ull;
+#pragma unroll
+          for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+              if (acc[rt][r] > mthr || !(acc[rt][r] == acc[rt][r])) {
+                const float v = 2.0f - 2.0f * acc[rt][r];
+                const float sv = v < 0.0f ? -INFINITY : __fsqrt_rn(v);
+                const unsigned long long k2 =
+                    ((unsigned long long)ord_bits(sv) << 32) | (uint32_t)(row0 + 16 * rt + 4 * lk + r);
+                ckey = k2 < ckey ? k2 : ckey;
+              }
+        } else {
+          const float v = 2.0f - 2.0f * m;
+          const float sv = v < 0.0f ? -INFINITY : __fsqrt_rn(v);
+          ckey = ((unsigned long long)ord_bits(sv) << 32) | (uint32_t)(row0 + ri + 4 * lk);
+        }
+        atomicMin(&colbest[j - cbeg], ckey);   // LDS: the 4 row quads of the wave and the 4 waves meet here
+      }
       bool any = false;  // one branch per 16 x 16*RT products instead of one per product
 #pragma unroll
       for (int rt = 0; rt < RT; ++rt)
@@ -170,103 +214,100 @@ __global__ __launch_bounds__(256) void row_argmin_kernel(const float* __restrict
         key = ok < key ? ok : key;
       }
       const int row = row0 + 16 * rt + 4 * lk + r;
-      if (li == 0 && row < Ns) atomicMin(&best[row], key);
+      if (live_wave && li == 0 && row < Ns) atomicMin(&best[row], key);
     }
+  // the chunk's columns: one global atomicMin each
+  __syncthreads();
+  for (int t = threadIdx.x; t < cend - cbeg; t += 256) {
+    const unsigned long long k2 = colbest[t];
+    if (k2 != ~0ull) atomicMin(&best_col[cbeg + t], k2);
+  }
 }
 
-__global__ void mutual_kernel(const int32_t* __restrict__ row_arg, const int32_t* __restrict__ col_arg, int Ns,
-                              int32_t* __restrict__ mutual) {
+// best_row [Ns] / best_col [Nt] keys -> arg-mins and the mutual flag (one launch over max(Ns, Nt))
+__global__ void unpack_mutual_kernel(const unsigned long long* __restrict__ best_row,
+                                     const unsigned long long* __restrict__ best_col, int Ns, int Nt,
+                                     int32_t* __restrict__ row_arg, int32_t* __restrict__ col_arg,
+                                     int32_t* __restrict__ mutual) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < Ns) mutual[i] = col_arg[row_arg[i]] == i ? 1 : 0;
+  if (i < Nt) col_arg[i] = (int32_t)(best_col[i] & 0xffffffffull);
+  if (i < Ns) {
+    const int32_t j = (int32_t)(best_row[i] & 0xffffffffull);
+    row_arg[i] = j;
+    if (mutual) mutual[i] = (j >= 0 && j < Nt && (int32_t)(best_col[j] & 0xffffffffull) == i) ? 1 : 0;
+  }
 }
 
-template <int C>
-int one_pass(const float* S, int Ns, const float* T, int Nt, int32_t* out, unsigned long long* best,
-             hipStream_t stream) {
-  // Measured on MI355X at 19.1k x 19.1k x 32 (profiles/matching_microbench.py): 2 row tiles per wave without software
-  // prefetch and ~2048 workgroups (0.60 ms) beat 4 row tiles / prefetch / 1024 workgroups (0.70 ms) and 1 row tile
-  // (0.73 ms): more resident waves hide the fragment loads better than the deeper register tiling saves them.
-  constexpr int RT = C <= 64 ? 2 : 1;
-  const int rows_per_wg = 64 * RT;
-  const int gx = d3f::cdiv(Ns, rows_per_wg);
-  int chunks = 2048 / gx;  // target range split so that the launch is ~8 workgroups per CU
+// workgroups along the target range: ~2048 in all (8 per CU), column chunks of whole tiles that fit the LDS table
+static void chunking(int gx, int Nt, int& chunks, int& cpc) {
+  chunks = 2048 / (gx > 0 ? gx : 1);
   const int max_chunks = d3f::cdiv(Nt, 4 * kColsPerTile);
   if (chunks > max_chunks) chunks = max_chunks;
+  const int min_chunks = d3f::cdiv(Nt, 4096);   // 32 KB of keys per workgroup at most
+  if (chunks < min_chunks) chunks = min_chunks;
   if (chunks < 1) chunks = 1;
-  int cpc = d3f::cdiv(Nt, chunks);
+  cpc = d3f::cdiv(Nt, chunks);
   cpc = d3f::cdiv(cpc, kColsPerTile) * kColsPerTile;
   chunks = d3f::cdiv(Nt, cpc);
-  fill_u64_kernel<<<d3f::cdiv(Ns, 256), 256, 0, stream>>>(best, Ns, ~0ull);
-  row_argmin_kernel<C, RT, false><<<dim3(gx, chunks), 256, 0, stream>>>(S, Ns, T, Nt, cpc, best);
-  unpack_arg_kernel<<<d3f::cdiv(Ns, 256), 256, 0, stream>>>(best, Ns, out);
-  D3F_LAUNCH_CHECK();
-  return D3F_OK;
 }
 
 template <int C>
 int run(const float* S, int Ns, const float* T, int Nt, int32_t* ra, int32_t* ca, int32_t* mu, void* ws,
         hipStream_t stream) {
-  unsigned long long* best = (unsigned long long*)ws;
-  int rc = one_pass<C>(S, Ns, T, Nt, ra, best, stream);
-  if (rc) return rc;
-  rc = one_pass<C>(T, Nt, S, Ns, ca, best, stream);
-  if (rc) return rc;
-  if (mu) mutual_kernel<<<d3f::cdiv(Ns, 256), 256, 0, stream>>>(ra, ca, Ns, mu);
+  // Measured on MI355X at 19.1k x 19.1k x 32 (profiles/matching_microbench.py): 2 row tiles per wave without software
+  // prefetch and ~2048 workgroups beat 4 row tiles / prefetch / 1024 workgroups and 1 row tile: more resident waves
+  // hide the fragment loads better than the deeper register tiling saves them.
+  constexpr int RT = C <= 64 ? 2 : 1;
+  unsigned long long* best_row = (unsigned long long*)ws;
+  unsigned long long* best_col = best_row + Ns;
+  const int gx = d3f::cdiv(Ns, 64 * RT);
+  int chunks, cpc;
+  chunking(gx, Nt, chunks, cpc);
+  fill_u64_kernel<<<d3f::cdiv(Ns + Nt, 256), 256, 0, stream>>>(best_row, Ns + Nt, ~0ull);
+  row_argmin_kernel<C, RT, false><<<dim3(gx, chunks), 256, sizeof(unsigned long long) * (size_t)cpc, stream>>>(
+      S, Ns, T, Nt, cpc, best_row, best_col);
+  unpack_mutual_kernel<<<d3f::cdiv(Ns > Nt ? Ns : Nt, 256), 256, 0, stream>>>(best_row, best_col, Ns, Nt, ra, ca, mu);
   D3F_LAUNCH_CHECK();
   return D3F_OK;
 }
 
+// which = 0: source segments (seg[4p], seg[4p+1]); 2: target segments
 __global__ void fill_seg_kernel(unsigned long long* __restrict__ p, const int32_t* __restrict__ seg, int which,
                                 int max_len) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   const int32_t* e = seg + 4 * blockIdx.y;
   if (i < e[which + 1] && i < max_len) p[e[which] + i] = ~0ull;
 }
-__global__ void unpack_seg_kernel(const unsigned long long* __restrict__ best, const int32_t* __restrict__ seg,
-                                  int which, int max_len, int32_t* __restrict__ out) {
+__global__ void unpack_mutual_seg_kernel(const unsigned long long* __restrict__ best_row,
+                                         const unsigned long long* __restrict__ best_col,
+                                         const int32_t* __restrict__ seg, int max_s, int max_t,
+                                         int32_t* __restrict__ row_arg, int32_t* __restrict__ col_arg,
+                                         int32_t* __restrict__ mutual) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   const int32_t* e = seg + 4 * blockIdx.y;
-  if (i < e[which + 1] && i < max_len) out[e[which] + i] = (int32_t)(best[e[which] + i] & 0xffffffffull);
-}
-__global__ void mutual_seg_kernel(const int32_t* __restrict__ row_arg, const int32_t* __restrict__ col_arg,
-                                  const int32_t* __restrict__ seg, int max_len, int32_t* __restrict__ mutual) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  const int32_t* e = seg + 4 * blockIdx.y;
-  if (i >= e[1] || i >= max_len) return;
-  const int j = row_arg[e[0] + i];
-  mutual[e[0] + i] = (j >= 0 && j < e[3] && col_arg[e[2] + j] == i) ? 1 : 0;
-}
-
-template <int C>
-int one_pass_batched(const float* S, const float* T, const int32_t* seg, int P, int swap, int max_s, int max_t,
-                     int32_t* out, unsigned long long* best, hipStream_t stream) {
-  constexpr int RT = C <= 64 ? 2 : 1;
-  const int gx = d3f::cdiv(max_s, 64 * RT);
-  int chunks = d3f::cdiv(2048, gx * P);  // the P pairs together fill the chip
-  const int max_chunks = d3f::cdiv(max_t, 4 * kColsPerTile);
-  if (chunks > max_chunks) chunks = max_chunks;
-  if (chunks < 1) chunks = 1;
-  int cpc = d3f::cdiv(max_t, chunks);
-  cpc = d3f::cdiv(cpc, kColsPerTile) * kColsPerTile;
-  chunks = d3f::cdiv(max_t, cpc);
-  const int which = swap ? 2 : 0;
-  fill_seg_kernel<<<dim3(d3f::cdiv(max_s, 256), P), 256, 0, stream>>>(best, seg, which, max_s);
-  row_argmin_kernel<C, RT, false><<<dim3(gx, chunks, P), 256, 0, stream>>>(S, 0, T, 0, cpc, best, seg, swap);
-  unpack_seg_kernel<<<dim3(d3f::cdiv(max_s, 256), P), 256, 0, stream>>>(best, seg, which, max_s, out);
-  D3F_LAUNCH_CHECK();
-  return D3F_OK;
+  if (i < e[3] && i < max_t) col_arg[e[2] + i] = (int32_t)(best_col[e[2] + i] & 0xffffffffull);
+  if (i < e[1] && i < max_s) {
+    const int32_t j = (int32_t)(best_row[e[0] + i] & 0xffffffffull);
+    row_arg[e[0] + i] = j;
+    if (mutual) mutual[e[0] + i] = (j >= 0 && j < e[3] && (int32_t)(best_col[e[2] + j] & 0xffffffffull) == i) ? 1 : 0;
+  }
 }
 
 template <int C>
 int run_batched(const float* S, const float* T, const int32_t* seg, int P, int max_s, int max_t, int32_t* ra,
                 int32_t* ca, int32_t* mu, void* ws, size_t half, hipStream_t stream) {
+  constexpr int RT = C <= 64 ? 2 : 1;
   unsigned long long* best_s = (unsigned long long*)ws;
   unsigned long long* best_t = (unsigned long long*)((char*)ws + half);
-  int rc = one_pass_batched<C>(S, T, seg, P, 0, max_s, max_t, ra, best_s, stream);
-  if (rc) return rc;
-  rc = one_pass_batched<C>(T, S, seg, P, 1, max_t, max_s, ca, best_t, stream);
-  if (rc) return rc;
-  if (mu) mutual_seg_kernel<<<dim3(d3f::cdiv(max_s, 256), P), 256, 0, stream>>>(ra, ca, seg, max_s, mu);
+  const int gx = d3f::cdiv(max_s, 64 * RT);
+  int chunks, cpc;
+  chunking(gx * P, max_t, chunks, cpc);   // the P pairs together fill the chip
+  fill_seg_kernel<<<dim3(d3f::cdiv(max_s, 256), P), 256, 0, stream>>>(best_s, seg, 0, max_s);
+  fill_seg_kernel<<<dim3(d3f::cdiv(max_t, 256), P), 256, 0, stream>>>(best_t, seg, 2, max_t);
+  row_argmin_kernel<C, RT, false><<<dim3(gx, chunks, P), 256, sizeof(unsigned long long) * (size_t)cpc, stream>>>(
+      S, 0, T, 0, cpc, best_s, best_t, seg);
+  unpack_mutual_seg_kernel<<<dim3(d3f::cdiv(max_s > max_t ? max_s : max_t, 256), P), 256, 0, stream>>>(
+      best_s, best_t, seg, max_s, max_t, ra, ca, mu);
   D3F_LAUNCH_CHECK();
   return D3F_OK;
 }
@@ -338,7 +379,9 @@ __global__ __launch_bounds__(kTopThreads) void topk_kernel(const float* __restri
 
 extern "C" {
 
-size_t d3f_mutual_nn_ws_bytes(int Ns, int Nt) { return d3f::align_up(8 * (size_t)(Ns > Nt ? Ns : Nt), 256); }
+size_t d3f_mutual_nn_ws_bytes(int Ns, int Nt) {
+  return d3f::align_up(8 * ((size_t)(Ns > 0 ? Ns : 1) + (size_t)(Nt > 0 ? Nt : 1)), 256);
+}
 
 int d3f_mutual_nn(const float* src_desc, int Ns, const float* tgt_desc, int Nt, int C, int32_t* row_argmin,
                   int32_t* col_argmin, int32_t* mutual, void* ws, size_t ws_bytes, void* stream) {

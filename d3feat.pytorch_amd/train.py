@@ -745,7 +745,7 @@ class TrainStep:
 
     def _use_scale(self):
         """The optimizer's gradient scale for THIS engine's steps (lanes: the join sets it)."""
-        if getattr(self, 'lane', None) is None:
+        if getattr(self, 'lane', None) is None and getattr(self, 'opt', None) is not None:   # (forward-only engines: none)
             self.opt.use_grad_scale(1.0 / (self.stack * max(1, self.world)))
 
     def _net_step(self, st):

@@ -15,9 +15,16 @@ any object with ``add_scalar(tag, value, step)`` (``args.writer``; tensorboardX 
 JSON-lines file under ``args.tboard_dir``.  With ``world_size > 1`` every rank walks the same shuffled order and takes
 every ``world_size``-th pair; rank 0 writes snapshots and logs.
 
-``args.pairs_in_flight`` (default 1 = the reference's one pair per optimizer step, dataloader.py:73) > 1 trains on that
-many pairs AT ONCE per GPU (train.PairLanes: a network graph per pair on streams of their own, one SGD step on the mean
-of their gradients -- the update a data-parallel step over as many more ranks makes); graph mode only.
+``args.pairs_in_flight`` (L, default 1) and ``args.stacked_pairs`` (Q, default 1) train on L x Q pairs per optimizer
+step and GPU: Q pairs STACKED into one pyramid + one network graph (TrainStep ``stack``), L such graphs in flight on
+streams of their own (train.PairLanes), one SGD step on the mean of the L x Q gradients -- the update a data-parallel
+step over L x Q times as many ranks makes; graph mode only.  L = Q = 1 is the reference's one pair per optimizer step
+(dataloader.py:73).  NOTE on the learning rate: the mean gradient of P pairs is the gradient of a batch of P, so the
+reference's schedule (lr 0.01, momentum 0.98, training_3DMatch.py:62-76), tuned for batches of one pair, sees P times
+fewer and less noisy updates per epoch; scale ``lr`` (or the epoch count) accordingly -- the trainer does not.
+With several ranks every per-step decision that changes which collectives a rank issues (graph step or eager
+fallback) is agreed between the ranks first (``_agree``), and pairs whose update was skipped are NOT re-run (a rank
+re-running alone would issue all-reduces nobody matches): the consistent skip of rounds 1-2.
 """
 import json
 import os
@@ -134,10 +141,14 @@ class Trainer(object):
             self.use_graph = False
         self._captured = False
         self.lanes = max(1, int(_get(args, 'pairs_in_flight', 1)))
-        if self.lanes > 1 and not self.use_graph:
+        self.stack = max(1, int(_get(args, 'stacked_pairs', 1)))
+        if self.lanes * self.stack > 1 and not self.use_graph:
             if self.rank == 0:
-                print("note: pairs_in_flight=%d needs the hipGraph path; training one pair per step" % self.lanes)
-            self.lanes = 1
+                print("note: pairs_in_flight=%d / stacked_pairs=%d need the hipGraph path; training one pair per step"
+                      % (self.lanes, self.stack))
+            self.lanes = self.stack = 1
+        self.group = self.lanes * self.stack          # pairs per optimizer step and GPU
+        self._agree_stream = None
         if _get(args, 'pretrain', ''):
             self._load_pretrain(args.pretrain)
 
@@ -201,16 +212,19 @@ class Trainer(object):
         self._rerun_overflowed(drain=True)
         flags, count = self.engine.check_status(raise_on_skip=False)
         rerun = getattr(self, 'rerun_pairs', 0) - getattr(self, '_rerun_reported', 0)
+        rerun_steps = getattr(self, 'rerun_steps', 0) - getattr(self, '_rerun_steps_reported', 0)
         self._rerun_reported = getattr(self, 'rerun_pairs', 0)
+        self._rerun_steps_reported = getattr(self, 'rerun_steps', 0)
         if rerun and self.rank == 0:
             print("note: %d pair(s) outgrew their capacity class and were trained on the eager path instead" % rerun)
-        count = max(0, count - rerun)
+        count = max(0, count - rerun_steps)       # skipped steps that were NOT made up for
         if rerun and not count:
             flags = 0
         if (count or flags) and self.rank == 0:
             from . import _native
-            print("warning: %d pair(s) skipped -- %s" % (count, _native.status_message(flags) or ("status %d" % flags)))
-        self.skipped_pairs = getattr(self, 'skipped_pairs', 0) + count
+            print("warning: %d step(s) of %d pair(s) skipped -- %s" % (
+                count, self.group, _native.status_message(flags) or ("status %d" % flags)))
+        self.skipped_pairs = getattr(self, 'skipped_pairs', 0) + count * self.group
         return count
 
     def _fetch(self, dataset, i):
@@ -224,18 +238,20 @@ class Trainer(object):
         self._engines = []
         keep = (eng.flat.data.clone(), eng.opt.buf.clone(), eng.opt.state.clone())
         for caps, member in self._capacity_classes(ds, classes=int(_get(self.config, 'capacity_classes', 3))):
-            if self.lanes > 1:        # several pairs in flight: the lanes of every class share streams and the join
+            caps = [self.stack * int(c) for c in caps]     # a stack holds `stack` pairs of the class
+            if self.lanes > 1:        # several graphs in flight: the lanes of every class share streams and the join
                 if not self._engines:
-                    e = PairLanes(eng, self.lanes)
+                    e = PairLanes(eng, self.lanes, stack=self.stack)
                     e.enable_graph(caps, num_corr=int(item[4].shape[0]))
                 else:
                     e = self._engines[0].clone_for_capacities(caps, num_corr=int(item[4].shape[0]))
             elif not self._engines:   # the first class lives in the engine itself, the others in clones of it
                 e = eng
-                e.enable_graph(caps, num_corr=int(item[4].shape[0]))
+                e.enable_graph(caps, num_corr=int(item[4].shape[0]), stack=self.stack)
             else:
-                e = eng.clone_for_capacities(caps, num_corr=int(item[4].shape[0]))
-            e.capture(self._fetch(ds, member))
+                e = eng.clone_for_capacities(caps, num_corr=int(item[4].shape[0]), stack=self.stack)
+            one = self._fetch(ds, member)
+            e.capture(one if self.lanes > 1 or self.stack == 1 else tuple([one] * self.stack))
             self._engines.append(e)
         for dst, src in zip((eng.flat.data, eng.opt.buf, eng.opt.state), keep):
             dst.copy_(src)
@@ -252,9 +268,14 @@ class Trainer(object):
         on the eager path (exact shapes) a few steps late instead of being dropped -- the reference trains on every
         pair (trainer.py:89-111)."""
         again = [x for e in getattr(self, '_engines', []) for x in e.take_overflowed(drain=drain)]
+        if again and self.world > 1:
+            return      # (a rank re-running alone would issue collectives no other rank matches: the skip stands)
         if again:
-            self._eager_steps([item for item, _ in again])
-            self.rerun_pairs = getattr(self, 'rerun_pairs', 0) + len(again)
+            pairs = [p for entry, _ in again for p in TrainStep.pairs_of(entry)]
+            self._eager_steps(pairs)
+            self.rerun_pairs = getattr(self, 'rerun_pairs', 0) + len(pairs)
+            # the optimizer counts skipped STEPS (state[3]); a step holds `group` pairs
+            self.rerun_steps = getattr(self, 'rerun_steps', 0) + max(1, len(pairs) // self.group)
 
     def _eager_steps(self, items):
         """Eager steps on the current stream.  With pairs in flight the lanes are drained first and wait for these
@@ -271,34 +292,63 @@ class Trainer(object):
             lanes.resync()
         return res
 
+    def _agree(self, flag):
+        """Logical AND of ``flag`` over the ranks (one tiny all-reduce on a stream of its own, so that reading it does
+        not wait for the training streams): decisions that change which collectives a rank issues must be common."""
+        if self.world == 1:
+            return bool(flag)
+        if self.device.type != 'cuda':
+            t = torch.tensor([1 if flag else 0], dtype=torch.int32)
+            dist.all_reduce(t, op=dist.ReduceOp.MIN)
+            return bool(int(t.item()))
+        if self._agree_stream is None:
+            self._agree_stream = torch.cuda.Stream(device=self.device)
+        with torch.cuda.stream(self._agree_stream):
+            t = torch.tensor([1 if flag else 0], dtype=torch.int32, device=self.device)
+            dist.all_reduce(t, op=dist.ReduceOp.MIN)
+            ok = bool(int(t.item()))
+        return ok
+
+    def _group_class(self, group):
+        """The smallest capacity class whose graphs take the ``group`` pairs of a step (None: eager fallback)."""
+        if group is None:
+            return None
+        for e in self._engines:
+            if (e.fits_group(group) if self.lanes > 1 else e.fits(tuple(group))):
+                return e
+        return None
+
     def _lanes_step(self, items, next_items):
-        """One joint step on ``pairs_in_flight`` pairs: the smallest capacity class that holds all of them (pairs that
-        fit no class -- or a group the graphs cannot take -- go through the eager step one by one).  Returns
-        [(desc, det, acc, d_pos, d_neg)] per pair, readable on the current stream."""
+        """One joint step on ``pairs_in_flight x stacked_pairs`` pairs: the smallest capacity class that holds all of
+        them (a group the graphs cannot take goes through the eager step pair by pair -- on EVERY rank when there are
+        several).  Returns [(desc, det, acc, d_pos, d_neg)] per pair, readable on the current stream."""
         if not self._captured:
             self._capture_classes(items[0])
-
-        def cls(group):
-            if group is None:
-                return None
-            for e in self._engines:
-                if all(e.fits(it) for it in group):
-                    return e
-            return None
-        e, res = cls(items), []
-        if e is None:
+        e = self._group_class(items)
+        if not self._agree(e is not None):
             return self._eager_steps(items)
-        nxt_e = cls(next_items)
+        nxt_e = self._group_class(next_items)
+        feed = (lambda g: g) if self.lanes > 1 else (lambda g: tuple(g))
         if nxt_e is e:
-            outs = e.step_graph(items, next_items)
+            outs = e.step_graph(feed(items), feed(next_items))
         else:
             if nxt_e is not None:
-                nxt_e.preload(next_items)
-            outs = e.step_graph(items, TrainStep.NO_PREFETCH)
-        e.make_visible()
-        for lane, out in zip(e.engines, outs):
+                nxt_e.preload(feed(next_items))
+            outs = e.step_graph(feed(items), TrainStep.NO_PREFETCH)
+        res = []
+        if self.lanes > 1:
+            e.make_visible()
+            lanes = list(zip(e.engines, outs))
+        else:
+            lanes = [(e, outs)]
+        for lane, out in lanes:
             fp, an = lane.last_distances
-            res.append((out[1], out[2], out[3], fp.mean(), an.mean()))
+            desc, det, acc = out[1].reshape(-1), out[2].reshape(-1), out[3].reshape(-1)
+            fpm, anm = fp.reshape(self.stack, -1).mean(dim=1), an.reshape(self.stack, -1).mean(dim=1)
+            for q in range(self.stack):
+                res.append((desc[q], det[q], acc[q], fpm[q], anm[q]))
+        if self.lanes > 1:
+            e.resync()   # the lanes' next replays (which overwrite these static outputs three steps on) follow the reads
         self._rerun_overflowed()      # a flagged pair and the pairs that shared its (skipped) step: eager, one by one
         return res
 
@@ -308,7 +358,7 @@ class Trainer(object):
             if not self._captured:
                 self._capture_classes(item)
             e = self._class_of(item)
-            if e is not None:
+            if self._agree(e is not None):
                 nxt_e = self._class_of(next_item) if next_item is not None else None
                 if nxt_e is e:
                     out = e.step_graph(item, next_item)
@@ -344,12 +394,12 @@ class Trainer(object):
     def train_epoch(self, epoch):
         ds = self.train_loader.dataset
         order = self._order(self.train_loader, epoch)
-        P = self.lanes
+        P = self.group
         num_iter = min(self.training_max_iter,
                        len(ds) // max(1, getattr(self.train_loader, 'batch_size', 1)) // self.world // P)
         meters = _Meters(self.device)
 
-        def group(it):      # lane k of step `it` on this rank (pairs_in_flight = 1: the reference's one pair per step)
+        def group(it):      # pair k of step `it` on this rank (P = 1: the reference's one pair per step)
             return [self._fetch(ds, order[(it * P + k) * self.world + self.rank]) for k in range(P)]
         items = group(0) if num_iter else None
         for it in range(num_iter):
@@ -376,8 +426,8 @@ class Trainer(object):
                                                           self._get_lr(), int(self.optimizer.skipped)))
         avg = meters.averages()
         self._report_skipped()
-        if self.lanes > 1 and self.device.type == 'cuda':
-            torch.cuda.synchronize(self.device)      # the lanes' last joint update, before evaluation / snapshots
+        if self.group > 1 and self.device.type == 'cuda':
+            torch.cuda.synchronize(self.device)      # the last joint update, before evaluation / snapshots
         if self.rank == 0:
             print("Epoch %d: Desc Loss: %.2f, Det Loss : %.2f, Accuracy: %.2f, D_pos: %.2f, D_neg: %.2f" % (
                 epoch, avg['desc_loss'], avg['det_loss'], avg['accuracy'], avg['d_pos'], avg['d_neg']))

@@ -495,16 +495,17 @@ int d3f_select_normalize_backward_pairs(const float* x, int N, int C, const int6
 
 /* ------------------------------------------------------------------------------------------------
  * Dense matching -- replaces build_correspondence (geometric_registration/common.py:5-21): the
- * [Ns,Nt] distance matrix sqrt(2 - 2 S.T^T) is never materialised; an f32 MFMA tile kernel keeps a running
- * row arg-min (and, with the operands swapped, the column arg-min); the target range is split over workgroups and
- * merged with one 64-bit atomicMin per row on (distance bits, column).  row_argmin [Ns], col_argmin [Nt] int32
+ * [Ns,Nt] distance matrix sqrt(2 - 2 S.T^T) is never materialised; ONE sweep of an f32 MFMA tile kernel over the
+ * S x T tiles (the reference forms S T^T once, common.py:9) keeps a running row arg-min in registers and the column
+ * arg-min of each workgroup's rows in LDS; the target range is split over workgroups and merged with one 64-bit
+ * atomicMin per row / per column on (distance bits, index).  row_argmin [Ns], col_argmin [Nt] int32
  * (lowest index on ties, like np.argmin), mutual [Ns] int32 (optional) = 1 where col_argmin[row_argmin[i]] == i.
  * C in {16, 32, 64, 128}.
  * ---------------------------------------------------------------------------------------------- */
 size_t d3f_mutual_nn_ws_bytes(int Ns, int Nt);
 int d3f_mutual_nn(const float* src_desc, int Ns, const float* tgt_desc, int Nt, int C, int32_t* row_argmin,
                   int32_t* col_argmin, int32_t* mutual, void* ws, size_t ws_bytes, void* stream);
-/* P independent matchings by ONE pair of launches (BASELINE configs[3]: 8 fragment pairs per inference batch).
+/* P independent matchings by ONE sweep launch (BASELINE configs[3]: 8 fragment pairs per inference batch).
  * seg [P,4] int32 ON THE DEVICE = {src_off, src_len, tgt_off, tgt_len} per pair: rows of src_desc / tgt_desc (which
  * may be the same stacked matrix).  max_src / max_tgt: host upper bounds of the lengths (they size the grid).
  * row_argmin [src_rows] / col_argmin [tgt_rows] / mutual [src_rows] are indexed by the row of the stacked matrix and

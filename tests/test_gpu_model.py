@@ -305,6 +305,90 @@ def test_model_forward_backward_s1_full_width(golden_s1):
     assert np.abs(fe.cpu().numpy()[g['features_eval.rows']] - g['features_eval.sample']).max() < 1e-4
 
 
+def test_bench_paths_at_s1_size_reproduce_the_reference_run(golden_s1):
+    """The paths bench.py times, at the size it times them: the full-width network (24.3M parameters) on the 38k-point
+    benchmark pair through (a) the captured graphs at exact capacities, (b) at 10 % head-room, (c) two lanes of two
+    STACKED pairs each (PairLanes(stack=2): one pyramid + one network graph per stack, joint update) -- every pair's
+    losses equal the reference run's (s1_full.npz: trainer.py:91-98 on the real reference), every gradient buffer holds
+    the reference gradient (norm of every parameter's gradient; sampled rows of three weight tensors) times the number of
+    pairs it sums.  lr = 0 keeps the parameters at the fixture's values through the warm-up steps of a capture.
+    Two replays from the same parameters bound what the float atomics left in backward (detector, coarse-level
+    scatter) may move: the deterministic kernels contribute nothing to it."""
+    from d3feat_pytorch_amd.train import PairLanes, TrainStep
+    g = golden_s1
+    cfg = cfgmod.default_config()
+    model = _load_model(cfg, g, full_sd=False)
+    raw = synthetic.make_pair(1, 2, _gpu_subsample)
+    item = tuple(torch.from_numpy(np.ascontiguousarray(a)).to(DEV) for a in raw)
+    limits = [int(x) for x in g['limits']]
+    ts = TrainStep(cfg, limits, torch.device(DEV), model=model)
+    ts.opt.lr = 0.0
+    names = {id(p): k for k, p in ts.model.named_parameters()}
+    want_desc, want_det = float(g['desc_loss']), float(g['det_loss'])
+    worst = {'loss': 0.0, 'norm': 0.0, 'rows': 0.0}
+
+    def check_buffer(grad, pairs, what):
+        off = 0
+        for p in ts.flat.params:
+            k, n = names[id(p)], p.numel()
+            gp = grad[off:off + n]
+            off += n
+            if ('gradnorm.' + k) in g.files and float(g['gradnorm.' + k]) > 1e-12:
+                ref = pairs * float(g['gradnorm.' + k])
+                err = abs(float(gp.double().norm()) - ref) / ref
+                worst['norm'] = max(worst['norm'], err)
+                assert err < 1e-3, (what, k, err)
+            if ('grad.' + k) in g.files:
+                got = gp.cpu().numpy().reshape(-1)[:40000] / pairs
+                err = rel_err(got, g['grad.' + k].reshape(-1))
+                worst['rows'] = max(worst['rows'], err)
+                assert err < 5e-4, (what, k, err)
+
+    def check_losses(desc, det, what):
+        for d, t in zip(desc.reshape(-1).tolist(), det.reshape(-1).tolist()):
+            err = max(abs(d - want_desc) / max(1.0, abs(want_desc)), abs(t - want_det))
+            worst['loss'] = max(worst['loss'], err)
+            assert err < 1e-4, (what, d, want_desc, t, want_det)
+    sizes = [[int(t.shape[0]) for t in ts.build_batch(item)['points']]]
+    engines = []
+    for slack in (1.0, 1.10):
+        caps = TrainStep.capacities_for(sizes, slack=slack)
+        if not engines:
+            ts.enable_graph(caps, num_corr=int(item[4].shape[0]))
+            eng = ts
+        else:
+            eng = ts.clone_for_capacities(caps, num_corr=int(item[4].shape[0]))
+        eng.capture(item)
+        engines.append(eng)
+        grads = []
+        for rep in range(2):
+            out = eng.step_graph(item, item)
+            torch.cuda.synchronize()
+            check_losses(out[1], out[2], 'graph x%.2f' % slack)
+            check_buffer(ts.flat.grad, 1, 'graph x%.2f' % slack)
+            grads.append(ts.flat.grad.clone())
+        drift = float((grads[0] - grads[1]).abs().max()) / float(grads[0].abs().max())
+        assert drift < 2e-5, ('replay drift', slack, drift)
+        assert eng.check_status() == (0, 0)
+    lanes = PairLanes(ts, 2, stack=2)
+    lanes.enable_graph(TrainStep.capacities_for([[2 * n for n in sizes[0]]], slack=1.0), num_corr=int(item[4].shape[0]))
+    lanes.capture(item)
+    for rep in range(2):
+        outs = lanes.step_graph([item] * 4, [item] * 4)
+        lanes.synchronize()
+        torch.cuda.synchronize()
+        for lane, out in enumerate(outs):
+            check_losses(out[1], out[2], 'lane %d' % lane)
+            check_buffer(ts.flat.lanes[lane][0], 2, 'lane %d' % lane)
+    assert lanes.check_status() == (0, 0) and int(ts.opt.skipped) == 0
+    # lr = 0: nothing above moved the parameters
+    for k, v in ts.model.state_dict().items():
+        srow = g['sdsum.' + k]
+        assert abs(float(v.double().sum()) - srow[0]) <= 1e-6 * max(1.0, srow[1]), k
+    print("bench paths at S1 size: worst loss error %.2e, gradient-norm error %.2e, sampled-row error %.2e" % (
+        worst['loss'], worst['norm'], worst['rows']))
+
+
 def test_encoder_blocks_s1_match_the_reference_block_outputs(golden_s1):
     """BASELINE configs[1]: the KPConv encoder on the 20k-point fragments -- the output rows of encoder blocks
     0, 1, 2 (strided), 3 and 12 that the reference run recorded (forward hooks on KPConv, make_golden.py:196-200)."""
@@ -1155,7 +1239,12 @@ def test_eight_pairs_per_batch_match_the_reference_runs(golden_s1):
         ref = g['p%d.scores' % p]
         got = se[off:off + n0 + n1]
         both = (got != 0) & (ref != 0)
-        assert ((got != 0) == (ref != 0)).mean() > 0.999 and np.abs(got[both] - ref[both]).max() < 1e-4, p
+        assert np.abs(got[both] - ref[both]).max() < 1e-4, p
+        if ((got != 0) != (ref != 0)).any():   # eval-gate flips must be float ties of the local-maximum test (and rare)
+            with torch.no_grad():
+                eb = dl.collate_fn_descriptor([it], cfg, limits)
+                x_raw, _ = model.forward_raw(eb)
+            assert_gate_flips_are_ties(got, ref, x_raw, eb['neighbors'][0])
         assert np.abs(fe[off:off + n0 + n1][g['p%d.feat_rows' % p]] - g['p%d.feat_sample' % p]).max() < 1e-4, p
         # keypoints: the reference's 250 and ours may swap rows whose scores differ by less than the score tolerance
         for cloud, key, base, n in ((2 * p, 'src_idx250', 0, n0), (2 * p + 1, 'tgt_idx250', n0, n1)):

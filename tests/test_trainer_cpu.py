@@ -186,12 +186,17 @@ def test_pairs_in_flight_needs_the_graph_path_and_groups_the_epoch(tmp_path, cap
     per rank (the tail that does not fill a group is left out, like a DataLoader's drop_last)."""
     from d3feat_pytorch_amd.trainer import Trainer
     tr = Trainer(_args(tmp_path, model=_small_model(), pairs_in_flight=3))
-    assert tr.lanes == 1 and "pairs_in_flight=3 needs the hipGraph path" in capsys.readouterr().out
-    assert Trainer(_args(tmp_path, model=_small_model())).lanes == 1          # the reference's one pair per step
+    assert tr.lanes == 1 and tr.group == 1 and "pairs_in_flight=3 / stacked_pairs=1 need the hipGraph path" in \
+        capsys.readouterr().out
+    tr = Trainer(_args(tmp_path, model=_small_model(), stacked_pairs=4))
+    assert tr.stack == 1 and tr.group == 1 and "stacked_pairs=4 need the hipGraph path" in capsys.readouterr().out
+    one = Trainer(_args(tmp_path, model=_small_model()))
+    assert one.lanes == 1 and one.stack == 1 and one.group == 1              # the reference's one pair per step
 
     class _Probe(Trainer):       # the epoch loop's grouping, without a device: record what each step is handed
-        def __init__(self, n, lanes):
-            self.lanes, self.world, self.rank, self.training_max_iter = lanes, 1, 0, 10 ** 9
+        def __init__(self, n, lanes, stack=1):
+            self.lanes, self.stack, self.group = lanes, stack, lanes * stack
+            self.world, self.rank, self.training_max_iter = 1, 0, 10 ** 9
             self.train_loader = type('L', (), {'dataset': list(range(n)), 'batch_size': 1, 'shuffle': False})()
             self.config, self.device, self.verbose, self.log_interval = type('C', (), {})(), torch.device('cpu'), False, 100
             self.steps = []
@@ -209,3 +214,6 @@ def test_pairs_in_flight_needs_the_graph_path_and_groups_the_epoch(tmp_path, cap
     p = _Probe(11, 4)
     p.train_epoch(1)
     assert [s[0] for s in p.steps] == [[0, 1, 2, 3], [4, 5, 6, 7]] and p.steps[0][1] == [4, 5, 6, 7] and p.steps[1][1] is None
+    p = _Probe(11, 2, stack=2)     # 2 graphs in flight x 2 stacked pairs: the same groups of four
+    p.train_epoch(1)
+    assert [s[0] for s in p.steps] == [[0, 1, 2, 3], [4, 5, 6, 7]]
