@@ -413,6 +413,8 @@ def main():
             stage("capturing %d lanes x %d stacked pairs, capacities %s" % (L, Q, lanes.caps))
             lanes.capture(tuple(items[j % len(items)] for j in range(P)))
             stage("captured")
+            lanes.probe_overlap()      # (after init_process_group: RCCL's queues are in place)
+            stage("lanes overlap %s" % (lanes.overlap,))
         except Exception as e:  # pragma: no cover - keep the benchmark alive: one pair in flight, as in rounds 1-2
             print("pairs in flight unavailable (%s: %s); running one pair per step" % (type(e).__name__, e),
                   file=sys.stderr)
@@ -620,7 +622,11 @@ def main():
     if world > 1:
         try:
             keep = (ts.flat.data.clone(), ts.opt.buf.clone())
-            ts_world, ts.world = ts.world, 1          # no exchange, same split graphs
+            ts_world = ts.world
+            if lanes is not None:
+                lanes.exchange = False                # the same two-stage step without its all-reduces
+            else:
+                ts.world = 1                          # no exchange, same split graphs
             for k in range(2):
                 run(args.warmup + k)
             torch.cuda.synchronize()
@@ -631,17 +637,15 @@ def main():
             torch.cuda.synchronize()
             t_noex = (time.perf_counter() - tn0) / args.steps
             ts.world = ts_world
+            if lanes is not None:
+                lanes.exchange = True
             ts.flat.data.copy_(keep[0])
             ts.opt.buf.copy_(keep[1])
             g = ts.flat.grad
             deep = g[ts.numel_shallow:]
             step = (deep.numel() + 2) // 3
 
-            def exchange_only():
-                if lanes is not None:   # the join of the lanes: the summed gradient in four buckets
-                    from d3feat_pytorch_amd.train import allreduce_mean_
-                    allreduce_mean_(g, world, average=False)
-                    return
+            def exchange_only():     # (lanes: the same buckets, of the lanes' summed gradient)
                 works = [dist.all_reduce(deep[b * step:min(deep.numel(), (b + 1) * step)], op=dist.ReduceOp.SUM,
                                          async_op=True) for b in range(3)]
                 works.append(dist.all_reduce(g[:ts.numel_shallow], op=dist.ReduceOp.SUM, async_op=True))
@@ -659,7 +663,8 @@ def main():
             t_step = (t1 - t0) / args.steps
             exposed = max(0.0, t_step - t_noex)
             exchange = {"rccl_ranks": world, "backend": dist.get_backend(), "bytes_per_step": int(g.numel() * 4),
-                        "buckets": "4 chunks of the lanes' summed gradient at the join (not overlapped)" if lanes is not None
+                        "buckets": "3 deep chunks of the lanes' summed gradient (exchanged under every lane's stage-2 "
+                                   "backward graph) + 1 shallow" if lanes is not None
                         else "3 deep chunks (overlapped with the stage-2 backward graph) + 1 shallow",
                         "step_ms": round(t_step * 1e3, 3), "step_without_exchange_ms": round(t_noex * 1e3, 3),
                         "exchange_alone_ms": round(t_comm * 1e3, 3), "exposed_ms": round(exposed * 1e3, 3),
@@ -945,6 +950,8 @@ def main():
                                        "one pair per optimizer step"),
                        "points_per_pair": n_pts, "neighbor_limits": limits, "pairs_per_rank": len(items),
                        "pairs_in_flight_per_gpu": P, "lanes": L, "stacked_pairs_per_lane": Q,
+                       "lanes_overlap_factor": None if lanes is None else getattr(lanes, "overlap", {}).get("factor"),
+                       "lanes_overlap_probe": None if lanes is None else getattr(lanes, "overlap", None),
                        "peak_hbm_allocated_gb": round(torch.cuda.max_memory_allocated(dev) / 2 ** 30, 2),
                        "side_stream_probe_ms": getattr(ts, "_side_probe", None),
                        "parallelism": "dp%d" % world if P == 1 else ("dp%d x %d lanes" % (world, L)) + (

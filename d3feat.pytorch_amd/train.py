@@ -460,6 +460,29 @@ class TrainStep:
         scores = m.detection_scores(batch, x)
         return self._loss_from_raw(x, scores, batch), cuts
 
+    def _lane_stages(self, st):
+        """(stage 1, stage 2) of a LANE's split step on the set's pair(s): gradients into the lane's own buffer, no
+        exchange and no optimizer step (the join owns both); a flagged pair poisons the deep bucket at the end of
+        stage 1, before the join sums and exchanges it."""
+        lane = self.lane
+
+        def stage1():
+            self.flat.bind(lane)
+            try:
+                out = self._backward_deep(self._set_batch(st))
+                self._poison_if_flagged(self.flat.grad[self.numel_shallow:], st.status.word)
+            finally:
+                self.flat.bind(0)
+            return out
+
+        def stage2():
+            self.flat.bind(lane)
+            try:
+                self._backward_shallow()
+            finally:
+                self.flat.bind(0)
+        return stage1, stage2
+
     def _backward_deep(self, batch):
         """Stage 1: forward + backward of the deep bucket; leaves the cut gradients in self._cuts."""
         self.flat.zero_grad()
@@ -603,7 +626,10 @@ class TrainStep:
         while len(self.flat.lanes) <= lane:
             self.flat.add_lane()
         other.lane = int(lane)
-        other.split_backward = False     # the exchange between ranks happens at the join, on the summed gradient
+        # several ranks: the lane's backward is cut like the one-pair engine's (stage 1 down to encoder block CUT, stage 2
+        # the fine levels) so that the join can exchange the deep gradient bucket under every lane's stage 2
+        # (PairLanes.step_graph); one rank: a single network graph per lane
+        other.split_backward = self.world > 1
         if stream is None or side is None:
             stream, side = fresh_streams(2, self.device)
         other.stream, other._side = stream, side
@@ -795,7 +821,11 @@ class TrainStep:
         with torch.cuda.stream(warm), tuning_missing_gemms():
             for k in range(3):
                 self._build_set(self.sets[(k + 1) % self.NSETS])
-                if self.split_backward:
+                if self.split_backward and getattr(self, 'lane', None) is not None:
+                    s1, s2 = self._lane_stages(self.sets[k % self.NSETS])
+                    out = s1()
+                    s2()
+                elif self.split_backward:
                     batch = self._set_batch(self.sets[k % self.NSETS])
                     out = self._exchange_and_step(lambda: self._backward_deep(batch), self._backward_shallow,
                                                   pair_status=self.sets[k % self.NSETS].status.word)
@@ -825,8 +855,12 @@ class TrainStep:
         self._choose_side_stream()
         for i in range(self.NSETS):
             g = torch.cuda.CUDAGraph()
+            lane_split = self.split_backward and getattr(self, 'lane', None) is not None
+            s1, s2 = self._lane_stages(self.sets[i]) if lane_split else (None, None)
             with torch.cuda.graph(g, pool=self.g_net[0].pool() if self.g_net else None, capture_error_mode=_CAPTURE_MODE):
-                if self.split_backward:
+                if lane_split:
+                    self._graph_out.append(s1())
+                elif self.split_backward:
                     self._graph_out.append(self._backward_deep(self._set_batch(self.sets[i])))
                 else:
                     self._graph_out.append(self._net_step(self.sets[i]))
@@ -835,7 +869,10 @@ class TrainStep:
             if self.split_backward:  # stage 2 of the same step: continues in the same pool
                 g = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(g, pool=self.g_net[0].pool(), capture_error_mode=_CAPTURE_MODE):
-                    self._backward_shallow()
+                    if lane_split:
+                        s2()
+                    else:
+                        self._backward_shallow()
                 self.g_net_b.append(g)
         torch.cuda.synchronize(dev)
         self.ev_net = [torch.cuda.Event() for _ in range(self.NSETS)]
@@ -936,7 +973,12 @@ class TrainStep:
                 st.status_host.copy_(st.status.word, non_blocking=True)
                 st.status_item = item
             self.ev_net[i].record(main)
-        if self.split_backward:
+        if self.split_backward and getattr(self, 'lane', None) is not None:
+            # a lane among several ranks: stage 1 now, stage 2 when PairLanes calls _launch_stage2 (the join exchanges
+            # the deep bucket in between)
+            self.g_net[i].replay()
+            self._stage2 = (i, done)
+        elif self.split_backward:
             def stage1():
                 self.g_net[i].replay()
                 return self._graph_out[i]
@@ -951,6 +993,13 @@ class TrainStep:
         self.cur = (i + 1) % self.NSETS
         self.last_distances = self._graph_dist[i]
         return self._graph_out[i]
+
+    def _launch_stage2(self):
+        """Second half of a lane's split step (see _launch_net), on the current stream."""
+        i, done = self._stage2
+        self._stage2 = None
+        self.g_net_b[i].replay()
+        done()
 
     def check_status(self, raise_on_skip=True):
         """One synchronisation: what the device flagged since the last call.
@@ -1051,12 +1100,20 @@ class PairLanes:
         for eng in self.engines:
             eng.stack = self.Q
         self.ev_lane = [torch.cuda.Event() for _ in range(self.P)]
+        self.ev_stage1 = [torch.cuda.Event() for _ in range(self.P)]
+        self.exchange = True     # (False: the multi-rank step without its all-reduces -- bench.py's overlap measurement)
         # the last joint update -- shared with the clones for other capacity classes (they step the same parameters)
         self._join = {'ev_step': torch.cuda.Event(), 'stepped': False}
         self._groups = {}
 
     caps = property(lambda self: self.engines[0].caps)
     pairs_per_step = property(lambda self: self.P * self.Q)
+
+    def _exchange_stream(self):
+        """The stream the multi-rank join runs on (shared with the clones for other capacity classes)."""
+        if self._join.get('xs') is None:
+            self._join['xs'] = torch.cuda.Stream(device=self.ts.device)
+        return self._join['xs']
 
     def clone_for_capacities(self, capacities, num_corr):
         """The same lanes (streams, gradient buffers, join) with buffer sets and graphs for other level capacities: one
@@ -1066,6 +1123,59 @@ class PairLanes:
         other.engines = [e.clone_for_capacities(capacities, num_corr) for e in self.engines]
         other._groups = {}
         return other
+
+    def probe_overlap(self, reps=3, redeal=True):
+        """Do the lanes' network graphs really run side by side?  After ``capture``: the P stage-1 graphs replayed one
+        after the other (a synchronisation in between) against all at once; the ratio is the overlap factor (1 = the
+        streams share a compute pipe and serialise).  Nothing in HIP says which pipe a stream's
+        hardware queue landed on, so this is measured: below 1.15 the lanes are dealt fresh streams once (graphs replay
+        on whatever stream is current) and the better deal is kept.  Lane graphs do not touch the parameters, so the
+        probe is free of side effects.  Returns {'serial_ms', 'concurrent_ms', 'factor', 'redealt'}."""
+        import time
+        import warnings
+        from . import HIP_WAS_INITIALISED_AT_IMPORT
+        if self.P < 2 or self.ts.device.type != 'cuda':
+            return {'factor': 1.0, 'redealt': False}
+        if HIP_WAS_INITIALISED_AT_IMPORT and os.environ.get("GPU_MAX_HW_QUEUES") == "32":
+            warnings.warn("the HIP runtime was initialised before d3feat_pytorch_amd was imported: GPU_MAX_HW_QUEUES=32 was "
+                          "not in effect, streams beyond four share hardware queues and the lanes may serialise")
+        dev = self.ts.device
+
+        def measure():
+            graphs = [eng.g_net[eng.cur] for eng in self.engines]
+            ser = con = float('inf')
+            for _ in range(reps):
+                torch.cuda.synchronize(dev)
+                t0 = time.perf_counter()
+                for eng, g in zip(self.engines, graphs):
+                    with torch.cuda.stream(eng.stream):
+                        g.replay()
+                    eng.stream.synchronize()
+                ser = min(ser, time.perf_counter() - t0)
+                t0 = time.perf_counter()
+                for eng, g in zip(self.engines, graphs):
+                    with torch.cuda.stream(eng.stream):
+                        g.replay()
+                torch.cuda.synchronize(dev)
+                con = min(con, time.perf_counter() - t0)
+            return ser, con
+        ser, con = measure()
+        out = {'serial_ms': round(ser * 1e3, 3), 'concurrent_ms': round(con * 1e3, 3), 'factor': round(ser / con, 3),
+               'redealt': False}
+        if redeal and ser / con < 1.15:
+            old = [(e.stream, e._side) for e in self.engines]
+            nets, sides = lane_streams(self.P, dev)
+            for e, sn, sd in zip(self.engines, nets, sides):
+                e.stream, e._side = sn, sd
+            ser2, con2 = measure()
+            if ser2 / con2 > ser / con:
+                out.update({'serial_ms': round(ser2 * 1e3, 3), 'concurrent_ms': round(con2 * 1e3, 3),
+                            'factor': round(ser2 / con2, 3), 'redealt': True})
+            else:
+                for e, (sn, sd) in zip(self.engines, old):
+                    e.stream, e._side = sn, sd
+        self.overlap = out
+        return out
 
     def deal(self, items):
         """The step's ``lanes * stack`` pairs as one input per lane: the pair itself, or a stack of ``stack`` pairs."""
@@ -1120,35 +1230,68 @@ class PairLanes:
         self.ts.opt.use_grad_scale(1.0 / (self.P * self.Q * max(1, self.ts.world)))
         outs = []
         host_join = os.environ.get("D3F_LANES_JOIN", "stream") == "host"     # measurement knob
+        split = self.ts.world > 1       # several ranks: two-stage lanes, the deep bucket exchanged under stage 2
         for k, eng in enumerate(self.engines):
             eng._ensure_loaded(items[k])
         for k, eng in enumerate(self.engines):     # every network graph first ...
             with torch.cuda.stream(eng.stream):
-                if k > 0 and self._join['stepped']:      # the parameters of the previous joint update
+                if (k > 0 or split) and self._join['stepped']:      # the parameters of the previous joint update
                     if host_join:
                         self._join['ev_step'].synchronize()
                     else:
                         eng.stream.wait_event(self._join['ev_step'])
                 outs.append(eng._launch_net(items[k]))
-                self.ev_lane[k].record(eng.stream)
+                (self.ev_stage1 if split else self.ev_lane)[k].record(eng.stream)
+        flat, opt = self.ts.flat, self.ts.opt
+        grads = [flat.lanes[k][0] for k in range(self.P)]
+        if split:
+            # the join runs on a stream of its own: deep buckets of the lanes summed into lane 0's and all-reduced in
+            # three chunks (xGMI rings are per-link bound: a few >= 30 MB messages) WHILE every lane's stage 2 -- the
+            # backward of the fine levels, about a third of a step -- executes; then the small shallow bucket, the guard on
+            # the reduced gradient and ONE update.  No pass of its own over the 97 MB for the mean (opt.grad_scale).
+            ns = self.ts.numel_shallow
+            xs = self._exchange_stream()
+            with torch.cuda.stream(xs):
+                for k in range(self.P):
+                    xs.wait_event(self.ev_stage1[k])
+                deep = grads[0][ns:]
+                for g in grads[1:]:
+                    deep.add_(g[ns:])
+                works, nb = [], 3
+                step = (deep.numel() + nb - 1) // nb
+                for b in range(nb):
+                    chunk = deep[b * step:min(deep.numel(), (b + 1) * step)]
+                    if chunk.numel() and self.exchange:
+                        works.append(dist.all_reduce(chunk, op=dist.ReduceOp.SUM, async_op=True))
+            for k, eng in enumerate(self.engines):
+                with torch.cuda.stream(eng.stream):
+                    eng._launch_stage2()
+                    self.ev_lane[k].record(eng.stream)
         for k, eng in enumerate(self.engines):     # ... then the following pairs' pyramids, under the running networks
             eng._prefetch_next(nxt[k], n=eng.cur)
-        s0 = self.engines[0].stream
-        flat, opt = self.ts.flat, self.ts.opt
-        with torch.cuda.stream(s0):
-            for k in range(1, self.P):
-                if host_join:
-                    self.ev_lane[k].synchronize()
-                else:
-                    s0.wait_event(self.ev_lane[k])
-            grads = [flat.lanes[k][0] for k in range(self.P)]
-            if self.ts.world > 1:
+        if split:
+            with torch.cuda.stream(xs):
+                for k in range(self.P):
+                    xs.wait_event(self.ev_lane[k])
+                shallow = grads[0][:ns]
                 for g in grads[1:]:
-                    grads[0].add_(g)
-                allreduce_mean_(grads[0], self.ts.world, average=False)    # the mean is opt.grad_scale
-                grads = grads[:1]
-            opt.step(want_ok=False, grads=grads)
-            self._join['ev_step'].record(s0)
+                    shallow.add_(g[:ns])
+                if self.exchange:
+                    works.append(dist.all_reduce(shallow, op=dist.ReduceOp.SUM, async_op=True))
+                for w in works:
+                    w.wait()                 # SUM over ranks; the 1 / (pairs x ranks) of the mean is opt.grad_scale
+                opt.step(want_ok=False, grads=grads[:1])
+                self._join['ev_step'].record(xs)
+        else:
+            s0 = self.engines[0].stream
+            with torch.cuda.stream(s0):
+                for k in range(1, self.P):
+                    if host_join:
+                        self.ev_lane[k].synchronize()
+                    else:
+                        s0.wait_event(self.ev_lane[k])
+                opt.step(want_ok=False, grads=grads)
+                self._join['ev_step'].record(s0)
         self._join['stepped'] = True
         group = tuple(items)
         for it in group:
@@ -1160,6 +1303,8 @@ class PairLanes:
     def synchronize(self):
         for eng in self.engines:
             eng.stream.synchronize()
+        if self._join.get('xs') is not None:
+            self._join['xs'].synchronize()
 
     def resync(self):
         """After the parameters were updated OUTSIDE the lanes (an eager step on the current stream; the caller has
@@ -1168,6 +1313,8 @@ class PairLanes:
         ev.record(torch.cuda.current_stream(self.ts.device))
         for eng in self.engines:
             eng.stream.wait_event(ev)
+        if self._join.get('xs') is not None:
+            self._join['xs'].wait_event(ev)
 
     def make_visible(self, stream=None):
         """The lanes' latest outputs (losses, distances) become readable on ``stream`` (default: the current one)."""

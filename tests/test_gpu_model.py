@@ -1052,7 +1052,8 @@ def test_two_rank_bench_control_flow_on_one_gpu():
     env = dict(os.environ, D3F_BENCH_SHARE_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
     env.pop("WORLD_SIZE", None)
     # launched PLAINLY: bench.py spawns its ranks through torch.distributed.run itself (and refuses to run 1 rank as 2)
-    cmd = [sys.executable, "bench.py", "--gpus", "2", "--steps", "4", "--warmup", "2", "--pairs", "2", "--lanes", "2", "--no-cpu-baseline"]
+    cmd = [sys.executable, "bench.py", "--gpus", "2", "--steps", "4", "--warmup", "2", "--pairs", "2", "--lanes", "2",
+           "--stack", "2", "--no-cpu-baseline"]
     r = subprocess.run(cmd, cwd=repo, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith('{"metric"')]
@@ -1061,11 +1062,14 @@ def test_two_rank_bench_control_flow_on_one_gpu():
     assert res["n_gpus"] == 2 and res["steps"] == 4 and res["scaling"] == "weak" and res["value"] > 0
     assert abs(res["value_per_gpu"] * 2 - res["value"]) < 0.01 * res["value"]
     cfg = res["config"]
-    assert cfg["parallelism"] == "dp2 x 2 lanes" and res["pairs_per_step"] == 4 and cfg["launch"].startswith("hipGraph replay")
+    # 2 ranks x 2 lanes x 2 stacked pairs: the lanes' two-stage step with the deep bucket exchanged under stage 2
+    assert cfg["parallelism"] == "dp2 x 2 lanes x 2 stacked" and res["pairs_per_step"] == 8
+    assert cfg["launch"].startswith("hipGraph replay") and cfg["lanes_overlap_factor"] > 0
     assert cfg["replica_param_checksum_spread"] == 0.0 and cfg["skipped_steps"] == 0
     assert np.isfinite(cfg["final_loss"]) and "cpu_baseline" not in res
     ex = res["exchange"]     # the overlap leg: step with / without the exchange, the exchange alone
     assert ex["rccl_ranks"] == 2 and "error" not in ex and ex["bytes_per_step"] > 9e7 and ex["exchange_alone_ms"] > 0
+    assert "overlap_frac" in ex and "under every lane's stage-2" in ex["buckets"]
 
 
 @pytest.mark.parametrize("w_desc,w_det", [(1.0, 1.0), (0.7, 1.3)])
