@@ -66,7 +66,36 @@ def gather_kernel_cost(edges, widths):
     return cost
 
 
-KERNEL_NAMES = {1: "kpconv_fwd_fused_kernel (KPConv forward: gather + influence + aggregation + contraction on f32 MFMA)",
+def atb_kernel_cost(R, _ns, _h, M, N, _k):
+    """A^T B weight gradient (linear.hip): both operands streamed once, the output block written once (SURVEY 8d counts
+    a GEMM operand once: nothing is gathered here)."""
+    b = 4 * R * (M + N) + 4 * M * N
+    return b, 2 * R * M * N, b
+
+
+def agg_fwd_kernel_cost(Nq, Ns, H, Cin, _cout, K):
+    """Forward aggregation kernel (kpconv_aggregate.hip): SURVEY 8d's KPConv forward bytes without the weights and the
+    output row, plus the written wf [Nq, K Cin]."""
+    b = 12 * Nq + 4 * Nq * H + Nq * H * (16 + 4 * Cin) + 4 * Nq * K * Cin
+    return b, 2 * Nq * H * K * Cin, 12 * Nq + 4 * Nq * H + 16 * Ns + 4 * Ns * Cin + 4 * Nq * K * Cin
+
+
+def agg_rev_kernel_cost(edges):
+    """Transposed aggregation over the exact-form reverse table: per TRUE edge the entry (16 B), 1/nn (4 B) and the
+    gathered gradient row; per support row the written [K Cout] block."""
+    def cost(Nq, Ns, W, _cin, Cout, K):
+        E = edges.get((Nq, Ns), Nq * 42)
+        b = E * (16 + 4 + 4 * Cout) + 4 * Ns * K * Cout
+        return b, 2 * E * K * Cout, 16 * Ns * W + 4 * Nq + 4 * Nq * Cout + 4 * Ns * K * Cout
+    return cost
+
+
+KERNEL_NAMES = {4: "atb_partial_kernel + atb_reduce_kernel (weight gradients C = A^T B of the unary blocks and of KPConv "
+                   "from the saved aggregation: reduction over the points spread over the chip, f32 MFMA, fixed-order sum)",
+                5: "kpconv_agg_fwd_kernel (KPConv neighbor aggregation wf = sum_h w x, registers -> HBM; contraction by GEMM)",
+                6: "kpconv_agg_rev_kernel (KPConv grad-input aggregation over the reverse table, registers -> HBM; "
+                   "contraction by GEMM, no atomics)",
+                1: "kpconv_fwd_fused_kernel (KPConv forward: gather + influence + aggregation + contraction on f32 MFMA)",
                 2: "kpconv_bwd_dx_kernel (KPConv grad-input, scatter form: gW tile on f32 MFMA + float atomics)",
                 3: "kpconv_dx_gather_kernel (KPConv grad-input, gather form over the reverse neighbor table: "
                    "aggregation + W^T contraction on f32 MFMA, no atomics)"}
@@ -77,7 +106,7 @@ def timed_kernels(lib, run_steps, costs, n_steps):
     (d3f_debug_kernel_timing_*), grouped by kernel: {which: stats}."""
     import ctypes
     cap = 2048
-    if lib.d3f_debug_kernel_timing_begin(-7, cap) != 0:
+    if lib.d3f_debug_kernel_timing_begin(-63, cap) != 0:
         return {}
     run_steps()
     torch.cuda.synchronize()
@@ -697,21 +726,35 @@ def main():
     # Roofline leg: the hand-written KPConv kernels are the largest kernels of the training stream (profiles/r02*);
     # every launch of them in 3 eager steps is bracketed by HIP events inside the library, on the stream it is launched
     # on, and the one with the most time per step is reported as `roofline`.
+    # ... at the shapes the timed region ran: with stacked pairs, a lane's step on its stack (static shapes, eager launches)
+    roof_eng = lanes.engines[0] if (lanes is not None and Q > 1) else None
+    roof_items = tuple(items[j % len(items)] for j in range(Q))
+
     def _three_steps():
         ts._pending = None
         for k in range(3):
-            ts.step(items[k % len(items)])
+            if roof_eng is not None:
+                roof_eng._static_step(roof_items)
+            else:
+                ts.step(items[k % len(items)])
     edges, widths = {}, {}
-    for k in range(0 if args.quick else min(3, len(items))):   # TRUE edges of the transposed tables = valid entries of the forward tables
-        b_k = ts.build_batch(items[k])
-        for tabs in (b_k['neighbors'], b_k['pools']):
-            for t in tabs:
-                r = getattr(t, '_d3f_rev', None)
-                if r is not None:
-                    edges[(r.Nq, r.Ns)] = int((t < r.Ns).sum())
-                    widths[(r.Nq, r.Ns)] = int(r.width)
+    if not args.quick:   # TRUE edges of the transposed tables = valid entries of the forward tables
+        if roof_eng is not None:
+            roof_eng._static_step(roof_items)
+            torch.cuda.synchronize()
+            batches = [roof_eng.sets[0].batch]
+        else:
+            batches = [ts.build_batch(items[k]) for k in range(min(3, len(items)))]
+        for b_k in batches:
+            for tabs in (b_k['neighbors'], b_k['pools']):
+                for t in tabs:
+                    r = getattr(t, '_d3f_rev', None)
+                    if r is not None:
+                        edges[(r.Nq, r.Ns)] = int((t < r.Ns).sum())
+                        widths[(r.Nq, r.Ns)] = int(r.width)
     kt = {} if args.quick else timed_kernels(
-        _native.lib(), _three_steps, {1: fwd_kernel_cost, 2: dx_kernel_cost, 3: gather_kernel_cost(edges, widths)}, 3)
+        _native.lib(), _three_steps, {1: fwd_kernel_cost, 2: dx_kernel_cost, 3: gather_kernel_cost(edges, widths),
+                                      4: atb_kernel_cost, 5: agg_fwd_kernel_cost, 6: agg_rev_kernel_cost(edges)}, 3)
     dom = max(kt, key=lambda w: kt[w]["us_per_step"]) if kt else None
     dx_t = kt.get(dom)
 
@@ -882,7 +925,9 @@ def main():
                     with open(os.path.join(REPO, "d3feat.pytorch_amd", "csrc", src), "rb") as fh:
                         traffic_stale = hashlib.sha256(fh.read()).hexdigest()[:16] != entry.get("source_sha16")
             counters = None   # L2 hit rate / MFMA-pipe busy of the same kernels (separate rocprofv3 --pmc passes)
-            cpath = os.path.join(REPO, "profiles", "r03_pmc_kpconv.json")
+            cpath = os.path.join(REPO, "profiles", "r04_pmc_kernels.json")
+            if not os.path.exists(cpath):
+                cpath = os.path.join(REPO, "profiles", "r03_pmc_kpconv.json")
             if os.path.exists(cpath):
                 with open(cpath) as f:
                     counters = json.load(f).get(KERNEL_NAMES[dom].split(" ")[0])
@@ -918,10 +963,11 @@ def main():
                                 "achieved_TFLOPs": round(v["tflops"], 2),
                                 "mfma_frac": round(v["tflops"] / F32_MFMA_PEAK_TFLOPS, 4)}
                                for w, v in sorted(kt.items()) if w != dom],
+                "pairs_per_timed_step": Q,
                 "measured": "hipEventRecord on the launch stream immediately before/after each launch of the kernel "
-                            "(d3f_debug_kernel_timing_*), 3 eager steps after the timed region; averages are "
-                            "time-weighted over all launches; the kernel reported is the hand-written kernel with the "
-                            "most time per training step"}
+                            "(d3f_debug_kernel_timing_*), 3 eager steps after the timed region on the shapes it ran (a "
+                            "lane's stack of %d pair(s)); averages are time-weighted over all launches; the kernel "
+                            "reported is the hand-written kernel with the most time per training step" % Q}
         res = {
             "metric": "fragment-pairs/sec (fwd+bwd) on 3DMatch-shaped pairs",
             "value": round(P * args.steps * world / elapsed, 3),

@@ -22,6 +22,10 @@
 
 namespace d3f {
 
+// measurement aid of bench.py (kpconv_fused.hip)
+void* kpconv_timing_open(int which, hipStream_t stream, int Nq, int Ns, int H, int Cin, int Cout, int K);
+void kpconv_timing_close(void* rec, hipStream_t stream);
+
 // kpconv_dx_gather.hip (phase A of the gather kernel: one chunk of <= 64 compacted reverse neighbors)
 template <int CV, int NSTEPS>
 __device__ __forceinline__ void agg_rev_core(int n_c, float qx, float qy, float qz, float inn, __amdgpu_buffer_rsrc_t rs_g,
@@ -178,6 +182,7 @@ int kpconv_aggregate_direct(const float* q_pts, int Nq, const float* s_pts, int 
   const int CV = Cin == 16 ? 1 : (Cin == 32 ? 2 : 4);
   dim3 grid(cdiv(Nq, 16), Cin / (16 * CV));
   const int nsteps = (H + 15) >> 4;   // H <= 64 (kpconv_fused_supported)
+  void* timing = kpconv_timing_open(5, stream, Nq, Ns, H, Cin, 0, K);
 #define D3F_AGGF(CVV, NS) \
   kpconv_agg_fwd_kernel<CVV, NS><<<grid, 256, 0, stream>>>(q_pts, spack, idx, x, kp, Nq, Ns, H, Cin, K, extent, wf_out, nn_out)
 #define D3F_AGGF_STEPS(CVV)            \
@@ -192,6 +197,7 @@ int kpconv_aggregate_direct(const float* q_pts, int Nq, const float* s_pts, int 
   else D3F_AGGF_STEPS(4)
 #undef D3F_AGGF_STEPS
 #undef D3F_AGGF
+  kpconv_timing_close(timing, stream);
   D3F_LAUNCH_CHECK();
   return D3F_OK;
 }
@@ -216,9 +222,11 @@ int d3f_kpconv_aggregate_transposed(const float* rev_rel, int rev_width, int Ns,
   const int CV = Cout == 16 ? 1 : (Cout == 32 ? 2 : 4);
   dim3 grid(d3f::cdiv(Ns, 16), Cout / (16 * CV));
   const float4* rel = (const float4*)rev_rel;
+  void* timing = d3f::kpconv_timing_open(6, st, Nq, Ns, rev_width, 0, Cout, K);
   if (CV == 1) d3f::kpconv_agg_rev_kernel<1><<<grid, 256, 0, st>>>(rel, rev_width, grad_out, nn, kernel_points, Ns, Nq, Cout, K, extent, agg_out);
   else if (CV == 2) d3f::kpconv_agg_rev_kernel<2><<<grid, 256, 0, st>>>(rel, rev_width, grad_out, nn, kernel_points, Ns, Nq, Cout, K, extent, agg_out);
   else d3f::kpconv_agg_rev_kernel<4><<<grid, 256, 0, st>>>(rel, rev_width, grad_out, nn, kernel_points, Ns, Nq, Cout, K, extent, agg_out);
+  d3f::kpconv_timing_close(timing, st);
   D3F_LAUNCH_CHECK();
   return D3F_OK;
 }

@@ -15,6 +15,10 @@
 
 namespace d3f {
 
+// measurement aid of bench.py (kpconv_fused.hip)
+void* kpconv_timing_open(int which, hipStream_t stream, int Nq, int Ns, int H, int Cin, int Cout, int K);
+void kpconv_timing_close(void* rec, hipStream_t stream);
+
 template <int TI, int TJ, int U>
 __global__ __launch_bounds__(256) void atb_partial_kernel(const float* __restrict__ A, const float* __restrict__ B,
                                                           const float* __restrict__ row_div, int R, int M, int N,
@@ -159,6 +163,7 @@ int atb_splitk(const float* A, const float* B, const float* row_div, int R, int 
   rpw = (rpw + 3) / 4 * 4;
   dim3 grid(P, (M / (16 * ti)) * (N / (16 * tj)));
   float* part = (float*)ws;
+  void* timing = kpconv_timing_open(4, stream, R, 0, 0, M, N, 0);   // (both launches: partial sums + their reduction)
   static const int deep = atb_tunable("D3F_ATB_U", 0);   // 0: the measured default per tile shape
 #define D3F_ATB(I, J)                                                                                      \
   {                                                                                                        \
@@ -187,6 +192,7 @@ int atb_splitk(const float* A, const float* B, const float* row_div, int R, int 
     atb_reduce_kernel<16><<<cdiv((long long)MN, 64), 1024, 0, stream>>>(part, P, MN, C, MN_out);
   else
     atb_reduce_kernel<4><<<cdiv((long long)MN, 64), 256, 0, stream>>>(part, P, MN, C, MN_out);
+  kpconv_timing_close(timing, stream);
   D3F_LAUNCH_CHECK();
   return D3F_OK;
 }
