@@ -3,12 +3,13 @@
 full D3Feat U-Net forward+backward on one fragment pair (~19k + 19k points, 32-d descriptors), circle + detector loss,
 radius search + grid subsampling ON THE DEVICE, SGD step included.
 
-    python bench.py --gpus 1 --steps 20 --warmup 5
+    python bench.py --gpus 1 --steps 20 --warmup 5            # default: 4 graphs in flight x 3 stacked pairs per GPU
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
-One "step" = one pass of the whole hot path over one pair: pyramid build (13 radius searches + 4 voxel levels) ->
-KPFCNN forward -> fused loss -> backward -> (all-reduce) -> guarded SGD.  Inputs (the two raw fragments, the sampled
+One "step" = one pass of the whole hot path over lanes x stack pairs per GPU (every pair: pyramid build with 13 radius
+searches + 4 voxel levels -> KPFCNN forward -> fused loss -> backward), one (all-reduce +) guarded SGD update on the mean
+of their gradients; `one_pair_in_flight` = the reference's schedule, one pair per optimizer step.  Inputs (the two raw fragments, the sampled
 correspondences and their distance matrix) are resident in HBM before the timed region.  Each rank processes its own
 pairs (weak scaling); the only data-path collective is the RCCL gradient all-reduce.  Rank 0 prints ONE JSON line.
 """
@@ -280,10 +281,11 @@ def main():
                                                                  "TunableOp table (d3feat.pytorch_amd/tuned/)")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
     ap.add_argument("--lanes", type=int, default=4,
-                    help="fragment pairs in flight per GPU (train.PairLanes): each on streams and graphs of its own, one "
-                         "optimizer step on the mean of their gradients per step.  1 = the reference's one pair per "
-                         "optimizer step (also measured and reported when this is > 1)")
-    ap.add_argument("--stack", type=int, default=1,
+                    help="network graphs in flight per GPU (train.PairLanes): each on streams and graphs of its own, one "
+                         "optimizer step on the mean of all their pairs' gradients per step.  --lanes 1 --stack 1 = the "
+                         "reference's one pair per optimizer step (also measured and reported otherwise: "
+                         "one_pair_in_flight)")
+    ap.add_argument("--stack", type=int, default=3,
                     help="fragment pairs STACKED into one pyramid + one network graph per lane (TrainStep stack): a step "
                          "trains on lanes x stack pairs, one optimizer step on the mean of their gradients")
     ap.add_argument("--quick", action="store_true", help="headline legs only (value, blocks, one_pair_in_flight): no "

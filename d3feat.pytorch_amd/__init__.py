@@ -18,6 +18,7 @@ import os as _os
 # streams that share a queue run back to back -- measured: two pairs in flight 244 pairs/s on 4 queues, 302 on 16 or more
 # (profiles/r03_queue_pipes.txt).  Read when the runtime initialises (first HIP call), so it is set at import; a value
 # the user exported wins.
+_HWQ_SET_HERE = "GPU_MAX_HW_QUEUES" not in _os.environ
 _os.environ.setdefault("GPU_MAX_HW_QUEUES", "32")
 # Library-GEMM selection (enable_tuned_gemms / tuning_missing_gemms below) considers rocBLAS solutions only.  Round 4,
 # measured: with hipBLASLt candidates in the race, shapes tuned during a capture (stacked pairs: 4160- and 8256-row
@@ -27,9 +28,10 @@ _os.environ.setdefault("GPU_MAX_HW_QUEUES", "32")
 # DESIGN.md section 5 that are not re-executed on replay).  368 of the 375 rows of the shipped table were rocBLAS
 # winners anyway.  Read by PyTorch when TunableOp first runs; a value the user exported wins.
 _os.environ.setdefault("PYTORCH_TUNABLEOP_HIPBLASLT_ENABLED", "0")
-# set when the HIP runtime was already up at import (GPU_MAX_HW_QUEUES is then ignored: train.PairLanes warns)
+# set when the variable had to be set HERE and the HIP runtime was already up (it is then ignored: train.PairLanes warns)
 import sys as _sys
-HIP_WAS_INITIALISED_AT_IMPORT = bool('torch' in _sys.modules and _sys.modules['torch'].cuda.is_initialized())
+HIP_WAS_INITIALISED_AT_IMPORT = bool(_HWQ_SET_HERE and 'torch' in _sys.modules
+                                     and _sys.modules['torch'].cuda.is_initialized())
 
 from . import _native  # noqa: F401,E402
 

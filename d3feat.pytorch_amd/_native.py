@@ -12,7 +12,7 @@ _REPO = os.path.dirname(_PKG_DIR)
 LIB_PATH = os.path.join(_PKG_DIR, "libd3feat_hip.so")
 CSRC = os.path.join(_PKG_DIR, "csrc")
 SOURCES = ["radius_neighbors.hip", "grid_subsample.hip", "kpconv.hip", "kpconv_fused.hip", "kpconv_aggregate.hip", "kpconv_small.hip", "kpconv_deform.hip", "pool.hip", "detection.hip", "loss.hip",
-           "reverse_table.hip", "kpconv_dx_gather.hip", "matching.hip", "elementwise.hip", "batchnorm.hip", "linear.hip", "gemm.hip", "optimizer.hip", "misc.hip"]
+           "reverse_table.hip", "kpconv_dx_gather.hip", "matching.hip", "elementwise.hip", "batchnorm.hip", "linear.hip", "optimizer.hip", "misc.hip"]
 
 _vp, _i, _f, _sz = C.c_void_p, C.c_int, C.c_float, C.c_size_t
 
@@ -22,7 +22,6 @@ SIGNATURES = {
     "d3f_device_arch_ok": (_i, []),
     "d3f_device_arch_name": (_i, [C.c_char_p, _i]),
     "d3f_debug_set_flags": (None, [_i]),
-    "d3f_debug_set_gemm_plan": (None, [_i, _i, _i, _i]),
     "d3f_debug_set_phase_clock": (None, [_vp]),
     "d3f_debug_kernel_timing_begin": (_i, [_i, _i]),
     "d3f_debug_kernel_timing_end": (_i, [_vp, _vp, _i]),
@@ -68,8 +67,6 @@ SIGNATURES = {
     "d3f_linear_grad_input": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp]),
     "d3f_linear_grad_weight_ws_bytes": (_sz, [_i, _i, _i]),
     "d3f_linear_grad_weight": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _sz, _vp]),
-    "d3f_gemm_ws_bytes": (_sz, [_i, _i, _i, _i]),
-    "d3f_gemm": (_i, [_vp, _vp, _sz, _vp]),
     "d3f_max_pool_forward": (_i, [_vp, _i, _i, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp]),
     "d3f_max_pool_backward": (_i, [_vp, _vp, _i, _i, _i, _vp, _i, _vp]),
     "d3f_closest_pool_forward": (_i, [_vp, _i, _i, _vp, _i, _i, _vp, _i, _vp, _vp, _vp]),
@@ -115,22 +112,6 @@ STATUS_BITS = {1: "a query has more in-radius candidates than the kernel can ran
                4: "voxel hash table full",
                8: "a pyramid level needs more rows than its capacity (raise the capacities)",
                16: "a point has more in-radius neighbors than the reverse (wide) table holds"}
-
-
-class GemmArgs(C.Structure):
-    """``d3f_gemm_args`` of include/d3feat_hip.h, field for field."""
-    _fields_ = [("A", _vp), ("B", _vp), ("C", _vp),
-                ("M", C.c_int32), ("N", C.c_int32), ("K", C.c_int32),
-                ("lda", C.c_int32), ("ldb", C.c_int32), ("ldc", C.c_int32),
-                ("a_layout", C.c_int32), ("b_layout", C.c_int32),
-                ("a_mask", _vp), ("mask_slope", _f),
-                ("rowsum", _vp), ("rowsum2", _vp),
-                ("row_div", _vp), ("bias1", _vp), ("bias2", _vp),
-                ("add", _vp), ("ldadd", C.c_int32), ("add_idx", _vp), ("idx_stride", C.c_int32),
-                ("add_rows", C.c_int32), ("slope", _f), ("zero_init", _vp), ("zero_n", C.c_int32)]
-
-
-GEMM_KC, GEMM_KS = 0, 1
 
 
 def build(verbose=False, jobs=None):

@@ -508,12 +508,6 @@ class _KPConvFn(torch.autograd.Function):
         return None, None, None, gx, None, (_adoptable(gw, ctx.gw_slot) if gw is not None else None), None, None, None
 
 
-# few-point KPConv contractions that run on the own GEMM (csrc/gemm.hip) with the /nn + bias + LeakyReLU epilogue fused:
-# at most this many query rows and at least this deep a reduction (K * Cin)
-_OWN_GEMM_MAX_ROWS = 700
-_OWN_GEMM_MIN_DEPTH = 3840
-
-
 class _KPConvGemmBiasActFn(torch.autograd.Function):
     """act(KPConv(x) + bias) for the few-point / wide layers (bottom of the U-Net), as
         aggregation kernel -> wf [Nq, K*Cin], nn      library GEMM  raw = wf @ W       epilogue  act(raw/nn + bias)
@@ -552,18 +546,11 @@ class _KPConvGemmBiasActFn(torch.autograd.Function):
         ctx.keep, ctx.gx_buf = keep, gx_buf
         want_b = bias is not None and ctx.needs_input_grad[6]
         gbuf = torch.empty((1, Cout), dtype=torch.float32, device=dev) if want_b else None
-        if Nq <= _OWN_GEMM_MAX_ROWS and K * Cin >= _OWN_GEMM_MIN_DEPTH and Cout % 4 == 0:
-            # few rows x deep reduction (levels 3-4: 159..640 rows x 3840..7680): act((wf @ W) / nn + bias) in ONE launch
-            # of the own split-reduction GEMM (profiles/r03_gemm_sweep.txt: 12.0 / 23.1 / 24.9 us against 16.4 / 24.1 /
-            # 28.6 us for library GEMM + epilogue launch); the bias-gradient accumulators are cleared on the side
-            out = gemm(wf, weights.view(K * Cin, Cout), b_ks=True, row_div=nn, bias1=bias, slope=float(slope),
-                       zero_init=gbuf)
-        else:
-            raw = torch.mm(wf, weights.view(K * Cin, Cout))
-            out = torch.empty_like(raw)
-            _native.check(L.d3f_bias_act_forward(_p(raw), _p(bias), None, None, float(slope), Nq, Cout, _p(out), _p(gbuf),
-                                                 Cout if want_b else 0, _p(nn), None, 0, 0, _stream()),
-                          "d3f_bias_act_forward")
+        raw = torch.mm(wf, weights.view(K * Cin, Cout))
+        out = torch.empty_like(raw)
+        _native.check(L.d3f_bias_act_forward(_p(raw), _p(bias), None, None, float(slope), Nq, Cout, _p(out), _p(gbuf),
+                                             Cout if want_b else 0, _p(nn), None, 0, 0, _stream()),
+                      "d3f_bias_act_forward")
         ctx.save_for_backward(q_pts, s_pts, idx, x, kernel_points, weights, nn, wf, out)
         ctx.gbuf, ctx.extent, ctx.slope, ctx.want_b = gbuf, float(extent), float(slope), want_b
         ctx.gw_slot = _grad_slot(weights)
@@ -822,77 +809,6 @@ def kpconv_deformable(q_pts, s_pts, neighb_inds, x, kernel_points, weights, exte
     return out, min_d2, deformed
 
 
-# ---------------------------------------------------------------------------------------------------------------
-# fused f32 GEMM (csrc/gemm.hip): C = epilogue(op(A) . op(B)) -- the unary blocks and few-point KPConv contractions
-# ---------------------------------------------------------------------------------------------------------------
-def _mat(t, name):
-    """2-D fp32 device matrix whose rows are contiguous (a row stride is fine: column blocks are used in place)."""
-    if not isinstance(t, torch.Tensor) or not t.is_cuda:
-        raise RuntimeError("%s must be a CUDA/HIP tensor (d3feat_pytorch_amd has no CPU path)" % name)
-    if t.dtype != torch.float32:
-        t = t.float()
-    if t.dim() != 2:
-        raise RuntimeError("%s must be 2-D" % name)
-    if t.shape[1] > 1 and t.stride(1) != 1:
-        t = t.contiguous()
-    if t.shape[0] > 1 and (t.stride(0) % 4 or t.data_ptr() % 16):
-        t = t.contiguous()
-    return t
-
-
-def _ld(t):
-    return int(t.stride(0)) if t.shape[0] > 1 else int(t.shape[1])
-
-
-def gemm(A, B, a_ks=False, b_ks=False, out=None, a_mask=None, mask_slope=1.0, rowsum=None, rowsum2=None, row_div=None,
-         bias1=None, bias2=None, add=None, add_idx=None, add_rows=0, slope=1.0, zero_init=None):
-    """C [M,N] = act(A' @ B' / row_div + bias1 + add + bias2) on the f32 matrix cores, one launch (two for few-row /
-    deep-reduction shapes).  ``A`` is [M,K] (or [K,M] with ``a_ks``), ``B`` is [N,K] -- the nn.Linear weight layout --
-    (or [K,N] with ``b_ks``); see d3f_gemm in include/d3feat_hip.h for the prologue / by-product / epilogue terms."""
-    A, B = _mat(A, "A"), _mat(B, "B")
-    K, M = (int(A.shape[0]), int(A.shape[1])) if a_ks else (int(A.shape[1]), int(A.shape[0]))
-    Kb, N = (int(B.shape[0]), int(B.shape[1])) if b_ks else (int(B.shape[1]), int(B.shape[0]))
-    if K != Kb:
-        raise RuntimeError("gemm: reduction lengths differ (%d vs %d)" % (K, Kb))
-    dev = A.device
-    if out is None:
-        out = torch.empty((M, N), dtype=torch.float32, device=dev)
-    elif tuple(out.shape) != (M, N) or out.dtype != torch.float32 or (N > 1 and out.stride(1) != 1):
-        raise RuntimeError("gemm: out must be a fp32 [%d,%d] matrix with contiguous rows" % (M, N))
-    a = _native.GemmArgs()
-    a.A, a.B, a.C = _p(A), _p(B), _p(out)
-    a.M, a.N, a.K, a.lda, a.ldb, a.ldc = M, N, K, _ld(A), _ld(B), _ld(out)
-    a.a_layout = _native.GEMM_KS if a_ks else _native.GEMM_KC
-    a.b_layout = _native.GEMM_KS if b_ks else _native.GEMM_KC
-    if a_mask is not None:
-        a_mask = _mat(a_mask, "a_mask")
-        if tuple(a_mask.shape) != tuple(A.shape) or _ld(a_mask) != _ld(A):
-            raise RuntimeError("gemm: a_mask must have A's shape and row stride")
-    a.a_mask, a.mask_slope = _p(a_mask), float(mask_slope)
-    a.rowsum, a.rowsum2 = _p(rowsum), _p(rowsum2)
-    a.row_div, a.bias1, a.bias2 = _p(row_div), _p(bias1), _p(bias2)
-    if add is not None:
-        add = _mat(add, "add")
-    a.add, a.ldadd = _p(add), (_ld(add) if add is not None else 0)
-    a.add_idx, a.idx_stride = _p(add_idx), (int(add_idx.stride(0)) if add_idx is not None else 0)
-    a.add_rows, a.slope = int(add_rows), float(slope)
-    a.zero_init, a.zero_n = _p(zero_init), (int(zero_init.numel()) if zero_init is not None else 0)
-    L = _native.lib()
-    nbytes = L.d3f_gemm_ws_bytes(M, N, K, 1 if rowsum is not None else 0)
-    ws = _ws(nbytes, dev) if nbytes else None
-    import ctypes
-    with _region("gemm[M=%d,N=%d,K=%d]" % (M, N, K), 4 * (M * K + N * K + M * N)):
-        _native.check(L.d3f_gemm(ctypes.byref(a), _p(ws), nbytes, _stream()), "d3f_gemm")
-    return out
-
-
-# ---------------------------------------------------------------------------------------------------------------
-# Two-branch gradient fusion.  The input of a bottleneck block feeds unary1 AND the shortcut (identity / max_pool /
-# linear, blocks.py:668-686); autograd would produce the two gradients separately and add them (one 5-us launch per
-# block, 13 per step).  The shortcut branch -- always the first to finish in backward, its nodes are younger than
-# unary1's -- DEPOSITS its input gradient in a GradHolder instead of returning it; unary1's grad-input GEMM picks it up
-# as the C operand (beta = 1, in place) and returns the sum.  If the order ever were the other way round the holder is
-# closed and the late branch returns its gradient the ordinary way, so the result is the same either way.
 # ---------------------------------------------------------------------------------------------------------------
 class GradHolder(object):
     __slots__ = ("tensor", "closed")

@@ -1136,7 +1136,7 @@ class PairLanes:
         from . import HIP_WAS_INITIALISED_AT_IMPORT
         if self.P < 2 or self.ts.device.type != 'cuda':
             return {'factor': 1.0, 'redealt': False}
-        if HIP_WAS_INITIALISED_AT_IMPORT and os.environ.get("GPU_MAX_HW_QUEUES") == "32":
+        if HIP_WAS_INITIALISED_AT_IMPORT:
             warnings.warn("the HIP runtime was initialised before d3feat_pytorch_amd was imported: GPU_MAX_HW_QUEUES=32 was "
                           "not in effect, streams beyond four share hardware queues and the lanes may serialise")
         dev = self.ts.device

@@ -46,13 +46,10 @@ void d3f_debug_set_flags(int flags);      /* profiling aid: ablation switches of
  * recorded (cleared by the caller), [1] = record capacity, record r at [8 + 8 r .. +5] = shader cycles one wave of the
  * fused KPConv forward / gather-form grad-input kernel spent in each of its phases (see the kernels). */
 void d3f_debug_set_phase_clock(void* counters);
-/* measurement aid (profiles/gemm_microbench.py): force the decomposition of d3f_gemm (0 = heuristic for each) -- fa =
- * 1 | 2 fragments per wave along M for a KC-layout A, fb = 2 | 4 along N for a KC-layout B, kw = 1 | 2 | 4 | 8 waves of a
- * workgroup splitting the reduction of one tile, split >= 1 grid-level slices of the reduction. */
-void d3f_debug_set_gemm_plan(int fa, int fb, int kw, int split);
 /* measurement aid (bench.py roofline leg): HIP events on the launch stream around every launch of ONE kernel
- * (which = 1 fused KPConv forward kernel, 2 scatter-form grad-input kernel, 3 gather-form grad-input kernel; or,
- * negative, minus a bit mask of several: -(1 | 2 | 4)) between begin and end.  end -- after the caller synchronised
+ * (which = 1 fused KPConv forward kernel, 2 scatter-form grad-input kernel, 3 gather-form grad-input kernel, 4 the
+ * A^T B weight-gradient kernels, 5 / 6 the forward / transposed KPConv aggregation kernels; or, negative, minus a bit
+ * mask of several: -(1 | 2 | 4 | 8 | 16 | 32)) between begin and end.  end -- after the caller synchronised
  * the device -- returns the number of launches seen and fills ms_out[i] and shapes_out[6*i .. 6*i+5] =
  * {Nq, Ns, H, Cin, Cout, K | which << 8} for the first `cap` of them. */
 int d3f_debug_kernel_timing_begin(int which, int max_launches);
@@ -268,44 +265,6 @@ int d3f_closest_pool_forward(const float* x, int Ns, int C, const int32_t* idx, 
                              int Cs, float* out, float* grad_x_clear, void* stream);
 int d3f_closest_pool_backward(const float* grad_out, int ld, const int32_t* idx, int Nq, int H, int C, int Ns,
                               float* grad_x, int grad_x_precleared, void* stream);
-
-/* ------------------------------------------------------------------------------------------------
- * Fused f32 GEMM of the point-wise layers -- replaces, per unary block (models/blocks.py:481-541: nn.Linear +
- *   BatchNormBlock bias + LeakyReLU, residual add :686) and per few-point KPConv contraction (blocks.py:375-380),
- *   the library GEMM plus the elementwise launches around it, forward and backward:
- *     C [M,N] = epilogue( A' . B' ),   A' [M,K], B' [K,N]
- *   a_layout / b_layout say how the operand lies in memory:
- *     D3F_GEMM_KC  reduction index contiguous:  A'[m][k] = A[m*lda + k]   B'[k][n] = B[n*ldb + k]
- *     D3F_GEMM_KS  reduction index = row:       A'[m][k] = A[k*lda + m]   B'[k][n] = B[k*ldb + n]
- *   so  y = x W^T (KC,KC),  grad_x = g W (KC,KS),  grad_W = g^T x (KS,KS),  wf W (KC,KS),  g W^T (KC,KC)  need no
- *   transposed copies.  Contiguous extents and leading dimensions must be multiples of 4 floats, bases 16-B aligned.
- *   prologue : a_mask (optional, same shape/layout as A): A' = A * (a_mask > 0 ? 1 : mask_slope) -- the LeakyReLU
- *              backward evaluated on the saved block output while the operand is loaded.
- *   by-product: rowsum / rowsum2 (optional, [M], KS layout of A only): sum_k A'[m][k] -- the bias gradient when
- *              A' = (masked gradient)^T in the weight-gradient GEMM; both buffers receive the same sums.
- *   epilogue : v = acc (/ row_div[m]) + bias1[n] + add[m*ldadd + n] + bias2[n];  C = v > 0 ? v : slope*v  (slope = 1:
- *              identity).  With add_idx (int32, row stride idx_stride) `add` is a COARSE matrix [add_rows, >=N] and
- *              row m receives add[add_idx[m*idx_stride]] (nothing for an index outside [0, add_rows)).
- *   zero_init (optional, zero_n floats) is cleared on the side (backward accumulators of the caller).
- * Few-row / deep-reduction shapes split the reduction over workgroups; partial tiles are summed in a fixed order by a
- * second launch that applies the epilogue (d3f_gemm_ws_bytes > 0 for those shapes).  Results are bit-reproducible.
- * With a KS-layout B, C and ldc must be 16-byte / 4-float aligned as well (float4 stores); rowsum buffers likewise.
- * ---------------------------------------------------------------------------------------------- */
-#define D3F_GEMM_KC 0
-#define D3F_GEMM_KS 1
-typedef struct d3f_gemm_args {
-  const float* A; const float* B; float* C;
-  int32_t M, N, K, lda, ldb, ldc;
-  int32_t a_layout, b_layout;
-  const float* a_mask; float mask_slope;
-  float* rowsum; float* rowsum2;
-  const float* row_div; const float* bias1; const float* bias2;
-  const float* add; int32_t ldadd; const int32_t* add_idx; int32_t idx_stride; int32_t add_rows;
-  float slope;
-  float* zero_init; int32_t zero_n;
-} d3f_gemm_args;
-size_t d3f_gemm_ws_bytes(int M, int N, int K, int with_rowsum);
-int d3f_gemm(const d3f_gemm_args* args, void* ws, size_t ws_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Block epilogue -- replaces BatchNormBlock's bias add (models/blocks.py:473, use_bn=False), nn.LeakyReLU(0.1)

@@ -8,6 +8,10 @@ from d3feat_pytorch_amd import _native
 # (rows, cout(M), cin(N)): KPConv dW = wf^T g as (M = K*Cin, N = Cout); unary dW of levels 0 / 1
 SHAPES = [(38180, 480, 32), (7920, 960, 64), (7920, 480, 64), (38180, 64, 32), (38180, 32, 64), (38180, 128, 64),
           (7920, 128, 64), (7920, 64, 256), (7920, 256, 128), (38180, 32, 32), (38180, 16, 32)]
+if len(sys.argv) > 1:   # Q pairs stacked (round 4): the rows of every level times Q, plus the level-2 KPConv gradients
+    Q = int(sys.argv[1])
+    SHAPES = [(Q * n, a, b) for n, a, b in SHAPES] + [(Q * 2053, 1920, 128), (Q * 2053, 960, 64), (Q * 2053, 128, 512),
+                                                       (Q * 2053, 512, 128)]
 L = _native.lib()
 dev = torch.device("cuda:0")
 st = torch.cuda.current_stream().cuda_stream

@@ -1,6 +1,7 @@
-"""Only the network step (forward, loss, backward, optimizer) of one pair, eagerly, N times -- for a rocprofv3
-kernel-count/-time table of the TRAINING STREAM alone (the pyramid runs once, before):
-    rocprofv3 --kernel-trace --stats -d gpurun_out/net -o net -- python profiles/net_step_only.py 20"""
+"""Only the network step (forward, loss, backward, optimizer) of one pair -- or of a stack of Q pairs (second argument)
+-- eagerly, N times: for a rocprofv3 kernel-count/-time table or --pmc counter passes of the TRAINING STREAM alone (the
+pyramid runs once, before):
+    rocprofv3 --kernel-trace --stats -d gpurun_out/net -o net -- python profiles/net_step_only.py 20 [Q]"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -26,11 +27,19 @@ item = tuple(torch.from_numpy(np.ascontiguousarray(a)).to(dev) for a in it)
 ts = TrainStep(cfg, [42] * 5, dev, seed=0)
 b = ts.build_batch(item)
 sizes = [[int(t.shape[0]) for t in b['points']]]
-ts.enable_graph(TrainStep.capacities_for(sizes, slack=1.0), num_corr=int(item[4].shape[0]))
+Q = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+if Q > 1:
+    others = [tuple(torch.from_numpy(np.ascontiguousarray(a)).to(dev) for a in synthetic.make_pair(2 * q + 1, 2 * q + 2, sub))
+              for q in range(1, Q)]
+    item = (item,) + tuple(others)
+    sizes = [[sum(int(ts.build_batch(it)['points'][l].shape[0]) for it in item) for l in range(5)]]
+ts.enable_graph(TrainStep.capacities_for(sizes, slack=1.0), num_corr=int(item[0][4].shape[0] if Q > 1 else item[4].shape[0]),
+                stack=Q)
+ts._use_scale()
 st = ts.sets[0]
 ts._load_inputs(st, item)
 ts._build_set(st)
 for _ in range(n):
     ts._net_step(st)
 torch.cuda.synchronize()
-print("steps:", n)
+print("steps:", n, "pairs per step:", Q)

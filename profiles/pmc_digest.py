@@ -28,7 +28,9 @@ for line in open(src):
         data[cur][m.group(1)] = float(m.group(2))
 
 KERNELS = {'kpconv_fwd_fused_kernel': 'kpconv_fwd_fused', 'kpconv_dx_gather_kernel': 'kpconv_dx_gather',
-           'kpconv_bwd_dx_kernel': 'kpconv_bwd_dx'}
+           'kpconv_bwd_dx_kernel': 'kpconv_bwd_dx', 'atb_partial_kernel': 'atb_partial',
+           'kpconv_agg_fwd_kernel': 'kpconv_agg_fwd', 'kpconv_agg_rev_kernel': 'kpconv_agg_rev',
+           'rowgemm_kernel': 'rowgemm'}
 rows, by_kernel = [], {}
 for name, v in data.items():
     if not v or 'GRBM_GUI_ACTIVE' not in v:
@@ -52,7 +54,7 @@ for name, v in data.items():
             by_kernel.setdefault(key, []).append(r)
 with open(out + '.txt', 'w') as f:
     f.write(__doc__.split('Normalisation')[1].join(['# Normalisation', '']) if False else '')
-    f.write("# unit utilisation of the KPConv kernels inside the network step (rocprofv3 --pmc, 5 passes; see pmc_digest.py for the normalisation)\n")
+    f.write("# unit utilisation of the hand-written kernels inside the network step (rocprofv3 --pmc, 5 passes; see pmc_digest.py for the normalisation)\n")
     f.write("%-44s %9s %9s %9s %8s %7s %8s %9s %10s %8s\n" % ("instantiation", "mfma_busy", "valu_busy", "lds_busy",
                                                              "ta_busy", "l2_hit", "wait_mem", "wait_issue", "issuing",
                                                              "lds_conf"))
@@ -66,7 +68,8 @@ for key, rs in by_kernel.items():
     tot = sum(r["gui_active_cycles"] for r in rs)
     summary[key] = {k: round(sum(r[k] * r["gui_active_cycles"] for r in rs if r[k] is not None) / tot, 3)
                     for k in ("mfma_busy", "valu_busy", "lds_busy", "ta_busy", "l2_hit", "wait_mem", "wait_issue")}
-    summary[key]["source"] = "rocprofv3 --pmc over profiles/net_step_only.py, time-weighted over the kernel's instantiations (profiles/r03_pmc_kpconv.txt)"
+    summary[key]["source"] = ("rocprofv3 --pmc over profiles/net_step_only.py, time-weighted over the kernel's "
+                              "instantiations (%s.txt)" % out)
 with open(out + '.json', 'w') as f:
     json.dump(summary, f, indent=1)
 print(open(out + '.txt').read())

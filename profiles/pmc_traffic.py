@@ -20,6 +20,8 @@ CSRC = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
 # traffic figure measured on an older kernel from a current one)
 KERNEL_FILES = {"kpconv_bwd_dx_kernel": "kpconv_fused.hip", "kpconv_fwd_fused_kernel": "kpconv_fused.hip",
                 "kpconv_dx_gather_kernel": "kpconv_dx_gather.hip", "atb_partial_kernel": "linear.hip",
+                "kpconv_agg_fwd_kernel": "kpconv_aggregate.hip", "kpconv_agg_rev_kernel": "kpconv_aggregate.hip",
+                "rowgemm_kernel": "linear.hip",
                 "bias_act_bwd_kernel": "elementwise.hip", "bias_act_fwd_kernel": "elementwise.hip",
                 "pack_supports_kernel": "kpconv_fused.hip", "radius_query_kernel": "radius_neighbors.hip",
                 "order_kernel": "grid_subsample.hip"}
