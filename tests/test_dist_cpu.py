@@ -122,6 +122,112 @@ def _split_worker(rank, world, port, ret):
     dist.destroy_process_group()
 
 
+def _agree_worker(rank, world, port, ret):
+    """trainer.Trainer._agree (logical AND over the ranks) and the stacked / laned join arithmetic on host tensors:
+    every rank sums the deep and shallow buckets of its lanes, the buckets are all-reduced (3 deep chunks + 1 shallow, as
+    PairLanes.step_graph does), ONE guarded update with scale 1 / (pairs x ranks) -- against a single model that sees
+    the mean gradient of all lanes x ranks batches."""
+    sys.path.insert(0, REPO)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from d3feat_pytorch_amd.train import FlatParams, GuardedSGD
+    from d3feat_pytorch_amd.trainer import Trainer
+    tr = Trainer.__new__(Trainer)
+    tr.world, tr.device, tr._agree_stream = world, torch.device('cpu'), None
+    ok = tr._agree(True) is True and tr._agree(rank == 0) is False and tr._agree(False) is False
+    torch.manual_seed(0)
+    mk = lambda: torch.nn.Sequential(torch.nn.Linear(7, 13), torch.nn.LeakyReLU(0.1), torch.nn.Linear(13, 5))   # noqa: E731
+    model, ref = mk(), mk()
+    ref.load_state_dict(model.state_dict())
+    flat = FlatParams(model)
+    lanes, stack = 2, 2                      # 2 lanes x 2 stacked pairs per rank: 8 "pairs" per update over 2 ranks
+    flat.add_lane()
+    opt = GuardedSGD(flat, lr=0.1, momentum=0.9, weight_decay=1e-3)
+    ref_opt = torch.optim.SGD(ref.parameters(), lr=0.1, momentum=0.9, weight_decay=1e-3)
+    ns = sum(p.numel() for p in model[0].parameters())        # "shallow" bucket = the first layer
+    for step in range(3):
+        g = torch.Generator().manual_seed(11 * step)
+        xs = [[[torch.randn(4, 7, generator=g) for _ in range(stack)] for _ in range(lanes)] for _ in range(world)]
+        ys = [[[torch.randn(4, 5, generator=g) for _ in range(stack)] for _ in range(lanes)] for _ in range(world)]
+        for lane in range(lanes):            # a lane's buffer = the SUM over its stack (total loss = sum of pair losses)
+            flat.bind(lane)
+            flat.zero_grad()
+            sum(((model(xs[rank][lane][q]) - ys[rank][lane][q]) ** 2).mean() for q in range(stack)).backward()
+            flat.gather_grads()
+        flat.bind(0)
+        grads = [flat.lanes[k][0] for k in range(lanes)]
+        opt.use_grad_scale(1.0 / (lanes * stack * world))
+        deep = grads[0][ns:]
+        for other in grads[1:]:
+            deep.add_(other[ns:])
+        nb = 3
+        chunk = (deep.numel() + nb - 1) // nb
+        works = [dist.all_reduce(deep[b * chunk:min(deep.numel(), (b + 1) * chunk)], async_op=True) for b in range(nb)]
+        shallow = grads[0][:ns]
+        for other in grads[1:]:
+            shallow.add_(other[:ns])
+        works.append(dist.all_reduce(shallow, async_op=True))
+        for w in works:
+            w.wait()
+        ok &= bool(opt.step(grads=grads[:1]))
+        ref_opt.zero_grad()
+        (sum(((ref(xs[r][k][q]) - ys[r][k][q]) ** 2).mean() for r in range(world) for k in range(lanes)
+             for q in range(stack)) / (world * lanes * stack)).backward()
+        ref_opt.step()
+        for p_, q_ in zip(model.parameters(), ref.parameters()):
+            ok &= torch.allclose(p_, q_, atol=1e-6)
+    # an eager one-pair step afterwards runs at ITS scale (ADVICE r3: it used to inherit 1 / pairs)
+    opt.use_grad_scale(1.0 / world)
+    ok &= opt.grad_scale == 1.0 / world
+    mine = flat.data.clone()
+    other = [torch.zeros_like(mine) for _ in range(world)]
+    dist.all_gather(other, mine)
+    ok &= all(torch.equal(o, other[0]) for o in other)
+    ret[rank] = bool(ok)
+    dist.destroy_process_group()
+
+
+def test_rank_agreement_and_laned_stacked_join_over_two_ranks():
+    world = 2
+    port = _free_port()
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_agree_worker, args=(world, port, ret), nprocs=world, join=True)
+    assert dict(ret) == {0: True, 1: True}
+
+
+def test_stack_inputs_and_gradient_scale_host_logic():
+    """What a stacked step is handed (train.is_stack / same_item / TrainStep.pairs_of, PairLanes.deal) and
+    GuardedSGD.use_grad_scale on host tensors."""
+    sys.path.insert(0, REPO)
+    from d3feat_pytorch_amd.train import FlatParams, GuardedSGD, PairLanes, TrainStep, is_stack, same_item
+    a, b, c = (torch.zeros(3, 3),) * 6, (torch.ones(2, 3),) * 6, (torch.ones(4, 3),) * 6
+    assert not is_stack(a) and is_stack((a, b)) and is_stack([a])
+    assert same_item(a, a) and not same_item(a, b) and same_item((a, b), (a, b)) and not same_item((a, b), (b, a))
+    assert not same_item((a, b), (a, b, c)) and not same_item(None, a) and not same_item((a, b), a)
+    assert TrainStep.pairs_of(a) == [a] and TrainStep.pairs_of((a, b)) == [a, b]
+    lanes = PairLanes.__new__(PairLanes)
+    lanes.P, lanes.Q = 2, 3
+    assert lanes.deal([a, b, c, c, b, a]) == [(a, b, c), (c, b, a)] and lanes.pairs_per_step == 6
+    with pytest.raises(ValueError):
+        lanes.deal([a, b, c])
+    lanes.Q = 1
+    assert lanes.deal([a, b]) == [a, b]
+    m = torch.nn.Linear(4, 2)
+    f = FlatParams(m)
+    o = GuardedSGD(f, lr=0.5, momentum=0.0, weight_decay=0.0)
+    f.grad.fill_(1.0)
+    before = f.data.clone()
+    o.use_grad_scale(0.25)
+    assert o.grad_scale == 0.25 and bool(o.step())
+    assert torch.allclose(f.data, before - 0.5 * 0.25)
+    o.use_grad_scale(0.25)            # asking for the scale in effect is free
+    o.use_grad_scale(1.0)
+    before = f.data.clone()
+    assert bool(o.step()) and torch.allclose(f.data, before - 0.5)
+
+
 def test_split_bucket_exchange_equals_one_allreduce_and_status_poison_is_collective():
     world = 2
     port = _free_port()
