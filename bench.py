@@ -452,9 +452,15 @@ def main():
             lanes, P, L, Q = None, 1, 1, 1
             ts.flat.bind(0)
 
+    # EXPERIMENT knob (never a benchmark number: the JSON line says so): every step trains on the pairs the graphs were
+    # captured on and builds no pyramid -- an upper bound on what shortening the pyramid builds could buy
+    frozen = os.environ.get("D3F_BENCH_FROZEN_PYRAMIDS") == "1" and lanes is not None
+
     def run(k):
         if lanes is None:
             return run_one(k)
+        if frozen:
+            return lanes.step_graph([items[j % len(items)] for j in range(P)], TrainStep.NO_PREFETCH)[0]
         cur = [items[(P * k + j) % len(items)] for j in range(P)]
         nxt = [items[(P * (k + 1) + j) % len(items)] for j in range(P)]
         return lanes.step_graph(cur, nxt)[0]
@@ -971,7 +977,8 @@ def main():
                             "lane's stack of %d pair(s)); averages are time-weighted over all launches; the kernel "
                             "reported is the hand-written kernel with the most time per training step" % Q}
         res = {
-            "metric": "fragment-pairs/sec (fwd+bwd) on 3DMatch-shaped pairs",
+            "metric": "fragment-pairs/sec (fwd+bwd) on 3DMatch-shaped pairs" + (
+                " -- EXPERIMENT, NOT A BENCHMARK: pyramids frozen (D3F_BENCH_FROZEN_PYRAMIDS)" if frozen else ""),
             "value": round(P * args.steps * world / elapsed, 3),
             "unit": "fragment-pairs/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,

@@ -126,6 +126,8 @@ __global__ __launch_bounds__(256) void row_argmin_kernel(const float* __restrict
 #pragma unroll
         for (int rt = 0; rt < RT; ++rt) acc[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(afrag[rt][u].w, bfrag[nb][u].w, acc[rt], 0, 0, 0);
       }
+      // (round 4: issuing block nb + 1's products before block nb's row / column bookkeeping was measured slower,
+      // 0.443 vs 0.411 ms at 19.1k x 19.1k x 32 -- the second accumulator set costs more than the overlap returns)
       // D layout: col = li (target col0 + 16nb + li), row = 4*lk + r of row tile rt.  Columns arrive in ascending
       // order within a lane, so a strict "<" keeps the earliest column among equals.
       const int j = col0 + 16 * nb + li;
@@ -220,7 +222,9 @@ __global__ __launch_bounds__(256) void row_argmin_kernel(const float* __restrict
   __syncthreads();
   for (int t = threadIdx.x; t < cend - cbeg; t += 256) {
     const unsigned long long k2 = colbest[t];
-    if (k2 != ~0ull) atomicMin(&best_col[cbeg + t], k2);
+    // most workgroups lose a column to an earlier one: a plain load first (a stale value is an older, LARGER key: it
+    // can only cause a redundant atomic, never a skipped one)
+    if (k2 != ~0ull && k2 < best_col[cbeg + t]) atomicMin(&best_col[cbeg + t], k2);
   }
 }
 
@@ -240,7 +244,8 @@ __global__ void unpack_mutual_kernel(const unsigned long long* __restrict__ best
 
 // workgroups along the target range: ~2048 in all (8 per CU), column chunks of whole tiles that fit the LDS table
 static void chunking(int gx, int Nt, int& chunks, int& cpc) {
-  chunks = 2048 / (gx > 0 ? gx : 1);
+  static const int target = getenv("D3F_MATCH_WGS") ? atoi(getenv("D3F_MATCH_WGS")) : 2048;   // (env: experiments)
+  chunks = target / (gx > 0 ? gx : 1);
   const int max_chunks = d3f::cdiv(Nt, 4 * kColsPerTile);
   if (chunks > max_chunks) chunks = max_chunks;
   const int min_chunks = d3f::cdiv(Nt, 4096);   // 32 KB of keys per workgroup at most

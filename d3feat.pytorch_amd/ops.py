@@ -396,6 +396,10 @@ _GEMM_PATH_MIN_CIN = int(__import__('os').environ.get('D3F_GEMM_PATH_MIN_CIN', 6
 _GEMM_DX_AGG_MIN_COUT = int(__import__('os').environ.get('D3F_GEMM_DX_AGG_MIN_COUT', 64))     # (env: experiments)
 
 
+_DW_LIBRARY_MIN_OUT = 1920 * 128
+_DW_LIBRARY_MAX_ROWS = 16384
+
+
 def _takes_gemm_path(Nq, Cin):
     return 0 < Nq < _GEMM_DX_MAX_ROWS or (Nq > 0 and Cin >= _GEMM_PATH_MIN_CIN)
 
@@ -576,8 +580,11 @@ class _KPConvGemmBiasActFn(torch.autograd.Function):
         gx = gw = None
         if ctx.needs_input_grad[5]:
             gw = ctx.gw_slot if ctx.gw_slot is not None else torch.empty_like(weights)
-            if Nq >= _SPLITK_MIN_ROWS and L.d3f_linear_grad_weight_supported(Nq, Cout, K * Cin):
-                # many rows: the reduction over the points is what has to be spread over the chip (csrc/linear.hip)
+            if Nq >= _SPLITK_MIN_ROWS and L.d3f_linear_grad_weight_supported(Nq, Cout, K * Cin) and not (
+                    K * Cin * Cout >= _DW_LIBRARY_MIN_OUT and Nq <= _DW_LIBRARY_MAX_ROWS):
+                # many rows: the reduction over the points is what has to be spread over the chip (csrc/linear.hip);
+                # a large output over a few thousand rows (1920 x 128 and up) is an ordinary GEMM again: 36 against 58 us
+                # at 6159 rows (profiles/r04_dw_library_vs_atb.txt)
                 nbytes = L.d3f_linear_grad_weight_ws_bytes(Nq, Cout, K * Cin)
                 ws = _ws(nbytes, x.device)
                 with _region("kpconv_dw_atb[Nq=%d,Cin=%d,Cout=%d]" % (Nq, Cin, Cout), 4 * Nq * (K * Cin + Cout)):

@@ -252,6 +252,8 @@ class Trainer(object):
                 e = eng.clone_for_capacities(caps, num_corr=int(item[4].shape[0]), stack=self.stack)
             one = self._fetch(ds, member)
             e.capture(one if self.lanes > 1 or self.stack == 1 else tuple([one] * self.stack))
+            if self.lanes > 1 and not self._engines:
+                self.lanes_overlap = e.probe_overlap()       # do the lanes' streams really run side by side?
             self._engines.append(e)
         for dst, src in zip((eng.flat.data, eng.opt.buf, eng.opt.state), keep):
             dst.copy_(src)

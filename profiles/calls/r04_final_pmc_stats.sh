@@ -1,0 +1,13 @@
+set -x
+cd $GRAFT_REPO_ROOT
+mkdir -p gpurun_out
+export TMPDIR=/tmp
+T=${1:-r04p}
+(timeout 300 python profiles/dw_library_vs_atb.py 3 2>&1 | grep -v amdgpu.ids) > gpurun_out/${T}_dw_library_vs_atb.txt
+cat gpurun_out/${T}_dw_library_vs_atb.txt
+# kernel-time table of the bench command (quick legs), rocprofv3 --stats
+(D3F_NO_TUNE_MISSING=1 timeout 400 rocprofv3 --kernel-trace --stats -d gpurun_out/st -o st -- python bench.py --steps 20 --warmup 5 --quick 2>&1 | tail -3) > gpurun_out/${T}_stats.log
+(python profiles/summarize_rocpd.py $(find gpurun_out/st -name "*.db" | head -1) "D3F_NO_TUNE_MISSING=1 rocprofv3 --kernel-trace --stats -- python bench.py --steps 20 --warmup 5 --quick  (round 4: 4 lanes x 3 stacked pairs; the trace serialises the lanes' dispatches, per-kernel durations are those of kernels running alone; capture warm-ups, the timed region, 5 more blocks and the one-pair legs included)" 25 2>&1) > gpurun_out/${T}_kernel_stats.txt
+rm -rf gpurun_out/st
+head -30 gpurun_out/${T}_kernel_stats.txt
+bash profiles/calls/r04_pmc.sh $T 3

@@ -19,4 +19,5 @@ for _ in range(5):
 e1.record()
 torch.cuda.synchronize()
 ms = e0.elapsed_time(e1) / 5
-print("N=%d C=%d: %.3f ms, %.1f TFLOP/s" % (n, c, ms, 4.0 * n * (n - 29) * c / ms / 1e9))
+# one sweep over the S x T tiles since round 4: 2 N^2 C flop
+print("N=%d C=%d: %.3f ms, %.1f TFLOP/s" % (n, c, ms, 2.0 * n * (n - 29) * c / ms / 1e9))

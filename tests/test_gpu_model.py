@@ -949,16 +949,19 @@ def test_trainer_size_classes_train_every_pair_like_the_eager_trainer():
     assert torch.isfinite(tr2.engine.flat.data).all() and not torch.equal(before, tr2.engine.flat.data)
 
 
-def test_trainer_with_two_pairs_in_flight_trains_on_the_mean_gradient_of_each_group():
-    """Trainer(pairs_in_flight=2) over a mix of ~5k- and ~30k-point pairs with two capacity classes: every step trains on
-    two pairs at once (train.PairLanes; the lanes of both classes share streams, gradient buffers and the join), a mixed
-    group goes to the class that holds both pairs, and after the epoch the parameters equal eager training on the mean
-    gradient of each group of two."""
+@pytest.mark.parametrize("n_lanes,stack", [(2, 1), (1, 2), (2, 2)])
+def test_trainer_with_two_pairs_in_flight_trains_on_the_mean_gradient_of_each_group(n_lanes, stack):
+    """Trainer(pairs_in_flight=L, stacked_pairs=Q) over a mix of ~5k- and ~30k-point pairs with two capacity classes: every
+    step trains on L x Q pairs at once (Q pairs stacked into one pyramid + network graph, L such graphs in flight as
+    train.PairLanes; the lanes of both classes share streams, gradient buffers and the join), a mixed group goes to the
+    class that holds all its pairs, and after the epoch the parameters equal eager training on the mean gradient of each
+    group."""
     from d3feat_pytorch_amd.train import PairLanes, TrainStep
     from d3feat_pytorch_amd.trainer import Trainer
     small = [synthetic.make_pair(31 + 2 * i, 32 + 2 * i, _gpu_subsample, n_raw=60000, scale=0.22, num_node=64) for i in range(2)]
     big = [synthetic.make_pair(41 + 2 * i, 42 + 2 * i, _gpu_subsample, n_raw=300000, scale=0.55, num_node=64) for i in range(2)]
     order = [small[0], small[1], big[0], big[1], big[0], small[0], small[1], small[0]]
+    P = n_lanes * stack
 
     class _Loader:
         dataset, batch_size, shuffle = order, 1, False
@@ -967,22 +970,27 @@ def test_trainer_with_two_pairs_in_flight_trains_on_the_mean_gradient_of_each_gr
     cfg.max_epoch, cfg.save_dir, cfg.tboard_dir, cfg.device = 1, None, None, DEV
     cfg.train_loader, cfg.val_max_iter, cfg.verbose, cfg.seed = _Loader(), 1, False, 3
     cfg.neighborhood_limits = [40, 40, 40, 40, 30]
-    cfg.graph, cfg.capacity_classes, cfg.pairs_in_flight = True, 2, 2
+    cfg.graph, cfg.capacity_classes, cfg.pairs_in_flight, cfg.stacked_pairs = True, 2, n_lanes, stack
     tr = Trainer(cfg)
     avg = tr.train_epoch(1)
     torch.cuda.synchronize()
-    assert tr.lanes == 2 and len(tr._engines) == 2 and all(isinstance(e, PairLanes) for e in tr._engines)
-    assert tr._engines[0].engines[0].stream is tr._engines[1].engines[0].stream      # the classes share the lanes
+    assert tr.lanes == n_lanes and tr.stack == stack and tr.group == P and len(tr._engines) == 2
+    if n_lanes > 1:
+        assert all(isinstance(e, PairLanes) for e in tr._engines)
+        assert tr._engines[0].engines[0].stream is tr._engines[1].engines[0].stream      # the classes share the lanes
+    else:
+        assert all(isinstance(e, TrainStep) and e.stack == stack for e in tr._engines)
     assert tr._engines[0].caps[0] < 0.5 * tr._engines[1].caps[0]
     assert tr._report_skipped() == 0 and getattr(tr, 'rerun_pairs', 0) == 0 and int(tr.optimizer.skipped) == 0
     assert np.isfinite(avg['desc_loss']) and 0.0 <= avg['accuracy'] <= 100.0
     ref = TrainStep(cfg, cfg.neighborhood_limits, torch.device(DEV), seed=3)
     start = ref.flat.data.clone()
-    ref.flat.add_lane()
-    ref.opt.grad_scale = 0.5
-    for g in range(len(order) // 2):
-        for k in range(2):
-            it = ref.upload(order[2 * g + k])
+    while len(ref.flat.lanes) < P:
+        ref.flat.add_lane()
+    ref.opt.use_grad_scale(1.0 / P)
+    for g in range(len(order) // P):
+        for k in range(P):
+            it = ref.upload(order[P * g + k])
             batch = ref.build_batch(it)
             batch['n0'] = int(it[0].shape[0])
             ref.flat.bind(k)
@@ -991,7 +999,7 @@ def test_trainer_with_two_pairs_in_flight_trains_on_the_mean_gradient_of_each_gr
             torch.autograd.backward(loss, ref._seed(loss))
             ref.flat.gather_grads()
         ref.flat.bind(0)
-        ref.opt.step(want_ok=False, grads=[ref.flat.lanes[0][0], ref.flat.lanes[1][0]])
+        ref.opt.step(want_ok=False, grads=[ref.flat.lanes[k][0] for k in range(P)])
     torch.cuda.synchronize()
     a, b = tr.engine.flat.data, ref.flat.data
     moved = float((b - start).abs().max())
