@@ -614,7 +614,7 @@ class TrainStep:
         other.enable_graph(capacities, num_corr, stack=stack)
         return other
 
-    def clone_for_lane(self, lane, stream=None, side=None):
+    def clone_for_lane(self, lane, stream=None, side=None, split=None):
         """An engine over the SAME model, parameters and optimizer whose network step leaves its gradient in buffer
         ``lane`` of the flat parameters and does NOT step the optimizer, with streams, static buffer sets and graphs of
         its own: one of the pairs in flight of ``PairLanes``."""
@@ -629,7 +629,7 @@ class TrainStep:
         # several ranks: the lane's backward is cut like the one-pair engine's (stage 1 down to encoder block CUT, stage 2
         # the fine levels) so that the join can exchange the deep gradient bucket under every lane's stage 2
         # (PairLanes.step_graph); one rank: a single network graph per lane
-        other.split_backward = self.world > 1
+        other.split_backward = (self.world > 1) if split is None else bool(split)
         if stream is None or side is None:
             stream, side = fresh_streams(2, self.device)
         other.stream, other._side = stream, side
@@ -1093,10 +1093,13 @@ class PairLanes:
     the update kernel).  With several ranks the summed gradient is all-reduced at the join.
     The reference trains one pair per optimizer step (dataloader.py:73); ``lanes=1`` keeps that."""
 
-    def __init__(self, ts, lanes=2, stack=1):
+    def __init__(self, ts, lanes=2, stack=1, split=None):
+        """``split``: two-stage lane graphs with the join on a stream of its own -- the multi-rank form; default: when
+        there are several ranks (True on one rank runs the same schedule without the all-reduces: tests)."""
         self.ts, self.P, self.Q = ts, int(lanes), int(stack)
+        self.split = (ts.world > 1) if split is None else bool(split)
         nets, sides = lane_streams(self.P, ts.device)
-        self.engines = [ts.clone_for_lane(k, nets[k], sides[k]) for k in range(self.P)]
+        self.engines = [ts.clone_for_lane(k, nets[k], sides[k], split=self.split) for k in range(self.P)]
         for eng in self.engines:
             eng.stack = self.Q
         self.ev_lane = [torch.cuda.Event() for _ in range(self.P)]
@@ -1230,7 +1233,7 @@ class PairLanes:
         self.ts.opt.use_grad_scale(1.0 / (self.P * self.Q * max(1, self.ts.world)))
         outs = []
         host_join = os.environ.get("D3F_LANES_JOIN", "stream") == "host"     # measurement knob
-        split = self.ts.world > 1       # several ranks: two-stage lanes, the deep bucket exchanged under stage 2
+        split = self.split              # several ranks: two-stage lanes, the deep bucket exchanged under stage 2
         for k, eng in enumerate(self.engines):
             eng._ensure_loaded(items[k])
         for k, eng in enumerate(self.engines):     # every network graph first ...
@@ -1261,7 +1264,7 @@ class PairLanes:
                 step = (deep.numel() + nb - 1) // nb
                 for b in range(nb):
                     chunk = deep[b * step:min(deep.numel(), (b + 1) * step)]
-                    if chunk.numel() and self.exchange:
+                    if chunk.numel() and self.exchange and self.ts.world > 1:
                         works.append(dist.all_reduce(chunk, op=dist.ReduceOp.SUM, async_op=True))
             for k, eng in enumerate(self.engines):
                 with torch.cuda.stream(eng.stream):
@@ -1276,7 +1279,7 @@ class PairLanes:
                 shallow = grads[0][:ns]
                 for g in grads[1:]:
                     shallow.add_(g[:ns])
-                if self.exchange:
+                if self.exchange and self.ts.world > 1:
                     works.append(dist.all_reduce(shallow, op=dist.ReduceOp.SUM, async_op=True))
                 for w in works:
                     w.wait()                 # SUM over ranks; the 1 / (pairs x ranks) of the mean is opt.grad_scale

@@ -679,14 +679,16 @@ def test_pair_lanes_make_the_update_of_a_two_rank_step(golden_s0, n_lanes):
     assert tight.check_status(raise_on_skip=False)[1] == 1
 
 
-@pytest.mark.parametrize("stack,n_lanes", [(2, 1), (3, 1), (2, 2)])
-def test_stacked_pairs_train_on_the_sum_of_their_eager_gradients(golden_s0, stack, n_lanes):
+@pytest.mark.parametrize("stack,n_lanes,split", [(2, 1, False), (3, 1, False), (2, 2, False), (2, 2, True)])
+def test_stacked_pairs_train_on_the_sum_of_their_eager_gradients(golden_s0, stack, n_lanes, split):
     """``stack`` fragment pairs stacked into ONE pyramid + ONE network graph (TrainStep.enable_graph(stack=Q)), alone or
     as the lanes of PairLanes: every pair's losses are the eager losses of that pair at the step's parameters, the
     flat gradient is the SUM of the pairs' eager gradients, and the parameters follow the eager mean-gradient SGD step
     after step.  The pairs of a stack differ in size and in the widths of their neighbor tables; what a reference batch
     of one pair shares (table widths dataloader.py:64-66, detector normaliser architectures.py:342, the M x M loss
-    trainer.py:91-98) stays per pair."""
+    trainer.py:91-98) stays per pair.  ``split``: the lanes in their multi-rank form -- every lane's backward in two
+    captured stages, the join (bucket sums, guard, update) on a stream of its own between and behind them -- on one rank,
+    i.e. without the all-reduces: same gradients, same trajectory."""
     from d3feat_pytorch_amd.train import PairLanes, TrainStep
     g = golden_s0
     cfg = cfgmod.default_config(first_features_dim=16, num_node=64)
@@ -715,11 +717,12 @@ def test_stacked_pairs_train_on_the_sum_of_their_eager_gradients(golden_s0, stac
         ref.flat.data.copy_(ts.flat.data)
         buf = ts.opt.buf.clone()
     else:
-        eng = PairLanes(ts, n_lanes, stack=stack)
+        eng = PairLanes(ts, n_lanes, stack=stack, split=split)
         eng.enable_graph(caps, num_corr=item[4].shape[0])
         eng.capture(tuple(steps[0]))
         torch.cuda.synchronize()
         assert torch.equal(ts.flat.data, ref.flat.data)
+        assert all(e.split_backward == split and len(e.g_net_b) == (e.NSETS if split else 0) for e in eng.engines)
         buf = torch.zeros_like(ref.flat.data)
     lr, mom, wd = ref.opt.lr, ref.opt.momentum, ref.opt.weight_decay
     for k, pairs in enumerate(steps):
@@ -747,6 +750,8 @@ def test_stacked_pairs_train_on_the_sum_of_their_eager_gradients(golden_s0, stac
             assert abs(got_det[q] - dets[q]) < 1e-4 * max(1.0, abs(dets[q])), (k, q, got_det[q], dets[q])
         for lane in range(n_lanes):        # each lane's buffer = the sum over ITS stack
             gsum = sum(grads[lane * stack + 1:(lane + 1) * stack], grads[lane * stack].clone())
+            if split and lane == 0:        # (the multi-rank join sums the lanes into lane 0's buffer before the exchange)
+                gsum = sum(grads[1:], grads[0].clone())
             gl = ts.flat.lanes[lane][0]
             assert float((gl - gsum).abs().max()) < 1e-3 * float(gsum.abs().max()), (k, lane)
         gmean = sum(grads[1:], grads[0].clone()) * (1.0 / n)
