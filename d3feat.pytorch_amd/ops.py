@@ -467,6 +467,13 @@ class _KPConvFn(torch.autograd.Function):
         go = grad_out.contiguous().float() if (need_x or need_w) else None
         gw_native, gx_native = gw, gx
         gon = None
+        big_dw = (need_w and wf is not None and Nq >= _SPLITK_MIN_ROWS and wf.shape[1] == K * Cin
+                  and L.d3f_linear_grad_weight_supported(Nq, Cout, K * Cin))
+        if big_dw:
+            # g / nn ONCE (one small elementwise launch) for both consumers: inside the A^T B kernel the division sat in
+            # every lane of every column block behind a dependent 4-byte load (round 4, bench per-launch table:
+            # 23.9k x 480 x 32 in 63 us against 24 us without it), and the gather kernel divided once per edge
+            gon = go / nn.unsqueeze(1)
         if need_x and ctx.rev is not None and Nq > 0:
             # gather over the reverse table: aggregate grad_out/nn around every support, then contract with W^T
             rev = ctx.rev
@@ -475,11 +482,19 @@ class _KPConvFn(torch.autograd.Function):
                 _native.check(L.d3f_kpconv_grad_input_gather(_p(q_pts), Nq, _p(s_pts), Ns, _p(rev.ptr), _p(rev.ent),
                                                              _p(rev.last_key), rev.width, rev.radius, _p(rev.rel),
                                                              _p(kernel_points), K, _p(weights), Cin, Cout, ctx.extent,
-                                                             _p(nn), _p(go), _p(gx),
+                                                             _p(nn) if gon is None else None,
+                                                             _p(go) if gon is None else _p(gon), _p(gx),
                                                              _p(rev.status.word) if rev.status is not None else None,
                                                              _stream()),
                               "d3f_kpconv_grad_input_gather")
             gx_native = None
+        if big_dw:
+            nbytes = L.d3f_linear_grad_weight_ws_bytes(Nq, Cout, K * Cin)
+            ws = _ws(nbytes, x.device)
+            with _region("kpconv_dw_atb[Nq=%d,Cin=%d,Cout=%d]" % (Nq, Cin, Cout), 4 * Nq * (K * Cin + Cout)):
+                _native.check(L.d3f_linear_grad_weight(_p(gon), _p(wf), Nq, Cout, K * Cin, _p(gw), _p(ws), nbytes,
+                                                       _stream()), "d3f_linear_grad_weight")
+            gw_native = None
         if need_w and wf is not None and Nq < _SPLITK_MIN_ROWS and wf.shape[1] == K * Cin:
             # few points, wide layers (bottom of the U-Net): grad_W = wf^T (g/nn) is an ordinary GEMM with a short
             # reduction -- a library call; the reduction-parallel kernel is for the tall-skinny upper levels

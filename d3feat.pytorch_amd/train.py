@@ -966,7 +966,13 @@ class TrainStep:
         st = self.sets[i]
         main = torch.cuda.current_stream(self.device)
         self._use_scale()
-        self.ev_pyr[i].synchronize()
+        side = getattr(self, '_side', None)
+        if not (side is not None and side.cuda_stream == main.cuda_stream):
+            self.ev_pyr[i].synchronize()
+        # (else -- four lanes: a lane builds its pyramids on its OWN stream -- stream order already puts the set's pyramid
+        # in front of this launch.  The host wait made the host follow the GPU step by step (round 4, bench
+        # `host_enqueue_ms_per_step` 20.6 of a 21.5 ms step): every lane's launch waited for that lane's previous step to
+        # drain, and for the lanes before it.)
 
         def done():   # queued behind the pair's network step: host mirror of its status word, then the set's event
             if st.status_host is not None and st.status is not None:

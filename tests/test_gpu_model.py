@@ -753,7 +753,10 @@ def test_stacked_pairs_train_on_the_sum_of_their_eager_gradients(golden_s0, stac
             if split and lane == 0:        # (the multi-rank join sums the lanes into lane 0's buffer before the exchange)
                 gsum = sum(grads[1:], grads[0].clone())
             gl = ts.flat.lanes[lane][0]
-            assert float((gl - gsum).abs().max()) < 1e-3 * float(gsum.abs().max()), (k, lane)
+            # (the float atomics left in backward -- detector, coarse-level scatter -- move single entries by up to
+            # ~1e-3 of the largest one from run to run, eager and replayed alike; the 2-norm is steadier)
+            assert float((gl - gsum).abs().max()) < 2e-3 * float(gsum.abs().max()), (k, lane)
+            assert float((gl - gsum).norm()) < 5e-4 * float(gsum.norm()), (k, lane)
         gmean = sum(grads[1:], grads[0].clone()) * (1.0 / n)
         d = gmean + wd * ref.flat.data
         buf = buf * mom + d
