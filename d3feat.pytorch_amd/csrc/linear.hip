@@ -20,12 +20,13 @@ void* kpconv_timing_open(int which, hipStream_t stream, int Nq, int Ns, int H, i
 void kpconv_timing_close(void* rec, hipStream_t stream);
 
 template <int TI, int TJ, int U>
-__global__ __launch_bounds__(256) void atb_partial_kernel(const float* __restrict__ A, const float* __restrict__ B,
-                                                          const float* __restrict__ row_div, int R, int M, int N,
-                                                          int rows_per_wg, float* __restrict__ part) {
+__global__ __launch_bounds__(256, 4) void atb_partial_kernel(const float* __restrict__ A, const float* __restrict__ B,
+                                                             const float* __restrict__ row_div, int R, int M, int N,
+                                                             int rows_per_wg, float* __restrict__ part) {
   typedef typename VecT<TI>::type VA;
   typedef typename VecT<TJ>::type VB;
-  __shared__ float red[3][TI * TJ * 256];
+  constexpr int HALVES = (TI * TJ >= 16) ? 2 : 1, TH = TI / HALVES;
+  __shared__ float red[3][TH * TJ * 256];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int li = lane & 15, lk = lane >> 4;
   const int nbj = N / (16 * TJ);
@@ -63,30 +64,39 @@ __global__ __launch_bounds__(256) void atb_partial_kernel(const float* __restric
           acc[t][u] = __builtin_amdgcn_mfma_f32_16x16x4f32(vget<TI>(a[s], t), bv, acc[t][u], 0, 0, 0);
       }
   }
-  // combine the 4 waves in a fixed order (wave 0 + 1 + 2 + 3) through LDS
-  if (wave > 0) {
-#pragma unroll
-    for (int t = 0; t < TI; ++t)
-#pragma unroll
-      for (int u = 0; u < TJ; ++u)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) red[wave - 1][((t * TJ + u) * 4 + r) * 64 + lane] = acc[t][u][r];
-  }
-  __syncthreads();
-  if (wave > 0) return;
+  // combine the 4 waves in a fixed order (wave 0 + 1 + 2 + 3) through LDS; 64 x 64 blocks in two rounds of half the
+  // A-side tiles each, so that the staging area is 24 KB instead of 48 (round 4: with the second launch bound -- 126
+  // instead of 184 registers -- a CU then holds four workgroups of this kernel instead of two)
   // D[i][j] (i = 4*lk + r, j = li) is C[m0 + TI*i + t][n0 + TJ*j + u]
   float* pp = part + (size_t)blockIdx.x * M * N;
 #pragma unroll
-  for (int t = 0; t < TI; ++t)
+  for (int h = 0; h < HALVES; ++h) {
+    if (h > 0) __syncthreads();   // wave 0 has read round h - 1
+    if (wave > 0) {
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      float* dst = pp + (size_t)(m0 + TI * (4 * lk + r) + t) * N + n0 + TJ * li;
+      for (int tt = 0; tt < TH; ++tt)
 #pragma unroll
-      for (int u = 0; u < TJ; ++u) {
-        const int e = ((t * TJ + u) * 4 + r) * 64 + lane;
-        dst[u] = ((acc[t][u][r] + red[0][e]) + red[1][e]) + red[2][e];
+        for (int u = 0; u < TJ; ++u)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) red[wave - 1][((tt * TJ + u) * 4 + r) * 64 + lane] = acc[h * TH + tt][u][r];
+    }
+    __syncthreads();
+    if (wave == 0) {
+#pragma unroll
+      for (int tt = 0; tt < TH; ++tt) {
+        const int t = h * TH + tt;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float* dst = pp + (size_t)(m0 + TI * (4 * lk + r) + t) * N + n0 + TJ * li;
+#pragma unroll
+          for (int u = 0; u < TJ; ++u) {
+            const int e = ((tt * TJ + u) * 4 + r) * 64 + lane;
+            dst[u] = ((acc[t][u][r] + red[0][e]) + red[1][e]) + red[2][e];
+          }
+        }
       }
     }
+  }
 }
 
 // C[e] = sum_p part[p][e]: SUBS threads per element each sum a strided share of the slabs, combined in a fixed order
