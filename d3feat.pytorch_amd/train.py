@@ -1093,11 +1093,15 @@ class PairLanes:
     latency.  Two independent steps replayed on two streams fill those holes (1.43x the pairs/s of one,
     profiles/r03_queue_pipes.txt).  ``lanes`` engines share the model, the flat parameter buffer and the optimizer;
     each has its own training stream, side stream, static buffer sets, graphs and GRADIENT buffer (FlatParams.add_lane).
-    A step trains on ``lanes`` pairs at once: every lane replays forward + loss + backward of its pair, then the join
-    (on lane 0's stream) applies ONE guarded SGD step on the sum of the lane gradients scaled by 1/(lanes * world) --
-    exactly the update a data-parallel step over that many ranks makes (d3f_sgd_guarded_step_lanes forms the sum inside
-    the update kernel).  With several ranks the summed gradient is all-reduced at the join.
-    The reference trains one pair per optimizer step (dataloader.py:73); ``lanes=1`` keeps that."""
+    A step trains on ``lanes * stack`` pairs at once: every lane replays forward + loss + backward of its pair -- or of
+    its STACK of ``stack`` pairs (TrainStep ``stack``: one pyramid, one network graph for all of them) --, then the join
+    (on lane 0's stream) applies ONE guarded SGD step on the sum of the lane gradients scaled by
+    1 / (lanes * stack * world) -- exactly the update a data-parallel step over that many ranks makes
+    (d3f_sgd_guarded_step_lanes forms the sum inside the update kernel).
+    With several ranks every lane's backward is captured in two stages and the join moves to a stream of its own: the
+    lanes' deep gradient buckets are summed and all-reduced while every lane's stage 2 (the fine levels) executes, the
+    shallow buckets follow, then the guard on the reduced gradient and the one update (``step_graph``).
+    The reference trains one pair per optimizer step (dataloader.py:73); ``lanes=1, stack=1`` keeps that."""
 
     def __init__(self, ts, lanes=2, stack=1, split=None):
         """``split``: two-stage lane graphs with the join on a stream of its own -- the multi-rank form; default: when
