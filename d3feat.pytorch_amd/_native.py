@@ -67,6 +67,10 @@ SIGNATURES = {
     "d3f_linear_grad_input": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp]),
     "d3f_linear_grad_weight_ws_bytes": (_sz, [_i, _i, _i]),
     "d3f_linear_grad_weight": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _sz, _vp]),
+    "d3f_linear_grad_weight_bias": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _sz, _vp, _i, _i, _vp, _vp, _vp]),
+    "d3f_bias_act_backward_blocks": (_i, [_i, _i]),
+    "d3f_bias_act_backward_partial": (_i, [_vp, _vp, _f, _i, _i, _vp, _vp, _vp, _sz, _vp]),
+    "d3f_bias_sum": (_i, [_vp, _i, _i, _vp, _vp, _vp]),
     "d3f_max_pool_forward": (_i, [_vp, _i, _i, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp]),
     "d3f_max_pool_backward": (_i, [_vp, _vp, _i, _i, _i, _vp, _i, _vp]),
     "d3f_closest_pool_forward": (_i, [_vp, _i, _i, _vp, _i, _i, _vp, _i, _vp, _vp, _vp]),

@@ -298,9 +298,41 @@ size_t d3f_bias_act_backward_ws_bytes(int N, int C) {
   return N >= 4096 ? d3f::align_up(sizeof(float) * (size_t)d3f::cdiv(N, 64) * (size_t)C, 256) : 0;
 }
 
+/* number of partial-sum rows the two-pass form writes into ws ([blocks, C] floats); 0: the one-pass form applies */
+int d3f_bias_act_backward_blocks(int N, int C) { return (N >= 4096 && C >= 1) ? d3f::cdiv(N, 64) : 0; }
+
+static int bias_act_backward_impl(const float* grad_out, const float* out, float slope, int N, int C, float* grad_x,
+                                  float* grad_bias, float* grad_bias2, int bias_prezeroed, const float* row_div,
+                                  void* ws, size_t ws_bytes, void* stream, bool partial_only);
+
+/* First pass only: grad_x (optional) and the per-block partial column sums in ws [d3f_bias_act_backward_blocks, C];
+ * the caller finishes the bias gradient with d3f_linear_grad_weight_bias (inside the weight gradient's second-stage
+ * launch) or d3f_bias_sum. */
+int d3f_bias_act_backward_partial(const float* grad_out, const float* out, float slope, int N, int C, float* grad_x,
+                                  const float* row_div, void* ws, size_t ws_bytes, void* stream) {
+  if (!grad_out || !out || !ws || N < 4096 || C < 1 || ws_bytes < d3f_bias_act_backward_ws_bytes(N, C))
+    return D3F_EINVAL;
+  return bias_act_backward_impl(grad_out, out, slope, N, C, grad_x, (float*)ws, nullptr, 1, row_div, ws, ws_bytes,
+                                stream, true);
+}
+
+int d3f_bias_sum(const float* part, int blocks, int C, float* grad_bias, float* grad_bias2, void* stream) {
+  if (!part || !grad_bias || blocks < 1 || C < 1) return D3F_EINVAL;
+  bias_sum_kernel<<<d3f::cdiv(C, 64), 1024, 0, (hipStream_t)stream>>>(part, blocks, C, grad_bias, grad_bias2);
+  D3F_LAUNCH_CHECK();
+  return D3F_OK;
+}
+
 int d3f_bias_act_backward(const float* grad_out, const float* out, float slope, int N, int C, float* grad_x,
                           float* grad_bias, float* grad_bias2, int bias_prezeroed, const float* row_div, void* ws,
                           size_t ws_bytes, void* stream) {
+  return bias_act_backward_impl(grad_out, out, slope, N, C, grad_x, grad_bias, grad_bias2, bias_prezeroed, row_div, ws,
+                                ws_bytes, stream, false);
+}
+
+static int bias_act_backward_impl(const float* grad_out, const float* out, float slope, int N, int C, float* grad_x,
+                                  float* grad_bias, float* grad_bias2, int bias_prezeroed, const float* row_div,
+                                  void* ws, size_t ws_bytes, void* stream, bool partial_only) {
   if (!grad_out || !out || N < 0 || C < 1 || (!grad_x && !grad_bias) || (grad_bias2 && !grad_bias)) return D3F_EINVAL;
   if (grad_bias && N >= 4096 && ws && ws_bytes >= d3f_bias_act_backward_ws_bytes(N, C)) {
     // many rows: per-block partial column sums + a second, tiny launch instead of contended atomics (deterministic)
@@ -321,11 +353,13 @@ int d3f_bias_act_backward(const float* grad_out, const float* out, float slope, 
 #undef D3F_BAB
     bias_act_bwd_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(grad_out, out, slope, N, C, rows, grad_x, grad_bias,
                                                                grad_bias2, row_div, (float*)ws);
-    bias_sum_kernel<<<d3f::cdiv(C, 64), 1024, 0, (hipStream_t)stream>>>((const float*)ws, (int)grid.x, C, grad_bias,
-                                                                       grad_bias2);
+    if (!partial_only)
+      bias_sum_kernel<<<d3f::cdiv(C, 64), 1024, 0, (hipStream_t)stream>>>((const float*)ws, (int)grid.x, C, grad_bias,
+                                                                         grad_bias2);
     D3F_LAUNCH_CHECK();
     return D3F_OK;
   }
+  if (partial_only) return D3F_EINVAL;
   if (!bias_prezeroed) {
     if (grad_bias && d3f::zero_async(grad_bias, sizeof(float) * (size_t)C, (hipStream_t)stream) != hipSuccess)
       return D3F_ELAUNCH;

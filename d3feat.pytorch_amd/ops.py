@@ -398,6 +398,7 @@ _GEMM_DX_AGG_MIN_COUT = int(__import__('os').environ.get('D3F_GEMM_DX_AGG_MIN_CO
 
 _DW_LIBRARY_MIN_OUT = 1920 * 128
 _DW_LIBRARY_MAX_ROWS = 16384
+_DW_LIBRARY = __import__('os').environ.get('D3F_DW_LIBRARY', '1') != '0'
 
 
 def _takes_gemm_path(Nq, Cin):
@@ -589,22 +590,20 @@ class _KPConvGemmBiasActFn(torch.autograd.Function):
             if gb is None:
                 gb, pre = torch.empty((1, Cout), dtype=torch.float32, device=go.device), 0
         gon = torch.empty_like(go)  # masked gradient / nn
-        wsb, nws = _bias_bwd_ws(Nq, Cout, go.device) if gb is not None else (None, 0)
-        _native.check(L.d3f_bias_act_backward(_p(go), _p(out), ctx.slope, Nq, Cout, _p(gon), _p(gb), None, pre, _p(nn),
-                                              _p(wsb), nws, _stream()), "d3f_bias_act_backward")
+        # many rows: the reduction over the points is what has to be spread over the chip (csrc/linear.hip); a large
+        # output over a few thousand rows (1920 x 128 and up) is an ordinary GEMM again: 36 against 58 us at 6159 rows
+        # (profiles/r04_dw_library_vs_atb.txt; D3F_DW_LIBRARY=0: never, round 5's kernel re-measures it)
+        atb = (ctx.needs_input_grad[5] and Nq >= _SPLITK_MIN_ROWS
+               and bool(L.d3f_linear_grad_weight_supported(Nq, Cout, K * Cin))
+               and not (_DW_LIBRARY and K * Cin * Cout >= _DW_LIBRARY_MIN_OUT and Nq <= _DW_LIBRARY_MAX_ROWS))
+        bias_part, bias_blocks = _epilogue_backward(go, out, ctx.slope, Nq, Cout, gon, gb, None, pre, nn,
+                                                    _FOLD_BIAS_SUM and atb)
         gx = gw = None
         if ctx.needs_input_grad[5]:
             gw = ctx.gw_slot if ctx.gw_slot is not None else torch.empty_like(weights)
-            if Nq >= _SPLITK_MIN_ROWS and L.d3f_linear_grad_weight_supported(Nq, Cout, K * Cin) and not (
-                    K * Cin * Cout >= _DW_LIBRARY_MIN_OUT and Nq <= _DW_LIBRARY_MAX_ROWS):
-                # many rows: the reduction over the points is what has to be spread over the chip (csrc/linear.hip);
-                # a large output over a few thousand rows (1920 x 128 and up) is an ordinary GEMM again: 36 against 58 us
-                # at 6159 rows (profiles/r04_dw_library_vs_atb.txt)
-                nbytes = L.d3f_linear_grad_weight_ws_bytes(Nq, Cout, K * Cin)
-                ws = _ws(nbytes, x.device)
-                with _region("kpconv_dw_atb[Nq=%d,Cin=%d,Cout=%d]" % (Nq, Cin, Cout), 4 * Nq * (K * Cin + Cout)):
-                    _native.check(L.d3f_linear_grad_weight(_p(gon), _p(wf), Nq, Cout, K * Cin, _p(gw), _p(ws), nbytes,
-                                                           _stream()), "d3f_linear_grad_weight")
+            if atb:
+                # x := g / nn [Nq, Cout], grad_out := wf [Nq, K Cin]: grad_W [K Cin, Cout] = wf^T (g / nn)
+                _grad_weight_atb(gon, wf, Nq, Cout, K * Cin, gw, bias_part, bias_blocks, gb, None, "kpconv_dw_atb")
             else:
                 torch.mm(wf.t(), gon, out=gw.view(K * Cin, Cout))
         rev = ctx.rev
@@ -958,16 +957,15 @@ class _LinearBiasActFn(torch.autograd.Function):
             rows = list(gbuf.unbind(0))
             g1 = rows.pop(0) if want1 else None
             g2 = rows.pop(0) if want2 else None
+        first, second = (g1, g2) if g1 is not None else (g2, None)
+        atb = ctx.needs_input_grad[1] and bool(L.d3f_linear_grad_weight_supported(N, Cin, Cout))
+        bias_part, bias_blocks = None, 0
         if ctx.slope == 1.0 and not (want1 or want2):
             gm = go
         else:
             gm = go if ctx.slope == 1.0 else torch.empty_like(go)
-            first, second = (g1, g2) if g1 is not None else (g2, None)
-            wsb, nws = _bias_bwd_ws(N, Cout, go.device) if first is not None else (None, 0)
-            _native.check(L.d3f_bias_act_backward(_p(go), _p(out), ctx.slope, N, Cout,
-                                                  _p(gm) if ctx.slope != 1.0 else None, _p(first), _p(second),
-                                                  pre if first is not None else 0, None, _p(wsb), nws, _stream()),
-                          "d3f_bias_act_backward")
+            bias_part, bias_blocks = _epilogue_backward(go, out, ctx.slope, N, Cout, gm if ctx.slope != 1.0 else None,
+                                                        first, second, pre, None, _FOLD_BIAS_SUM and atb)
         gx = gw = None
         if ctx.needs_input_grad[0]:
             gx = torch.empty_like(x)
@@ -981,17 +979,144 @@ class _LinearBiasActFn(torch.autograd.Function):
                 gx = None
         if ctx.needs_input_grad[1]:
             slot = ctx.gw_slot
-            if L.d3f_linear_grad_weight_supported(N, Cin, Cout):
+            if atb:
                 gw = slot if slot is not None else torch.empty_like(weight)
-                nbytes = L.d3f_linear_grad_weight_ws_bytes(N, Cin, Cout)
-                ws = _ws(nbytes, x.device)
-                with _region("linear_dw[N=%d,Cin=%d,Cout=%d]" % (N, Cin, Cout), 4 * N * (Cin + Cout) + 4 * Cin * Cout):
-                    _native.check(L.d3f_linear_grad_weight(_p(x), _p(gm), N, Cin, Cout, _p(gw), _p(ws), nbytes,
-                                                           _stream()), "d3f_linear_grad_weight")
+                _grad_weight_atb(x, gm, N, Cin, Cout, gw, bias_part, bias_blocks, first, second, "linear_dw")
+                bias_part = None
             else:
                 gw = torch.mm(gm.t(), x, out=slot) if slot is not None else torch.mm(gm.t(), x)
+        if bias_part is not None:      # (not reached: the fold implies the A^T B path)
+            _native.check(L.d3f_bias_sum(_p(bias_part), bias_blocks, Cout, _p(first), _p(second), _stream()),
+                          "d3f_bias_sum")
         return (gx, (_adoptable(gw, ctx.gw_slot) if gw is not None else None), g1,
                 gm if ctx.has[1] and ctx.needs_input_grad[3] else None, g2, None, None, None)
+
+
+# The bias gradient's second pass rides in the weight gradient's second-stage launch (csrc/linear.hip,
+# atb_reduce_bias_kernel) whenever both are two-pass forms: N >= 4096 rows for the epilogue's backward and the A^T B
+# kernel for grad_W.  D3F_FOLD_BIAS_SUM=0: two launches as before (experiments).
+_FOLD_BIAS_SUM = __import__('os').environ.get('D3F_FOLD_BIAS_SUM', '1') != '0'
+
+
+def _epilogue_backward(go, out, slope, N, C, gm, first, second, pre, row_div, fold):
+    """grad through act(. + biases): masked gradient into ``gm`` (None: not wanted) and the bias gradient(s).  With
+    ``fold`` only the first pass runs; returns (partials, blocks) for d3f_linear_grad_weight_bias, else (None, 0)."""
+    L = _native.lib()
+    wsb, nws = _bias_bwd_ws(N, C, go.device) if first is not None else (None, 0)
+    nblk = int(L.d3f_bias_act_backward_blocks(N, C)) if (fold and first is not None and wsb is not None) else 0
+    if nblk > 0:
+        _native.check(L.d3f_bias_act_backward_partial(_p(go), _p(out), float(slope), N, C, _p(gm), _p(row_div), _p(wsb),
+                                                      nws, _stream()), "d3f_bias_act_backward_partial")
+        return wsb, nblk
+    _native.check(L.d3f_bias_act_backward(_p(go), _p(out), float(slope), N, C, _p(gm), _p(first), _p(second),
+                                          pre if first is not None else 0, _p(row_div), _p(wsb), nws, _stream()),
+                  "d3f_bias_act_backward")
+    return None, 0
+
+
+def _grad_weight_atb(x, gm, N, Cin, Cout, gw, bias_part, bias_blocks, first, second, label):
+    """grad_W [Cout, Cin] = gm^T x on the reduction-parallel kernel; with ``bias_part`` its second stage also sums the
+    bias partials into ``first`` (/ ``second``)."""
+    L = _native.lib()
+    nbytes = L.d3f_linear_grad_weight_ws_bytes(N, Cin, Cout)
+    ws = _ws(nbytes, x.device)
+    with _region("%s[N=%d,Cin=%d,Cout=%d]" % (label, N, Cin, Cout), 4 * N * (Cin + Cout) + 4 * Cin * Cout):
+        if bias_part is not None:
+            _native.check(L.d3f_linear_grad_weight_bias(_p(x), _p(gm), N, Cin, Cout, _p(gw), _p(ws), nbytes,
+                                                        _p(bias_part), int(bias_blocks), int(first.numel()),
+                                                        _p(first), _p(second), _stream()), "d3f_linear_grad_weight_bias")
+        else:
+            _native.check(L.d3f_linear_grad_weight(_p(x), _p(gm), N, Cin, Cout, _p(gw), _p(ws), nbytes, _stream()),
+                          "d3f_linear_grad_weight")
+
+
+class _LinearLibBiasActFn(torch.autograd.Function):
+    """act(x W^T + b1 + add + b2) as library GEMM + one epilogue launch, as ONE autograd node (round 5; it used to be
+    _LinearFn followed by _BiasActFn): the backward runs the epilogue's backward, grad_x = g W (library; a sibling
+    branch's deposited gradient accumulated by the GEMM) and grad_W = g^T x, and because both live in one node the bias
+    gradient's second pass is folded into grad_W's second-stage launch.  ``pack``: see bias_act."""
+
+    @staticmethod
+    def forward(ctx, x, weight, b1, add, b2, slope, holder=None, deposit=None, pack=None):
+        L = _native.lib()
+        ctx.holder, ctx.dep = holder, deposit
+        N, C = int(x.shape[0]), int(weight.shape[0])
+        raw = torch.mm(x, weight.t())
+        out = torch.empty_like(raw)
+        nb = int(b1 is not None and ctx.needs_input_grad[2]) + int(b2 is not None and ctx.needs_input_grad[4])
+        gbuf = torch.empty((nb, C), dtype=torch.float32, device=x.device) if nb else None
+        ctx.gbuf, ctx.slope = gbuf, float(slope)
+        ctx.has = (b1 is not None, add is not None, b2 is not None)
+        ctx.gw_slot = _grad_slot(weight)
+        if pack is not None:
+            s_pts, want_clear = pack
+            spack = torch.empty(16 * N, dtype=torch.uint8, device=x.device)
+            gx_clear = torch.empty_like(raw) if want_clear else None
+            _native.check(L.d3f_bias_act_forward_pack(
+                _p(raw), _p(b1), _p(add), _p(b2), float(slope), N, C, _p(out), _p(gbuf), nb * C, None, None, 0, 0,
+                _p(s_pts), _p(spack), _p(gx_clear), _stream()), "d3f_bias_act_forward_pack")
+            ctx.save_for_backward(x, weight, out)
+            ctx.mark_non_differentiable(spack)
+            if gx_clear is not None:
+                ctx.mark_non_differentiable(gx_clear)
+            ctx.set_materialize_grads(False)
+            return out, spack, gx_clear
+        _native.check(L.d3f_bias_act_forward(_p(raw), _p(b1), _p(add), _p(b2), float(slope), N, C, _p(out), _p(gbuf),
+                                             nb * C, None, None, 0, 0, _stream()), "d3f_bias_act_forward")
+        ctx.save_for_backward(x, weight, out)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out, *_unused):
+        x, weight, out = ctx.saved_tensors
+        none = (None,) * 9
+        if grad_out is None:
+            return none
+        L = _native.lib()
+        N, Cin, Cout = int(x.shape[0]), int(x.shape[1]), int(weight.shape[0])
+        go = grad_out.contiguous()
+        want1 = ctx.has[0] and ctx.needs_input_grad[2]
+        want2 = ctx.has[2] and ctx.needs_input_grad[4]
+        g1 = g2 = None
+        pre = 0
+        if want1 or want2:
+            gbuf, pre = ctx.gbuf, 1
+            ctx.gbuf = None
+            if gbuf is None:
+                gbuf, pre = torch.empty((int(want1) + int(want2), Cout), dtype=torch.float32, device=go.device), 0
+            rows = list(gbuf.unbind(0))
+            g1 = rows.pop(0) if want1 else None
+            g2 = rows.pop(0) if want2 else None
+        first, second = (g1, g2) if g1 is not None else (g2, None)
+        need_w = ctx.needs_input_grad[1]
+        atb = need_w and N >= _SPLITK_MIN_ROWS and bool(L.d3f_linear_grad_weight_supported(N, Cin, Cout))
+        bias_part, bias_blocks = None, 0
+        identity = ctx.slope == 1.0
+        if identity and first is None:
+            gm = go
+        else:
+            gm = go if identity else torch.empty_like(go)
+            bias_part, bias_blocks = _epilogue_backward(go, out, ctx.slope, N, Cout, None if identity else gm, first,
+                                                        second, pre, None, _FOLD_BIAS_SUM and atb)
+        gx = _add_deposited(ctx.holder, gm, weight) if ctx.needs_input_grad[0] else None
+        if gx is not None and ctx.dep is not None and ctx.dep.deposit(gx):
+            gx = None
+        gw = None
+        if need_w:
+            slot = ctx.gw_slot
+            if atb:
+                gw = slot if slot is not None else torch.empty_like(weight)
+                _grad_weight_atb(x, gm, N, Cin, Cout, gw, bias_part, bias_blocks, first, second, "linear_dw")
+                bias_part = None
+            elif slot is not None:
+                gw = torch.mm(gm.t(), x, out=slot)
+            else:
+                gw = torch.mm(gm.t(), x)
+        if bias_part is not None:      # (not reached: fold implies the A^T B path)
+            _native.check(L.d3f_bias_sum(_p(bias_part), bias_blocks, Cout, _p(first), _p(second), _stream()),
+                          "d3f_bias_sum")
+        return (gx, (_adoptable(gw, ctx.gw_slot) if gw is not None else None), g1,
+                gm if ctx.has[1] and ctx.needs_input_grad[3] else None, g2, None, None, None, None)
 
 
 class _UpsampleLinearFn(torch.autograd.Function):
@@ -1047,10 +1172,10 @@ class _UpsampleLinearFn(torch.autograd.Function):
             g2 = rows.pop(0) if want2 else None
         gm = torch.empty_like(go)
         first, second = (g1, g2) if g1 is not None else (g2, None)
-        wsb, nws = _bias_bwd_ws(N, Cout, go.device) if first is not None else (None, 0)
-        _native.check(L.d3f_bias_act_backward(_p(go), _p(out), ctx.slope, N, Cout, _p(gm), _p(first), _p(second),
-                                              pre if first is not None else 0, None, _p(wsb), nws, _stream()),
-                      "d3f_bias_act_backward")
+        atb = (ctx.needs_input_grad[3] and N >= _SPLITK_MIN_ROWS
+               and bool(L.d3f_linear_grad_weight_supported(N, Cs, Cout)))
+        bias_part, bias_blocks = _epilogue_backward(go, out, ctx.slope, N, Cout, gm, first, second, pre, None,
+                                                    _FOLD_BIAS_SUM and atb)
         # pooled gradient of the coarse product: g_t[m] = sum_{n: idx[n,0] = m} gm[n]
         gt, ctx.gt_buf = ctx.gt_buf, None
         pre_t = 1 if gt is not None else 0
@@ -1068,12 +1193,9 @@ class _UpsampleLinearFn(torch.autograd.Function):
             slot = ctx.gw_slot
             gw = slot if slot is not None else torch.empty_like(weight)
             torch.mm(gt.t(), xc, out=gw[:, :Cc])      # the GEMMs write their column block of W's gradient in place
-            if N >= _SPLITK_MIN_ROWS and L.d3f_linear_grad_weight_supported(N, Cs, Cout):
+            if atb:
                 tmp = torch.empty((Cout, Cs), dtype=torch.float32, device=go.device)
-                nbytes = L.d3f_linear_grad_weight_ws_bytes(N, Cs, Cout)
-                ws = _ws(nbytes, go.device)
-                _native.check(L.d3f_linear_grad_weight(_p(skip), _p(gm), N, Cs, Cout, _p(tmp), _p(ws), nbytes,
-                                                       _stream()), "d3f_linear_grad_weight")
+                _grad_weight_atb(skip, gm, N, Cs, Cout, tmp, bias_part, bias_blocks, first, second, "linear_dw")
                 gw[:, Cc:].copy_(tmp)
             else:
                 torch.mm(gm.t(), skip, out=gw[:, Cc:])
@@ -1097,6 +1219,8 @@ def upsample_linear_bias_act(x_coarse, inds, skip, weight, bias1=None, bias2=Non
 
 # rows from which the unary blocks use the fused row-streaming kernels instead of library GEMM + epilogue launch
 _FUSED_LINEAR_MIN_ROWS = 4096
+# library GEMM + epilogue as ONE autograd node (_LinearLibBiasActFn); D3F_MERGED_UNARY=0: the two nodes of rounds 1-4
+_MERGED_UNARY = __import__('os').environ.get('D3F_MERGED_UNARY', '1') != '0'
 
 
 def linear_bias_act(x, weight, bias1=None, add=None, bias2=None, slope=0.1, grad_holder=None, grad_deposit=None,
@@ -1114,6 +1238,18 @@ def linear_bias_act(x, weight, bias1=None, add=None, bias2=None, slope=0.1, grad
         b2 = _f32(bias2, "bias2") if bias2 is not None else None
         a = _f32(add, "add") if add is not None else None
         return _LinearBiasActFn.apply(x, weight, b1, a, b2, float(slope), grad_holder, grad_deposit)
+    if _MERGED_UNARY and x.dim() == 2 and x.is_cuda and (add is None or add.shape == (N, Cout)):
+        b1 = _f32(bias1, "bias1") if bias1 is not None else None
+        b2 = _f32(bias2, "bias2") if bias2 is not None else None
+        a = _f32(add, "add") if add is not None else None
+        if pack_for is not None and N > 0 and _native.lib().d3f_bias_act_packs(Cout) and N * Cout < 2 ** 32 and \
+                int(pack_for[0].shape[0]) == N:
+            s_pts = _f32(pack_for[0], "s_pts")
+            out, spack, gx_clear = _LinearLibBiasActFn.apply(x, weight, b1, a, b2, float(slope), grad_holder,
+                                                             grad_deposit, (s_pts, bool(pack_for[1])))
+            out._d3f_spack = PackedSupports(spack, gx_clear, s_pts, N, Cout)
+            return out
+        return _LinearLibBiasActFn.apply(x, weight, b1, a, b2, float(slope), grad_holder, grad_deposit)
     return bias_act(linear_nobias(x, weight, grad_holder, grad_deposit), bias1, add, bias2, slope=slope,
                     pack_for=pack_for)
 

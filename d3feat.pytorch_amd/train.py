@@ -844,9 +844,18 @@ class TrainStep:
         # recorded against them.  Each pyramid graph owns its memory pool: in a shared pool the scratch of one build
         # would be laid over the adopted outputs of another set, which a network graph may be reading at that moment.
         # (The network graphs never run concurrently and replay in capture order: they do share a pool.)
+        # A lane's graphs are captured ON THE LANE'S OWN STREAM, not on torch.cuda.graph's default capture stream (one per
+        # process): PyTorch keeps one BLAS workspace per (handle, stream) and a captured library GEMM has the workspace of
+        # its CAPTURE stream baked in -- graphs of different lanes captured on the shared default stream would all hold
+        # the same workspace and then replay CONCURRENTLY on the lanes' streams, their split-K partial sums / semaphores
+        # on top of each other (round 5: the root of round 4's "hipBLASLt winner never finishes on a later replay",
+        # profiles/r05_hipblaslt_hang.txt; with rocBLAS split-K solutions the same sharing is a silent race).
+        cap = getattr(self, 'stream', None) if getattr(self, 'lane', None) is not None else None
+        if os.environ.get('D3F_SHARED_CAPTURE_STREAM') == '1':     # (experiments: rounds 1-4's behaviour)
+            cap = None
         for i in range(self.NSETS):
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g, capture_error_mode=_CAPTURE_MODE):
+            with torch.cuda.graph(g, stream=cap, capture_error_mode=_CAPTURE_MODE):
                 self._build_set(self.sets[i], adopt=True)
             self.g_pyr.append(g)
         for g in self.g_pyr:    # a capture records, it does not run: fill the adopted tensors (inputs are loaded)
@@ -857,7 +866,8 @@ class TrainStep:
             g = torch.cuda.CUDAGraph()
             lane_split = self.split_backward and getattr(self, 'lane', None) is not None
             s1, s2 = self._lane_stages(self.sets[i]) if lane_split else (None, None)
-            with torch.cuda.graph(g, pool=self.g_net[0].pool() if self.g_net else None, capture_error_mode=_CAPTURE_MODE):
+            with torch.cuda.graph(g, pool=self.g_net[0].pool() if self.g_net else None, stream=cap,
+                                  capture_error_mode=_CAPTURE_MODE):
                 if lane_split:
                     self._graph_out.append(s1())
                 elif self.split_backward:
@@ -868,7 +878,7 @@ class TrainStep:
             self.g_net.append(g)
             if self.split_backward:  # stage 2 of the same step: continues in the same pool
                 g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g, pool=self.g_net[0].pool(), capture_error_mode=_CAPTURE_MODE):
+                with torch.cuda.graph(g, pool=self.g_net[0].pool(), stream=cap, capture_error_mode=_CAPTURE_MODE):
                     if lane_split:
                         s2()
                     else:

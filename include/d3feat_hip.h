@@ -239,6 +239,13 @@ int d3f_linear_grad_input(const float* grad_out, const float* weight, int N, int
 size_t d3f_linear_grad_weight_ws_bytes(int N, int Cin, int Cout);
 int d3f_linear_grad_weight(const float* x, const float* grad_out, int N, int Cin, int Cout, float* grad_w, void* ws,
                            size_t ws_bytes, void* stream);
+/* The same, and the second-stage launch (the fixed-order sum of the partial gradient slabs) also finishes the bias
+ * gradient of the block -- autograd's grad_out.sum(0) for the bias of nn.Linear / BatchNormBlock's bias
+ * (models/blocks.py:473,497): grad_bias[c] (and grad_bias2[c], optional) = sum_b bias_part[b][c] over the
+ * bias_blocks x bias_cols partial column sums d3f_bias_act_backward_partial wrote. */
+int d3f_linear_grad_weight_bias(const float* x, const float* grad_out, int N, int Cin, int Cout, float* grad_w, void* ws,
+                                size_t ws_bytes, const float* bias_part, int bias_blocks, int bias_cols,
+                                float* grad_bias, float* grad_bias2, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Pools -- replace models/blocks.py:94-110 (max_pool) and :79-91 (closest_pool).
@@ -298,6 +305,13 @@ size_t d3f_bias_act_backward_ws_bytes(int N, int C);
 int d3f_bias_act_backward(const float* grad_out, const float* out, float slope, int N, int C, float* grad_x,
                           float* grad_bias, float* grad_bias2, int bias_prezeroed, const float* row_div, void* ws,
                           size_t ws_bytes, void* stream);
+/* The two passes of the many-row form separately (N >= 4096: d3f_bias_act_backward_blocks(N, C) > 0 partial rows):
+ * _partial writes grad_x (optional) and the partial column sums ws [blocks, C]; the bias gradient is finished either by
+ * d3f_linear_grad_weight_bias -- inside the launch that sums the weight gradient's slabs -- or by d3f_bias_sum. */
+int d3f_bias_act_backward_blocks(int N, int C);
+int d3f_bias_act_backward_partial(const float* grad_out, const float* out, float slope, int N, int C, float* grad_x,
+                                  const float* row_div, void* ws, size_t ws_bytes, void* stream);
+int d3f_bias_sum(const float* part, int blocks, int C, float* grad_bias, float* grad_bias2, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Deformable KPConv -- replaces the deformable=True branch of KPConv.forward (models/blocks.py:243-257,286-324,365-366).
