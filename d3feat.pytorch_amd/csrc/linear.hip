@@ -210,7 +210,7 @@ extern __shared__ __attribute__((aligned(1024))) unsigned char atb_smem[];
 template <int TI, int TJ, int KS, int S, bool DIV>
 __global__ __launch_bounds__(256, (TI * TJ > 16) ? 1 : 2) void atb2_partial_kernel(
     const float* __restrict__ A, const float* __restrict__ B, const float* __restrict__ row_div, int R, int M, int N,
-    int rows_per_wg, int P, float* __restrict__ part) {
+    int rows_per_wg, int P, float* __restrict__ part, int dbg) {
   constexpr int BM = 16 * TI, BN = 16 * TJ, ROWS = 4 * KS;
   constexpr int A_BYTES = ROWS * BM * 4, B_BYTES = ROWS * BN * 4, D_BYTES = DIV ? 256 : 0;
   constexpr int SB = A_BYTES + B_BYTES + D_BYTES;
@@ -263,12 +263,14 @@ __global__ __launch_bounds__(256, (TI * TJ > 16) ? 1 : 2) void atb2_partial_kern
     }
   };
 
+  // dbg (measurement only, D3F_ATB2_DBG): 1 = no loads (the MFMA / LDS-read side alone), 2 = no MFMAs (the LDS-DMA side
+  // alone); results are garbage then
 #pragma unroll
   for (int i = 0; i < S; ++i)
-    if (i < n_my) issue(i, i);
+    if (i < n_my && !(dbg & 1)) issue(i, i);
   int slot = 0;
   for (int it = 0; it < n_my; ++it) {
-    wait_groups<G, S - 1>(min(S - 1, n_my - 1 - it));    // group `it` has landed
+    if (!(dbg & 1)) wait_groups<G, S - 1>(min(S - 1, n_my - 1 - it));    // group `it` has landed
     const int rg = r0 + (wave + 4 * it) * ROWS;
     const float* sA = (const float*)(ring + slot * SB);
     const float* sB = (const float*)(ring + slot * SB + A_BYTES);
@@ -285,6 +287,7 @@ __global__ __launch_bounds__(256, (TI * TJ > 16) ? 1 : 2) void atb2_partial_kern
       if constexpr (DIV) sc[ks] = (rg + row < r1) ? 1.0f / sD[row] : 0.0f;
     }
     __builtin_amdgcn_sched_barrier(0);   // (the scheduler otherwise sinks every read back in front of its own MFMAs)
+    if (!(dbg & 2))
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
 #pragma unroll
@@ -294,7 +297,7 @@ __global__ __launch_bounds__(256, (TI * TJ > 16) ? 1 : 2) void atb2_partial_kern
         for (int t = 0; t < TI; ++t) acc[t][u] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[ks][t], bv, acc[t][u], 0, 0, 0);
       }
     }
-    if (it + S < n_my) {
+    if (it + S < n_my && !(dbg & 1)) {
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the slot's reads have returned before it is refilled
       issue(it + S, slot);
     }
@@ -407,7 +410,7 @@ static Atb2Cfg atb2_config(int R, int M, int N, bool div) {
   c.tj = tile_width2(N, tmax);
   if (c.ti == 8 && c.tj == 8) c.tj = 4;                  // (64 accumulator tiles per wave spill; 128 x 64 blocks)
   c.ks = env_int("D3F_ATB2_KS", 4);
-  c.s = env_int("D3F_ATB2_S", 3);
+  c.s = env_int("D3F_ATB2_S", 2);
   if (div || c.ti == 1 || c.tj == 1) c.ks = 4;            // (16-wide panels: 16 rows fill one wave-instruction)
   if (div && c.s > 3) c.s = 3;
   if (c.ks != 2 && c.ks != 4) c.ks = 4;
@@ -418,26 +421,39 @@ static Atb2Cfg atb2_config(int R, int M, int N, bool div) {
   c.ok = c.lds <= 160 * 1024;
   const long long nblk = (long long)(M / (16 * c.ti)) * (N / (16 * c.tj));
   const int rows = 4 * c.ks;
-  // workgroups: one or two per CU (LDS decides), every wave with a few ring revolutions of work
+  // Row partitions.  The kernel keeps every output block of partition p on XCD p % 8, so partitions come in multiples
+  // of 8 (fewer would leave whole XCDs idle: measured, 6208 x 512 x 512 on P = 4 took 81 us against 41 on P = 8) and
+  // one XCD's share of the launch, (P / 8) nblk workgroups, should fit its 32 CUs in ONE round -- a second, partly
+  // filled round costs as much as the first (23872 x 960 x 64: P = 34 put 75 workgroups on two XCDs' 64 slots).
   int per_cu = (int)((160 * 1024) / c.lds);
-  if (per_cu > 2) per_cu = 2;
-  if (c.ti * c.tj > 16) per_cu = 1;
-  const int target = env_int("D3F_ATB2_WGS", 0) ? env_int("D3F_ATB2_WGS", 0) : 256 * per_cu;
-  long long P = (target + nblk / 2) / nblk;
-  const int min_groups = env_int("D3F_ATB2_MIN_GROUPS", 2 * c.s);     // groups per WAVE
-  const long long max_by_rows = (long long)R / ((long long)4 * rows * min_groups);
-  if (P > max_by_rows) P = max_by_rows;
-  if (P > 1024) P = 1024;
-  if (P < 1) P = 1;
-  long long rpw = (R + P - 1) / P;
+  if (per_cu > 4) per_cu = 4;
+  if (c.ti * c.tj > 16) per_cu = 1;                       // (launch bound of the 32-tile instantiations)
+  if (per_cu < 1) per_cu = 1;
+  const long long slots = env_int("D3F_ATB2_WGS", 0) ? env_int("D3F_ATB2_WGS", 0) / 8 : 32LL * per_cu;   // per XCD
+  long long q = slots / nblk;
+  const int min_groups = env_int("D3F_ATB2_MIN_GROUPS", c.s);         // groups per WAVE: one ring revolution
+  const long long q_rows = (long long)R / ((long long)8 * 4 * rows * min_groups);
+  if (q > q_rows) q = q_rows;
+  if (q > 128) q = 128;
+  if (q < 1) q = 1;
+  long long rpw = (R + 8 * q - 1) / (8 * q);
   rpw = (rpw + 4 * rows - 1) / (4 * rows) * (4 * rows);  // whole groups for every wave
   c.rpw = (int)rpw;
   c.P = (int)((R + rpw - 1) / rpw);
   return c;
 }
-static bool atb2_wanted(const float* A, const float* B, const float* row_div) {
-  if (env_int("D3F_ATB_V", 2) < 2) return false;
-  return (((uintptr_t)A | (uintptr_t)B) & 15) == 0 && (((uintptr_t)row_div) & 3) == 0;
+// Which form runs (profiles/r05_atb_sweep.txt, 28 launches of a 3-pair stack's step: first form 762 us, second form
+// everywhere 688, the better of the two per shape 648): the second form where there is arithmetic to pipeline -- from
+// 1.4 GFLOP per launch, and for the wide-by-narrow KPConv gradients (960 x 64, 480 x 32) from 0.7 --, the first form,
+// whose workgroups start faster, on the small launches.  D3F_ATB_V = 1 / 3: always the first / second form.
+static bool atb2_wanted(const float* A, const float* B, const float* row_div, int R, int M, int N) {
+  const int v = env_int("D3F_ATB_V", 2);
+  if (v < 2) return false;
+  if ((((uintptr_t)A | (uintptr_t)B) & 15) != 0 || (((uintptr_t)row_div) & 3) != 0) return false;
+  if (v >= 3) return true;
+  const double flops = 2.0 * R * (double)M * N;
+  const int wide = M > N ? M : N, narrow = M > N ? N : M;
+  return flops >= 1.4e9 || (wide >= 480 && narrow <= 64 && flops >= 0.7e9);
 }
 
 size_t atb_ws_bytes(int R, int M, int N) {
@@ -517,7 +533,8 @@ static int atb2_launch(const Atb2Cfg& c, const float* A, const float* B, const f
   }
   const long long nblk = (long long)(M / (16 * TI)) * (N / (16 * TJ));
   const long long P8 = ((long long)c.P + 7) / 8 * 8;      // (partitions past P exit at once: see the XCD mapping)
-  kern<<<(unsigned)(P8 * nblk), 256, c.lds, stream>>>(A, B, row_div, R, M, N, c.rpw, c.P, part);
+  kern<<<(unsigned)(P8 * nblk), 256, c.lds, stream>>>(A, B, row_div, R, M, N, c.rpw, c.P, part,
+                                                      env_int("D3F_ATB2_DBG", 0));
   return D3F_OK;
 }
 
@@ -574,7 +591,7 @@ int atb_splitk_bias(const float* A, const float* B, const float* row_div, int R,
   void* timing = kpconv_timing_open(4, stream, R, 0, 0, M, N, 0);   // (both launches: partial sums + their reduction)
   int P = 0;
   bool launched = false;
-  if (atb2_wanted(A, B, row_div)) {
+  if (atb2_wanted(A, B, row_div, R, M, N)) {
     const Atb2Cfg c = atb2_config(R, M, N, row_div != nullptr);
     if (c.ok) {
       const int rc = row_div ? atb2_dispatch<true>(c, A, B, row_div, R, M, N, part, stream)

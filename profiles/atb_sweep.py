@@ -22,17 +22,17 @@ SHAPES = [(114688, 32, 384), (23872, 256, 256), (6208, 512, 512), (6208, 128, 51
 COUNT = {(6208, 128, 512): 2, (6208, 512, 128): 2, (23872, 64, 256): 2, (23872, 256, 64): 2, (23872, 960, 64): 2}
 
 CONFIGS = [("v1", {"D3F_ATB_V": "1"}),
-           ("k4s3", {"D3F_ATB_V": "2", "D3F_ATB2_KS": "4", "D3F_ATB2_S": "3"}),
-           ("k4s2", {"D3F_ATB_V": "2", "D3F_ATB2_KS": "4", "D3F_ATB2_S": "2"}),
            ("k2s4", {"D3F_ATB_V": "2", "D3F_ATB2_KS": "2", "D3F_ATB2_S": "4"}),
-           ("k4s4", {"D3F_ATB_V": "2", "D3F_ATB2_KS": "4", "D3F_ATB2_S": "4"}),
-           ("k4s3t8", {"D3F_ATB_V": "2", "D3F_ATB2_KS": "4", "D3F_ATB2_S": "3", "D3F_ATB2_TMAX": "8"}),
+           ("k2s3", {"D3F_ATB_V": "2", "D3F_ATB2_KS": "2", "D3F_ATB2_S": "3"}),
+           ("k2s2", {"D3F_ATB_V": "2", "D3F_ATB2_KS": "2", "D3F_ATB2_S": "2"}),
+           ("k4s2", {"D3F_ATB_V": "2", "D3F_ATB2_KS": "4", "D3F_ATB2_S": "2"}),
+           ("k4s3", {"D3F_ATB_V": "2", "D3F_ATB2_KS": "4", "D3F_ATB2_S": "3"}),
+           ("k2s4g2", {"D3F_ATB_V": "2", "D3F_ATB2_KS": "2", "D3F_ATB2_S": "4", "D3F_ATB2_MIN_GROUPS": "2"}),
+           ("k2s4g8", {"D3F_ATB_V": "2", "D3F_ATB2_KS": "2", "D3F_ATB2_S": "4", "D3F_ATB2_MIN_GROUPS": "8"}),
+           ("k2s4w1k", {"D3F_ATB_V": "2", "D3F_ATB2_KS": "2", "D3F_ATB2_S": "4", "D3F_ATB2_WGS": "1024"}),
+           ("k2s4w256", {"D3F_ATB_V": "2", "D3F_ATB2_KS": "2", "D3F_ATB2_S": "4", "D3F_ATB2_WGS": "256"}),
            ("k2s4t8", {"D3F_ATB_V": "2", "D3F_ATB2_KS": "2", "D3F_ATB2_S": "4", "D3F_ATB2_TMAX": "8"}),
-           ("k4s3w512", {"D3F_ATB_V": "2", "D3F_ATB2_KS": "4", "D3F_ATB2_S": "3", "D3F_ATB2_WGS": "512"}),
-           ("k2s4w768", {"D3F_ATB_V": "2", "D3F_ATB2_KS": "2", "D3F_ATB2_S": "4", "D3F_ATB2_WGS": "768"}),
-           ("k4s3w128", {"D3F_ATB_V": "2", "D3F_ATB2_KS": "4", "D3F_ATB2_S": "3", "D3F_ATB2_WGS": "128"}),
-           ("k4s3g3", {"D3F_ATB_V": "2", "D3F_ATB2_KS": "4", "D3F_ATB2_S": "3", "D3F_ATB2_MIN_GROUPS": "3"}),
-           ("k4s3g12", {"D3F_ATB_V": "2", "D3F_ATB2_KS": "4", "D3F_ATB2_S": "3", "D3F_ATB2_MIN_GROUPS": "12"})]
+           ("k2s2t8", {"D3F_ATB_V": "2", "D3F_ATB2_KS": "2", "D3F_ATB2_S": "2", "D3F_ATB2_TMAX": "8"})]
 KEYS = sorted({k for _, e in CONFIGS for k in e})
 if len(sys.argv) > 1 and sys.argv[1] == "quick":
     CONFIGS = CONFIGS[:3]
