@@ -697,6 +697,34 @@ def main():
                 exchange_only()
             torch.cuda.synchronize()
             t_comm = (time.perf_counter() - tc0) / args.steps
+            # ... and the same three legs for the REFERENCE's schedule (one pair per optimizer step and rank: the hard case,
+            # 97 MB of gradients per ~4 ms step): the one-pair engine's split graphs without their all-reduces
+            if lanes is not None and one_in_flight is not None:
+                try:
+                    keep1 = (ts.flat.data.clone(), ts.opt.buf.clone())
+                    ts.world = 1
+                    for k in range(2):
+                        run_one(k)
+                    torch.cuda.synchronize()
+                    dist.barrier()
+                    tq0 = time.perf_counter()
+                    for k in range(args.steps):
+                        run_one(2 + k)
+                    torch.cuda.synchronize()
+                    t_noex1 = (time.perf_counter() - tq0) / args.steps
+                    ts.world = ts_world
+                    ts.flat.data.copy_(keep1[0])
+                    ts.opt.buf.copy_(keep1[1])
+                    t_step1 = one_in_flight["ms_per_step"] * 1e-3
+                    exposed1 = max(0.0, t_step1 - t_noex1)
+                    one_in_flight["exchange"] = {
+                        "step_ms": round(t_step1 * 1e3, 3), "step_without_exchange_ms": round(t_noex1 * 1e3, 3),
+                        "exchange_alone_ms": round(t_comm * 1e3, 3), "exposed_ms": round(exposed1 * 1e3, 3),
+                        "overlap_frac": round(1.0 - exposed1 / t_comm, 3) if t_comm > 0 else None,
+                        "buckets": "3 deep chunks (overlapped with the stage-2 backward graph) + 1 shallow"}
+                except Exception as e:  # pragma: no cover
+                    ts.world = ts_world
+                    one_in_flight["exchange"] = {"error": "%s: %s" % (type(e).__name__, e)}
             t_step = (t1 - t0) / args.steps
             exposed = max(0.0, t_step - t_noex)
             exchange = {"rccl_ranks": world, "backend": dist.get_backend(), "bytes_per_step": int(g.numel() * 4),

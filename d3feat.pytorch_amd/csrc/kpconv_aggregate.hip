@@ -70,9 +70,10 @@ __device__ __forceinline__ void store_agg_row(float* __restrict__ out_row, int K
 
 // forward direction: grid (query tiles of 16, channel chunks of 16 CV); NSTEPS = ceil(H / 16)
 // (second launch bound = waves per SIMD the register allocation aims for: 114 instead of 136 VGPRs at 64 channels x 48
-// neighbors, four resident waves instead of three; no spills below 49 neighbors)
+// neighbors, four resident waves instead of three; no spills below 49 neighbors.  The 49..64-neighbor body -- 16 gathers
+// in flight per lane -- does not fit 128 registers: it asks for three waves per SIMD instead of spilling)
 template <int CV, int NSTEPS>
-__global__ __launch_bounds__(256, 4) void kpconv_agg_fwd_kernel(const float* __restrict__ q_pts,
+__global__ __launch_bounds__(256, (NSTEPS >= 4 ? 3 : 4)) void kpconv_agg_fwd_kernel(const float* __restrict__ q_pts,
                                                              const float4* __restrict__ spack,
                                                              const int32_t* __restrict__ idx, const float* __restrict__ x,
                                                              const float* __restrict__ kp, int Nq, int Ns, int H, int Cin,

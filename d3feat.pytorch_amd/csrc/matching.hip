@@ -140,14 +140,18 @@ __global__ __launch_bounds__(256) void row_argmin_kernel(const float* __restrict
         for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
           for (int r = 0; r < 4; ++r) m = fmaxf(m, acc[rt][r]);
-        const float mthr = m - 4e-7f;
+        // Margin: two products can share the rounded sqrt(2 - 2a) when they differ by less than ~ulp(sqrt v) sqrt v +
+        // ulp(v) / 2 <= 3.6e-7 (worst case v ~ 4, a ~ -1: anti-correlated descriptors); 1e-6 leaves a factor of 2.7.
+        // `!(a <= mthr)` also counts a NaN product (fmaxf drops NaNs, so m alone does not see one next to finite
+        // products): any NaN in the lane takes the slow path, which looks at every candidate on its own.
+        const float mthr = m - 1e-6f;
         int ri = 0, near = 0;
 #pragma unroll
         for (int rt = RT - 1; rt >= 0; --rt)
 #pragma unroll
           for (int r = 3; r >= 0; --r) {
             if (acc[rt][r] == m) ri = 16 * rt + r;
-            near += acc[rt][r] > mthr ? 1 : 0;
+            near += !(acc[rt][r] <= mthr) ? 1 : 0;
           }
         unsigned long long ckey;
         if (near > 1 || !(m == m)) {   // (rare; NaN products: every candidate is looked at)

@@ -138,7 +138,7 @@ __global__ __launch_bounds__(kQueryWaves * 64) void radius_query_kernel(
     const int32_t* __restrict__ end, const float4* __restrict__ pts, const uint64_t* __restrict__ key, int width,
     int32_t* __restrict__ out_idx, int32_t* __restrict__ out_counts, int32_t* __restrict__ max_count,
     int32_t* __restrict__ status, int32_t* __restrict__ out_wide, int wide_width, uint64_t* __restrict__ out_last_key,
-    int max_count_group) {
+    int max_count_group, float r2_prefix) {
   __shared__ WaveScratch scratch[kQueryWaves];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int qi = blockIdx.x * kQueryWaves + wave;
@@ -183,6 +183,10 @@ __global__ __launch_bounds__(kQueryWaves * 64) void radius_query_kernel(
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 
+  // prefix mode (r2_prefix > 0, d3f_radius_query_prefix): only the entries within the PREFIX radius are ranked; of the
+  // others the nearest is carried along as a running minimum of the same (d2, index) keys
+  const bool prefix = r2_prefix > 0.0f;
+  uint64_t nearest = ~0ull;
   int T = 0;
   for (int p0 = 0; p0 < P; p0 += 64) {
     const int p = p0 + lane;
@@ -201,6 +205,10 @@ __global__ __launch_bounds__(kQueryWaves * 64) void radius_query_kernel(
         const float d2 = d3f::sqdist_exact(qx, qy, qz, sp.x, sp.y, sp.z);
         ok = d2 < r2;
         packed = ((uint64_t)__float_as_uint(d2) << 32) | (uint32_t)__float_as_int(sp.w);
+        if (prefix) {
+          if (ok && packed < nearest) nearest = packed;
+          ok = d2 < r2_prefix;          // (r2_prefix <= r2: checked by the launcher)
+        }
       }
     }
     const uint64_t m = __ballot(ok);
@@ -209,6 +217,20 @@ __global__ __launch_bounds__(kQueryWaves * 64) void radius_query_kernel(
       if (slot < kCand) cand[slot] = packed;
     }
     T += __popcll(m);
+  }
+  if (prefix) {
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const uint64_t other = shfl_xor_u64(nearest, o);
+      nearest = other < nearest ? other : nearest;
+    }
+    if (T == 0 && nearest != ~0ull) {     // nothing within the prefix radius: the row is the one nearest entry
+      if (lane == 0) cand[0] = nearest;
+      T = 1;
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
   }
   if (lane == 0) {
     if (out_counts) out_counts[qi] = T;
@@ -227,14 +249,20 @@ __global__ __launch_bounds__(kQueryWaves * 64) void radius_query_kernel(
   if (Tc <= 64) {
     // rank in registers: 64-key bitonic network over the wave
     uint64_t v = lane < Tc ? cand[lane] : ~0ull;
+    // <= 16 (32) keys sit in the first 16 (32) lanes: the network's stages up to that width sort them (the other lane
+    // groups hold ~0 only) -- 10 (15) compare-exchange steps instead of 21 for the short rows of the coarse levels and
+    // of the prefix form
+    const int kmax = Tc <= 16 ? 16 : (Tc <= 32 ? 32 : 64);
 #pragma unroll
     for (int k = 2; k <= 64; k <<= 1) {
+      if (k <= kmax) {
 #pragma unroll
-      for (int j = k >> 1; j > 0; j >>= 1) {
-        const uint64_t o = shfl_xor_u64(v, j);
-        const bool up = (lane & k) == 0, lower = (lane & j) == 0;
-        const uint64_t mn = v < o ? v : o, mx = v < o ? o : v;
-        v = (lower == up) ? mn : mx;
+        for (int j = k >> 1; j > 0; j >>= 1) {
+          const uint64_t o = shfl_xor_u64(v, j);
+          const bool up = (lane & k) == 0, lower = (lane & j) == 0;
+          const uint64_t mn = v < o ? v : o, mx = v < o ? o : v;
+          v = (lower == up) ? mn : mx;
+        }
       }
     }
     if (row) {
@@ -279,21 +307,71 @@ __global__ __launch_bounds__(kQueryWaves * 64) void radius_query_kernel(
   if (out_last_key && lane == 0) out_last_key[qi] = Tc > width ? cand[width - 1] : ~0ull;
 }
 
+struct ZeroJobs {
+  uint32_t* p[8];
+  size_t words[8];
+  int n;
+};
+__global__ void zero_many_kernel(ZeroJobs jobs) {
+  const size_t stride = (size_t)gridDim.x * blockDim.x, t0 = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  for (int j = 0; j < jobs.n; ++j)
+    for (size_t i = t0; i < jobs.words[j]; i += stride) jobs.p[j][i] = 0u;
+}
+
 }  // namespace
 
 extern "C" {
 
 size_t d3f_radius_grid_ws_bytes(int Ns) { return grid_layout(nullptr, Ns).bytes; }
 
+/* bytes at the START of a cell-list workspace that d3f_radius_grid_build clears (its bucket counters) */
+size_t d3f_radius_grid_zero_bytes(int Ns) { return sizeof(int32_t) * ((size_t)table_size_for(Ns) + 64); }
+
+/* clears up to 8 buffers in ONE launch (a pyramid build's five cell lists + its counters: one launch instead of nine) */
+int d3f_zero_buffers(void* const* ptrs, const size_t* bytes, int n, void* stream_) {
+  if (n < 0 || n > 8 || (n > 0 && (!ptrs || !bytes))) return D3F_EINVAL;
+  ZeroJobs jobs;
+  jobs.n = 0;
+  size_t most = 0;
+  for (int j = 0; j < n; ++j) {
+    if (!ptrs[j] || bytes[j] == 0) continue;
+    if (((uintptr_t)ptrs[j] & 3) || (bytes[j] & 3)) return D3F_EINVAL;
+    jobs.p[jobs.n] = (uint32_t*)ptrs[j];
+    jobs.words[jobs.n] = bytes[j] / 4;
+    if (jobs.words[jobs.n] > most) most = jobs.words[jobs.n];
+    ++jobs.n;
+  }
+  if (jobs.n == 0) return D3F_OK;
+  size_t blocks = (most + 255) / 256;
+  if (blocks > 2048) blocks = 2048;
+  zero_many_kernel<<<(unsigned)blocks, 256, 0, (hipStream_t)stream_>>>(jobs);
+  D3F_LAUNCH_CHECK();
+  return D3F_OK;
+}
+
+static int radius_grid_build_impl(const float* supports, int Ns, const int32_t* s_len, int B, float radius, void* grid_ws,
+                                  size_t grid_ws_bytes, int32_t* status, void* stream_, bool prezeroed);
+
 int d3f_radius_grid_build(const float* supports, int Ns, const int32_t* s_len, int B, float radius, void* grid_ws,
                           size_t grid_ws_bytes, int32_t* status, void* stream_) {
+  return radius_grid_build_impl(supports, Ns, s_len, B, radius, grid_ws, grid_ws_bytes, status, stream_, false);
+}
+
+/* the same when the caller has cleared the first d3f_radius_grid_zero_bytes(Ns) bytes of grid_ws already (d3f_zero_buffers) */
+int d3f_radius_grid_build_prezeroed(const float* supports, int Ns, const int32_t* s_len, int B, float radius,
+                                    void* grid_ws, size_t grid_ws_bytes, int32_t* status, void* stream_) {
+  return radius_grid_build_impl(supports, Ns, s_len, B, radius, grid_ws, grid_ws_bytes, status, stream_, true);
+}
+
+static int radius_grid_build_impl(const float* supports, int Ns, const int32_t* s_len, int B, float radius, void* grid_ws,
+                                  size_t grid_ws_bytes, int32_t* status, void* stream_, bool prezeroed) {
   if (!supports || !s_len || !grid_ws || !status || Ns < 0 || B < 1 || B > D3F_MAX_BATCH || !(radius > 0.0f))
     return D3F_EINVAL;
   hipStream_t stream = (hipStream_t)stream_;
   GridLayout g = grid_layout(grid_ws, Ns);
   if (grid_ws_bytes < g.bytes) return D3F_EWORKSPACE;
   const double inv_cell = 1.0 / ((double)radius * kCellSlack);
-  if (d3f::zero_async(g.cnt, sizeof(int32_t) * (g.M + 64), stream) != hipSuccess) return D3F_ELAUNCH;
+  if (!prezeroed && d3f::zero_async(g.cnt, sizeof(int32_t) * (g.M + 64), stream) != hipSuccess) return D3F_ELAUNCH;
   if (Ns > 0) {
     grid_count_kernel<<<d3f::cdiv(Ns, 256), 256, 0, stream>>>(supports, Ns, s_len, B, inv_cell, g.M - 1, g.cnt,
                                                              g.key_tmp, status);
@@ -309,10 +387,39 @@ int d3f_radius_grid_build(const float* supports, int Ns, const int32_t* s_len, i
   return D3F_OK;
 }
 
+static int radius_query_launch(const void* grid_ws, const float* queries, int Nq, const int32_t* q_len, int Ns,
+                               const int32_t* s_len, int B, float grid_radius, float radius, int width,
+                               int32_t* out_idx, int32_t* out_counts, int32_t* max_count, int32_t* out_wide,
+                               int wide_width, uint64_t* out_last_key, int max_count_group, int32_t* status,
+                               void* stream_, float prefix_radius);
+
 int d3f_radius_query_ex(const void* grid_ws, const float* queries, int Nq, const int32_t* q_len, int Ns,
                         const int32_t* s_len, int B, float grid_radius, float radius, int width, int32_t* out_idx,
                         int32_t* out_counts, int32_t* max_count, int32_t* out_wide, int wide_width,
                         uint64_t* out_last_key, int max_count_group, int32_t* status, void* stream_) {
+  return radius_query_launch(grid_ws, queries, Nq, q_len, Ns, s_len, B, grid_radius, radius, width, out_idx, out_counts,
+                             max_count, out_wide, wide_width, out_last_key, max_count_group, status, stream_, 0.0f);
+}
+
+/* Prefix form of a search (the pyramid's upsampling tables inside the training engine): row q = the supports within
+ * prefix_radius of q, ranked as in d3f_radius_query -- i.e. the leading part of the row a search with `radius` would
+ * produce -- or, when there is none, the single nearest support within `radius`.  Column 0 is the nearest support
+ * either way (what closest_pool reads, models/blocks.py:79-91) and the leading part is what the transpose of a pooling
+ * table is read from (d3f_reverse_table_filter with rev_radius = prefix_radius); the entries between the two radii,
+ * which nothing in the training step reads, are neither ranked nor stored. */
+int d3f_radius_query_prefix(const void* grid_ws, const float* queries, int Nq, const int32_t* q_len, int Ns,
+                            const int32_t* s_len, int B, float grid_radius, float radius, float prefix_radius,
+                            int width, int32_t* out_idx, int32_t* status, void* stream_) {
+  if (!(prefix_radius > 0.0f) || !(prefix_radius <= radius) || !out_idx) return D3F_EINVAL;
+  return radius_query_launch(grid_ws, queries, Nq, q_len, Ns, s_len, B, grid_radius, radius, width, out_idx, nullptr,
+                             nullptr, nullptr, 0, nullptr, 0, status, stream_, prefix_radius);
+}
+
+static int radius_query_launch(const void* grid_ws, const float* queries, int Nq, const int32_t* q_len, int Ns,
+                               const int32_t* s_len, int B, float grid_radius, float radius, int width,
+                               int32_t* out_idx, int32_t* out_counts, int32_t* max_count, int32_t* out_wide,
+                               int wide_width, uint64_t* out_last_key, int max_count_group, int32_t* status,
+                               void* stream_, float prefix_radius) {
   if (!grid_ws || !queries || !q_len || !s_len || (!out_idx && !out_wide) || !status || Nq < 0 || Ns < 0 || B < 1 ||
       max_count_group < 0 ||
       B > D3F_MAX_BATCH || width < 1 || width > kCand || !(radius > 0.0f) || !(grid_radius >= radius) ||
@@ -325,7 +432,8 @@ int d3f_radius_query_ex(const void* grid_ws, const float* queries, int Nq, const
   const float r2 = radius * radius;  // float32 product, like neighbors.cpp:226
   radius_query_kernel<<<d3f::cdiv(Nq, kQueryWaves), kQueryWaves * 64, 0, stream>>>(
       queries, Nq, q_len, s_len, B, Ns, inv_cell, r2, g.M - 1, g.start, g.end, g.pts, g.key, width, out_idx,
-      out_counts, max_count, status, out_wide, wide_width, out_last_key, max_count_group);
+      out_counts, max_count, status, out_wide, wide_width, out_last_key, max_count_group,
+      prefix_radius > 0.0f ? prefix_radius * prefix_radius : 0.0f);
   D3F_LAUNCH_CHECK();
   return D3F_OK;
 }

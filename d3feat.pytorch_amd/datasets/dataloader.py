@@ -146,18 +146,25 @@ def _conv_table(grid_for, pts, lens, level, e, lim, reverse_tables, want_max=Fal
     return (tab, res[1]) if want_max else tab
 
 
-def _pool_tables(grid_for, pts, lens, level, e, lim, reverse_tables, status, group=0):
+def _pool_tables(grid_for, pts, lens, level, e, lim, reverse_tables, status, group=0, engine_upsamples=False,
+                 mx_out=None):
     """(pools[l], device max count, upsamples[l]) (dataloader.py:141-152).  The transpose of the pooling table (coarse
     points around every fine point, radius r) is the leading part of the rows of the upsampling table (same point
     pairs, radius 2r, nearest first): nothing extra is searched, the pooling query only adds its last-kept keys."""
     grid = grid_for(level, e['pool_r'])
     ns = pts[level].shape[0]
-    up = grid_for(level + 1, e['up_r']).query(pts[level], lens[level], lim)
+    if engine_upsamples:
+        # inside the training engine the upsampling table is read in two places only: column 0 (closest_pool) and the part
+        # of every row within the POOLING radius (the transpose below) -- the prefix form ranks just that (the 2 r rows
+        # are ~68 entries wide, the part within r ~9: no LDS sorting network, 156 -> 80 us at level 0 of a 3-pair stack)
+        up = grid_for(level + 1, e['up_r']).query_prefix(pts[level], lens[level], lim, e['pool_r'])
+    else:
+        up = grid_for(level + 1, e['up_r']).query(pts[level], lens[level], lim)
     if not (reverse_tables and ops.wants_reverse_table(ns)):
-        tab, mx = grid.query(pts[level + 1], lens[level + 1], lim, want_max=True, max_group=group)
+        tab, mx = grid.query(pts[level + 1], lens[level + 1], lim, want_max=True, max_group=group, mx_out=mx_out)
         return tab, mx, up
     tab, mx, lkey = grid.query(pts[level + 1], lens[level + 1], lim, want_max=True, want_last_key=True,
-                               max_group=group)
+                               max_group=group, mx_out=mx_out)
     rev = ops.filter_reverse_table(ops.ReverseTable(up, pts[level + 1].shape[0], lim, ns, last_key=lkey,
                                                     radius=e['pool_r'], status=status), pts[level + 1], pts[level])
     ops.attach_reverse_table(tab, rev)
@@ -165,7 +172,8 @@ def _pool_tables(grid_for, pts, lens, level, e, lim, reverse_tables, status, gro
 
 
 def build_pyramid_static(points, lengths, config, neighborhood_limits, capacities, order=ops.ORDER_REFERENCE,
-                         reverse_tables=False, status=None, conv_widths=True, group=0):
+                         reverse_tables=False, status=None, conv_widths=True, group=0, engine_upsamples=False,
+                         clear_status=False):
     """Capacity-shaped pyramid: every level l has ``capacities[l]`` rows, the live row counts stay on the device.
 
     No host synchronisation at all (hipGraph-capturable): voxel levels write into fixed-capacity buffers (rows past
@@ -177,10 +185,21 @@ def build_pyramid_static(points, lengths, config, neighborhood_limits, capacitie
     group 2).  Clouds never see each other in any search; what a reference batch shares is the WIDTH of its tables
     (min(limit, max count of that batch), dataloader.py:64-66) and the detector's normaliser, so the width entries come
     per group (int32 [B/group]) and the batch carries ``_group`` for the operators that need it."""
+    # ``engine_upsamples``: the upsampling tables in their prefix form (ops.RadiusGrid.query_prefix) -- for consumers that
+    # read column 0 and the part within the pooling radius only (train.TrainStep); the reference's rows otherwise.
     dev = points.device
     walk = _Walk(config)
     status = status if status is not None else ops.DeviceStatus(dev)   # (a caller's word collects flags across builds)
     pts, lens = [points], [ops._lens(lengths, dev, "lengths")]
+    # one cell list per level (conv / pool searches of level l and the upsampling search of level l - 1 share its radius);
+    # their bucket counters, the pooling tables' max-count words and (``clear_status``) the build's status word are
+    # cleared by ONE launch in front of everything else (ten launches before)
+    n_pool = sum(1 for e in walk.layers if e['pool'])
+    rows = [int(points.shape[0])] + [int(capacities[l]) for l in range(1, n_pool + 1)]
+    n_mx = -(-int(lens[0].numel()) // int(group)) if group else 1
+    mx_all = torch.empty(max(1, n_pool * n_mx), dtype=torch.int32, device=dev)
+    spaces = [ops.RadiusGrid.workspace(n, dev) for n in rows]
+    ops.zero_buffers([z for _, z in spaces] + [mx_all] + ([status.word] if clear_status else []))
     for e in walk.layers:
         if e['pool']:
             out, out_len, _, _ = ops.grid_subsample_raw(pts[-1], lens[-1], e['dl'], order=order, status=status,
@@ -188,14 +207,19 @@ def build_pyramid_static(points, lengths, config, neighborhood_limits, capacitie
             pts.append(out)
             lens.append(out_len)
     grids = {}
+    used = set()
 
     def grid_for(level, radius):
         key = (level, float(radius))
         if key not in grids:
-            grids[key] = ops.RadiusGrid(pts[level], lens[level], radius, status=status)
+            ws = None
+            if level not in used:      # (a second radius on the same level builds, and clears, a list of its own)
+                used.add(level)
+                ws = spaces[level][0]
+            grids[key] = ops.RadiusGrid(pts[level], lens[level], radius, status=status, ws=ws)
         return grids[key]
 
-    empty_idx = torch.zeros((0, 1), dtype=torch.int32, device=dev)
+    empty_idx = torch.empty((0, 1), dtype=torch.int32, device=dev)
     neighbors, neighbors_width, pools, pools_width, upsamples = [], [], [], [], []
     level = 0
     for li, e in enumerate(walk.layers):
@@ -211,7 +235,8 @@ def build_pyramid_static(points, lengths, config, neighborhood_limits, capacitie
         if e['pool']:
             # static width = the limit; the reference trims to min(limit, max_count) (dataloader.py:64-66).  Only max_pool
             # can tell the difference (a full row gains zero-valued shadow candidates): it gets max_count, on the device
-            tab, mx, up = _pool_tables(grid_for, pts, lens, level, e, lim, reverse_tables, status, group=group)
+            tab, mx, up = _pool_tables(grid_for, pts, lens, level, e, lim, reverse_tables, status, group=group,
+                                       engine_upsamples=engine_upsamples, mx_out=mx_all[level * n_mx:(level + 1) * n_mx])
             pools.append(tab)
             pools_width.append(mx)
             upsamples.append(up)

@@ -142,7 +142,9 @@ class DeviceStatus:
 class RadiusGrid:
     """Cell list of one support cloud for one radius; serves any number of query sets."""
 
-    def __init__(self, supports, s_len, radius, status=None):
+    def __init__(self, supports, s_len, radius, status=None, ws=None):
+        """``ws``: a workspace (``RadiusGrid.workspace(Ns, device)``) whose bucket counters the caller has cleared already
+        (``zero_buffers``): a pyramid build clears all of its cell lists with one launch."""
         self.supports = _f32(supports, "supports")
         if self.supports.dim() != 2 or self.supports.shape[1] != 3:
             raise RuntimeError("Wrong dimensions : support.shape is not (N, 3)")
@@ -153,21 +155,47 @@ class RadiusGrid:
         L = _native.lib()
         self.Ns = int(self.supports.shape[0])
         nbytes = L.d3f_radius_grid_ws_bytes(self.Ns)
-        self.ws = _ws(nbytes, dev)
+        build = L.d3f_radius_grid_build if ws is None else L.d3f_radius_grid_build_prezeroed
+        if ws is not None and ws.numel() < nbytes:
+            raise RuntimeError("cell-list workspace of %d bytes, %d needed" % (ws.numel(), nbytes))
+        self.ws = _ws(nbytes, dev) if ws is None else ws
         with _region("radius_grid_build[Ns=%d]" % self.Ns, 12 * self.Ns + 24 * self.Ns):
-            _native.check(L.d3f_radius_grid_build(_p(self.supports), self.Ns, _p(self.s_len),
-                                                  int(self.s_len.numel()), self.radius, _p(self.ws), nbytes,
-                                                  _p(self.status.word), _stream()), "d3f_radius_grid_build")
+            _native.check(build(_p(self.supports), self.Ns, _p(self.s_len), int(self.s_len.numel()), self.radius,
+                                _p(self.ws), nbytes, _p(self.status.word), _stream()), "d3f_radius_grid_build")
+
+    @staticmethod
+    def workspace(Ns, device):
+        """(workspace for a cell list over ``Ns`` supports, the leading part of it that must be cleared before the build)"""
+        L = _native.lib()
+        ws = _ws(L.d3f_radius_grid_ws_bytes(int(Ns)), device)
+        return ws, ws[:int(L.d3f_radius_grid_zero_bytes(int(Ns)))]
+
+    def query_prefix(self, queries, q_len, width, prefix_radius, radius=None):
+        """Prefix form (d3f_radius_query_prefix): int32 [Nq, width] rows = the supports within ``prefix_radius``, ranked as
+        the leading part of the ``query`` row -- or the single nearest support within the search radius when there is
+        none.  For tables of which only column 0 and the part within ``prefix_radius`` are ever read (the upsampling
+        tables inside the training engine)."""
+        q = _f32(queries, "queries")
+        q_len = _lens(q_len, q.device, "q_batches")
+        Nq = int(q.shape[0])
+        r = self.radius if radius is None else float(radius)
+        out = torch.empty((Nq, int(width)), dtype=torch.int32, device=q.device)
+        with _region("radius_query_prefix[Nq=%d,Ns=%d]" % (Nq, self.Ns), 12 * Nq + 12 * self.Ns + 4 * Nq * int(width)):
+            _native.check(_native.lib().d3f_radius_query_prefix(
+                _p(self.ws), _p(q), Nq, _p(q_len), self.Ns, _p(self.s_len), int(q_len.numel()), self.radius, r,
+                float(prefix_radius), int(width), _p(out), _p(self.status.word), _stream()), "d3f_radius_query_prefix")
+        return out
 
     def query(self, queries, q_len, width, want_counts=False, want_max=False, radius=None, wide=0, want_last_key=False,
-              table=True, max_group=0):
+              table=True, max_group=0, mx_out=None):
         """int32 [Nq, width] neighbor table (+ per-query uncapped counts, + device max count).
 
         ``radius`` (<= the grid's): search radius when it differs from the one the cell list was built for.
         ``wide`` > 0: additionally the whole ranked list of every query as an int32 [Nq, wide] table; ``want_last_key``:
         uint64 [Nq] rank key of the last entry each capped row keeps -- together the transposed form of a table for the
         gather-form KPConv grad-input (d3f_radius_query_ex).  ``table=False`` skips the capped table itself.
-        ``max_group`` > 0: the max count comes per group of that many consecutive clouds (int32 [ceil(B/max_group)])."""
+        ``max_group`` > 0: the max count comes per group of that many consecutive clouds (int32 [ceil(B/max_group)]).
+        ``mx_out``: where the max count(s) go -- int32 counters the caller has cleared (``zero_buffers``)."""
         q = _f32(queries, "queries")
         if q.dim() != 2 or q.shape[1] != 3:
             raise RuntimeError("Wrong dimensions : query.shape is not (N, 3)")
@@ -181,7 +209,11 @@ class RadiusGrid:
         out = torch.empty((Nq, int(width)), dtype=torch.int32, device=q.device) if table else None
         counts = torch.empty(Nq, dtype=torch.int32, device=q.device) if want_counts else None
         n_mx = -(-int(q_len.numel()) // int(max_group)) if max_group else 1
-        mx = torch.zeros(n_mx, dtype=torch.int32, device=q.device) if want_max else None
+        mx = None
+        if want_max:
+            mx = mx_out if mx_out is not None else torch.zeros(n_mx, dtype=torch.int32, device=q.device)
+            if mx.numel() != n_mx or mx.dtype != torch.int32:
+                raise RuntimeError("mx_out must hold %d int32 counters" % n_mx)
         wtab = torch.empty((Nq, int(wide)), dtype=torch.int32, device=q.device) if wide else None
         lkey = torch.empty(Nq, dtype=torch.int64, device=q.device) if want_last_key else None
         with _region("radius_query[Nq=%d,Ns=%d]" % (Nq, self.Ns), 12 * Nq + 12 * self.Ns + 4 * Nq * (int(width) + int(wide))):
@@ -195,6 +227,17 @@ class RadiusGrid:
             if flag:
                 res += (t,)
         return res if len(res) != 1 else res[0]
+
+
+def zero_buffers(tensors):
+    """Clear up to 8 device buffers (4-byte multiples) with ONE launch (d3f_zero_buffers)."""
+    import ctypes
+    ts = [t for t in tensors if t is not None and t.numel()]
+    for k in range(0, len(ts), 8):
+        part = ts[k:k + 8]
+        ptrs = (ctypes.c_void_p * len(part))(*[t.data_ptr() for t in part])
+        sizes = (ctypes.c_size_t * len(part))(*[t.numel() * t.element_size() for t in part])
+        _native.check(_native.lib().d3f_zero_buffers(ptrs, sizes, len(part), _stream()), "d3f_zero_buffers")
 
 
 # ---------------------------------------------------------------------------------------------------------------

@@ -377,6 +377,9 @@ class TrainStep:
 
     # training builds the transposes of the KPConv tables with the pyramid (gather-form grad-input); inference does not
     reverse_tables = True
+    # the captured / static-shape pyramids carry their upsampling tables in the prefix form (column 0 + the part within
+    # the pooling radius: all the step reads; datasets.dataloader._pool_tables).  D3F_FULL_UPSAMPLES=1: the full 2 r rows
+    engine_upsamples = os.environ.get("D3F_FULL_UPSAMPLES") != "1"
 
     def build_batch(self, item):
         batch = dl.collate_fn_descriptor([item], self.config, self.limits, device=self.device, exact_width=False,
@@ -738,12 +741,13 @@ class TrainStep:
         are copied into the existing ones so that an already captured network graph keeps seeing its addresses."""
         if st.status is None:
             st.status = ops.DeviceStatus(self.device)
-        else:
-            st.status.word.zero_()   # the word describes THIS pair; what it caused is kept by the optimizer (state[2:4])
+        # (the word describes THIS pair -- what an earlier one caused is kept by the optimizer, state[2:4] --: it is cleared
+        # by the build's first launch, together with the cell lists' counters)
         batch = dl.build_pyramid_static(st.pts, st.lens, self.config, self.limits, self.caps,
                                         reverse_tables=self.reverse_tables, status=st.status,
                                         conv_widths=not self.reverse_tables,   # (the eval-mode gate's input: inference)
-                                        group=2 if self.stack > 1 else getattr(self, 'group', 0))
+                                        group=2 if self.stack > 1 else getattr(self, 'group', 0),
+                                        engine_upsamples=self.engine_upsamples, clear_status=True)
         batch.pop('_status')
         if st.batch is None or adopt:
             st.batch = batch
@@ -1118,6 +1122,10 @@ class PairLanes:
         there are several ranks (True on one rank runs the same schedule without the all-reduces: tests)."""
         self.ts, self.P, self.Q = ts, int(lanes), int(stack)
         self.split = (ts.world > 1) if split is None else bool(split)
+        if ts.world > 1 and not self.split:
+            # (the one-rank join -- sum of the lanes inside the update kernel -- exchanges nothing: several ranks would
+            # silently train unsynchronised replicas at a gradient scale of 1 / (lanes x stack x ranks))
+            raise ValueError("PairLanes over several ranks needs split=True: the join that exchanges the gradients")
         nets, sides = lane_streams(self.P, ts.device)
         self.engines = [ts.clone_for_lane(k, nets[k], sides[k], split=self.split) for k in range(self.P)]
         for eng in self.engines:

@@ -311,6 +311,41 @@ class Trainer(object):
             ok = bool(int(t.item()))
         return ok
 
+    # The agreement for a step is POSTED one step ahead (its pairs are known then: the caller hands every step the
+    # following step's pairs) as an asynchronous all-reduce and READ when the step starts: the read waits for a
+    # collective issued a whole step earlier -- queued behind the exchange of the step before that one, long finished --
+    # so the host keeps its run-ahead over the device (an all-reduce + .item() inside every step made the host
+    # wait for the previous step's gradient exchange to drain).  Every rank posts and reads in the same order.
+    def _post_agreement(self, key, flag):
+        if self.world == 1:
+            return
+        if self.device.type != 'cuda':
+            t = torch.tensor([1 if flag else 0], dtype=torch.int32)
+            self._pending_agree = (key, t, dist.all_reduce(t, op=dist.ReduceOp.MIN, async_op=True))
+            return
+        if self._agree_stream is None:
+            self._agree_stream = torch.cuda.Stream(device=self.device)
+        with torch.cuda.stream(self._agree_stream):
+            t = torch.tensor([1 if flag else 0], dtype=torch.int32, device=self.device)
+            work = dist.all_reduce(t, op=dist.ReduceOp.MIN, async_op=True)
+        self._pending_agree = (key, t, work)
+
+    def _agreed(self, key, flag):
+        """The ranks' common decision for the step ``key`` (logical AND of ``flag``): the posted one when there is one."""
+        if self.world == 1:
+            return bool(flag)
+        pend, self._pending_agree = getattr(self, '_pending_agree', None), None
+        if pend is not None and pend[0] == key:
+            _, t, work = pend
+            work.wait()
+            if t.is_cuda:
+                with torch.cuda.stream(self._agree_stream):
+                    return bool(int(t.item()))
+            return bool(int(t.item()))
+        if pend is not None:          # (a posted agreement nobody reads would leave the ranks' collectives out of step)
+            pend[2].wait()
+        return self._agree(flag)
+
     def _group_class(self, group):
         """The smallest capacity class whose graphs take the ``group`` pairs of a step (None: eager fallback)."""
         if group is None:
@@ -327,9 +362,13 @@ class Trainer(object):
         if not self._captured:
             self._capture_classes(items[0])
         e = self._group_class(items)
-        if not self._agree(e is not None):
-            return self._eager_steps(items)
+        self._step_no = getattr(self, '_step_no', 0) + 1
+        ok = self._agreed(self._step_no, e is not None)
         nxt_e = self._group_class(next_items)
+        if next_items is not None:
+            self._post_agreement(self._step_no + 1, nxt_e is not None)
+        if not ok:
+            return self._eager_steps(items)
         feed = (lambda g: g) if self.lanes > 1 else (lambda g: tuple(g))
         if nxt_e is e:
             outs = e.step_graph(feed(items), feed(next_items))
@@ -360,8 +399,12 @@ class Trainer(object):
             if not self._captured:
                 self._capture_classes(item)
             e = self._class_of(item)
-            if self._agree(e is not None):
-                nxt_e = self._class_of(next_item) if next_item is not None else None
+            self._step_no = getattr(self, '_step_no', 0) + 1
+            ok = self._agreed(self._step_no, e is not None)
+            nxt_e = self._class_of(next_item) if next_item is not None else None
+            if next_item is not None:
+                self._post_agreement(self._step_no + 1, nxt_e is not None)
+            if ok:
                 if nxt_e is e:
                     out = e.step_graph(item, next_item)
                 else:

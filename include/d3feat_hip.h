@@ -66,6 +66,13 @@ size_t d3f_radius_grid_ws_bytes(int Ns);
 /* Build the cell list of `supports` for `radius` into grid_ws. */
 int d3f_radius_grid_build(const float* supports, int Ns, const int32_t* s_len, int B, float radius,
                           void* grid_ws, size_t grid_ws_bytes, int32_t* status, void* stream);
+/* A pyramid build clears the bucket counters of its five cell lists (the first d3f_radius_grid_zero_bytes(Ns) bytes of each
+ * grid_ws) and its per-table counters with ONE launch (d3f_zero_buffers, up to 8 buffers of 4-byte multiples) and builds
+ * the lists with d3f_radius_grid_build_prezeroed. */
+size_t d3f_radius_grid_zero_bytes(int Ns);
+int d3f_zero_buffers(void* const* ptrs, const size_t* bytes, int n, void* stream);
+int d3f_radius_grid_build_prezeroed(const float* supports, int Ns, const int32_t* s_len, int B, float radius,
+                                    void* grid_ws, size_t grid_ws_bytes, int32_t* status, void* stream);
 /* Query: out_idx [Nq,width] gets, per query, the in-radius supports of the same batch element, ordered by
  * (d2, index) ascending, first `width` kept, padded with Ns.  out_counts [Nq] (optional) = uncapped count;
  * max_count (optional, 1 int32, caller-zeroed) = max over queries.  d2 arithmetic and the strict d2 < r2 test
@@ -89,6 +96,14 @@ int d3f_radius_query_ex(const void* grid_ws, const float* queries, int Nq, const
                         const int32_t* s_len, int B, float grid_radius, float radius, int width, int32_t* out_idx,
                         int32_t* out_counts, int32_t* max_count, int32_t* out_wide, int wide_width,
                         uint64_t* out_last_key, int max_count_group, int32_t* status, void* stream);
+/* Prefix form of a search, for the upsampling tables INSIDE the training engine (datasets/dataloader.py:148-150 builds
+ * them with radius 2 r; the network reads column 0, models/blocks.py:79-91, and this build reads the transpose of the
+ * pooling table off their leading part): row q = the supports within prefix_radius of q, ranked exactly like the leading
+ * part of the d3f_radius_query row, or -- when there is none -- the single nearest support within `radius`.  The entries
+ * between the two radii are neither ranked nor stored.  collate_fn_descriptor's tables keep the full rows. */
+int d3f_radius_query_prefix(const void* grid_ws, const float* queries, int Nq, const int32_t* q_len, int Ns,
+                            const int32_t* s_len, int B, float grid_radius, float radius, float prefix_radius,
+                            int width, int32_t* out_idx, int32_t* status, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Grid subsampling -- replaces grid_subsampling.subsample_batch, points-only branch

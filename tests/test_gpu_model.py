@@ -308,7 +308,8 @@ def test_model_forward_backward_s1_full_width(golden_s1):
 def test_bench_paths_at_s1_size_reproduce_the_reference_run(golden_s1):
     """The paths bench.py times, at the size it times them: the full-width network (24.3M parameters) on the 38k-point
     benchmark pair through (a) the captured graphs at exact capacities, (b) at 10 % head-room, (c) two lanes of two
-    STACKED pairs each (PairLanes(stack=2): one pyramid + one network graph per stack, joint update) -- every pair's
+    STACKED pairs each (PairLanes(stack=2): one pyramid + one network graph per stack, joint update) and FOUR lanes of
+    THREE stacked pairs (bench.py's default: what the driver times) -- every pair's
     losses equal the reference run's (s1_full.npz: trainer.py:91-98 on the real reference), every gradient buffer holds
     the reference gradient (norm of every parameter's gradient; sampled rows of three weight tensors) times the number of
     pairs it sums.  lr = 0 keeps the parameters at the fixture's values through the warm-up steps of a capture.
@@ -370,17 +371,22 @@ def test_bench_paths_at_s1_size_reproduce_the_reference_run(golden_s1):
         drift = float((grads[0] - grads[1]).abs().max()) / float(grads[0].abs().max())
         assert drift < 2e-5, ('replay drift', slack, drift)
         assert eng.check_status() == (0, 0)
-    lanes = PairLanes(ts, 2, stack=2)
-    lanes.enable_graph(TrainStep.capacities_for([[2 * n for n in sizes[0]]], slack=1.0), num_corr=int(item[4].shape[0]))
-    lanes.capture(item)
-    for rep in range(2):
-        outs = lanes.step_graph([item] * 4, [item] * 4)
-        lanes.synchronize()
-        torch.cuda.synchronize()
-        for lane, out in enumerate(outs):
-            check_losses(out[1], out[2], 'lane %d' % lane)
-            check_buffer(ts.flat.lanes[lane][0], 2, 'lane %d' % lane)
-    assert lanes.check_status() == (0, 0) and int(ts.opt.skipped) == 0
+    # (c) lanes x stacked pairs: 2 x 2, and 4 x 3 -- bench.py's default, the configuration the driver's number is measured
+    # on (114 688-row level 0, its own tuned-GEMM rows and stream deal)
+    for n_lanes, n_stack in ((2, 2), (4, 3)):
+        lanes = PairLanes(ts, n_lanes, stack=n_stack)
+        lanes.enable_graph(TrainStep.capacities_for([[n_stack * n for n in sizes[0]]], slack=1.0),
+                           num_corr=int(item[4].shape[0]))
+        lanes.capture(item)
+        for rep in range(2):
+            outs = lanes.step_graph([item] * (n_lanes * n_stack), [item] * (n_lanes * n_stack))
+            lanes.synchronize()
+            torch.cuda.synchronize()
+            for lane, out in enumerate(outs):
+                check_losses(out[1], out[2], '%d x %d lane %d' % (n_lanes, n_stack, lane))
+                check_buffer(ts.flat.lanes[lane][0], n_stack, '%d x %d lane %d' % (n_lanes, n_stack, lane))
+        assert lanes.check_status() == (0, 0) and int(ts.opt.skipped) == 0
+        del lanes
     # lr = 0: nothing above moved the parameters
     for k, v in ts.model.state_dict().items():
         srow = g['sdsum.' + k]
@@ -1086,6 +1092,29 @@ def test_two_rank_bench_control_flow_on_one_gpu():
     ex = res["exchange"]     # the overlap leg: step with / without the exchange, the exchange alone
     assert ex["rccl_ranks"] == 2 and "error" not in ex and ex["bytes_per_step"] > 9e7 and ex["exchange_alone_ms"] > 0
     assert "overlap_frac" in ex and "under every lane's stage-2" in ex["buckets"]
+    # ... and the same legs for the reference's schedule (one pair per rank and update), in the same JSON line
+    one = res["one_pair_in_flight"]
+    assert one["value"] > 0 and "error" not in one["exchange"] and "overlap_frac" in one["exchange"]
+    assert one["exchange"]["exposed_ms"] >= 0 and one["exchange"]["exchange_alone_ms"] > 0
+
+
+def test_two_rank_lanes_join_equals_the_eager_mean_gradient_step():
+    """The product's multi-rank join on VALUES (tests/dist_join_worker.py): two ranks on cuda:0 over gloo, each driving
+    the real PairLanes.step_graph (2 lanes x 2 stacked pairs, two-stage lane graphs, bucketed exchange under stage 2,
+    guard on the reduced gradient, one update); after each of three joint updates the parameters equal the eager
+    mean-gradient SGD step over all 8 pairs (reference trainer.py:89-111 per pair, mean over the data-parallel group) and
+    the replicas agree bit for bit."""
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+           "127.0.0.1", "--master-port", "29653", os.path.join(repo, "tests", "dist_join_worker.py")]
+    r = subprocess.run(cmd, cwd=repo, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-5000:]
+    assert r.stdout.count("JOIN_OK") == 2, r.stdout[-3000:]
 
 
 @pytest.mark.parametrize("w_desc,w_det", [(1.0, 1.0), (0.7, 1.3)])

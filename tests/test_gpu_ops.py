@@ -158,6 +158,40 @@ def test_radius_neighbors_edge_cases(native):
     assert np.array_equal(got, ref)
 
 
+@pytest.mark.parametrize("radius,prefix,width", [(0.30, 0.15, 40), (0.30, 0.05, 24), (0.2, 0.2, 64), (0.35, 0.12, 8)])
+def test_radius_query_prefix_rows_are_the_leading_part_of_the_full_rows(native, radius, prefix, width):
+    """d3f_radius_query_prefix (the upsampling tables inside the training engine): row q = the entries of the full ranked
+    row (oracle: the reference's batch_query, neighbors.cpp:211-333) within the prefix radius, in the same order, or the
+    single nearest entry when there is none; bit-exact."""
+    rng = np.random.default_rng(11)
+    sl, ql = np.array([2100, 1500], np.int32), np.array([1300, 900], np.int32)
+    s, q = _cloud(rng, int(sl.sum())), _cloud(rng, int(ql.sum()))
+    q[:40] += 3.0                                          # some queries with nothing in range at all
+    full = native.batch_query(q, s, ql, sl, radius=radius, max_neighbors=0)     # uncapped ranked rows
+    ns = s.shape[0]
+    grid = ops.RadiusGrid(cu(s), cu(sl), radius)
+    got = grid.query_prefix(cu(q), cu(ql), width, prefix).cpu().numpy()
+    grid.status.raise_if_set()
+    assert got.shape == (q.shape[0], width) and got.dtype == np.int32
+    r2 = np.float32(prefix) * np.float32(prefix)
+    some_empty = some_nearest_only = some_prefix = 0
+    for i in range(q.shape[0]):
+        row = full[i][full[i] < ns]
+        d = (q[i] - s[row]).astype(np.float32)
+        d2 = (d[:, 0] * d[:, 0] + d[:, 1] * d[:, 1]) + d[:, 2] * d[:, 2]
+        want = row[d2 < r2]
+        if want.size == 0:
+            want = row[:1]
+            some_nearest_only += int(row.size > 0)
+            some_empty += int(row.size == 0)
+        else:
+            some_prefix += 1
+        want = want[:width]
+        assert np.array_equal(got[i, :want.size], want), i
+        assert np.all(got[i, want.size:] == ns), i
+    assert some_empty and some_nearest_only and some_prefix
+
+
 # ------------------------------------------------------------------------------------------------ KPConv
 def _kpconv_case(rng, nq, ns, h, cin, cout, shadow_frac=0.15, k=15):
     q, s = _cloud(rng, nq, (1, 1, 1)), _cloud(rng, ns, (1, 1, 1))
