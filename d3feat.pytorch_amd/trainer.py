@@ -105,6 +105,8 @@ def _get(args, name, default):
 
 
 class Trainer(object):
+    AUTO_LANES, AUTO_STACK, AUTO_MIN_STEPS = 4, 3, 8      # the default schedule of the hipGraph path (see __init__)
+
     def __init__(self, args):
         self.config = args
         self.start_epoch = 0
@@ -140,8 +142,27 @@ class Trainer(object):
                 print("note: use_batch_norm=True -> eager training path (no hipGraph replay)")
             self.use_graph = False
         self._captured = False
+        # Pairs per optimizer step and GPU.  Unless pinned (``pairs_in_flight`` / ``stacked_pairs``) or opted out of
+        # (``reference_schedule = True``: one pair per step, reference dataloader.py:73), the hipGraph path trains on
+        # AUTO_LANES x AUTO_STACK pairs per step -- what an MI355X needs to be busy (bench.py: 566 pairs/s against 267 on
+        # the reference's schedule) -- when an epoch holds at least AUTO_MIN_STEPS such steps per rank.
+        pinned = _get(args, 'pairs_in_flight', None) is not None or _get(args, 'stacked_pairs', None) is not None
         self.lanes = max(1, int(_get(args, 'pairs_in_flight', 1)))
         self.stack = max(1, int(_get(args, 'stacked_pairs', 1)))
+        if _get(args, 'reference_schedule', False):
+            self.lanes = self.stack = 1
+        elif not pinned and self.use_graph and self.device.type == 'cuda':
+            per_rank = len(self.train_loader.dataset) // max(1, getattr(self.train_loader, 'batch_size', 1)) // self.world
+            if per_rank >= self.AUTO_MIN_STEPS * self.AUTO_LANES * self.AUTO_STACK:
+                self.lanes, self.stack = self.AUTO_LANES, self.AUTO_STACK
+                if self.rank == 0:
+                    print("note: training on %d x %d = %d fragment pairs per optimizer step and GPU (%d network graphs in "
+                          "flight x %d pairs stacked in each); every update is the MEAN gradient of those pairs x %d rank(s) "
+                          "-- a batch of %d where the reference steps once per pair (dataloader.py:73) -- at the configured "
+                          "learning rate %g (scale it if you want the per-pair step size).  args.reference_schedule = True, "
+                          "or pairs_in_flight / stacked_pairs, pins the schedule."
+                          % (self.lanes, self.stack, self.lanes * self.stack, self.lanes, self.stack, self.world,
+                             self.lanes * self.stack * self.world, float(_get(args, 'lr', 0.0))))
         if self.lanes * self.stack > 1 and not self.use_graph:
             if self.rank == 0:
                 print("note: pairs_in_flight=%d / stacked_pairs=%d need the hipGraph path; training one pair per step"

@@ -1060,6 +1060,32 @@ def test_trainer_consumes_threedmatch_pickles(golden_s0, tmp_path):
     assert not torch.equal(before, tr.engine.flat.data)
 
 
+def test_trainer_default_schedule_fills_the_gpu_unless_opted_out(capsys):
+    """Trainer(args) on the hipGraph path: 4 network graphs in flight x 3 stacked pairs per optimizer step unless the
+    schedule is pinned or ``reference_schedule`` asks for the reference's one pair per step (dataloader.py:73); an epoch
+    too short for 8 such steps keeps the reference schedule.  The batch-size consequence is printed, not only documented."""
+    from d3feat_pytorch_amd.trainer import Trainer
+
+    def args(n, **kw):
+        cfg = cfgmod.default_config(first_features_dim=16, num_node=64)
+        cfg.max_epoch, cfg.save_dir, cfg.tboard_dir, cfg.device, cfg.graph = 1, None, None, DEV, True
+        cfg.train_loader = type('L', (), {'dataset': list(range(n)), 'batch_size': 1, 'shuffle': False,
+                                          'limits': [30, 30, 30, 30, 30]})()
+        for k, v in kw.items():
+            setattr(cfg, k, v)
+        return cfg
+    tr = Trainer(args(200))
+    out = capsys.readouterr().out
+    assert (tr.lanes, tr.stack, tr.group) == (4, 3, 12) and "12 fragment pairs per optimizer step" in out
+    assert "reference_schedule" in out and "learning rate" in out
+    tr = Trainer(args(200, reference_schedule=True))
+    assert (tr.lanes, tr.stack) == (1, 1) and "fragment pairs per optimizer step" not in capsys.readouterr().out
+    tr = Trainer(args(200, pairs_in_flight=2))
+    assert (tr.lanes, tr.stack) == (2, 1)
+    tr = Trainer(args(40))               # 3 steps of 12 per epoch: not worth a 12-pair schedule
+    assert (tr.lanes, tr.stack) == (1, 1)
+
+
 def test_two_rank_bench_control_flow_on_one_gpu():
     """bench.py --gpus 2 launched plainly (it re-launches itself through torch.distributed.run, the driver's command
     for N = 2), both ranks on cuda:0 with gloo standing in

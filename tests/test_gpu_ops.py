@@ -189,7 +189,7 @@ def test_radius_query_prefix_rows_are_the_leading_part_of_the_full_rows(native, 
         want = want[:width]
         assert np.array_equal(got[i, :want.size], want), i
         assert np.all(got[i, want.size:] == ns), i
-    assert some_empty and some_nearest_only and some_prefix
+    assert some_empty and some_prefix and (some_nearest_only or prefix > 0.06)   # (the 0.05 case has nearest-only rows)
 
 
 # ------------------------------------------------------------------------------------------------ KPConv
