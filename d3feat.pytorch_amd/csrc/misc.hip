@@ -3,7 +3,70 @@
 
 #include "common.hpp"
 
+namespace {
+
+// One launch moves the inputs of a training step into its static buffers: up to 24 jobs, job j by the workgroups with
+// blockIdx.y == j.  kind 0: dst words = src words (device-to-device copy of a 4-byte multiple); kind 1: dst bytes =
+// (src doubles > threshold) -- the "negative" mask of the circle loss, dist_keypts > safe_radius (reference
+// utils/loss.py:119), computed while the keypoint distances are being copied anyway.
+struct CopyJobs {
+  const void* src[24];
+  void* dst[24];
+  size_t n[24];       // words (kind 0) / elements (kind 1)
+  int kind[24];
+  double thr;
+};
+__global__ __launch_bounds__(256) void copy_many_kernel(CopyJobs jobs) {
+  const int j = blockIdx.y;
+  const size_t stride = (size_t)gridDim.x * blockDim.x, t0 = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t n = jobs.n[j];
+  if (jobs.kind[j] == 0) {
+    const uint32_t* s = (const uint32_t*)jobs.src[j];
+    uint32_t* d = (uint32_t*)jobs.dst[j];
+    for (size_t i = t0; i < n; i += stride) d[i] = s[i];
+  } else {
+    const double* s = (const double*)jobs.src[j];
+    uint8_t* d = (uint8_t*)jobs.dst[j];
+    for (size_t i = t0; i < n; i += stride) d[i] = s[i] > jobs.thr ? 1 : 0;
+  }
+}
+
+}  // namespace
+
 extern "C" {
+
+/* Replaces the ~25 separate copy launches with which a stacked training step's inputs (2Q clouds, their features, Q
+ * correspondence tables and keypoint-distance matrices: the dataset item of reference datasets/ThreeDMatch.py:135-149,
+ * Q times) reach the step's static buffers, and the two launches of the loss's neighbor mask.
+ * kinds[j] = 0: copy bytes[j] (a multiple of 4) from srcs[j] to dsts[j]; 1: dsts[j][i] (uint8) = srcs[j][i] (float64) >
+ * threshold for i < bytes[j] / 8.  n <= 24. */
+int d3f_copy_buffers(const void* const* srcs, void* const* dsts, const size_t* bytes, const int* kinds, int n,
+                     double threshold, void* stream) {
+  if (n < 0 || n > 24 || (n > 0 && (!srcs || !dsts || !bytes || !kinds))) return D3F_EINVAL;
+  CopyJobs jobs;
+  jobs.thr = threshold;
+  int m = 0;
+  size_t most = 0;
+  for (int j = 0; j < n; ++j) {
+    if (bytes[j] == 0) continue;
+    if (!srcs[j] || !dsts[j] || (kinds[j] != 0 && kinds[j] != 1)) return D3F_EINVAL;
+    if (kinds[j] == 0 && (((uintptr_t)srcs[j] | (uintptr_t)dsts[j] | bytes[j]) & 3)) return D3F_EINVAL;
+    if (kinds[j] == 1 && (((uintptr_t)srcs[j] | bytes[j]) & 7)) return D3F_EINVAL;
+    jobs.src[m] = srcs[j];
+    jobs.dst[m] = dsts[j];
+    jobs.n[m] = kinds[j] == 0 ? bytes[j] / 4 : bytes[j] / 8;
+    jobs.kind[m] = kinds[j];
+    if (jobs.n[m] > most) most = jobs.n[m];
+    ++m;
+  }
+  if (m == 0) return D3F_OK;
+  size_t blocks = (most + 1023) / 1024;     // ~4 elements per thread of the largest job
+  if (blocks > 256) blocks = 256;
+  if (blocks < 1) blocks = 1;
+  copy_many_kernel<<<dim3((unsigned)blocks, (unsigned)m), 256, 0, (hipStream_t)stream>>>(jobs);
+  D3F_LAUNCH_CHECK();
+  return D3F_OK;
+}
 
 const char* d3f_version(void) { return "d3feat-hip 0.1 (gfx950)"; }
 

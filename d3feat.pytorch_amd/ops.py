@@ -229,6 +229,22 @@ class RadiusGrid:
         return res if len(res) != 1 else res[0]
 
 
+def copy_buffers(jobs, threshold=0.0):
+    """``jobs`` = [(src, dst)] device-to-device copies of equal byte size, or (src float64, dst uint8, 'mask') for
+    dst = src > threshold -- all in ONE launch per 24 jobs (d3f_copy_buffers).  The caller guarantees contiguous tensors."""
+    import ctypes
+    jobs = [j for j in jobs if j[0].numel()]
+    for k in range(0, len(jobs), 24):
+        part = jobs[k:k + 24]
+        n = len(part)
+        srcs = (ctypes.c_void_p * n)(*[j[0].data_ptr() for j in part])
+        dsts = (ctypes.c_void_p * n)(*[j[1].data_ptr() for j in part])
+        sizes = (ctypes.c_size_t * n)(*[j[0].numel() * j[0].element_size() for j in part])
+        kinds = (ctypes.c_int * n)(*[1 if len(j) > 2 else 0 for j in part])
+        _native.check(_native.lib().d3f_copy_buffers(srcs, dsts, sizes, kinds, n, float(threshold), _stream()),
+                      "d3f_copy_buffers")
+
+
 def zero_buffers(tensors):
     """Clear up to 8 device buffers (4-byte multiples) with ONE launch (d3f_zero_buffers)."""
     import ctypes

@@ -698,6 +698,8 @@ class TrainStep:
                                "%d pair(s), capacity %d, corr %s)" % (
                                    len(pairs), sum(int(it[0].shape[0]) + int(it[1].shape[0]) for it in pairs),
                                    tuple(pairs[0][4].shape), self.stack, self.caps[0], tuple(self.sets[0].corr.shape[-2:])))
+        if self._load_inputs_fused(st, item):
+            return
         if self.stack == 1:
             p0, p1, _, _, corr, dk = item
             n0, n1 = int(p0.shape[0]), int(p1.shape[0])
@@ -732,6 +734,50 @@ class TrainStep:
             else:
                 st.lens.copy_(torch.tensor(lens, dtype=torch.int32))
         st.mask.copy_(st.dk > self.circle.safe_radius)   # with the upload, off the training stream (utils/loss.py:119)
+
+    def _load_inputs_fused(self, st, item):
+        """The same loads as ONE launch (ops.copy_buffers: clouds, features, correspondences, keypoint distances and the
+        loss's neighbor mask) when every tensor of the item already sits on the device in the buffers' dtypes and is
+        contiguous -- what ``upload`` returns; ~25 copy launches per stacked step before, on the stream that also replays
+        the lane's graphs.  Returns False (nothing done) otherwise."""
+        if self.device.type != 'cuda' or os.environ.get("D3F_SEPARATE_INPUT_COPIES") == "1":
+            return False
+        pairs = self.pairs_of(item)
+        jobs, off, lens = [], 0, []
+
+        def ok(t, dtype):
+            return isinstance(t, torch.Tensor) and t.device == self.device and t.dtype == dtype and t.is_contiguous()
+        for q, it in enumerate(pairs):
+            corr, dk = it[4], it[5]
+            if not (ok(corr, torch.int64) and ok(dk, torch.float64)):
+                return False
+            for p, f in ((it[0], it[2]), (it[1], it[3])):
+                if not ok(p, torch.float32) or (f is not None and not ok(f, torch.float32)):
+                    return False
+                n = int(p.shape[0])
+                jobs.append((p, st.pts[off:off + n]))
+                if f is not None:
+                    if f.numel() != n * st.feat.shape[1]:
+                        return False
+                    jobs.append((f, st.feat[off:off + n]))
+                off += n
+                lens.append(n)
+            dst_corr, dst_dk, dst_mask = (st.corr, st.dk, st.mask) if self.stack == 1 else (st.corr[q], st.dk[q], st.mask[q])
+            jobs += [(corr, dst_corr), (dk, dst_dk), (dk, dst_mask, 'mask')]
+        if self.stack == 1:
+            st.lens[0] = lens[0]
+            st.lens[1] = lens[1]
+        elif st.lens_host is not None:
+            if st.lens_ev is not None:     # the set's previous load (three steps ago in the pipelined loop) has read it
+                st.lens_ev.synchronize()
+            st.lens_host.copy_(torch.tensor(lens, dtype=torch.int32))
+            st.lens.copy_(st.lens_host, non_blocking=True)
+            st.lens_ev = st.lens_ev or torch.cuda.Event()
+            st.lens_ev.record(torch.cuda.current_stream(self.device))
+        else:
+            st.lens.copy_(torch.tensor(lens, dtype=torch.int32))
+        ops.copy_buffers(jobs, threshold=float(self.circle.safe_radius))
+        return True
 
     def _build_set(self, st, adopt=False):
         """Pyramid of the pair in ``st``'s input buffers -> ``st.batch``.  Every kernel of the build (and of the

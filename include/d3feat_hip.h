@@ -71,6 +71,11 @@ int d3f_radius_grid_build(const float* supports, int Ns, const int32_t* s_len, i
  * the lists with d3f_radius_grid_build_prezeroed. */
 size_t d3f_radius_grid_zero_bytes(int Ns);
 int d3f_zero_buffers(void* const* ptrs, const size_t* bytes, int n, void* stream);
+/* One launch for the inputs of a (stacked) training step -- the dataset item of reference datasets/ThreeDMatch.py:135-149:
+ * kinds[j] = 0 copies bytes[j] (4-byte multiple) srcs[j] -> dsts[j] on the device; 1 writes the circle loss's mask
+ * dsts[j][i] (uint8) = srcs[j][i] (float64 dist_keypts) > threshold (utils/loss.py:119), i < bytes[j] / 8.  n <= 24. */
+int d3f_copy_buffers(const void* const* srcs, void* const* dsts, const size_t* bytes, const int* kinds, int n,
+                     double threshold, void* stream);
 int d3f_radius_grid_build_prezeroed(const float* supports, int Ns, const int32_t* s_len, int B, float radius,
                                     void* grid_ws, size_t grid_ws_bytes, int32_t* status, void* stream);
 /* Query: out_idx [Nq,width] gets, per query, the in-radius supports of the same batch element, ordered by
