@@ -33,7 +33,7 @@ SIGNATURES = {
     "d3f_zero_buffers": (_i, [_vp, _vp, _i, _vp]),
     "d3f_copy_buffers": (_i, [_vp, _vp, _vp, _vp, _i, C.c_double, _vp]),
     "d3f_radius_grid_build_prezeroed": (_i, [_vp, _i, _vp, _i, _f, _vp, _sz, _vp, _vp]),
-    "d3f_radius_query_prefix": (_i, [_vp, _vp, _i, _vp, _i, _vp, _i, _f, _f, _f, _i, _vp, _vp, _vp]),
+    "d3f_radius_query_prefix": (_i, [_vp, _vp, _i, _vp, _i, _vp, _i, _f, _f, _f, _f, _i, _vp, _vp, _vp]),
     "d3f_grid_subsample_ws_bytes": (_sz, [_i, _i]),
     "d3f_grid_subsample": (_i, [_vp, _i, _vp, _i, _f, _i, _i, _vp, _i, _vp, _vp, _vp, _sz, _vp, _vp]),
     "d3f_grid_subsample_ex": (_i, [_vp, _i, _vp, _i, _f, _i, _i, _vp, _i, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _sz,

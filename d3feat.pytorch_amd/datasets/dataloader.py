@@ -157,7 +157,10 @@ def _pool_tables(grid_for, pts, lens, level, e, lim, reverse_tables, status, gro
         # inside the training engine the upsampling table is read in two places only: column 0 (closest_pool) and the part
         # of every row within the POOLING radius (the transpose below) -- the prefix form ranks just that (the 2 r rows
         # are ~68 entries wide, the part within r ~9: no LDS sorting network, 156 -> 80 us at level 0 of a 3-pair stack)
-        up = grid_for(level + 1, e['up_r']).query_prefix(pts[level], lens[level], lim, e['pool_r'])
+        # the nearest coarse point of a fine point is at most its own voxel's barycentre away: within the voxel diagonal
+        # dl sqrt(3) (dl = 0.8 r for the reference's radii: 1.39 r); 1.1 of that, capped by the search radius
+        bound = min(float(e['up_r']), max(float(e['pool_r']), 1.1 * float(e['dl']) * 3.0 ** 0.5))
+        up = grid_for(level + 1, e['up_r']).query_prefix(pts[level], lens[level], lim, e['pool_r'], nearest_bound=bound)
     else:
         up = grid_for(level + 1, e['up_r']).query(pts[level], lens[level], lim)
     if not (reverse_tables and ops.wants_reverse_table(ns)):

@@ -170,11 +170,12 @@ class RadiusGrid:
         ws = _ws(L.d3f_radius_grid_ws_bytes(int(Ns)), device)
         return ws, ws[:int(L.d3f_radius_grid_zero_bytes(int(Ns)))]
 
-    def query_prefix(self, queries, q_len, width, prefix_radius, radius=None):
+    def query_prefix(self, queries, q_len, width, prefix_radius, radius=None, nearest_bound=0.0):
         """Prefix form (d3f_radius_query_prefix): int32 [Nq, width] rows = the supports within ``prefix_radius``, ranked as
         the leading part of the ``query`` row -- or the single nearest support within the search radius when there is
         none.  For tables of which only column 0 and the part within ``prefix_radius`` are ever read (the upsampling
-        tables inside the training engine)."""
+        tables inside the training engine).  ``nearest_bound`` > 0: the caller guarantees a support within that distance
+        of every query; cells beyond it are not scanned."""
         q = _f32(queries, "queries")
         q_len = _lens(q_len, q.device, "q_batches")
         Nq = int(q.shape[0])
@@ -183,7 +184,8 @@ class RadiusGrid:
         with _region("radius_query_prefix[Nq=%d,Ns=%d]" % (Nq, self.Ns), 12 * Nq + 12 * self.Ns + 4 * Nq * int(width)):
             _native.check(_native.lib().d3f_radius_query_prefix(
                 _p(self.ws), _p(q), Nq, _p(q_len), self.Ns, _p(self.s_len), int(q_len.numel()), self.radius, r,
-                float(prefix_radius), int(width), _p(out), _p(self.status.word), _stream()), "d3f_radius_query_prefix")
+                float(prefix_radius), float(nearest_bound), int(width), _p(out), _p(self.status.word), _stream()),
+                "d3f_radius_query_prefix")
         return out
 
     def query(self, queries, q_len, width, want_counts=False, want_max=False, radius=None, wide=0, want_last_key=False,

@@ -105,10 +105,13 @@ int d3f_radius_query_ex(const void* grid_ws, const float* queries, int Nq, const
  * them with radius 2 r; the network reads column 0, models/blocks.py:79-91, and this build reads the transpose of the
  * pooling table off their leading part): row q = the supports within prefix_radius of q, ranked exactly like the leading
  * part of the d3f_radius_query row, or -- when there is none -- the single nearest support within `radius`.  The entries
- * between the two radii are neither ranked nor stored.  collate_fn_descriptor's tables keep the full rows. */
+ * between the two radii are neither ranked nor stored.  collate_fn_descriptor's tables keep the full rows.
+ * nearest_bound (0: none; else prefix_radius <= nearest_bound <= radius): the caller's guarantee that every query has a
+ * support within that distance -- a fine point lies within the voxel diagonal 0.8 r sqrt(3) < 1.5 r of its own voxel's
+ * barycentre, the coarse point it was subsampled into (dataloader.py:141-146) -- so cells beyond it are not scanned. */
 int d3f_radius_query_prefix(const void* grid_ws, const float* queries, int Nq, const int32_t* q_len, int Ns,
                             const int32_t* s_len, int B, float grid_radius, float radius, float prefix_radius,
-                            int width, int32_t* out_idx, int32_t* status, void* stream);
+                            float nearest_bound, int width, int32_t* out_idx, int32_t* status, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Grid subsampling -- replaces grid_subsampling.subsample_batch, points-only branch

@@ -190,6 +190,21 @@ def test_radius_query_prefix_rows_are_the_leading_part_of_the_full_rows(native, 
         assert np.array_equal(got[i, :want.size], want), i
         assert np.all(got[i, want.size:] == ns), i
     assert some_empty and some_prefix and (some_nearest_only or prefix > 0.06)   # (the 0.05 case has nearest-only rows)
+    # with a nearest bound (cells beyond it are not scanned): the same rows wherever the nearest support is within it
+    bound = max(prefix, 0.7 * radius)
+    gotb = grid.query_prefix(cu(q), cu(ql), width, prefix, nearest_bound=bound).cpu().numpy()
+    b2 = np.float32(bound) * np.float32(bound)
+    checked = 0
+    for i in range(q.shape[0]):
+        row = full[i][full[i] < ns]
+        if row.size == 0:
+            assert np.all(gotb[i] == ns)
+            continue
+        d = (q[i] - s[row[0]]).astype(np.float32)
+        if (d[0] * d[0] + d[1] * d[1]) + d[2] * d[2] < b2:
+            assert np.array_equal(gotb[i], got[i]), i
+            checked += 1
+    assert checked > q.shape[0] // 2
 
 
 # ------------------------------------------------------------------------------------------------ KPConv
