@@ -901,6 +901,8 @@ class TrainStep:
         # on top of each other (round 5: the root of round 4's "hipBLASLt winner never finishes on a later replay",
         # profiles/r05_hipblaslt_hang.txt; with rocBLAS split-K solutions the same sharing is a silent race).
         cap = getattr(self, 'stream', None) if getattr(self, 'lane', None) is not None else None
+        if os.environ.get('D3F_CLEAR_BLAS_WS') == '1':
+            torch._C._cuda_clearCublasWorkspaces()
         if os.environ.get('D3F_SHARED_CAPTURE_STREAM') == '1':     # (experiments: rounds 1-4's behaviour)
             cap = None
         for i in range(self.NSETS):

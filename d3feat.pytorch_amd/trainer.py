@@ -155,6 +155,13 @@ class Trainer(object):
             per_rank = len(self.train_loader.dataset) // max(1, getattr(self.train_loader, 'batch_size', 1)) // self.world
             if per_rank >= self.AUTO_MIN_STEPS * self.AUTO_LANES * self.AUTO_STACK:
                 self.lanes, self.stack = self.AUTO_LANES, self.AUTO_STACK
+                # the stacked shapes run on TunableOp-selected library GEMMs, like bench.py: the shipped table for the
+                # S1-class capacities, the other shapes tuned while a capacity class is captured (rocBLAS candidates).
+                # On the library's DEFAULT picks one of the 4 x 3 shapes gets a solution that never finishes on a later
+                # graph replay (profiles/r05_hipblaslt_hang.txt); D3F_NO_TUNED_GEMMS=1 leaves the process untouched
+                if os.environ.get("D3F_NO_TUNED_GEMMS") != "1" and not torch.cuda.tunable.is_enabled():
+                    from . import enable_tuned_gemms
+                    enable_tuned_gemms()
                 if self.rank == 0:
                     print("note: training on %d x %d = %d fragment pairs per optimizer step and GPU (%d network graphs in "
                           "flight x %d pairs stacked in each); every update is the MEAN gradient of those pairs x %d rank(s) "

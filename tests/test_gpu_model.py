@@ -373,7 +373,14 @@ def test_bench_paths_at_s1_size_reproduce_the_reference_run(golden_s1):
         assert eng.check_status() == (0, 0)
     # (c) lanes x stacked pairs: 2 x 2, and 4 x 3 -- bench.py's default, the configuration the driver's number is measured
     # on (114 688-row level 0, its own tuned-GEMM rows and stream deal)
+    import d3feat_pytorch_amd as d3f
     for n_lanes, n_stack in ((2, 2), (4, 3)):
+        if (n_lanes, n_stack) == (4, 3):
+            # bench.py's configuration INCLUDING its library-GEMM selection (the shipped TunableOp table holds these
+            # shapes): on the library's default picks one of the 4 x 3 shapes gets a solution that never finishes on a
+            # later graph replay (profiles/r05_hipblaslt_hang.txt: memset graph nodes lose their fill value on this HIP
+            # runtime), with the table the engine captures the solutions the driver's run captures
+            assert d3f.enable_tuned_gemms()
         lanes = PairLanes(ts, n_lanes, stack=n_stack)
         lanes.enable_graph(TrainStep.capacities_for([[n_stack * n for n in sizes[0]]], slack=1.0),
                            num_corr=int(item[4].shape[0]))
@@ -387,6 +394,7 @@ def test_bench_paths_at_s1_size_reproduce_the_reference_run(golden_s1):
                 check_buffer(ts.flat.lanes[lane][0], n_stack, '%d x %d lane %d' % (n_lanes, n_stack, lane))
         assert lanes.check_status() == (0, 0) and int(ts.opt.skipped) == 0
         del lanes
+    torch.cuda.tunable.enable(False)       # (the other tests run on the library's default picks, as before)
     # lr = 0: nothing above moved the parameters
     for k, v in ts.model.state_dict().items():
         srow = g['sdsum.' + k]
@@ -1084,6 +1092,8 @@ def test_trainer_default_schedule_fills_the_gpu_unless_opted_out(capsys):
     assert (tr.lanes, tr.stack) == (2, 1)
     tr = Trainer(args(40))               # 3 steps of 12 per epoch: not worth a 12-pair schedule
     assert (tr.lanes, tr.stack) == (1, 1)
+    assert torch.cuda.tunable.is_enabled()        # (the default schedule brought the tuned library-GEMM selection along)
+    torch.cuda.tunable.enable(False)
 
 
 def test_two_rank_bench_control_flow_on_one_gpu():
