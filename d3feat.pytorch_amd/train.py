@@ -242,6 +242,35 @@ class GuardedSGD:
         return ok
 
 
+def new_graph():
+    """A torch.cuda.CUDAGraph whose hipGraph_t template is KEPT next to the instantiated executable graph.
+
+    Round 5 (profiles/r05_hipblaslt_hang.txt, memset_node_fix_experiment.py): on this HIP runtime a memset node of an
+    executable graph keeps reading its fill value from the TEMPLATE graph's node, and PyTorch destroys the template right
+    after instantiation (keep_graph=False, the default) -- from the second replay on a small hipMemsetAsync captured into
+    a graph writes 0xA0 bytes (freed memory) instead of its value.  Nothing in this package captures a memset (every
+    clear is a kernel), but library GEMM solutions that clear a semaphore / split-K workspace with hipMemsetAsync do:
+    they then never finish on a later replay (hipBLASLt winners in round 4; the library's default pick for one of the
+    4 x 3 stacked shapes).  With the template alive the node replays correctly.  D3F_DROP_GRAPH_TEMPLATES=1: rounds 1-4."""
+    if os.environ.get("D3F_DROP_GRAPH_TEMPLATES") == "1":
+        return torch.cuda.CUDAGraph()
+    try:
+        return torch.cuda.CUDAGraph(keep_graph=True)
+    except TypeError:      # (an older PyTorch without the option)
+        return torch.cuda.CUDAGraph()
+
+
+def finish_graph(g):
+    """After the capture: a kept-template graph is instantiated explicitly (the default form does it in capture_end)."""
+    inst = getattr(g, 'instantiate', None)
+    if inst is not None and os.environ.get("D3F_DROP_GRAPH_TEMPLATES") != "1":
+        try:
+            inst()
+        except RuntimeError:       # (already instantiated: the default form)
+            pass
+    return g
+
+
 _WARM = {}
 
 
@@ -906,16 +935,16 @@ class TrainStep:
         if os.environ.get('D3F_SHARED_CAPTURE_STREAM') == '1':     # (experiments: rounds 1-4's behaviour)
             cap = None
         for i in range(self.NSETS):
-            g = torch.cuda.CUDAGraph()
+            g = new_graph()
             with torch.cuda.graph(g, stream=cap, capture_error_mode=_CAPTURE_MODE):
                 self._build_set(self.sets[i], adopt=True)
-            self.g_pyr.append(g)
+            self.g_pyr.append(finish_graph(g))
         for g in self.g_pyr:    # a capture records, it does not run: fill the adopted tensors (inputs are loaded)
             g.replay()
         torch.cuda.synchronize(dev)
         self._choose_side_stream()
         for i in range(self.NSETS):
-            g = torch.cuda.CUDAGraph()
+            g = new_graph()
             lane_split = self.split_backward and getattr(self, 'lane', None) is not None
             s1, s2 = self._lane_stages(self.sets[i]) if lane_split else (None, None)
             with torch.cuda.graph(g, pool=self.g_net[0].pool() if self.g_net else None, stream=cap,
@@ -927,15 +956,15 @@ class TrainStep:
                 else:
                     self._graph_out.append(self._net_step(self.sets[i]))
                 self._graph_dist.append(self.last_distances)   # held: the pool keeps these addresses for this graph
-            self.g_net.append(g)
+            self.g_net.append(finish_graph(g))
             if self.split_backward:  # stage 2 of the same step: continues in the same pool
-                g = torch.cuda.CUDAGraph()
+                g = new_graph()
                 with torch.cuda.graph(g, pool=self.g_net[0].pool(), stream=cap, capture_error_mode=_CAPTURE_MODE):
                     if lane_split:
                         s2()
                     else:
                         self._backward_shallow()
-                self.g_net_b.append(g)
+                self.g_net_b.append(finish_graph(g))
         torch.cuda.synchronize(dev)
         self.ev_net = [torch.cuda.Event() for _ in range(self.NSETS)]
         self.ev_pyr = [torch.cuda.Event() for _ in range(self.NSETS)]

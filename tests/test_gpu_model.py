@@ -375,7 +375,7 @@ def test_bench_paths_at_s1_size_reproduce_the_reference_run(golden_s1):
     # on (114 688-row level 0, its own tuned-GEMM rows and stream deal)
     import d3feat_pytorch_amd as d3f
     for n_lanes, n_stack in ((2, 2), (4, 3)):
-        if (n_lanes, n_stack) == (4, 3):
+        if (n_lanes, n_stack) == (4, 3) and os.environ.get('D3F_TEST_NO_TABLE') != '1':
             # bench.py's configuration INCLUDING its library-GEMM selection (the shipped TunableOp table holds these
             # shapes): on the library's default picks one of the 4 x 3 shapes gets a solution that never finishes on a
             # later graph replay (profiles/r05_hipblaslt_hang.txt: memset graph nodes lose their fill value on this HIP
