@@ -245,13 +245,14 @@ class GuardedSGD:
 def new_graph():
     """A torch.cuda.CUDAGraph whose hipGraph_t template is KEPT next to the instantiated executable graph.
 
-    Round 5 (profiles/r05_hipblaslt_hang.txt, memset_node_fix_experiment.py): on this HIP runtime a memset node of an
+    Round 5 (profiles/memset_node_repro.py, memset_node_fix_experiment.py): on this HIP runtime a memset node of an
     executable graph keeps reading its fill value from the TEMPLATE graph's node, and PyTorch destroys the template right
     after instantiation (keep_graph=False, the default) -- from the second replay on a small hipMemsetAsync captured into
-    a graph writes 0xA0 bytes (freed memory) instead of its value.  Nothing in this package captures a memset (every
-    clear is a kernel), but library GEMM solutions that clear a semaphore / split-K workspace with hipMemsetAsync do:
-    they then never finish on a later replay (hipBLASLt winners in round 4; the library's default pick for one of the
-    4 x 3 stacked shapes).  With the template alive the node replays correctly.  D3F_DROP_GRAPH_TEMPLATES=1: rounds 1-4."""
+    a graph writes 0xA0 bytes (freed memory) instead of its value; with the template alive it replays correctly.  Nothing
+    in this package captures a memset (every clear is a kernel, csrc/common.hpp), but a library call inside a captured
+    step may.  (This does NOT cure the library-GEMM solutions that never finish on a later replay -- hipBLASLt winners,
+    the default pick of one 4 x 3 stacked shape: they hang with the templates kept as well, profiles/r05_hipblaslt_hang.txt;
+    the engine captures TunableOp-selected rocBLAS solutions.)  D3F_DROP_GRAPH_TEMPLATES=1: the default form."""
     if os.environ.get("D3F_DROP_GRAPH_TEMPLATES") == "1":
         return torch.cuda.CUDAGraph()
     try:
