@@ -92,7 +92,9 @@ def agg_rev_kernel_cost(edges):
 
 
 KERNEL_NAMES = {4: "atb_partial_kernel + atb_reduce_kernel (weight gradients C = A^T B of the unary blocks and of KPConv "
-                   "from the saved aggregation: reduction over the points spread over the chip, f32 MFMA, fixed-order sum)",
+                   "from the saved aggregation: reduction over the points spread over the chip, f32 MFMA, fixed-order sum; "
+                   "round 5: both forms of the partial kernel -- direct loads / per-wave LDS rings fed by LDS-DMA, chosen "
+                   "per shape -- and the second stage that also finishes the block's bias gradient)",
                 5: "kpconv_agg_fwd_kernel (KPConv neighbor aggregation wf = sum_h w x, registers -> HBM; contraction by GEMM)",
                 6: "kpconv_agg_rev_kernel (KPConv grad-input aggregation over the reverse table, registers -> HBM; "
                    "contraction by GEMM, no atomics)",
@@ -961,9 +963,10 @@ def main():
                     with open(os.path.join(REPO, "d3feat.pytorch_amd", "csrc", src), "rb") as fh:
                         traffic_stale = hashlib.sha256(fh.read()).hexdigest()[:16] != entry.get("source_sha16")
             counters = None   # L2 hit rate / MFMA-pipe busy of the same kernels (separate rocprofv3 --pmc passes)
-            cpath = os.path.join(REPO, "profiles", "r04_pmc_kernels.json")
-            if not os.path.exists(cpath):
-                cpath = os.path.join(REPO, "profiles", "r03_pmc_kpconv.json")
+            cpath = os.path.join(REPO, "profiles", "r05_pmc_kernels.json")
+            for older in ("r04_pmc_kernels.json", "r03_pmc_kpconv.json"):
+                if not os.path.exists(cpath):
+                    cpath = os.path.join(REPO, "profiles", older)
             if os.path.exists(cpath):
                 with open(cpath) as f:
                     counters = json.load(f).get(KERNEL_NAMES[dom].split(" ")[0])

@@ -208,7 +208,7 @@ __device__ __forceinline__ void lds_frag(const float* __restrict__ row, int li, 
 extern __shared__ __attribute__((aligned(1024))) unsigned char atb_smem[];
 
 template <int TI, int TJ, int KS, int S, bool DIV>
-__global__ __launch_bounds__(256, (TI * TJ > 16) ? 1 : 2) void atb2_partial_kernel(
+__global__ __launch_bounds__(256, (TI * TJ > 16) ? 1 : 2) void atb_partial_kernel2(
     const float* __restrict__ A, const float* __restrict__ B, const float* __restrict__ row_div, int R, int M, int N,
     int rows_per_wg, int P, float* __restrict__ part, int dbg) {
   constexpr int BM = 16 * TI, BN = 16 * TJ, ROWS = 4 * KS;
@@ -523,7 +523,7 @@ __global__ __launch_bounds__(1024) void atb_reduce_bias_kernel(const float* __re
 template <int TI, int TJ, int KS, int S, bool DIV>
 static int atb2_launch(const Atb2Cfg& c, const float* A, const float* B, const float* row_div, int R, int M, int N,
                        float* part, hipStream_t stream) {
-  auto kern = atb2_partial_kernel<TI, TJ, KS, S, DIV>;
+  auto kern = atb_partial_kernel2<TI, TJ, KS, S, DIV>;
   // more than 64 KB of dynamic LDS needs the opt-in, a per-device function attribute: asked for on every call (a
   // host-side table update, no stream operation; a process may drive several devices and threads)
   if (c.lds > 64 * 1024 &&
