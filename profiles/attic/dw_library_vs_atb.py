@@ -2,7 +2,7 @@
 library GEMM torch.mm(A.t(), B) with TunableOp tuning on (rocBLAS candidates), hipGraph-replayed:
     python profiles/dw_library_vs_atb.py [Q]        (Q pairs stacked: rows = Q x the one-pair level sizes)"""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 import d3feat_pytorch_amd as d3f
 from d3feat_pytorch_amd import _native

@@ -1,7 +1,7 @@
 """GPU time and achieved bandwidth of the block epilogue kernels per network shape.
 Run on the GPU box: python profiles/epilogue_microbench.py"""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from d3feat_pytorch_amd import _native
 

@@ -11,7 +11,7 @@ import sys
 import numpy as np
 import torch
 
-REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REPO = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, REPO)
 from d3feat_pytorch_amd import config as cfgmod, ops, synthetic  # noqa: E402
 from d3feat_pytorch_amd.datasets import dataloader as dl  # noqa: E402

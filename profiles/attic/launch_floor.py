@@ -7,7 +7,7 @@ all-in price of one small dependent launch.  Three bodies: the library's own epi
 import os
 import sys
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from d3feat_pytorch_amd import ops
 

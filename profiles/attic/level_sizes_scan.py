@@ -1,6 +1,6 @@
 """Level sizes of the S1-class synthetic pairs used by bench.py on ranks 0..7 (seeds 100r+2i+1, 100r+2i+2)."""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 import torch
 from d3feat_pytorch_amd import config as cfgmod, synthetic

@@ -1,7 +1,7 @@
 """Times the reduction-parallel grad_W kernel against the library GEMM for the unary-block shapes of the full net.
 Run on the GPU box: python profiles/linear_microbench.py"""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 import d3feat_pytorch_amd as d3
 from d3feat_pytorch_amd import ops, _native

@@ -2,7 +2,7 @@
 gather rate limited by L2 locality?  Same cloud, same tables up to the row permutation.
 python profiles/locality_experiment.py"""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 import torch
 from d3feat_pytorch_amd import ops, synthetic

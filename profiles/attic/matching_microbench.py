@@ -1,6 +1,6 @@
 """Dense mutual-NN matching alone: python profiles/matching_microbench.py [N] [C]"""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from d3feat_pytorch_amd import ops
 

@@ -3,7 +3,7 @@ s_memtime at their phase boundaries when d3f_debug_set_phase_clock is armed; thi
 pair one at a time and prints, per layer, the average shader cycles per wave and phase.
     python profiles/phase_clock.py"""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 import torch
 from d3feat_pytorch_amd import _native, config as cfgmod, ops, synthetic

@@ -8,7 +8,7 @@ import sys
 import threading
 import time
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 import torch
 import d3feat_pytorch_amd as d3f   # noqa: F401  (GPU_MAX_HW_QUEUES before the first HIP call)
