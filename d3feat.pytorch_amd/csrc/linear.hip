@@ -473,9 +473,31 @@ size_t atb_ws_bytes(int R, int M, int N) {
 __global__ __launch_bounds__(1024) void atb_reduce_bias_kernel(const float* __restrict__ part, int P, size_t MN,
                                                                float* __restrict__ C, size_t MN_out, int c_blocks,
                                                                const float* __restrict__ bpart, int nblocks, int BC,
-                                                               float* __restrict__ gb, float* __restrict__ gb2) {
+                                                               float* __restrict__ gb, float* __restrict__ gb2,
+                                                               int fan16) {
   __shared__ float sh[16][64];
   const int col = threadIdx.x & 63, sub = threadIdx.x >> 6;
+  if ((int)blockIdx.x < c_blocks && !fan16) {
+    // few slabs (the usual case: 8..32 partitions): 256 elements x 4 row lanes per workgroup, every lane sums a quarter
+    // of the slabs in two chains -- 16 lanes per element spent their time in the LDS combine (7.0 us a launch against
+    // 4.7 for the plain 4-lane reduce)
+    float* sh4 = &sh[0][0];                  // [4][256]
+    const int el = threadIdx.x & 255, s4 = threadIdx.x >> 8;
+    const size_t e = (size_t)blockIdx.x * 256 + el;
+    float s0 = 0.f, s1 = 0.f;
+    if (e < MN) {
+      int p = s4;
+      for (; p + 4 < P; p += 8) {
+        s0 += part[(size_t)p * MN + e];
+        s1 += part[(size_t)(p + 4) * MN + e];
+      }
+      if (p < P) s0 += part[(size_t)p * MN + e];
+    }
+    sh4[s4 * 256 + el] = s0 + s1;
+    __syncthreads();
+    if (s4 == 0 && e < MN_out) C[e] = ((sh4[el] + sh4[256 + el]) + sh4[512 + el]) + sh4[768 + el];
+    return;
+  }
   if ((int)blockIdx.x < c_blocks) {
     const size_t e = (size_t)blockIdx.x * 64 + col;
     float s0 = 0.f, s1 = 0.f;
@@ -634,9 +656,11 @@ int atb_splitk_bias(const float* A, const float* B, const float* row_div, int R,
   const size_t MN_out = (M_out > 0 && M_out < M) ? (size_t)M_out * N : MN;
   static const int fan = atb_tunable("D3F_ATB_FAN", 0);
   if (bias_part) {
-    const int cb = cdiv((long long)MN, 64);
+    const int fan16 = (fan ? fan >= 16 : (P >= 64 && MN <= 65536)) ? 1 : 0;
+    const int cb = cdiv((long long)MN, fan16 ? 64 : 256);
     atb_reduce_bias_kernel<<<cb + cdiv(bias_cols, 64), 1024, 0, stream>>>(part, P, MN, C, MN_out, cb, bias_part,
-                                                                         bias_blocks, bias_cols, grad_bias, grad_bias2);
+                                                                         bias_blocks, bias_cols, grad_bias, grad_bias2,
+                                                                         fan16);
   } else if (fan ? fan >= 16 : (P >= 64 && MN <= 65536)) {
     atb_reduce_kernel<16><<<cdiv((long long)MN, 64), 1024, 0, stream>>>(part, P, MN, C, MN_out);
   } else {
