@@ -144,7 +144,7 @@ class Trainer(object):
         self._captured = False
         # Pairs per optimizer step and GPU.  Unless pinned (``pairs_in_flight`` / ``stacked_pairs``) or opted out of
         # (``reference_schedule = True``: one pair per step, reference dataloader.py:73), the hipGraph path trains on
-        # AUTO_LANES x AUTO_STACK pairs per step -- what an MI355X needs to be busy (bench.py: 566 pairs/s against 267 on
+        # AUTO_LANES x AUTO_STACK pairs per step -- what an MI355X needs to be busy (bench.py: 576 pairs/s against 269 on
         # the reference's schedule) -- when an epoch holds at least AUTO_MIN_STEPS such steps per rank.
         pinned = _get(args, 'pairs_in_flight', None) is not None or _get(args, 'stacked_pairs', None) is not None
         self.lanes = max(1, int(_get(args, 'pairs_in_flight', 1)))
