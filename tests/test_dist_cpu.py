@@ -136,6 +136,17 @@ def _agree_worker(rank, world, port, ret):
     tr = Trainer.__new__(Trainer)
     tr.world, tr.device, tr._agree_stream = world, torch.device('cpu'), None
     ok = tr._agree(True) is True and tr._agree(rank == 0) is False and tr._agree(False) is False
+    # the agreement of step k + 1 is POSTED during step k (asynchronous all-reduce) and READ when step k + 1 starts
+    # (round 5: no collective + .item() inside the step that needs the answer); an unposted step falls back to _agree,
+    # a posted-but-unread one is drained so that the ranks' collectives stay in step
+    ok &= tr._agreed(1, True) is True                      # nothing posted: synchronous
+    tr._post_agreement(2, rank == 0)                       # rank 1 cannot take the graph path for step 2
+    ok &= tr._agreed(2, True) is False                     # ... so nobody does (the local flag at read time is not used)
+    tr._post_agreement(3, True)
+    ok &= tr._agreed(3, False) is True                     # the posted (common) decision wins
+    tr._post_agreement(5, True)
+    ok &= tr._agreed(4, rank == 1) is False                # a stale post is waited for, then a fresh agreement is made
+    ok &= getattr(tr, '_pending_agree', None) is None
     torch.manual_seed(0)
     mk = lambda: torch.nn.Sequential(torch.nn.Linear(7, 13), torch.nn.LeakyReLU(0.1), torch.nn.Linear(13, 5))   # noqa: E731
     model, ref = mk(), mk()
