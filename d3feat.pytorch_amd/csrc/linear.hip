@@ -383,9 +383,28 @@ static int atb_partitions(int R, int M, int N) {
 }
 
 // ---- second form: configuration ------------------------------------------------------------------------------
-static int env_int(const char* name, int dflt) {   // read at every call: the sweep scripts change them between launches
+// Tunables of the second form.  Read ONCE per variable (first use) in normal operation; with D3F_ATB_SWEEP set (the sweep
+// scripts of profiles/, which change them between launches of one process) at every call.  The cache is keyed by the
+// address of the name literal: a call site is one entry (benign race: two threads may both fill an entry with the same value).
+static int env_int(const char* name, int dflt) {
+  static const bool live = getenv("D3F_ATB_SWEEP") != nullptr;
+  if (live) {
+    const char* v = getenv(name);
+    return v ? atoi(v) : dflt;
+  }
+  struct Entry { const char* name; int value; };
+  static Entry cache[32];
+  static int n_cached = 0;
+  for (int i = 0; i < n_cached; ++i)
+    if (cache[i].name == name) return cache[i].value;
   const char* v = getenv(name);
-  return v ? atoi(v) : dflt;
+  const int value = v ? atoi(v) : dflt;
+  if (n_cached < 32) {
+    cache[n_cached].value = value;
+    cache[n_cached].name = name;
+    ++n_cached;
+  }
+  return value;
 }
 static inline int tile_width2(int n, int tmax) {
   if (tmax >= 8 && n % 128 == 0) return 8;

@@ -5,6 +5,7 @@ import os
 import sys
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+os.environ["D3F_ATB_SWEEP"] = "1"     # the library re-reads its D3F_ATB* tunables at every call
 import torch  # noqa: E402
 from d3feat_pytorch_amd import _native  # noqa: E402
 
