@@ -74,6 +74,14 @@ def atb_kernel_cost(R, _ns, _h, M, N, _k):
     return b, 2 * R * M * N, b
 
 
+def atb_group_cost(_n, mi_flop, ki_bytes, _tasks, _z, _k):
+    """One GROUPED weight-gradient launch pair (linear.hip, round 6: atb_grouped_kernel + atb_grouped_reduce_kernel over
+    every queued problem of a backward stage).  The library records the sums over its problems: 2 R M N in MiFLOP and the
+    A^T B byte model above, 4 R (M + N) + 4 M N, in KiB."""
+    b = ki_bytes * 1024.0
+    return b, mi_flop * 1048576.0, b
+
+
 def agg_fwd_kernel_cost(Nq, Ns, H, Cin, _cout, K):
     """Forward aggregation kernel (kpconv_aggregate.hip): SURVEY 8d's KPConv forward bytes without the weights and the
     output row, plus the written wf [Nq, K Cin]."""
@@ -95,6 +103,10 @@ KERNEL_NAMES = {4: "atb_partial_kernel + atb_reduce_kernel (weight gradients C =
                    "from the saved aggregation: reduction over the points spread over the chip, f32 MFMA, fixed-order sum; "
                    "round 5: both forms of the partial kernel -- direct loads / per-wave LDS rings fed by LDS-DMA, chosen "
                    "per shape -- and the second stage that also finishes the block's bias gradient)",
+                7: "atb_grouped_kernel + atb_grouped_reduce_kernel (round 6: EVERY weight gradient C = A^T B of a backward "
+                   "stage -- unary blocks and KPConv from the saved aggregation -- in ONE launch over all problems' (row "
+                   "partition, output block) tasks, per-wave LDS rings fed by LDS-DMA, f32 MFMA, plus ONE launch that sums "
+                   "all slabs in a fixed order and finishes the bias gradients; a 'launch' below = one such pair)",
                 5: "kpconv_agg_fwd_kernel (KPConv neighbor aggregation wf = sum_h w x, registers -> HBM; contraction by GEMM)",
                 6: "kpconv_agg_rev_kernel (KPConv grad-input aggregation over the reverse table, registers -> HBM; "
                    "contraction by GEMM, no atomics)",
@@ -109,7 +121,7 @@ def timed_kernels(lib, run_steps, costs, n_steps):
     (d3f_debug_kernel_timing_*), grouped by kernel: {which: stats}."""
     import ctypes
     cap = 2048
-    if lib.d3f_debug_kernel_timing_begin(-63, cap) != 0:
+    if lib.d3f_debug_kernel_timing_begin(-127, cap) != 0:
         return {}
     run_steps()
     torch.cuda.synchronize()
@@ -127,7 +139,8 @@ def timed_kernels(lib, run_steps, costs, n_steps):
         g[2] += b
         g[3] += f
         g[4] += u
-        g[5].append({"shape": dict(zip(("Nq", "Ns", "H", "Cin", "Cout", "K"), shape)), "us": round(ms[i] * 1e3, 2),
+        keys = ("problems", "MiFLOP", "KiB", "workgroups", "_", "__") if which == 7 else ("Nq", "Ns", "H", "Cin", "Cout", "K")
+        g[5].append({"shape": dict(zip(keys, shape)), "us": round(ms[i] * 1e3, 2),
                      "bytes": int(b), "flops": int(f)})
     return {w: {"launches": g[0], "avg_us": g[1] / g[0] * 1e3, "us_per_step": g[1] / n_steps * 1e3,
                 "bytes_per_launch": g[2] / g[0], "flops_per_launch": g[3] / g[0], "unique_bytes_per_launch": g[4] / g[0],
@@ -792,7 +805,8 @@ def main():
                         widths[(r.Nq, r.Ns)] = int(r.width)
     kt = {} if args.quick else timed_kernels(
         _native.lib(), _three_steps, {1: fwd_kernel_cost, 2: dx_kernel_cost, 3: gather_kernel_cost(edges, widths),
-                                      4: atb_kernel_cost, 5: agg_fwd_kernel_cost, 6: agg_rev_kernel_cost(edges)}, 3)
+                                      4: atb_kernel_cost, 5: agg_fwd_kernel_cost, 6: agg_rev_kernel_cost(edges),
+                                      7: atb_group_cost}, 3)
     dom = max(kt, key=lambda w: kt[w]["us_per_step"]) if kt else None
     dx_t = kt.get(dom)
 
@@ -963,8 +977,8 @@ def main():
                     with open(os.path.join(REPO, "d3feat.pytorch_amd", "csrc", src), "rb") as fh:
                         traffic_stale = hashlib.sha256(fh.read()).hexdigest()[:16] != entry.get("source_sha16")
             counters = None   # L2 hit rate / MFMA-pipe busy of the same kernels (separate rocprofv3 --pmc passes)
-            cpath = os.path.join(REPO, "profiles", "r05_pmc_kernels.json")
-            for older in ("r04_pmc_kernels.json", "r03_pmc_kpconv.json"):
+            cpath = os.path.join(REPO, "profiles", "r06_pmc_kernels.json")
+            for older in ("r05_pmc_kernels.json", "r04_pmc_kernels.json", "r03_pmc_kpconv.json"):
                 if not os.path.exists(cpath):
                     cpath = os.path.join(REPO, "profiles", older)
             if os.path.exists(cpath):

@@ -16,12 +16,30 @@ SOURCES = ["radius_neighbors.hip", "grid_subsample.hip", "kpconv.hip", "kpconv_f
 
 _vp, _i, _f, _sz = C.c_void_p, C.c_int, C.c_float, C.c_size_t
 
+
+class Tunables(C.Structure):
+    """d3f_tunables of include/d3feat_hip.h: the library's knobs (it never reads the environment)."""
+    _fields_ = [("atb_task_us", C.c_int32), ("atb_form", C.c_int32), ("atb_first_form_wgs", C.c_int32),
+                ("match_wgs", C.c_int32), ("agg_through_lds", C.c_int32), ("reserved", C.c_int32 * 11)]
+
+
+class AtbProblem(C.Structure):
+    """d3f_atb_problem of include/d3feat_hip.h: one queued weight gradient grad_w [Cout, ldw] = grad_out^T x."""
+    _fields_ = [("x", _vp), ("grad_out", _vp), ("grad_w", _vp), ("N", C.c_int32), ("Cin", C.c_int32),
+                ("Cout", C.c_int32), ("ldw", C.c_int32), ("bias_part", _vp), ("bias_blocks", C.c_int32),
+                ("bias_cols", C.c_int32), ("grad_bias", _vp), ("grad_bias2", _vp)]
+
+
 # name -> (restype, argtypes); mirrors include/d3feat_hip.h one to one
 SIGNATURES = {
     "d3f_version": (C.c_char_p, []),
     "d3f_device_arch_ok": (_i, []),
     "d3f_device_arch_name": (_i, [C.c_char_p, _i]),
     "d3f_debug_set_flags": (None, [_i]),
+    "d3f_get_tunables": (None, [C.POINTER(Tunables)]),
+    "d3f_set_tunables": (_i, [C.POINTER(Tunables)]),
+    "d3f_linear_grad_weight_group_ws_bytes": (_sz, [C.POINTER(AtbProblem), _i]),
+    "d3f_linear_grad_weight_group": (_i, [C.POINTER(AtbProblem), _i, _vp, _sz, _vp]),
     "d3f_debug_set_phase_clock": (None, [_vp]),
     "d3f_debug_kernel_timing_begin": (_i, [_i, _i]),
     "d3f_debug_kernel_timing_end": (_i, [_vp, _vp, _i]),
@@ -208,6 +226,20 @@ def check(rc, what):
         torch.cuda.synchronize()
     if rc != 0:
         raise RuntimeError("%s failed: %s" % (what, ERRORS.get(rc, "error %d" % rc)))
+
+
+def set_tunables(**kw):
+    """Change fields of the library's d3f_tunables (experiments / tests); returns the previous values as a dict."""
+    L = lib()
+    t = Tunables()
+    L.d3f_get_tunables(C.byref(t))
+    old = {name: getattr(t, name) for name, _ in Tunables._fields_ if name != "reserved"}
+    for k, v in kw.items():
+        if k not in old:
+            raise RuntimeError("d3f_tunables has no field %r" % k)
+        setattr(t, k, int(v))
+    check(L.d3f_set_tunables(C.byref(t)), "d3f_set_tunables")
+    return old
 
 
 def status_message(word):

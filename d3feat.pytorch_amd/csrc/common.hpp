@@ -29,6 +29,9 @@ static inline hipError_t zero_async(void* p, size_t bytes, hipStream_t stream) {
   return hipGetLastError();
 }
 
+// the library's tunables (misc.hip; d3f_set_tunables): plain loads of a process-wide struct, no environment reads
+const d3f_tunables& tunables();
+
 static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 static inline int cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
 

@@ -429,9 +429,9 @@ int d3f_kpconv_aggregate(const float* q_pts, int Nq, const float* s_pts, int Ns,
       !(extent > 0.0f) || !kpconv_fused_supported(Cin, 64, K, H, Ns))
     return D3F_EINVAL;
   if (ws_bytes < d3f_kpconv_ws_bytes(Nq, Ns, H, K, Cin, 64)) return D3F_EWORKSPACE;
-  // registers -> HBM (kpconv_aggregate.hip); D3F_AGG_LDS=1 keeps the round-1 form (phase A of the fused kernel, through
-  // its LDS tile) for A/B measurements
-  static const bool through_lds = getenv("D3F_AGG_LDS") != nullptr;
+  // registers -> HBM (kpconv_aggregate.hip); tunables().agg_through_lds keeps the round-1 form (phase A of the fused
+  // kernel, through its LDS tile) for A/B measurements
+  const bool through_lds = d3f::tunables().agg_through_lds != 0;
   if (!through_lds)
     return kpconv_aggregate_direct(q_pts, Nq, s_pts, Ns, idx, H, x, Cin, kernel_points, K, extent, wf_out, nn_out,
                                    spack_keep, grad_x_clear, ws, (hipStream_t)stream_);

@@ -51,7 +51,8 @@ static int g_timed_mask = 0, g_timed_cap = 0, g_timed_n = 0;
 
 // which: 1 fused forward, 2 scatter-form grad input, 3 gather-form grad input (kpconv_dx_gather.hip), 4 the A^T B weight
 // gradient (linear.hip: partial + reduce launches; shape = {R, 0, 0, M, N, 0}), 5 / 6 the forward / transposed aggregation
-// kernels (kpconv_aggregate.hip; 6: shape = {Nq, Ns, table width, 0, Cout, K}).  The kernel id is kept in the record as
+// kernels (kpconv_aggregate.hip; 6: shape = {Nq, Ns, table width, 0, Cout, K}), 7 a GROUPED A^T B launch pair
+// (linear.hip: shape = {problems, MiFLOP, KiB, workgroups, 0, 0}).  The kernel id is kept in the record as
 // shape[5] = K | which << 8.
 void* kpconv_timing_open(int which, hipStream_t stream, int Nq, int Ns, int H, int Cin, int Cout, int K) {
   if (!g_timed || !(g_timed_mask & (1 << (which - 1))) || g_timed_n >= g_timed_cap) return nullptr;
@@ -73,10 +74,10 @@ struct TimingScope {
   ~TimingScope() { kpconv_timing_close(t, st); }
 };
 
-// which: one kernel id (1..6) or, negative, a mask of ids: -(bit0 | bit1 | ... | bit5)
+// which: one kernel id (1..7) or, negative, a mask of ids: -(bit0 | bit1 | ... | bit6)
 int kpconv_timing_begin(int which, int max_launches) {
-  const int mask = which < 0 ? -which : (which >= 1 && which <= 6 ? 1 << (which - 1) : 0);
-  if (g_timed || mask == 0 || mask > 63 || max_launches < 1) return D3F_EINVAL;
+  const int mask = which < 0 ? -which : (which >= 1 && which <= 7 ? 1 << (which - 1) : 0);
+  if (g_timed || mask == 0 || mask > 127 || max_launches < 1) return D3F_EINVAL;
   g_timed = new TimedLaunch[max_launches];
   for (int i = 0; i < max_launches; ++i)
     if (hipEventCreate(&g_timed[i].e0) != hipSuccess || hipEventCreate(&g_timed[i].e1) != hipSuccess) return D3F_ELAUNCH;

@@ -11,6 +11,10 @@
 //   slabs in a fixed order.
 // No atomics: the result is bit-reproducible run to run.
 // fp32-MFMA bound when M*N is large, HBM bound (R*(M+N)*4 bytes, each read once per column/row block) otherwise.
+#include <math.h>
+
+#include <vector>
+
 #include "kpconv_tile.hpp"
 
 namespace d3f {
@@ -128,21 +132,31 @@ __global__ __launch_bounds__(64 * SUBS) void atb_reduce_kernel(const float* __re
 }
 
 // ------------------------------------------------------------------------------------------------------------------
-// Second form of the partial-sum kernel (round 5).  The first form feeds every MFMA straight from a global load: with
-// the one workgroup per CU the reduction split affords (more partitions = more slab traffic) a SIMD holds ONE wave with
-// two k-steps of loads in flight, and the counters show it waiting on memory 45-78 % of the time with the matrix pipe
-// <= 0.27 busy (profiles/r04_pmc_kernels.txt).  Here the prefetch depth is decoupled from the registers:
-//   * every wave owns a private ring of S slots in LDS; a slot holds KS k-steps (4 KS rows) of the wave's A columns and
-//     B columns (+ their row divisors), filled by LDS-DMA (global_load_lds_dwordx4: 1 KiB per wave-instruction, lane l
-//     writes ring + 16 l, so a slot is simply the row-major [4 KS][16 TI] / [4 KS][16 TJ] panels);
-//   * S - 1 slots are in flight while one is consumed -- (S - 1)(TI + TJ) KS KiB per wave, no VGPR behind them; the only
-//     synchronisation is the wave's own counted s_waitcnt vmcnt (no workgroup barrier inside the reduction loop: a wave
-//     reads only what it loaded itself);
-//   * the MFMA operands come out of the slot with one 16 / 8 / 4-byte LDS read per operand vector (conflict-free:
-//     16 lanes cover one 64 TI-byte row segment), same fragment layout as the first form;
-//   * blockIdx -> (row partition, output block) keeps all output blocks of one row partition on ONE XCD (block b runs
-//     on XCD b % 8): the A / B panels that those workgroups share are fetched from HBM once and served from that L2.
-// 128-wide tiles (TI / TJ = 8 = two 64-column halves) halve the re-reads of the other operand for the wide gradients.
+// Grouped form (round 6): EVERY weight gradient of a backward stage in ONE launch, their slabs summed by ONE more.
+//
+// A weight gradient has no consumer before the optimizer, so nothing forces C_i = A_i^T B_i of layer i to run between
+// the grad-input kernels of layers i and i - 1.  Launched one by one (rounds 1-5: 27 launches + 27 second stages per
+// stack) every problem paid its own ramp-up, ring prologue, 4-wave combine, slab write and tail on a chip it could not
+// fill (256-512 workgroups, ONE round), and the memory-bound problems (32-wide operands) never overlapped with the
+// matrix-bound ones.  Here the host side queues the problems of a stage (ops.WeightGradGroup) and
+//   * atb_grouped_kernel walks them all: workgroup L -> (problem, row partition, output block) through a prefix table in
+//     the kernel argument (captured by value in the hipGraph node: no descriptor upload, no extra launch); partitions
+//     are sized by a TIME model (a task ~ atb_task_us of one workgroup slot, the larger of its matrix time and its share
+//     of the HBM stream), the chip is filled by the sum of all problems, so a problem takes as few partitions (slabs) as
+//     its work needs, and problems are ordered longest task first;
+//   * the inner loop is the per-wave LDS ring of round 5: a slot = 16 rows of the wave's A / B column panels filled by
+//     LDS-DMA (global_load_lds_dwordx4, 1 KiB per wave-instruction; lane l writes ring + 16 l, so a slot is simply the
+//     row-major [16][16 TI] / [16][16 TJ] panels), (S - 1) slots in flight behind a counted s_waitcnt vmcnt, no
+//     workgroup barrier in the loop (a wave reads only what it loaded itself), MFMA operands by one LDS vector read
+//     each; a slot is refilled as soon as its fragments are in registers, i.e. BEFORE its MFMAs issue;
+//   * 16 KiB of ring per wave = 64 KiB per workgroup = two workgroups per CU: one wave's fragment reads and DMA issue
+//     sit under its SIMD partner's MFMAs;
+//   * XCD-aware: every problem's tasks start at a multiple of 8, task t of a problem is partition (t % 8) + 8 (t / 8 /
+//     nblk), so all output blocks of one row partition run on ONE XCD (workgroup L runs on XCD L % 8) and the panels
+//     they share come out of that L2;
+//   * atb_grouped_reduce_kernel sums the slabs of ALL problems (fixed order, float4 per thread) and the bias gradients'
+//     partial column sums.
+// No atomics anywhere: bit-reproducible.  The single-problem entry points use the same two kernels with one problem.
 __device__ __forceinline__ void lds_dma16(const void* gsrc, unsigned lds_addr) {
   unsigned keep;   // M0 = LDS base of the wave-instruction (compiler-reserved: saved and restored in the statement)
   asm volatile(
@@ -150,18 +164,6 @@ __device__ __forceinline__ void lds_dma16(const void* gsrc, unsigned lds_addr) {
       "s_mov_b32 m0, %2\n\t"
       "s_nop 0\n\t"
       "global_load_lds_dwordx4 %1, off\n\t"
-      "s_mov_b32 m0, %0"
-      : "=&s"(keep)
-      : "v"(gsrc), "s"(lds_addr)
-      : "memory");
-}
-__device__ __forceinline__ void lds_dma4(const void* gsrc, unsigned lds_addr) {
-  unsigned keep;
-  asm volatile(
-      "s_mov_b32 %0, m0\n\t"
-      "s_mov_b32 m0, %2\n\t"
-      "s_nop 0\n\t"
-      "global_load_lds_dword %1, off\n\t"
       "s_mov_b32 m0, %0"
       : "=&s"(keep)
       : "v"(gsrc), "s"(lds_addr)
@@ -182,19 +184,9 @@ __device__ __forceinline__ void wait_groups(int rem) {
     else wait_groups<G, K - 1>(rem);
   }
 }
-
-// column of fragment element t of lane-column i in a 16 T wide tile: T <= 4: T i + t (one T-wide vector per lane);
-// T = 8: two 64-column halves, 4 i + t and 64 + 4 i + (t - 4) (two 16-byte vectors per lane)
-template <int T>
-__device__ __forceinline__ int frag_col(int i, int t) {
-  return T <= 4 ? T * i + t : (t < 4 ? 4 * i + t : 64 + 4 * i + (t - 4));
-}
 template <int T>
 __device__ __forceinline__ void lds_frag(const float* __restrict__ row, int li, float (&v)[T]) {
-  if constexpr (T == 8) {
-    const float4 a = *(const float4*)(row + 4 * li), b = *(const float4*)(row + 64 + 4 * li);
-    v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
-  } else if constexpr (T == 4) {
+  if constexpr (T == 4) {
     const float4 a = *(const float4*)(row + 4 * li);
     v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w;
   } else if constexpr (T == 2) {
@@ -205,40 +197,55 @@ __device__ __forceinline__ void lds_frag(const float* __restrict__ row, int li, 
   }
 }
 
+constexpr int ATB_GROUP_MAX = 48;          // problems per launch (both kernel-argument tables stay below 4 KiB)
+constexpr int ATB_RING_BYTES = 16 * 1024;  // LDS ring of one wave
+constexpr int ATB_LDS_BYTES = 4 * ATB_RING_BYTES;
+
+struct AtbTask {       // one problem of a grouped launch, first stage
+  const float* A;      // [R, M]
+  const float* B;      // [R, N]
+  float* part;         // slabs [P][M N]
+  int R, M, N;
+  int rpw, P;          // rows per partition (a multiple of 64), live partitions
+  int tile;            // 16 TI + TJ
+};
+struct AtbGroup {
+  int n, pad;
+  int task0[ATB_GROUP_MAX];   // first workgroup of every problem (multiples of 8, ascending)
+  AtbTask t[ATB_GROUP_MAX];
+};
+
 extern __shared__ __attribute__((aligned(1024))) unsigned char atb_smem[];
 
-template <int TI, int TJ, int KS, int S, bool DIV>
-__global__ __launch_bounds__(256, (TI * TJ > 16) ? 1 : 2) void atb_partial_kernel2(
-    const float* __restrict__ A, const float* __restrict__ B, const float* __restrict__ row_div, int R, int M, int N,
-    int rows_per_wg, int P, float* __restrict__ part, int dbg) {
-  constexpr int BM = 16 * TI, BN = 16 * TJ, ROWS = 4 * KS;
-  constexpr int A_BYTES = ROWS * BM * 4, B_BYTES = ROWS * BN * 4, D_BYTES = DIV ? 256 : 0;
-  constexpr int SB = A_BYTES + B_BYTES + D_BYTES;
-  constexpr int NA = A_BYTES / 1024, NB = B_BYTES / 1024, G = NA + NB + (DIV ? 1 : 0);
-  static_assert(A_BYTES % 1024 == 0 && B_BYTES % 1024 == 0, "a slot panel is a whole number of wave-instructions");
+// task t of a problem: partition p = (t % 8) + 8 (t / 8 / nblk), output block (t / 8) % nblk
+template <int TI, int TJ>
+__device__ __forceinline__ void atb_task_body(const float* __restrict__ A, const float* __restrict__ B,
+                                              float* __restrict__ part, int R, int M, int N, int rpw, int P, int t) {
+  constexpr int KS = 4, ROWS = 4 * KS, BM = 16 * TI, BN = 16 * TJ;
+  constexpr int A_BYTES = ROWS * BM * 4, B_BYTES = ROWS * BN * 4, SB = A_BYTES + B_BYTES;
+  constexpr int NA = A_BYTES / 1024, NB = B_BYTES / 1024, G = NA + NB;   // (= TI, TJ, TI + TJ)
+  constexpr int S = (ATB_RING_BYTES / SB) > 8 ? 8 : (ATB_RING_BYTES / SB);
+  static_assert(S >= 2, "two slots of the widest tile fit a wave's ring");
   static_assert((S - 1) * G <= 63, "vmcnt is a 6-bit counter");
-  static_assert(ROWS <= 64, "one divisor request per slot");
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int li = lane & 15, lk = lane >> 4;
   const int nbj = N / BN, nblk = (M / BM) * nbj;
-  // XCD-aware: workgroup L runs on XCD L % 8; all nblk output blocks of row partition p live on XCD p % 8
-  const int L = blockIdx.x;
-  const int p = (L & 7) + 8 * ((L >> 3) / nblk), blk = (L >> 3) % nblk;
-  if (p >= P) return;
+  const int p = (t & 7) + 8 * ((t >> 3) / nblk), blk = (t >> 3) % nblk;
+  if (p >= P) return;                                   // (padding tasks of the last group of 8 partitions)
   const int m0 = (blk / nbj) * BM, n0 = (blk % nbj) * BN;
-  const int r0 = p * rows_per_wg, r1 = min(R, r0 + rows_per_wg);
+  const int r0 = p * rpw, r1 = min(R, r0 + rpw);
   const int ngroups = (r1 - r0 + ROWS - 1) / ROWS;
-  const int n_my = (ngroups - wave + 3) >> 2;   // the 4 waves interleave groups of ROWS rows
-  unsigned char* ring = atb_smem + wave * (S * SB);
+  const int n_my = (ngroups - wave + 3) >> 2;           // the 4 waves interleave groups of ROWS rows
+  unsigned char* ring = atb_smem + wave * ATB_RING_BYTES;
   const unsigned ring_addr = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)ring);
   const float* Ab = A + m0;
   const float* Bb = B + n0;
 
   f32x4 acc[TI][TJ];
 #pragma unroll
-  for (int t = 0; t < TI; ++t)
+  for (int i = 0; i < TI; ++i)
 #pragma unroll
-    for (int u = 0; u < TJ; ++u) acc[t][u] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int u = 0; u < TJ; ++u) acc[i][u] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
   auto issue = [&](int it, int slot) {
     const int rg = r0 + (wave + 4 * it) * ROWS;
@@ -257,232 +264,188 @@ __global__ __launch_bounds__(256, (TI * TJ > 16) ? 1 : 2) void atb_partial_kerne
       const int gr = min(rg + row, r1 - 1);
       lds_dma16(Bb + (size_t)gr * N + col, sa + A_BYTES + j * 1024);
     }
-    if constexpr (DIV) {
-      const int gr = min(rg + (lane & (ROWS - 1)), r1 - 1);
-      lds_dma4(row_div + gr, sa + A_BYTES + B_BYTES);
-    }
   };
 
-  // dbg (measurement only, D3F_ATB2_DBG): 1 = no loads (the MFMA / LDS-read side alone), 2 = no MFMAs (the LDS-DMA side
-  // alone); results are garbage then
 #pragma unroll
   for (int i = 0; i < S; ++i)
-    if (i < n_my && !(dbg & 1)) issue(i, i);
+    if (i < n_my) issue(i, i);
   int slot = 0;
   for (int it = 0; it < n_my; ++it) {
-    if (!(dbg & 1)) wait_groups<G, S - 1>(min(S - 1, n_my - 1 - it));    // group `it` has landed
+    // groups it .. min(it + S, n_my) - 1 are in flight; group `it` has landed once at most the others are outstanding
+    wait_groups<G, S - 1>(min(S - 1, n_my - 1 - it));
     const int rg = r0 + (wave + 4 * it) * ROWS;
     const float* sA = (const float*)(ring + slot * SB);
     const float* sB = (const float*)(ring + slot * SB + A_BYTES);
-    const float* sD = (const float*)(ring + slot * SB + A_BYTES + B_BYTES);
-    // every fragment of the slot is requested before the first MFMA: the LDS latency is paid once per slot, not once
-    // per k-step (a wave alone on its SIMD has nobody to hide it behind)
-    float a[KS][TI], b[KS][TJ], sc[KS];
+    // every fragment of the slot is requested before the first MFMA: the LDS latency is paid once per slot
+    float a[KS][TI], b[KS][TJ];
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
       const int row = 4 * ks + lk;
       lds_frag<TI>(sA + row * BM, li, a[ks]);
       lds_frag<TJ>(sB + row * BN, li, b[ks]);
-      sc[ks] = (rg + row < r1) ? 1.0f : 0.0f;
-      if constexpr (DIV) sc[ks] = (rg + row < r1) ? 1.0f / sD[row] : 0.0f;
-    }
-    __builtin_amdgcn_sched_barrier(0);   // (the scheduler otherwise sinks every read back in front of its own MFMAs)
-    if (!(dbg & 2))
+      if (rg + row >= r1) {                              // (rows past the slice: the re-read row counts 0 times)
 #pragma unroll
-    for (int ks = 0; ks < KS; ++ks) {
-#pragma unroll
-      for (int u = 0; u < TJ; ++u) {
-        const float bv = b[ks][u] * sc[ks];
-#pragma unroll
-        for (int t = 0; t < TI; ++t) acc[t][u] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[ks][t], bv, acc[t][u], 0, 0, 0);
+        for (int u = 0; u < TJ; ++u) b[ks][u] = 0.0f;
       }
     }
-    if (it + S < n_my && !(dbg & 1)) {
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the slot's reads have returned before it is refilled
-      issue(it + S, slot);
+    if (it + S < n_my) {
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the slot's fragments are in registers: refill it now,
+      issue(it + S, slot);                                 // under this slot's own MFMAs
     }
+    __builtin_amdgcn_sched_barrier(0);   // (the scheduler otherwise sinks every read back in front of its own MFMAs)
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+      for (int u = 0; u < TJ; ++u)
+#pragma unroll
+        for (int i = 0; i < TI; ++i)
+          acc[i][u] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[ks][i], b[ks][u], acc[i][u], 0, 0, 0);
     slot = (slot + 1 == S) ? 0 : slot + 1;
   }
 
-  // combine the 4 waves in a fixed order (wave 0 + 1 + 2 + 3) through LDS -- the rings are free now --, 16 tiles a round
-  constexpr int NT = TI * TJ, TPR = NT < 16 ? NT : 16, ROUNDS = NT / TPR;
-  float* red = (float*)atb_smem;                          // [3][TPR * 256]
+  // combine the 4 waves in a fixed order (wave 0 + 1 + 2 + 3) through LDS -- the rings are free now
+  constexpr int NT = TI * TJ;
+  float* red = (float*)atb_smem;                          // [3][NT * 256]
   float* pp = part + (size_t)p * M * N;
+  __syncthreads();                                        // every wave is out of its ring
+  if (wave > 0) {
 #pragma unroll
-  for (int h = 0; h < ROUNDS; ++h) {
-    __syncthreads();          // every wave is out of its ring (h = 0) / wave 0 has read round h - 1
-    if (wave > 0) {
+    for (int i = 0; i < TI; ++i)
 #pragma unroll
-      for (int tt = 0; tt < TPR; ++tt) {
-        const int tile = h * TPR + tt, t = tile / TJ, u = tile % TJ;
+      for (int u = 0; u < TJ; ++u)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) red[(wave - 1) * (TPR * 256) + (tt * 4 + r) * 64 + lane] = acc[t][u][r];
-      }
-    }
-    __syncthreads();
-    if (wave == 0) {
-      // D[i][j] (i = 4 lk + r, j = li) of tile (t, u) is C[m0 + frag_col<TI>(i, t)][n0 + frag_col<TJ>(j, u)]: a lane
-      // stores its TJ columns of one row as 16 / 8 / 4-byte vectors
+        for (int r = 0; r < 4; ++r) red[(wave - 1) * (NT * 256) + ((i * TJ + u) * 4 + r) * 64 + lane] = acc[i][u][r];
+  }
+  __syncthreads();
+  if (wave == 0) {
+    // D[i][j] (i = 4 lk + r, j = li) of tile (ti, u) is C[m0 + TI i + ti][n0 + TJ j + u]: a lane stores its TJ columns of
+    // one row as one 16 / 8 / 4-byte vector
 #pragma unroll
-      for (int tl = 0; tl < TPR / TJ; ++tl) {
-        const int t = h * (TPR / TJ) + tl;
+    for (int i = 0; i < TI; ++i)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          float v[TJ];
+      for (int r = 0; r < 4; ++r) {
+        float v[TJ];
 #pragma unroll
-          for (int u = 0; u < TJ; ++u) {
-            const int e = ((tl * TJ + u) * 4 + r) * 64 + lane;
-            v[u] = ((acc[t][u][r] + red[e]) + red[TPR * 256 + e]) + red[2 * TPR * 256 + e];
-          }
-          float* dst = pp + (size_t)(m0 + frag_col<TI>(4 * lk + r, t)) * N + n0;
-          if constexpr (TJ == 8) {
-            *(float4*)(dst + 4 * li) = make_float4(v[0], v[1], v[2], v[3]);
-            *(float4*)(dst + 64 + 4 * li) = make_float4(v[TJ > 4 ? 4 : 0], v[TJ > 5 ? 5 : 0], v[TJ > 6 ? 6 : 0], v[TJ > 7 ? 7 : 0]);
-          } else if constexpr (TJ == 4) {
-            *(float4*)(dst + 4 * li) = make_float4(v[0], v[TJ > 1 ? 1 : 0], v[TJ > 2 ? 2 : 0], v[TJ > 3 ? 3 : 0]);
-          } else if constexpr (TJ == 2) {
-            *(float2*)(dst + 2 * li) = make_float2(v[0], v[TJ > 1 ? 1 : 0]);
-          } else {
-            dst[li] = v[0];
-          }
+        for (int u = 0; u < TJ; ++u) {
+          const int e = ((i * TJ + u) * 4 + r) * 64 + lane;
+          v[u] = ((acc[i][u][r] + red[e]) + red[NT * 256 + e]) + red[2 * NT * 256 + e];
         }
+        float* dst = pp + (size_t)(m0 + TI * (4 * lk + r) + i) * N + n0 + TJ * li;
+        if constexpr (TJ == 4) *(float4*)dst = make_float4(v[0], v[TJ > 1 ? 1 : 0], v[TJ > 2 ? 2 : 0], v[TJ > 3 ? 3 : 0]);
+        else if constexpr (TJ == 2) *(float2*)dst = make_float2(v[0], v[TJ > 1 ? 1 : 0]);
+        else dst[0] = v[0];
+      }
+  }
+}
+
+__global__ __launch_bounds__(256, 2) void atb_grouped_kernel(const AtbGroup g) {
+  const int L = blockIdx.x;
+  // problem of this workgroup = number of table entries <= L, minus one (ascending, unused entries INT_MAX): the whole
+  // table comes in with three wide scalar loads, no dependent load per step
+  int i = -1;
+#pragma unroll
+  for (int j = 0; j < ATB_GROUP_MAX; ++j) i += (g.task0[j] <= L) ? 1 : 0;
+  i = __builtin_amdgcn_readfirstlane(i);
+  const AtbTask& k = g.t[i];
+  const int t = L - g.task0[i];
+#define D3F_ATB_TILE(I, J) \
+  case (I) * 16 + (J): atb_task_body<I, J>(k.A, k.B, k.part, k.R, k.M, k.N, k.rpw, k.P, t); break
+  switch (k.tile) {
+    D3F_ATB_TILE(1, 1); D3F_ATB_TILE(1, 2); D3F_ATB_TILE(1, 4);
+    D3F_ATB_TILE(2, 1); D3F_ATB_TILE(2, 2); D3F_ATB_TILE(2, 4);
+    D3F_ATB_TILE(4, 1); D3F_ATB_TILE(4, 2); D3F_ATB_TILE(4, 4);
+    default: break;
+  }
+#undef D3F_ATB_TILE
+}
+
+// Second stage of a grouped launch.  Problem i owns blocks [block0[i], block0[i + 1]): its first c_blocks blocks sum the
+// slabs -- 256 float4 elements x 4 slab lanes per workgroup, lane s sums slabs s, s + 4, ... in two chains, the four
+// lanes combined in a fixed order --, the rest finish the bias gradient gb[c] = sum_b bpart[b][c] (16 row lanes x 4
+// chains, fixed-order LDS combine: what bias_sum_kernel of elementwise.hip does, without a launch of its own).
+struct AtbReduceTask {
+  const float* part;   // [P][M N]
+  float* C;            // [M, ldc]
+  const float* bpart;  // [nblocks, BC] or null
+  float* gb;
+  float* gb2;
+  int P, MN4, N, ldc;  // MN4 = M N / 4
+  int c_blocks, nblocks, BC, vec;   // vec: C rows are 16-byte aligned
+};
+struct AtbReduceGroup {
+  int n, pad;
+  int block0[ATB_GROUP_MAX];
+  AtbReduceTask t[ATB_GROUP_MAX];
+};
+static_assert(sizeof(AtbGroup) <= 4096 && sizeof(AtbReduceGroup) <= 4096, "kernel arguments are limited to 4 KiB");
+
+__global__ __launch_bounds__(1024) void atb_grouped_reduce_kernel(const AtbReduceGroup g) {
+  __shared__ float4 sh4[4][256];
+  const int L = blockIdx.x;
+  int i = -1;
+#pragma unroll
+  for (int j = 0; j < ATB_GROUP_MAX; ++j) i += (g.block0[j] <= L) ? 1 : 0;
+  i = __builtin_amdgcn_readfirstlane(i);
+  const AtbReduceTask& k = g.t[i];
+  const int lb = L - g.block0[i];
+  if (lb < k.c_blocks) {
+    const int el = threadIdx.x & 255, s4 = threadIdx.x >> 8;
+    const int e4 = lb * 256 + el;
+    const float4* part4 = (const float4*)k.part;
+    float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f), s1 = s0;
+    if (e4 < k.MN4) {
+      int p = s4;
+      for (; p + 4 < k.P; p += 8) {
+        const float4 u = part4[(size_t)p * k.MN4 + e4], w = part4[(size_t)(p + 4) * k.MN4 + e4];
+        s0.x += u.x; s0.y += u.y; s0.z += u.z; s0.w += u.w;
+        s1.x += w.x; s1.y += w.y; s1.z += w.z; s1.w += w.w;
+      }
+      if (p < k.P) {
+        const float4 u = part4[(size_t)p * k.MN4 + e4];
+        s0.x += u.x; s0.y += u.y; s0.z += u.z; s0.w += u.w;
       }
     }
+    sh4[s4][el] = make_float4(s0.x + s1.x, s0.y + s1.y, s0.z + s1.z, s0.w + s1.w);
+    __syncthreads();
+    if (s4 == 0 && e4 < k.MN4) {
+      const float4 a = sh4[0][el], b = sh4[1][el], c = sh4[2][el], d = sh4[3][el];
+      const float4 v = make_float4(((a.x + b.x) + c.x) + d.x, ((a.y + b.y) + c.y) + d.y, ((a.z + b.z) + c.z) + d.z,
+                                   ((a.w + b.w) + c.w) + d.w);
+      const int e = 4 * e4, row = e / k.N, col = e % k.N;   // (N is a multiple of 16: the four stay in one row)
+      float* dst = k.C + (size_t)row * k.ldc + col;
+      if (k.vec) {
+        *(float4*)dst = v;
+      } else {
+        dst[0] = v.x; dst[1] = v.y; dst[2] = v.z; dst[3] = v.w;
+      }
+    }
+    return;
   }
-}
-
-#ifndef D3F_ATB_TARGET_WGS
-#define D3F_ATB_TARGET_WGS 512
-#endif
-static inline int tile_width(int n) { return n % 64 == 0 ? 4 : (n % 32 == 0 ? 2 : (n % 16 == 0 ? 1 : 0)); }
-
-bool atb_supported(int R, int M, int N) { return R >= 1 && tile_width(M) && tile_width(N); }
-
-// number of row partitions = workgroups along the reduction
-static int atb_tunable(const char* name, int dflt) {
-  const char* v = getenv(name);
-  return v ? atoi(v) : dflt;
-}
-static int atb_partitions(int R, int M, int N) {
-  static const int forced = atb_tunable("D3F_ATB_WGS", 0);
-  const long long nblocks = (long long)(M / (16 * tile_width(M))) * (N / (16 * tile_width(N)));
-  // one workgroup per CU is enough unless the operands are long AND wide (profiles/atb_microbench.py: 512 partitions'
-  // worth of slabs cost the small outputs 3 us each in the reduce pass; the 38k x 480 x 32 KPConv gradient wants them)
-  int target = forced ? forced : ((R >= 30000 && nblocks >= 8) ? D3F_ATB_TARGET_WGS : 256);
-  // the counts above were measured on one S1-class pair (<= 38k rows); several pairs stacked into one batch (round 4)
-  // multiply the rows: keep the ROWS per workgroup where they were instead of the workgroup count (stacked x 4, 153k rows
-  // x 480 x 32: 198 us on 525 workgroups, profiles/r04_step_timeline_stack4.txt)
-  static const int scale_rows = atb_tunable("D3F_ATB_SCALE_ROWS", 40000);
-  if (!forced && scale_rows > 0 && R > scale_rows) target = (int)((long long)target * R / scale_rows);
-  long long wgs = (target + nblocks - 1) / nblocks;  // workgroups over the whole launch (256 CUs)
-  const long long max_by_rows = (R + 63) / 64;            // >= 16 rows (4 MFMA k-steps) per wave
-  if (wgs > max_by_rows) wgs = max_by_rows;
-  if (wgs > 512) wgs = 512;
-  if (wgs < 1) wgs = 1;
-  return (int)wgs;
-}
-
-// ---- second form: configuration ------------------------------------------------------------------------------
-// Tunables of the second form.  Read ONCE per variable (first use) in normal operation; with D3F_ATB_SWEEP set (the sweep
-// scripts of profiles/, which change them between launches of one process) at every call.  The cache is keyed by the
-// address of the name literal: a call site is one entry (benign race: two threads may both fill an entry with the same value).
-static int env_int(const char* name, int dflt) {
-  static const bool live = getenv("D3F_ATB_SWEEP") != nullptr;
-  if (live) {
-    const char* v = getenv(name);
-    return v ? atoi(v) : dflt;
+  float* sh = (float*)&sh4[0][0];          // [16][64]
+  const int col = threadIdx.x & 63, sub = threadIdx.x >> 6;
+  const int c = (lb - k.c_blocks) * 64 + col;
+  const float* bpart = k.bpart;
+  const int BC = k.BC, nblocks = k.nblocks;
+  float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;
+  if (c < BC) {
+    int b = sub;
+    for (; b + 48 < nblocks; b += 64) {
+      s0 += bpart[(size_t)b * BC + c];
+      s1 += bpart[(size_t)(b + 16) * BC + c];
+      s2 += bpart[(size_t)(b + 32) * BC + c];
+      s3 += bpart[(size_t)(b + 48) * BC + c];
+    }
+    for (; b < nblocks; b += 16) s0 += bpart[(size_t)b * BC + c];
   }
-  struct Entry { const char* name; int value; };
-  static Entry cache[32];
-  static int n_cached = 0;
-  for (int i = 0; i < n_cached; ++i)
-    if (cache[i].name == name) return cache[i].value;
-  const char* v = getenv(name);
-  const int value = v ? atoi(v) : dflt;
-  if (n_cached < 32) {
-    cache[n_cached].value = value;
-    cache[n_cached].name = name;
-    ++n_cached;
+  sh[sub * 64 + col] = (s0 + s1) + (s2 + s3);
+  __syncthreads();
+  if (sub == 0 && c < BC) {
+    float v = sh[col];
+#pragma unroll
+    for (int j = 1; j < 16; ++j) v += sh[j * 64 + col];
+    k.gb[c] = v;
+    if (k.gb2) k.gb2[c] = v;
   }
-  return value;
-}
-static inline int tile_width2(int n, int tmax) {
-  if (tmax >= 8 && n % 128 == 0) return 8;
-  return tile_width(n);
-}
-struct Atb2Cfg {
-  int ti, tj, ks, s, P, rpw;
-  size_t lds;
-  bool ok;
-};
-static size_t atb2_lds_bytes(int ti, int tj, int ks, int s, bool div) {
-  const size_t sb = (size_t)256 * ks * (ti + tj) + (div ? 256 : 0);
-  const size_t ring = 4 * s * sb;
-  const int nt = ti * tj, tpr = nt < 16 ? nt : 16;
-  const size_t red = (size_t)3 * tpr * 1024;
-  return ring > red ? ring : red;
-}
-static Atb2Cfg atb2_config(int R, int M, int N, bool div) {
-  Atb2Cfg c;
-  const int tmax = div ? 4 : env_int("D3F_ATB2_TMAX", 4);
-  c.ti = tile_width2(M, tmax);
-  c.tj = tile_width2(N, tmax);
-  if (c.ti == 8 && c.tj == 8) c.tj = 4;                  // (64 accumulator tiles per wave spill; 128 x 64 blocks)
-  c.ks = env_int("D3F_ATB2_KS", 4);
-  c.s = env_int("D3F_ATB2_S", 2);
-  if (div || c.ti == 1 || c.tj == 1) c.ks = 4;            // (16-wide panels: 16 rows fill one wave-instruction)
-  if (div && c.s > 3) c.s = 3;
-  if (c.ks != 2 && c.ks != 4) c.ks = 4;
-  if (c.s < 2) c.s = 2;
-  if (c.s > 4) c.s = 4;
-  while (c.s > 2 && atb2_lds_bytes(c.ti, c.tj, c.ks, c.s, div) > 160 * 1024) --c.s;
-  c.lds = atb2_lds_bytes(c.ti, c.tj, c.ks, c.s, div);
-  c.ok = c.lds <= 160 * 1024;
-  const long long nblk = (long long)(M / (16 * c.ti)) * (N / (16 * c.tj));
-  const int rows = 4 * c.ks;
-  // Row partitions.  The kernel keeps every output block of partition p on XCD p % 8, so partitions come in multiples
-  // of 8 (fewer would leave whole XCDs idle: measured, 6208 x 512 x 512 on P = 4 took 81 us against 41 on P = 8) and
-  // one XCD's share of the launch, (P / 8) nblk workgroups, should fit its 32 CUs in ONE round -- a second, partly
-  // filled round costs as much as the first (23872 x 960 x 64: P = 34 put 75 workgroups on two XCDs' 64 slots).
-  int per_cu = (int)((160 * 1024) / c.lds);
-  if (per_cu > 4) per_cu = 4;
-  if (c.ti * c.tj > 16) per_cu = 1;                       // (launch bound of the 32-tile instantiations)
-  if (per_cu < 1) per_cu = 1;
-  const long long slots = env_int("D3F_ATB2_WGS", 0) ? env_int("D3F_ATB2_WGS", 0) / 8 : 32LL * per_cu;   // per XCD
-  long long q = slots / nblk;
-  const int min_groups = env_int("D3F_ATB2_MIN_GROUPS", c.s);         // groups per WAVE: one ring revolution
-  const long long q_rows = (long long)R / ((long long)8 * 4 * rows * min_groups);
-  if (q > q_rows) q = q_rows;
-  if (q > 128) q = 128;
-  if (q < 1) q = 1;
-  long long rpw = (R + 8 * q - 1) / (8 * q);
-  rpw = (rpw + 4 * rows - 1) / (4 * rows) * (4 * rows);  // whole groups for every wave
-  c.rpw = (int)rpw;
-  c.P = (int)((R + rpw - 1) / rpw);
-  return c;
-}
-// Which form runs (profiles/r05_atb_sweep.txt, 28 launches of a 3-pair stack's step: first form 762 us, second form
-// everywhere 688, the better of the two per shape 648): the second form where there is arithmetic to pipeline -- from
-// 1.4 GFLOP per launch, and for the wide-by-narrow KPConv gradients (960 x 64, 480 x 32) from 0.7 --, the first form,
-// whose workgroups start faster, on the small launches.  D3F_ATB_V = 1 / 3: always the first / second form.
-static bool atb2_wanted(const float* A, const float* B, const float* row_div, int R, int M, int N) {
-  const int v = env_int("D3F_ATB_V", 2);
-  if (v < 2) return false;
-  if ((((uintptr_t)A | (uintptr_t)B) & 15) != 0 || (((uintptr_t)row_div) & 3) != 0) return false;
-  if (v >= 3) return true;
-  const double flops = 2.0 * R * (double)M * N;
-  const int wide = M > N ? M : N, narrow = M > N ? N : M;
-  return flops >= 1.4e9 || (wide >= 480 && narrow <= 64 && flops >= 0.7e9);
-}
-
-size_t atb_ws_bytes(int R, int M, int N) {
-  if (!atb_supported(R, M, N)) return 0;
-  size_t P = (size_t)atb_partitions(R, M, N);
-  for (int div = 0; div < 2; ++div) {
-    const Atb2Cfg c = atb2_config(R, M, N, div != 0);
-    if (c.ok && (size_t)c.P > P) P = (size_t)c.P;
-  }
-  return align_up(sizeof(float) * P * M * N, 256);
 }
 
 // second stage of the weight gradient.  Blocks [0, c_blocks): C[e] = sum_p part[p][e] (as atb_reduce_kernel<16>);
@@ -561,64 +524,193 @@ __global__ __launch_bounds__(1024) void atb_reduce_bias_kernel(const float* __re
   }
 }
 
-template <int TI, int TJ, int KS, int S, bool DIV>
-static int atb2_launch(const Atb2Cfg& c, const float* A, const float* B, const float* row_div, int R, int M, int N,
-                       float* part, hipStream_t stream) {
-  auto kern = atb_partial_kernel2<TI, TJ, KS, S, DIV>;
-  // more than 64 KB of dynamic LDS needs the opt-in, a per-device function attribute: asked for on every call (a
-  // host-side table update, no stream operation; a process may drive several devices and threads)
-  if (c.lds > 64 * 1024 &&
-      hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c.lds) != hipSuccess) {
-    (void)hipGetLastError();
-    return D3F_EINVAL;
+static inline int tile_width(int n) { return n % 64 == 0 ? 4 : (n % 32 == 0 ? 2 : (n % 16 == 0 ? 1 : 0)); }
+
+bool atb_supported(int R, int M, int N) { return R >= 1 && tile_width(M) && tile_width(N); }
+
+// ---- first form: number of row partitions = workgroups along the reduction ------------------------------------------
+static int atb_partitions(int R, int M, int N) {
+  const int forced = tunables().atb_first_form_wgs;
+  const long long nblocks = (long long)(M / (16 * tile_width(M))) * (N / (16 * tile_width(N)));
+  // one workgroup per CU is enough unless the operands are long AND wide (profiles/atb_microbench.py: 512 partitions'
+  // worth of slabs cost the small outputs 3 us each in the reduce pass; the 38k x 480 x 32 KPConv gradient wants them)
+  int target = forced > 0 ? forced : ((R >= 30000 && nblocks >= 8) ? 512 : 256);
+  // the counts above were measured on one S1-class pair (<= 38k rows); several pairs stacked into one batch (round 4)
+  // multiply the rows: keep the ROWS per workgroup where they were instead of the workgroup count
+  if (forced <= 0 && R > 40000) target = (int)((long long)target * R / 40000);
+  long long wgs = (target + nblocks - 1) / nblocks;  // workgroups over the whole launch (256 CUs)
+  const long long max_by_rows = (R + 63) / 64;            // >= 16 rows (4 MFMA k-steps) per wave
+  if (wgs > max_by_rows) wgs = max_by_rows;
+  if (wgs > 512) wgs = 512;
+  if (wgs < 1) wgs = 1;
+  return (int)wgs;
+}
+
+// ---- grouped form: partition plan of one problem ----------------------------------------------------------------------
+// A task (one workgroup: one row partition x one output block) should last about atb_task_us on one of the chip's 512
+// workgroup slots (2 per CU).  Its duration is modelled as the larger of its matrix time (f32 MFMA peak / 512 per slot)
+// and its share of the HBM stream (the A panel of a partition is fetched once for the nbj blocks that read it -- they
+// run on one XCD --, the B panel once for nbi; 6.3 TB/s / 512 per slot).
+struct AtbPlan {
+  int ti, tj, nbi, nbj, P, rpw;
+  long long ntasks;         // 8 ceil(P / 8) nblk
+  double task_s;            // modelled duration of one task
+  size_t slab_floats;       // P M N
+};
+static AtbPlan atb_plan(int R, int M, int N) {
+  AtbPlan a;
+  a.ti = tile_width(M);
+  a.tj = tile_width(N);
+  const int BM = 16 * a.ti, BN = 16 * a.tj;
+  a.nbi = M / BM;
+  a.nbj = N / BN;
+  const double f_slot = 157.3e12 / 512, w_slot = 6.3e12 / 512;
+  const double row_s = fmax(2.0 * BM * BN / f_slot, 4.0 * ((double)BM / a.nbj + (double)BN / a.nbi) / w_slot);
+  int us = tunables().atb_task_us;
+  if (us < 1) us = 20;
+  double rows = us * 1e-6 / row_s;
+  if (rows < 256) rows = 256;
+  long long q = (long long)((double)R / (8.0 * rows) + 0.5);
+  if (q < 1) q = 1;
+  if (q > 64) q = 64;
+  long long rpw = ((long long)R + 8 * q - 1) / (8 * q);
+  rpw = (rpw + 63) / 64 * 64;                           // whole groups of 16 rows for every wave
+  a.rpw = (int)rpw;
+  a.P = (int)(((long long)R + rpw - 1) / rpw);
+  a.ntasks = (long long)((a.P + 7) / 8) * 8 * a.nbi * a.nbj;
+  a.task_s = row_s * (double)rpw;
+  a.slab_floats = (size_t)a.P * M * N;
+  return a;
+}
+
+struct AtbProblem {   // host side of one problem: C [M, ldc] = A^T [M, R] B [R, N] (+ the bias gradient of the same block)
+  const float* A;
+  const float* B;
+  float* C;
+  int R, M, N, ldc;
+  const float* bias_part;
+  int bias_blocks, bias_cols;
+  float* grad_bias;
+  float* grad_bias2;
+};
+
+static bool atb_problem_ok(const AtbProblem& p) {
+  if (!p.A || !p.B || !p.C || !atb_supported(p.R, p.M, p.N) || p.ldc < p.N) return false;
+  if ((((uintptr_t)p.A | (uintptr_t)p.B) & 15) != 0 || (((uintptr_t)p.C) & 3) != 0) return false;   // (LDS-DMA moves 16 B)
+  if (p.bias_part && (p.bias_blocks < 1 || p.bias_cols < 1 || !p.grad_bias)) return false;
+  return true;
+}
+
+size_t atb_group_ws_bytes(const AtbProblem* probs, int n) {
+  size_t total = 0;
+  for (int i = 0; i < n; ++i) {
+    if (!atb_supported(probs[i].R, probs[i].M, probs[i].N)) return 0;
+    total += align_up(sizeof(float) * atb_plan(probs[i].R, probs[i].M, probs[i].N).slab_floats, 256);
   }
-  const long long nblk = (long long)(M / (16 * TI)) * (N / (16 * TJ));
-  const long long P8 = ((long long)c.P + 7) / 8 * 8;      // (partitions past P exit at once: see the XCD mapping)
-  kern<<<(unsigned)(P8 * nblk), 256, c.lds, stream>>>(A, B, row_div, R, M, N, c.rpw, c.P, part,
-                                                      env_int("D3F_ATB2_DBG", 0));
+  return total;
+}
+
+// all problems of `probs` in ceil(n / ATB_GROUP_MAX) x 2 launches; ws >= atb_group_ws_bytes
+int atb_group_launch(const AtbProblem* probs, int n, void* ws, hipStream_t stream) {
+  if (n < 1) return D3F_OK;
+  for (int i = 0; i < n; ++i)
+    if (!atb_problem_ok(probs[i])) return D3F_EINVAL;
+  // measurement aid of bench.py: ONE record for both launches of a group; shape = {problems, MiFLOP, KiB, tasks, 0, 0}
+  double flops = 0.0, bytes = 0.0;
+  long long all_tasks = 0;
+  for (int i = 0; i < n; ++i) {
+    flops += 2.0 * probs[i].R * (double)probs[i].M * probs[i].N;
+    bytes += 4.0 * probs[i].R * ((double)probs[i].M + probs[i].N) + 4.0 * (double)probs[i].M * probs[i].N;
+    all_tasks += atb_plan(probs[i].R, probs[i].M, probs[i].N).ntasks;
+  }
+  void* timing = kpconv_timing_open(7, stream, n, (int)(flops / 1048576.0), (int)(bytes / 1024.0), (int)all_tasks, 0, 0);
+  char* wsp = (char*)ws;
+  for (int c0 = 0; c0 < n; c0 += ATB_GROUP_MAX) {
+    const int m = (n - c0 < ATB_GROUP_MAX) ? n - c0 : ATB_GROUP_MAX;
+    AtbPlan plan[ATB_GROUP_MAX];
+    int order[ATB_GROUP_MAX];
+    float* part[ATB_GROUP_MAX];
+    for (int i = 0; i < m; ++i) {
+      const AtbProblem& p = probs[c0 + i];
+      plan[i] = atb_plan(p.R, p.M, p.N);
+      part[i] = (float*)wsp;
+      wsp += align_up(sizeof(float) * plan[i].slab_floats, 256);
+      order[i] = i;
+    }
+    // longest task first (insertion sort, stable: equal problems keep their queue order -- the plan is deterministic)
+    for (int i = 1; i < m; ++i) {
+      const int o = order[i];
+      int j = i;
+      while (j > 0 && plan[order[j - 1]].task_s < plan[o].task_s) {
+        order[j] = order[j - 1];
+        --j;
+      }
+      order[j] = o;
+    }
+    AtbGroup g;
+    AtbReduceGroup rg;
+    g.n = rg.n = m;
+    g.pad = rg.pad = 0;
+    long long task = 0, block = 0;
+    for (int s = 0; s < m; ++s) {
+      const int i = order[s];
+      const AtbProblem& p = probs[c0 + i];
+      g.task0[s] = (int)task;
+      g.t[s].A = p.A;
+      g.t[s].B = p.B;
+      g.t[s].part = part[i];
+      g.t[s].R = p.R;
+      g.t[s].M = p.M;
+      g.t[s].N = p.N;
+      g.t[s].rpw = plan[i].rpw;
+      g.t[s].P = plan[i].P;
+      g.t[s].tile = plan[i].ti * 16 + plan[i].tj;
+      task += plan[i].ntasks;
+      AtbReduceTask& r = rg.t[s];
+      rg.block0[s] = (int)block;
+      r.part = part[i];
+      r.C = p.C;
+      r.bpart = p.bias_part;
+      r.gb = p.grad_bias;
+      r.gb2 = p.grad_bias2;
+      r.P = plan[i].P;
+      r.MN4 = (int)((size_t)p.M * p.N / 4);
+      r.N = p.N;
+      r.ldc = p.ldc;
+      r.c_blocks = cdiv(r.MN4, 256);
+      r.nblocks = p.bias_part ? p.bias_blocks : 0;
+      r.BC = p.bias_part ? p.bias_cols : 0;
+      r.vec = ((((uintptr_t)p.C) & 15) == 0 && (p.ldc & 3) == 0) ? 1 : 0;
+      block += r.c_blocks + (p.bias_part ? cdiv(p.bias_cols, 64) : 0);
+    }
+    for (int s = m; s < ATB_GROUP_MAX; ++s) g.task0[s] = rg.block0[s] = 0x7fffffff;
+    if (task >= 0x7fffffffLL || block >= 0x7fffffffLL) return D3F_EINVAL;
+    atb_grouped_kernel<<<(unsigned)task, 256, ATB_LDS_BYTES, stream>>>(g);
+    D3F_LAUNCH_CHECK();
+    atb_grouped_reduce_kernel<<<(unsigned)block, 1024, 0, stream>>>(rg);
+    D3F_LAUNCH_CHECK();
+  }
+  kpconv_timing_close(timing, stream);
   return D3F_OK;
 }
 
-template <int TI, int TJ, bool DIV>
-static int atb2_dispatch_ring(const Atb2Cfg& c, const float* A, const float* B, const float* row_div, int R, int M,
-                              int N, float* part, hipStream_t stream) {
-  constexpr int W = TI + TJ;
-  if constexpr (TI >= 2 && TJ >= 2 && !DIV) {
-    if (c.ks == 2) {
-      if (c.s >= 4) return atb2_launch<TI, TJ, 2, 4, DIV>(c, A, B, row_div, R, M, N, part, stream);
-      if (c.s == 3) return atb2_launch<TI, TJ, 2, 3, DIV>(c, A, B, row_div, R, M, N, part, stream);
-      return atb2_launch<TI, TJ, 2, 2, DIV>(c, A, B, row_div, R, M, N, part, stream);
-    }
-  }
-  if constexpr (!DIV && W <= 12) {
-    if (c.s >= 4) return atb2_launch<TI, TJ, 4, 4, DIV>(c, A, B, row_div, R, M, N, part, stream);
-  }
-  if constexpr (W <= 12) {
-    if (c.s >= 3) return atb2_launch<TI, TJ, 4, 3, DIV>(c, A, B, row_div, R, M, N, part, stream);
-  }
-  return atb2_launch<TI, TJ, 4, 2, DIV>(c, A, B, row_div, R, M, N, part, stream);
+// Which form a SINGLE problem runs (the C-ABI's one-problem entry points and the KPConv kernels' own weight gradient):
+// the grouped kernels where there is arithmetic to pipeline (from 0.7 GFLOP, profiles/r05_atb_sweep.txt), the first
+// form -- whose workgroups start faster and which applies a row divisor -- on the small launches.
+// tunables().atb_form = 1 / 2: always the first form / the grouped kernels.
+static bool atb_grouped_wanted(const float* A, const float* B, const float* row_div, int R, int M, int N, int M_out) {
+  const int v = tunables().atb_form;
+  if (v == 1 || row_div || (M_out > 0 && M_out < M)) return false;
+  if ((((uintptr_t)A | (uintptr_t)B) & 15) != 0) return false;
+  if (v == 2) return true;
+  return 2.0 * R * (double)M * N >= 0.7e9;
 }
 
-template <bool DIV>
-static int atb2_dispatch(const Atb2Cfg& c, const float* A, const float* B, const float* row_div, int R, int M, int N,
-                         float* part, hipStream_t stream) {
-#define D3F_ATB2(I, J) \
-  case (I) * 16 + (J): return atb2_dispatch_ring<I, J, DIV>(c, A, B, row_div, R, M, N, part, stream)
-  switch (c.ti * 16 + c.tj) {
-    D3F_ATB2(1, 1); D3F_ATB2(1, 2); D3F_ATB2(1, 4);
-    D3F_ATB2(2, 1); D3F_ATB2(2, 2); D3F_ATB2(2, 4);
-    D3F_ATB2(4, 1); D3F_ATB2(4, 2); D3F_ATB2(4, 4);
-    default: break;
-  }
-  if constexpr (!DIV) {
-    switch (c.ti * 16 + c.tj) {
-      D3F_ATB2(1, 8); D3F_ATB2(2, 8); D3F_ATB2(4, 8);
-      D3F_ATB2(8, 1); D3F_ATB2(8, 2); D3F_ATB2(8, 4);
-      default: break;
-    }
-  }
-#undef D3F_ATB2
-  return D3F_EINVAL;
+size_t atb_ws_bytes(int R, int M, int N) {
+  if (!atb_supported(R, M, N)) return 0;
+  const size_t first = align_up(sizeof(float) * (size_t)atb_partitions(R, M, N) * M * N, 256);
+  const size_t grouped = align_up(sizeof(float) * atb_plan(R, M, N).slab_floats, 256);
+  return first > grouped ? first : grouped;
 }
 
 // C [M,N] = A^T [M,R] (B [R,N] / row_div [R]); ws >= atb_ws_bytes.  bias_*: the second stage also finishes a bias
@@ -628,59 +720,42 @@ int atb_splitk_bias(const float* A, const float* B, const float* row_div, int R,
                     float* grad_bias, float* grad_bias2) {
   if (!atb_supported(R, M, N)) return D3F_EINVAL;
   if (bias_part && (bias_blocks < 1 || bias_cols < 1 || !grad_bias)) return D3F_EINVAL;
+  if (atb_grouped_wanted(A, B, row_div, R, M, N, M_out)) {
+    const AtbProblem p = {A, B, C, R, M, N, N, bias_part, bias_blocks, bias_cols, grad_bias, grad_bias2};
+    return atb_group_launch(&p, 1, ws, stream);
+  }
   float* part = (float*)ws;
   void* timing = kpconv_timing_open(4, stream, R, 0, 0, M, N, 0);   // (both launches: partial sums + their reduction)
-  int P = 0;
-  bool launched = false;
-  if (atb2_wanted(A, B, row_div, R, M, N)) {
-    const Atb2Cfg c = atb2_config(R, M, N, row_div != nullptr);
-    if (c.ok) {
-      const int rc = row_div ? atb2_dispatch<true>(c, A, B, row_div, R, M, N, part, stream)
-                             : atb2_dispatch<false>(c, A, B, row_div, R, M, N, part, stream);
-      if (rc == D3F_OK) {
-        launched = true;
-        P = c.P;
-      }
-    }
+  const int ti = tile_width(M), tj = tile_width(N);
+  const int P = atb_partitions(R, M, N);
+  int rpw = (R + P - 1) / P;
+  rpw = (rpw + 3) / 4 * 4;
+  dim3 grid(P, (M / (16 * ti)) * (N / (16 * tj)));
+  // U = k-steps whose loads are issued together: the measured default per tile shape (2 for >= 8 accumulator tiles)
+#define D3F_ATB(I, J) \
+  atb_partial_kernel<I, J, ((I) * (J) >= 8) ? 2 : 4><<<grid, 256, 0, stream>>>(A, B, row_div, R, M, N, rpw, part)
+  switch (ti * 8 + tj) {
+    case 1 * 8 + 1: D3F_ATB(1, 1); break;
+    case 1 * 8 + 2: D3F_ATB(1, 2); break;
+    case 1 * 8 + 4: D3F_ATB(1, 4); break;
+    case 2 * 8 + 1: D3F_ATB(2, 1); break;
+    case 2 * 8 + 2: D3F_ATB(2, 2); break;
+    case 2 * 8 + 4: D3F_ATB(2, 4); break;
+    case 4 * 8 + 1: D3F_ATB(4, 1); break;
+    case 4 * 8 + 2: D3F_ATB(4, 2); break;
+    default: D3F_ATB(4, 4); break;
   }
-  if (!launched) {
-    const int ti = tile_width(M), tj = tile_width(N);
-    P = atb_partitions(R, M, N);
-    int rpw = (R + P - 1) / P;
-    rpw = (rpw + 3) / 4 * 4;
-    dim3 grid(P, (M / (16 * ti)) * (N / (16 * tj)));
-    static const int deep = atb_tunable("D3F_ATB_U", 0);   // 0: the measured default per tile shape
-#define D3F_ATB(I, J)                                                                                      \
-  {                                                                                                        \
-    const int u = deep ? deep : (((I) * (J) >= 8) ? 2 : 4);                                                \
-    if (u >= 8) atb_partial_kernel<I, J, 8><<<grid, 256, 0, stream>>>(A, B, row_div, R, M, N, rpw, part);  \
-    else if (u >= 4) atb_partial_kernel<I, J, 4><<<grid, 256, 0, stream>>>(A, B, row_div, R, M, N, rpw, part); \
-    else atb_partial_kernel<I, J, 2><<<grid, 256, 0, stream>>>(A, B, row_div, R, M, N, rpw, part);         \
-  }
-    switch (ti * 8 + tj) {
-      case 1 * 8 + 1: D3F_ATB(1, 1); break;
-      case 1 * 8 + 2: D3F_ATB(1, 2); break;
-      case 1 * 8 + 4: D3F_ATB(1, 4); break;
-      case 2 * 8 + 1: D3F_ATB(2, 1); break;
-      case 2 * 8 + 2: D3F_ATB(2, 2); break;
-      case 2 * 8 + 4: D3F_ATB(2, 4); break;
-      case 4 * 8 + 1: D3F_ATB(4, 1); break;
-      case 4 * 8 + 2: D3F_ATB(4, 2); break;
-      default: D3F_ATB(4, 4); break;
-    }
 #undef D3F_ATB
-  }
   D3F_LAUNCH_CHECK();
   const size_t MN = (size_t)M * N;
   const size_t MN_out = (M_out > 0 && M_out < M) ? (size_t)M_out * N : MN;
-  static const int fan = atb_tunable("D3F_ATB_FAN", 0);
   if (bias_part) {
-    const int fan16 = (fan ? fan >= 16 : (P >= 64 && MN <= 65536)) ? 1 : 0;
+    const int fan16 = (P >= 64 && MN <= 65536) ? 1 : 0;
     const int cb = cdiv((long long)MN, fan16 ? 64 : 256);
     atb_reduce_bias_kernel<<<cb + cdiv(bias_cols, 64), 1024, 0, stream>>>(part, P, MN, C, MN_out, cb, bias_part,
                                                                          bias_blocks, bias_cols, grad_bias, grad_bias2,
                                                                          fan16);
-  } else if (fan ? fan >= 16 : (P >= 64 && MN <= 65536)) {
+  } else if (P >= 64 && MN <= 65536) {
     atb_reduce_kernel<16><<<cdiv((long long)MN, 64), 1024, 0, stream>>>(part, P, MN, C, MN_out);
   } else {
     atb_reduce_kernel<4><<<cdiv((long long)MN, 64), 256, 0, stream>>>(part, P, MN, C, MN_out);
@@ -844,6 +919,33 @@ int d3f_linear_grad_weight_bias(const float* x, const float* grad_out, int N, in
   if (ws_bytes < d3f::atb_ws_bytes(N, Cout, Cin)) return D3F_EWORKSPACE;
   return d3f::atb_splitk_bias(grad_out, x, nullptr, N, Cout, Cin, grad_w, ws, (hipStream_t)stream, 0, bias_part,
                               bias_blocks, bias_cols, grad_bias, grad_bias2);
+}
+
+static bool group_convert(const d3f_atb_problem* in, int n, d3f::AtbProblem* out) {
+  for (int i = 0; i < n; ++i) {
+    const d3f_atb_problem& q = in[i];
+    // grad_w [Cout, Cin] = grad_out^T x: A = grad_out (M = Cout), B = x (N = Cin)
+    out[i] = d3f::AtbProblem{q.grad_out, q.x, q.grad_w, q.N, q.Cout, q.Cin, q.ldw, q.bias_part, q.bias_blocks,
+                             q.bias_cols, q.grad_bias, q.grad_bias2};
+    if (!d3f::atb_problem_ok(out[i])) return false;
+  }
+  return true;
+}
+
+size_t d3f_linear_grad_weight_group_ws_bytes(const d3f_atb_problem* problems_host, int n) {
+  if (!problems_host || n < 1 || n > 4096) return 0;
+  std::vector<d3f::AtbProblem> p((size_t)n);
+  if (!group_convert(problems_host, n, p.data())) return 0;
+  return d3f::atb_group_ws_bytes(p.data(), n);
+}
+
+int d3f_linear_grad_weight_group(const d3f_atb_problem* problems_host, int n, void* ws, size_t ws_bytes, void* stream) {
+  if (n == 0) return D3F_OK;
+  if (!problems_host || n < 0 || n > 4096 || !ws) return D3F_EINVAL;
+  std::vector<d3f::AtbProblem> p((size_t)n);
+  if (!group_convert(problems_host, n, p.data())) return D3F_EINVAL;
+  if (ws_bytes < d3f::atb_group_ws_bytes(p.data(), n)) return D3F_EWORKSPACE;
+  return d3f::atb_group_launch(p.data(), n, ws, (hipStream_t)stream);
 }
 
 int d3f_linear_fused_supported(int N, int Cin, int Cout) {

@@ -248,7 +248,7 @@ __global__ void unpack_mutual_kernel(const unsigned long long* __restrict__ best
 
 // workgroups along the target range: ~2048 in all (8 per CU), column chunks of whole tiles that fit the LDS table
 static void chunking(int gx, int Nt, int& chunks, int& cpc) {
-  static const int target = getenv("D3F_MATCH_WGS") ? atoi(getenv("D3F_MATCH_WGS")) : 2048;   // (env: experiments)
+  const int target = d3f::tunables().match_wgs > 0 ? d3f::tunables().match_wgs : 2048;
   chunks = target / (gx > 0 ? gx : 1);
   const int max_chunks = d3f::cdiv(Nt, 4 * kColsPerTile);
   if (chunks > max_chunks) chunks = max_chunks;

@@ -33,7 +33,23 @@ __global__ __launch_bounds__(256) void copy_many_kernel(CopyJobs jobs) {
 
 }  // namespace
 
+namespace d3f {
+static d3f_tunables g_tunables = {};   // all zero = every built-in choice
+const d3f_tunables& tunables() { return g_tunables; }
+}  // namespace d3f
+
 extern "C" {
+
+void d3f_get_tunables(d3f_tunables* out) {
+  if (out) *out = d3f::g_tunables;
+}
+int d3f_set_tunables(const d3f_tunables* in) {
+  if (!in || in->atb_task_us < 0 || in->atb_form < 0 || in->atb_form > 2 || in->atb_first_form_wgs < 0 ||
+      in->match_wgs < 0)
+    return D3F_EINVAL;
+  d3f::g_tunables = *in;
+  return D3F_OK;
+}
 
 /* Replaces the ~25 separate copy launches with which a stacked training step's inputs (2Q clouds, their features, Q
  * correspondence tables and keypoint-distance matrices: the dataset item of reference datasets/ThreeDMatch.py:135-149,

@@ -551,11 +551,8 @@ class _KPConvFn(torch.autograd.Function):
                               "d3f_kpconv_grad_input_gather")
             gx_native = None
         if big_dw:
-            nbytes = L.d3f_linear_grad_weight_ws_bytes(Nq, Cout, K * Cin)
-            ws = _ws(nbytes, x.device)
-            with _region("kpconv_dw_atb[Nq=%d,Cin=%d,Cout=%d]" % (Nq, Cin, Cout), 4 * Nq * (K * Cin + Cout)):
-                _native.check(L.d3f_linear_grad_weight(_p(gon), _p(wf), Nq, Cout, K * Cin, _p(gw), _p(ws), nbytes,
-                                                       _stream()), "d3f_linear_grad_weight")
+            # x := g / nn [Nq, Cout], grad_out := wf [Nq, K Cin]: grad_W [K Cin, Cout] = wf^T (g / nn)
+            _grad_weight_atb(gon, wf, Nq, Cout, K * Cin, gw.view(K * Cin, Cout), None, 0, None, None, "kpconv_dw_atb")
             gw_native = None
         if need_w and wf is not None and Nq < _SPLITK_MIN_ROWS and wf.shape[1] == K * Cin:
             # few points, wide layers (bottom of the U-Net): grad_W = wf^T (g/nn) is an ordinary GEMM with a short
@@ -664,7 +661,8 @@ class _KPConvGemmBiasActFn(torch.autograd.Function):
             gw = ctx.gw_slot if ctx.gw_slot is not None else torch.empty_like(weights)
             if atb:
                 # x := g / nn [Nq, Cout], grad_out := wf [Nq, K Cin]: grad_W [K Cin, Cout] = wf^T (g / nn)
-                _grad_weight_atb(gon, wf, Nq, Cout, K * Cin, gw, bias_part, bias_blocks, gb, None, "kpconv_dw_atb")
+                _grad_weight_atb(gon, wf, Nq, Cout, K * Cin, gw.view(K * Cin, Cout), bias_part, bias_blocks, gb, None,
+                                 "kpconv_dw_atb")
             else:
                 torch.mm(wf.t(), gon, out=gw.view(K * Cin, Cout))
         rev = ctx.rev
@@ -934,6 +932,10 @@ def _add_deposited(holder, go, weight):
     if c is None:
         return torch.mm(go, weight)
     if c.is_contiguous() and c.dtype == go.dtype and c.shape == (go.shape[0], weight.shape[1]):
+        if _WG_GROUP is not None:
+            # the deposited buffer may be a queued operand of a weight gradient that has not run yet (the masked gradient
+            # of the block's last unary layer IS the shortcut's gradient): accumulate out of place
+            return torch.addmm(c, go, weight)
         return c.addmm_(go, weight)      # beta = 1, in place: the deposited buffer has no other reader left
     return torch.mm(go, weight).add_(c)
 
@@ -964,11 +966,7 @@ class _LinearFn(torch.autograd.Function):
             slot = ctx.gw_slot
             if N >= _SPLITK_MIN_ROWS and L.d3f_linear_grad_weight_supported(N, Cin, Cout):
                 gw = slot if slot is not None else torch.empty_like(weight)
-                nbytes = L.d3f_linear_grad_weight_ws_bytes(N, Cin, Cout)
-                ws = _ws(nbytes, x.device)
-                with _region("linear_dw[N=%d,Cin=%d,Cout=%d]" % (N, Cin, Cout), 4 * N * (Cin + Cout) + 4 * Cin * Cout):
-                    _native.check(L.d3f_linear_grad_weight(_p(x), _p(go), N, Cin, Cout, _p(gw), _p(ws), nbytes,
-                                                           _stream()), "d3f_linear_grad_weight")
+                _grad_weight_atb(x, go, N, Cin, Cout, gw, None, 0, None, None, "linear_dw")
             elif slot is not None:
                 gw = torch.mm(go.t(), x, out=slot)
             else:
@@ -1075,10 +1073,100 @@ def _epilogue_backward(go, out, slope, N, C, gm, first, second, pre, row_div, fo
     return None, 0
 
 
+class WeightGradGroup(object):
+    """The weight gradients of ONE backward stage, queued by the autograd nodes and computed together when the stage
+    ends (d3f_linear_grad_weight_group: one launch over every problem's tasks + one that sums all slabs and finishes
+    the queued bias gradients).  A weight gradient has no consumer before the optimizer (reference trainer.py:103-111),
+    so nothing orders it between the grad-input kernels; queued, the 27 problems of a stacked step share one launch's
+    ramp-up and tail and the memory-bound ones run beside the matrix-bound ones.
+
+        with ops.weight_grad_group():
+            torch.autograd.backward(loss, ...)
+        # <- here every p.grad / flat-buffer slot is final
+
+    The queue keeps every operand alive until the flush (under hipGraph capture a freed block would be handed to a
+    later allocation of the same capture) and the nodes never modify a queued operand in place (``_add_deposited``).
+    Backward runs on autograd's worker thread: the active group is a module global, one backward at a time."""
+
+    def __init__(self):
+        self.problems, self.keep = [], []
+
+    def add(self, x, gm, N, Cin, Cout, gw, bias_part, bias_blocks, first, second):
+        ldw = int(gw.stride(0)) if gw.dim() == 2 else int(Cin)
+        if gw.dim() == 2 and (gw.stride(1) != 1 or gw.shape[0] != Cout or gw.shape[1] != Cin):
+            raise RuntimeError("weight-gradient target of shape %s (strides %s) for a [%d, %d] gradient" % (
+                tuple(gw.shape), tuple(gw.stride()), Cout, Cin))
+        self.problems.append((_p(x), _p(gm), _p(gw), int(N), int(Cin), int(Cout), ldw,
+                              _p(bias_part), int(bias_blocks) if bias_part is not None else 0,
+                              int(first.numel()) if bias_part is not None else 0,
+                              _p(first) if bias_part is not None else None,
+                              _p(second) if bias_part is not None else None))
+        # held through FRESH tensor objects on the same storage: autograd adopts an incoming gradient as p.grad without a
+        # copy only while nobody else holds the tensor object -- a second reference to gw / first / second would make it
+        # clone them here, before the flush has written them
+        self.keep.append(tuple(t.detach() if t is not None else None for t in (x, gm, gw, bias_part, first, second)))
+
+    def flush(self):
+        """Launch the queued problems on the current stream and empty the queue."""
+        n = len(self.problems)
+        if n == 0:
+            return 0
+        L = _native.lib()
+        arr = (_native.AtbProblem * n)()
+        for q, t in zip(arr, self.problems):
+            (q.x, q.grad_out, q.grad_w, q.N, q.Cin, q.Cout, q.ldw, q.bias_part, q.bias_blocks, q.bias_cols,
+             q.grad_bias, q.grad_bias2) = t
+        nbytes = int(L.d3f_linear_grad_weight_group_ws_bytes(arr, n))
+        if nbytes == 0:
+            raise RuntimeError("d3f_linear_grad_weight_group: unsupported problem in the queue")
+        dev = self.keep[0][0].device
+        ws = _ws(nbytes, dev)
+        flops = sum(2 * t[3] * t[4] * t[5] for t in self.problems)
+        with _region("weight_grad_group[n=%d,GFLOP=%.2f]" % (n, flops * 1e-9),
+                     sum(4 * t[3] * (t[4] + t[5]) + 4 * t[4] * t[5] for t in self.problems)):
+            _native.check(L.d3f_linear_grad_weight_group(arr, n, _p(ws), nbytes, _stream()),
+                          "d3f_linear_grad_weight_group")
+        self.problems, self.keep = [], []
+        return n
+
+
+_WG_GROUP = None
+# False: every weight gradient is launched where autograd reaches it (rounds 1-5; experiments and A/B tests)
+GROUP_WEIGHT_GRADS = True
+
+
+class weight_grad_group(object):
+    """Context manager around ONE backward pass (or one stage of a split backward): see WeightGradGroup."""
+
+    def __enter__(self):
+        global _WG_GROUP
+        if _WG_GROUP is not None:
+            raise RuntimeError("weight_grad_group: a backward stage is already collecting weight gradients")
+        self.group = WeightGradGroup() if GROUP_WEIGHT_GRADS else None
+        _WG_GROUP = self.group
+        return self.group
+
+    def __exit__(self, exc_type, exc, tb):
+        global _WG_GROUP
+        g, _WG_GROUP = _WG_GROUP, None
+        if g is not None and exc_type is None:
+            g.flush()
+        return False
+
+
 def _grad_weight_atb(x, gm, N, Cin, Cout, gw, bias_part, bias_blocks, first, second, label):
-    """grad_W [Cout, Cin] = gm^T x on the reduction-parallel kernel; with ``bias_part`` its second stage also sums the
-    bias partials into ``first`` (/ ``second``)."""
+    """grad_W [Cout, Cin] = gm^T x on the reduction-parallel kernels; with ``bias_part`` the second stage also sums the
+    bias partials into ``first`` (/ ``second``).  Inside a weight_grad_group the problem is only queued."""
     L = _native.lib()
+    g = _WG_GROUP
+    if g is not None and x.data_ptr() % 16 == 0 and gm.data_ptr() % 16 == 0:
+        g.add(x, gm, N, Cin, Cout, gw, bias_part, bias_blocks, first, second)
+        return
+    if gw.dim() == 2 and not gw.is_contiguous():      # (a column block of a wider matrix: only the group writes in place)
+        tmp = torch.empty((Cout, Cin), dtype=torch.float32, device=x.device)
+        _grad_weight_atb(x, gm, N, Cin, Cout, tmp, bias_part, bias_blocks, first, second, label)
+        gw.copy_(tmp)
+        return
     nbytes = L.d3f_linear_grad_weight_ws_bytes(N, Cin, Cout)
     ws = _ws(nbytes, x.device)
     with _region("%s[N=%d,Cin=%d,Cout=%d]" % (label, N, Cin, Cout), 4 * N * (Cin + Cout) + 4 * Cin * Cout):
@@ -1254,10 +1342,8 @@ class _UpsampleLinearFn(torch.autograd.Function):
             slot = ctx.gw_slot
             gw = slot if slot is not None else torch.empty_like(weight)
             torch.mm(gt.t(), xc, out=gw[:, :Cc])      # the GEMMs write their column block of W's gradient in place
-            if atb:
-                tmp = torch.empty((Cout, Cs), dtype=torch.float32, device=go.device)
-                _grad_weight_atb(skip, gm, N, Cs, Cout, tmp, bias_part, bias_blocks, first, second, "linear_dw")
-                gw[:, Cc:].copy_(tmp)
+            if atb:   # (the grouped second stage writes the column block of W's gradient in place: row stride Cc + Cs)
+                _grad_weight_atb(skip, gm, N, Cs, Cout, gw[:, Cc:], bias_part, bias_blocks, first, second, "linear_dw")
             else:
                 torch.mm(gm.t(), skip, out=gw[:, Cc:])
             gw = _adoptable(gw, slot)

@@ -521,7 +521,8 @@ class TrainStep:
         self.flat.zero_grad()
         (loss, desc, det, acc), cuts = self._forward_loss_cut(batch)
         deep = self.flat.params[self.n_shallow:]
-        torch.autograd.backward(loss, self._seed(loss), inputs=deep + [leaf for _, leaf in cuts])
+        with ops.weight_grad_group():     # the deep bucket's weight gradients: ONE grouped launch at the stage's end,
+            torch.autograd.backward(loss, self._seed(loss), inputs=deep + [leaf for _, leaf in cuts])   # before its all-reduce
         self._cuts = cuts
         self.flat.gather_grads(self.n_shallow, None)
         return loss.detach(), desc.detach(), det.detach(), acc.detach()
@@ -529,8 +530,9 @@ class TrainStep:
     def _backward_shallow(self):
         """Stage 2: backward of the fine encoder levels from the cut gradients."""
         cuts, self._cuts = self._cuts, None
-        torch.autograd.backward([t for t, _ in cuts], [leaf.grad for _, leaf in cuts],
-                                inputs=self.flat.params[:self.n_shallow])
+        with ops.weight_grad_group():
+            torch.autograd.backward([t for t, _ in cuts], [leaf.grad for _, leaf in cuts],
+                                    inputs=self.flat.params[:self.n_shallow])
         self.flat.gather_grads(0, self.n_shallow)
 
     def _poison_if_flagged(self, grad, pair_status):
@@ -864,7 +866,8 @@ class TrainStep:
         try:
             self.flat.zero_grad()
             loss, desc, det, acc = self.forward_loss(batch)
-            torch.autograd.backward(loss, self._seed(loss))
+            with ops.weight_grad_group():     # every weight gradient of the step in one grouped launch (ops.WeightGradGroup)
+                torch.autograd.backward(loss, self._seed(loss))
             grad = self.flat.gather_grads()
             if lane is None:
                 self.opt.step(want_ok=False, pair_status=st.status.word)
@@ -1168,7 +1171,8 @@ class TrainStep:
                                            pair_status=pair_status)
         self.flat.zero_grad()
         loss, desc, det, acc = self.forward_loss(batch)
-        torch.autograd.backward(loss, self._seed(loss))
+        with ops.weight_grad_group():
+            torch.autograd.backward(loss, self._seed(loss))
         if self.world > 1 and pair_status is not None:
             self._poison_if_flagged(self.flat.gather_grads(), pair_status)
             pair_status = None

@@ -48,12 +48,30 @@ void d3f_debug_set_flags(int flags);      /* profiling aid: ablation switches of
 void d3f_debug_set_phase_clock(void* counters);
 /* measurement aid (bench.py roofline leg): HIP events on the launch stream around every launch of ONE kernel
  * (which = 1 fused KPConv forward kernel, 2 scatter-form grad-input kernel, 3 gather-form grad-input kernel, 4 the
- * A^T B weight-gradient kernels, 5 / 6 the forward / transposed KPConv aggregation kernels; or, negative, minus a bit
- * mask of several: -(1 | 2 | 4 | 8 | 16 | 32)) between begin and end.  end -- after the caller synchronised
- * the device -- returns the number of launches seen and fills ms_out[i] and shapes_out[6*i .. 6*i+5] =
- * {Nq, Ns, H, Cin, Cout, K | which << 8} for the first `cap` of them. */
+ * A^T B weight-gradient kernels launched one problem at a time, 5 / 6 the forward / transposed KPConv aggregation
+ * kernels, 7 the GROUPED A^T B weight-gradient launches (d3f_linear_grad_weight_group: one record per group, both
+ * launches); or, negative, minus a bit mask of several: -(1 | 2 | ... | 64)) between begin and end.  end -- after the
+ * caller synchronised the device -- returns the number of launches seen and fills ms_out[i] and
+ * shapes_out[6*i .. 6*i+5] = {Nq, Ns, H, Cin, Cout, K | which << 8} for the first `cap` of them (which = 7:
+ * {problems, sum of 2 R M N in MiFLOP, sum of 4 R (M + N) + 4 M N in KiB, workgroups, 0, 7 << 8}). */
 int d3f_debug_kernel_timing_begin(int which, int max_launches);
 int d3f_debug_kernel_timing_end(float* ms_out, int32_t* shapes_out, int cap);
+
+/* Tunables of the library -- ONE struct instead of environment variables: the library itself never reads the
+ * environment.  d3f_get_tunables fills the current values (defaults at load), d3f_set_tunables replaces them all
+ * (process-wide; set them before the launches they concern, not concurrently with them).  The experiment scripts under
+ * profiles/ and the tests are the only callers; 0 = "the built-in choice" for every field. */
+typedef struct d3f_tunables {
+  int32_t atb_task_us;        /* grouped A^T B: modelled duration of one workgroup's task in us (0 = 20) */
+  int32_t atb_form;           /* one-problem weight gradients: 0 = by size, 1 = always the first (direct-load) form,
+                               * 2 = always the grouped (LDS-DMA ring) kernels */
+  int32_t atb_first_form_wgs; /* first form: workgroups along the reduction (0 = by shape) */
+  int32_t match_wgs;          /* d3f_mutual_nn: target number of workgroups (0 = 2048) */
+  int32_t agg_through_lds;    /* general-path KPConv aggregation: 1 = stage the tile through LDS (experiment) */
+  int32_t reserved[11];
+} d3f_tunables;
+void d3f_get_tunables(d3f_tunables* out);
+int d3f_set_tunables(const d3f_tunables* in);
 
 /* ------------------------------------------------------------------------------------------------
  * Radius neighbors -- replaces radius_neighbors.batch_query
@@ -269,6 +287,27 @@ int d3f_linear_grad_weight(const float* x, const float* grad_out, int N, int Cin
 int d3f_linear_grad_weight_bias(const float* x, const float* grad_out, int N, int Cin, int Cout, float* grad_w, void* ws,
                                 size_t ws_bytes, const float* bias_part, int bias_blocks, int bias_cols,
                                 float* grad_bias, float* grad_bias2, void* stream);
+/* ALL weight gradients of a backward stage in two launches (round 6).  A weight gradient has no consumer before the
+ * optimizer (reference trainer.py:103-111: loss.backward() completes, then optimizer.step()), so the autograd nodes of
+ * the host mirror only QUEUE their problem -- the nn.Linear weights of the unary blocks (models/blocks.py:481-515,
+ * autograd's grad_out^T @ x) and the KPConv weights (blocks.py:369-374, with x := g / nn [Nq, Cout],
+ * grad_out := weighted features [Nq, K Cin], grad_w viewed as [K Cin, Cout]) -- and the stage ends with ONE call:
+ * one launch walks every problem's (row partition, output block) tasks, one more sums every problem's slabs in a fixed
+ * order and finishes the queued bias gradients (as d3f_linear_grad_weight_bias).  Bit-reproducible, no atomics.
+ * problems / n: HOST array.  grad_w [Cout, ldw]: row stride ldw >= Cin (a column block of a wider weight matrix is
+ * written in place).  x, grad_out 16-byte aligned; Cin, Cout multiples of 16.  bias_part == NULL: no bias gradient. */
+typedef struct d3f_atb_problem {
+  const float* x;        /* [N, Cin] */
+  const float* grad_out; /* [N, Cout] */
+  float* grad_w;         /* [Cout, ldw] */
+  int32_t N, Cin, Cout, ldw;
+  const float* bias_part;
+  int32_t bias_blocks, bias_cols;
+  float* grad_bias;
+  float* grad_bias2;
+} d3f_atb_problem;
+size_t d3f_linear_grad_weight_group_ws_bytes(const d3f_atb_problem* problems_host, int n);
+int d3f_linear_grad_weight_group(const d3f_atb_problem* problems_host, int n, void* ws, size_t ws_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Pools -- replace models/blocks.py:94-110 (max_pool) and :79-91 (closest_pool).

@@ -7,7 +7,7 @@ import pytest
 import torch
 
 from d3feat_pytorch_amd import config as cfgmod
-from d3feat_pytorch_amd import ops
+from d3feat_pytorch_amd import _native, ops
 from d3feat_pytorch_amd.datasets import dataloader as dl
 from d3feat_pytorch_amd.geometric_registration.common import build_correspondence
 from oracle import ops_ref
@@ -518,6 +518,149 @@ def test_linear_weight_gradient(n, cin, cout, min_rows, monkeypatch):
     tw2 = cu(w).requires_grad_(True)
     ops.linear_nobias(cu(x), tw2).backward(cu(go))
     assert torch.equal(tw2.grad, tw.grad)
+
+
+def _group_call(problems):
+    """d3f_linear_grad_weight_group on [(x, grad_out, grad_w 2-D view, bias_part or None, bias rows, gb, gb2)]."""
+    import ctypes
+    L = _native.lib()
+    n = len(problems)
+    arr = (_native.AtbProblem * n)()
+    for q, (x, go, gw, bpart, gb, gb2) in zip(arr, problems):
+        q.x, q.grad_out, q.grad_w = x.data_ptr(), go.data_ptr(), gw.data_ptr()
+        q.N, q.Cin, q.Cout, q.ldw = x.shape[0], x.shape[1], go.shape[1], gw.stride(0)
+        if bpart is not None:
+            q.bias_part, q.bias_blocks, q.bias_cols = bpart.data_ptr(), bpart.shape[0], bpart.shape[1]
+            q.grad_bias, q.grad_bias2 = gb.data_ptr(), (gb2.data_ptr() if gb2 is not None else None)
+    nbytes = L.d3f_linear_grad_weight_group_ws_bytes(arr, n)
+    assert nbytes > 0
+    ws = torch.empty(nbytes, dtype=torch.uint8, device="cuda")
+    _native.check(L.d3f_linear_grad_weight_group(arr, n, ws.data_ptr(), nbytes, torch.cuda.current_stream().cuda_stream),
+                  "d3f_linear_grad_weight_group")
+    return nbytes
+
+
+# (rows, Cin, Cout): every tile shape of the grouped kernel (16 / 32 / 64-wide panels on either side), >= 1.4 GFLOP
+# problems, rows that are no multiple of 16, row counts whose last partition is ragged, partition counts that are no
+# multiple of 8, a problem with fewer rows than one partition group, the S1 stack's largest shapes
+_GROUP_SHAPES = [(114688, 384, 32), (23872, 256, 256), (6208, 512, 512), (6208, 128, 1920), (23871, 64, 960),
+                 (114683, 32, 480), (38001, 64, 128), (4099, 16, 16), (5003, 48, 80), (7001, 32, 16), (9013, 16, 64),
+                 (333, 64, 64), (61, 32, 32), (100003, 16, 48), (12345, 96, 160)]
+
+
+@pytest.mark.parametrize("task_us", [0, 5])
+def test_grouped_weight_gradients_match_float64(task_us):
+    """d3f_linear_grad_weight_group: ALL problems in one launch pair == float64 grad_out^T x per problem, bit-identical
+    on a second run and when a problem is computed alone; bias partial sums finished by the same second stage; a
+    strided target (column block of a wider matrix) written in place with its neighbours untouched.  task_us = 5:
+    four times as many row partitions (ragged last partitions, partition counts off the multiples of 8)."""
+    old = _native.set_tunables(atb_task_us=task_us)
+    try:
+        rng = np.random.default_rng(5)
+        probs, refs = [], []
+        for k, (n, cin, cout) in enumerate(_GROUP_SHAPES):
+            x = torch.from_numpy(rng.normal(size=(n, cin)).astype(np.float32)).cuda()
+            go = torch.from_numpy(rng.normal(size=(n, cout)).astype(np.float32)).cuda()
+            pad = 16 if k % 3 == 1 else 0                       # every third target is a column block
+            full = torch.full((cout, pad + cin + pad), 7.0, dtype=torch.float32, device="cuda")
+            gw = full[:, pad:pad + cin]
+            bpart = gb = gb2 = None
+            if k % 2 == 0:
+                bpart = torch.from_numpy(rng.normal(size=(37 + k, cout)).astype(np.float32)).cuda()
+                gb = torch.empty(cout, device="cuda")
+                gb2 = torch.empty(cout, device="cuda") if k % 4 == 0 else None
+            probs.append((x, go, gw, bpart, gb, gb2))
+            refs.append((full, pad, (go.double().t() @ x.double()).cpu().numpy()))
+        _group_call(probs)
+        torch.cuda.synchronize()
+        first = []
+        for (x, go, gw, bpart, gb, gb2), (full, pad, ref) in zip(probs, refs):
+            assert rel_err(gw.cpu().numpy(), ref) < 2e-5, (tuple(x.shape), tuple(go.shape))
+            if pad:
+                assert bool((full[:, :pad] == 7.0).all()) and bool((full[:, -pad:] == 7.0).all())
+            if bpart is not None:
+                assert rel_err(gb.cpu().numpy(), bpart.double().sum(0).cpu().numpy()) < 1e-5
+                if gb2 is not None:
+                    assert torch.equal(gb, gb2)
+            first.append((gw.clone(), gb.clone() if gb is not None else None))
+            gw.fill_(0.0)
+        _group_call(probs)                                      # no atomics: the same bits
+        for (x, go, gw, bpart, gb, gb2), (w0, b0) in zip(probs, first):
+            assert torch.equal(gw, w0)
+            assert b0 is None or torch.equal(gb, b0)
+        for k in (1, 4, 9):                                     # a problem alone == the problem inside the group
+            x, go, gw, bpart, gb, gb2 = probs[k]
+            gw.fill_(0.0)
+            _group_call([probs[k]])
+            assert torch.equal(gw, first[k][0])
+    finally:
+        _native.set_tunables(**old)
+
+
+def test_grouped_launch_with_more_problems_than_one_table_holds():
+    """60 problems > the 48 entries of one kernel-argument table: the call splits into two launch pairs."""
+    rng = np.random.default_rng(6)
+    probs = []
+    for k in range(60):
+        n, cin, cout = 4096 + 37 * k, 16 * (1 + k % 3), 16 * (1 + (k // 3) % 4)
+        x = torch.from_numpy(rng.normal(size=(n, cin)).astype(np.float32)).cuda()
+        go = torch.from_numpy(rng.normal(size=(n, cout)).astype(np.float32)).cuda()
+        probs.append((x, go, torch.empty((cout, cin), device="cuda"), None, None, None))
+    _group_call(probs)
+    for x, go, gw, *_ in probs:
+        assert rel_err(gw.cpu().numpy(), (go.double().t() @ x.double()).cpu().numpy()) < 2e-5
+
+
+def test_grouped_launch_rejects_bad_problems():
+    L = _native.lib()
+    x = torch.zeros((4096, 32), device="cuda")
+    go = torch.zeros((4096, 24), device="cuda")       # 24 is no multiple of 16
+    gw = torch.zeros((24, 32), device="cuda")
+    arr = (_native.AtbProblem * 1)()
+    arr[0].x, arr[0].grad_out, arr[0].grad_w = x.data_ptr(), go.data_ptr(), gw.data_ptr()
+    arr[0].N, arr[0].Cin, arr[0].Cout, arr[0].ldw = 4096, 32, 24, 32
+    assert L.d3f_linear_grad_weight_group_ws_bytes(arr, 1) == 0
+    ws = torch.empty(1 << 20, dtype=torch.uint8, device="cuda")
+    assert L.d3f_linear_grad_weight_group(arr, 1, ws.data_ptr(), 1 << 20, None) == -1
+    arr[0].Cout, arr[0].ldw = 32, 16                  # row stride below the row length
+    assert L.d3f_linear_grad_weight_group(arr, 1, ws.data_ptr(), 1 << 20, None) == -1
+    arr[0].ldw = 32
+    assert L.d3f_linear_grad_weight_group(arr, 1, ws.data_ptr(), 16, None) == -2   # workspace too small
+    assert L.d3f_linear_grad_weight_group(arr, 0, None, 0, None) == 0
+
+
+def test_weight_grad_group_defers_and_equals_immediate_launches(monkeypatch):
+    """ops.weight_grad_group around a backward pass: every unary / KPConv weight gradient and bias gradient equals the
+    one-launch-per-layer result (rounds 1-5) -- including the shortcut whose deposited gradient is accumulated by the
+    next GEMM (out of place while operands are queued) and the decoder's column-block target."""
+    rng = np.random.default_rng(11)
+    n, nc = 9000, 2300
+    x0 = rng.normal(size=(n, 128)).astype(np.float32)
+    xc = rng.normal(size=(nc, 256)).astype(np.float32)
+    idx = rng.integers(0, nc, size=(n, 1)).astype(np.int32)
+    # two 128 -> 128 layers on the library-GEMM path (the second adds the block input: its masked gradient is BOTH the
+    # queued operand of its weight gradient and the buffer the first layer's grad-input GEMM would accumulate into)
+    ws_ = [(rng.normal(size=s) / np.sqrt(s[1])).astype(np.float32) for s in ((128, 128), (128, 128), (64, 256 + 128))]
+    bs = [rng.normal(size=c).astype(np.float32) for c in (128, 128, 64)]
+
+    def run(grouped):
+        monkeypatch.setattr(ops, "GROUP_WEIGHT_GRADS", grouped)
+        t = cu(x0).requires_grad_(True)
+        W = [cu(w).requires_grad_(True) for w in ws_]
+        B = [cu(b).requires_grad_(True) for b in bs]
+        holder = ops.GradHolder()     # the identity shortcut's gradient is accumulated by the first layer's grad-input GEMM
+        h = ops.linear_bias_act(t, W[0], B[0], slope=0.1, grad_holder=holder)
+        h = ops.linear_bias_act(h, W[1], B[1], add=ops.grad_tap(t, holder), slope=0.1)
+        y = ops.upsample_linear_bias_act(cu(xc), cu(idx), h, W[2], B[2], slope=0.1)
+        with ops.weight_grad_group() as g:
+            y.sum().backward()
+            assert (g is not None and len(g.problems) >= 3) if grouped else g is None
+        torch.cuda.synchronize()
+        return [p.grad.clone() for p in W + B + [t]]
+
+    a, b = run(True), run(False)
+    for u, v in zip(a, b):
+        assert rel_err(u.cpu().numpy(), v.cpu().numpy()) < 2e-5
 
 
 @pytest.mark.parametrize("n,cin,cout,with_add,slope", [(5000, 64, 32, False, 0.1), (4133, 32, 128, True, 0.1),
