@@ -197,17 +197,19 @@ __device__ __forceinline__ void lds_frag(const float* __restrict__ row, int li, 
   }
 }
 
-constexpr int ATB_GROUP_MAX = 48;          // problems per launch (both kernel-argument tables stay below 4 KiB)
+constexpr int ATB_GROUP_MAX = 60;          // problems per launch (both kernel-argument tables stay below 4 KiB)
 constexpr int ATB_RING_BYTES = 16 * 1024;  // LDS ring of one wave
 constexpr int ATB_LDS_BYTES = 4 * ATB_RING_BYTES;
 
 struct AtbTask {       // one problem of a grouped launch, first stage
   const float* A;      // [R, M]
   const float* B;      // [R, N]
-  float* part;         // slabs [P][M N]
+  float* part;         // slabs [P][M N] -- or, for an undivided reduction (P == 1, `direct`), the result C itself
   int R, M, N;
   int rpw, P;          // rows per partition (a multiple of 64), live partitions
   int tile;            // 16 TI + TJ
+  int ldp;             // row stride of `part` (N for slabs, the caller's ldc when direct)
+  int direct;          // 1: task t = output block t (no partitions, no slab, no second stage)
 };
 struct AtbGroup {
   int n, pad;
@@ -220,7 +222,8 @@ extern __shared__ __attribute__((aligned(1024))) unsigned char atb_smem[];
 // task t of a problem: partition p = (t % 8) + 8 (t / 8 / nblk), output block (t / 8) % nblk
 template <int TI, int TJ>
 __device__ __forceinline__ void atb_task_body(const float* __restrict__ A, const float* __restrict__ B,
-                                              float* __restrict__ part, int R, int M, int N, int rpw, int P, int t) {
+                                              float* __restrict__ part, int R, int M, int N, int rpw, int P, int t,
+                                              int ldp, int direct) {
   constexpr int KS = 4, ROWS = 4 * KS, BM = 16 * TI, BN = 16 * TJ;
   constexpr int A_BYTES = ROWS * BM * 4, B_BYTES = ROWS * BN * 4, SB = A_BYTES + B_BYTES;
   constexpr int NA = A_BYTES / 1024, NB = B_BYTES / 1024, G = NA + NB;   // (= TI, TJ, TI + TJ)
@@ -230,8 +233,11 @@ __device__ __forceinline__ void atb_task_body(const float* __restrict__ A, const
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int li = lane & 15, lk = lane >> 4;
   const int nbj = N / BN, nblk = (M / BM) * nbj;
-  const int p = (t & 7) + 8 * ((t >> 3) / nblk), blk = (t >> 3) % nblk;
-  if (p >= P) return;                                   // (padding tasks of the last group of 8 partitions)
+  // direct: few rows against a large output (the bottom levels' weight gradients): one task per output block, the
+  // column block n0 -- hence the B panel -- of consecutive tasks cycles, so with nbj a multiple of 8 every XCD keeps
+  // its own column blocks
+  const int p = direct ? 0 : (t & 7) + 8 * ((t >> 3) / nblk), blk = direct ? t : (t >> 3) % nblk;
+  if (p >= P || blk >= nblk) return;                    // (padding tasks of the last group of 8)
   const int m0 = (blk / nbj) * BM, n0 = (blk % nbj) * BN;
   const int r0 = p * rpw, r1 = min(R, r0 + rpw);
   const int ngroups = (r1 - r0 + ROWS - 1) / ROWS;
@@ -306,7 +312,7 @@ __device__ __forceinline__ void atb_task_body(const float* __restrict__ A, const
   // combine the 4 waves in a fixed order (wave 0 + 1 + 2 + 3) through LDS -- the rings are free now
   constexpr int NT = TI * TJ;
   float* red = (float*)atb_smem;                          // [3][NT * 256]
-  float* pp = part + (size_t)p * M * N;
+  float* pp = part + (size_t)p * M * N;                   // (direct: p = 0)
   __syncthreads();                                        // every wave is out of its ring
   if (wave > 0) {
 #pragma unroll
@@ -330,7 +336,7 @@ __device__ __forceinline__ void atb_task_body(const float* __restrict__ A, const
           const int e = ((i * TJ + u) * 4 + r) * 64 + lane;
           v[u] = ((acc[i][u][r] + red[e]) + red[NT * 256 + e]) + red[2 * NT * 256 + e];
         }
-        float* dst = pp + (size_t)(m0 + TI * (4 * lk + r) + i) * N + n0 + TJ * li;
+        float* dst = pp + (size_t)(m0 + TI * (4 * lk + r) + i) * ldp + n0 + TJ * li;
         if constexpr (TJ == 4) *(float4*)dst = make_float4(v[0], v[TJ > 1 ? 1 : 0], v[TJ > 2 ? 2 : 0], v[TJ > 3 ? 3 : 0]);
         else if constexpr (TJ == 2) *(float2*)dst = make_float2(v[0], v[TJ > 1 ? 1 : 0]);
         else dst[0] = v[0];
@@ -349,7 +355,7 @@ __global__ __launch_bounds__(256, 2) void atb_grouped_kernel(const AtbGroup g) {
   const AtbTask& k = g.t[i];
   const int t = L - g.task0[i];
 #define D3F_ATB_TILE(I, J) \
-  case (I) * 16 + (J): atb_task_body<I, J>(k.A, k.B, k.part, k.R, k.M, k.N, k.rpw, k.P, t); break
+  case (I) * 16 + (J): atb_task_body<I, J>(k.A, k.B, k.part, k.R, k.M, k.N, k.rpw, k.P, t, k.ldp, k.direct); break
   switch (k.tile) {
     D3F_ATB_TILE(1, 1); D3F_ATB_TILE(1, 2); D3F_ATB_TILE(1, 4);
     D3F_ATB_TILE(2, 1); D3F_ATB_TILE(2, 2); D3F_ATB_TILE(2, 4);
@@ -369,9 +375,10 @@ struct AtbReduceTask {
   const float* bpart;  // [nblocks, BC] or null
   float* gb;
   float* gb2;
-  int P, MN4, N, ldc;  // MN4 = M N / 4
-  int c_blocks, nblocks, BC, vec;   // vec: C rows are 16-byte aligned
+  int P, MN4, N, ldc;  // MN4 = M N / 4; P = 0: no slabs to sum (a direct problem, present for its bias gradient)
+  int nblocks, BC_vec; // BC_vec = 2 BC + (C rows are 16-byte aligned)
 };
+static_assert(sizeof(AtbReduceTask) == 64, "table entry");
 struct AtbReduceGroup {
   int n, pad;
   int block0[ATB_GROUP_MAX];
@@ -388,7 +395,8 @@ __global__ __launch_bounds__(1024) void atb_grouped_reduce_kernel(const AtbReduc
   i = __builtin_amdgcn_readfirstlane(i);
   const AtbReduceTask& k = g.t[i];
   const int lb = L - g.block0[i];
-  if (lb < k.c_blocks) {
+  const int c_blocks = k.P > 0 ? (k.MN4 + 255) / 256 : 0;
+  if (lb < c_blocks) {
     const int el = threadIdx.x & 255, s4 = threadIdx.x >> 8;
     const int e4 = lb * 256 + el;
     const float4* part4 = (const float4*)k.part;
@@ -413,7 +421,7 @@ __global__ __launch_bounds__(1024) void atb_grouped_reduce_kernel(const AtbReduc
                                    ((a.w + b.w) + c.w) + d.w);
       const int e = 4 * e4, row = e / k.N, col = e % k.N;   // (N is a multiple of 16: the four stay in one row)
       float* dst = k.C + (size_t)row * k.ldc + col;
-      if (k.vec) {
+      if (k.BC_vec & 1) {
         *(float4*)dst = v;
       } else {
         dst[0] = v.x; dst[1] = v.y; dst[2] = v.z; dst[3] = v.w;
@@ -423,9 +431,9 @@ __global__ __launch_bounds__(1024) void atb_grouped_reduce_kernel(const AtbReduc
   }
   float* sh = (float*)&sh4[0][0];          // [16][64]
   const int col = threadIdx.x & 63, sub = threadIdx.x >> 6;
-  const int c = (lb - k.c_blocks) * 64 + col;
+  const int c = (lb - c_blocks) * 64 + col;
   const float* bpart = k.bpart;
-  const int BC = k.BC, nblocks = k.nblocks;
+  const int BC = k.BC_vec >> 1, nblocks = k.nblocks;
   float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;
   if (c < BC) {
     int b = sub;
@@ -552,12 +560,13 @@ static int atb_partitions(int R, int M, int N) {
 // and its share of the HBM stream (the A panel of a partition is fetched once for the nbj blocks that read it -- they
 // run on one XCD --, the B panel once for nbi; 6.3 TB/s / 512 per slot).
 struct AtbPlan {
-  int ti, tj, nbi, nbj, P, rpw;
-  long long ntasks;         // 8 ceil(P / 8) nblk
+  int ti, tj, nbi, nbj, P, rpw, direct;
+  long long ntasks;         // 8 ceil(P / 8) nblk (direct: nblk rounded up to 8)
   double task_s;            // modelled duration of one task
-  size_t slab_floats;       // P M N
+  size_t slab_floats;       // P M N (direct: 0)
 };
-static AtbPlan atb_plan(int R, int M, int N) {
+// can_direct: the target admits 16-byte row stores (the kernel then writes C itself when the reduction is not split)
+static AtbPlan atb_plan(int R, int M, int N, bool can_direct = false) {
   AtbPlan a;
   a.ti = tile_width(M);
   a.tj = tile_width(N);
@@ -570,6 +579,19 @@ static AtbPlan atb_plan(int R, int M, int N) {
   if (us < 1) us = 20;
   double rows = us * 1e-6 / row_s;
   if (rows < 256) rows = 256;
+  a.direct = 0;
+  // Few rows against a large output (weight gradients of the bottom levels: 462 / 1713 rows x 7680 x 512 ...): the
+  // output blocks alone fill the chip, splitting the reduction would only add slab traffic (8 x 15.7 MB for one of
+  // them) -- one task per output block over ALL rows, result written straight to C.
+  if (can_direct && (long long)a.nbi * a.nbj >= 128 && (double)R <= 2.5 * rows) {
+    a.direct = 1;
+    a.P = 1;
+    a.rpw = (R + 63) / 64 * 64;
+    a.ntasks = ((long long)a.nbi * a.nbj + 7) / 8 * 8;
+    a.task_s = row_s * (double)R;
+    a.slab_floats = 0;
+    return a;
+  }
   long long q = (long long)((double)R / (8.0 * rows) + 0.5);
   if (q < 1) q = 1;
   if (q > 64) q = 64;
@@ -594,6 +616,7 @@ struct AtbProblem {   // host side of one problem: C [M, ldc] = A^T [M, R] B [R,
   float* grad_bias2;
 };
 
+static bool atb_can_direct(const AtbProblem& p) { return (((uintptr_t)p.C) & 15) == 0 && (p.ldc & 3) == 0; }
 static bool atb_problem_ok(const AtbProblem& p) {
   if (!p.A || !p.B || !p.C || !atb_supported(p.R, p.M, p.N) || p.ldc < p.N) return false;
   if ((((uintptr_t)p.A | (uintptr_t)p.B) & 15) != 0 || (((uintptr_t)p.C) & 3) != 0) return false;   // (LDS-DMA moves 16 B)
@@ -602,10 +625,11 @@ static bool atb_problem_ok(const AtbProblem& p) {
 }
 
 size_t atb_group_ws_bytes(const AtbProblem* probs, int n) {
-  size_t total = 0;
+  size_t total = 256;     // (never 0 for a valid queue: 0 is the C ABI's "unsupported problem")
   for (int i = 0; i < n; ++i) {
     if (!atb_supported(probs[i].R, probs[i].M, probs[i].N)) return 0;
-    total += align_up(sizeof(float) * atb_plan(probs[i].R, probs[i].M, probs[i].N).slab_floats, 256);
+    total += align_up(sizeof(float) * atb_plan(probs[i].R, probs[i].M, probs[i].N, atb_can_direct(probs[i])).slab_floats,
+                      256);
   }
   return total;
 }
@@ -621,7 +645,7 @@ int atb_group_launch(const AtbProblem* probs, int n, void* ws, hipStream_t strea
   for (int i = 0; i < n; ++i) {
     flops += 2.0 * probs[i].R * (double)probs[i].M * probs[i].N;
     bytes += 4.0 * probs[i].R * ((double)probs[i].M + probs[i].N) + 4.0 * (double)probs[i].M * probs[i].N;
-    all_tasks += atb_plan(probs[i].R, probs[i].M, probs[i].N).ntasks;
+    all_tasks += atb_plan(probs[i].R, probs[i].M, probs[i].N, atb_can_direct(probs[i])).ntasks;
   }
   void* timing = kpconv_timing_open(7, stream, n, (int)(flops / 1048576.0), (int)(bytes / 1024.0), (int)all_tasks, 0, 0);
   char* wsp = (char*)ws;
@@ -632,8 +656,8 @@ int atb_group_launch(const AtbProblem* probs, int n, void* ws, hipStream_t strea
     float* part[ATB_GROUP_MAX];
     for (int i = 0; i < m; ++i) {
       const AtbProblem& p = probs[c0 + i];
-      plan[i] = atb_plan(p.R, p.M, p.N);
-      part[i] = (float*)wsp;
+      plan[i] = atb_plan(p.R, p.M, p.N, atb_can_direct(p));
+      part[i] = plan[i].direct ? p.C : (float*)wsp;
       wsp += align_up(sizeof(float) * plan[i].slab_floats, 256);
       order[i] = i;
     }
@@ -665,6 +689,8 @@ int atb_group_launch(const AtbProblem* probs, int n, void* ws, hipStream_t strea
       g.t[s].rpw = plan[i].rpw;
       g.t[s].P = plan[i].P;
       g.t[s].tile = plan[i].ti * 16 + plan[i].tj;
+      g.t[s].ldp = plan[i].direct ? p.ldc : p.N;
+      g.t[s].direct = plan[i].direct;
       task += plan[i].ntasks;
       AtbReduceTask& r = rg.t[s];
       rg.block0[s] = (int)block;
@@ -673,22 +699,22 @@ int atb_group_launch(const AtbProblem* probs, int n, void* ws, hipStream_t strea
       r.bpart = p.bias_part;
       r.gb = p.grad_bias;
       r.gb2 = p.grad_bias2;
-      r.P = plan[i].P;
+      r.P = plan[i].direct ? 0 : plan[i].P;
       r.MN4 = (int)((size_t)p.M * p.N / 4);
       r.N = p.N;
       r.ldc = p.ldc;
-      r.c_blocks = cdiv(r.MN4, 256);
       r.nblocks = p.bias_part ? p.bias_blocks : 0;
-      r.BC = p.bias_part ? p.bias_cols : 0;
-      r.vec = ((((uintptr_t)p.C) & 15) == 0 && (p.ldc & 3) == 0) ? 1 : 0;
-      block += r.c_blocks + (p.bias_part ? cdiv(p.bias_cols, 64) : 0);
+      r.BC_vec = 2 * (p.bias_part ? p.bias_cols : 0) + (atb_can_direct(p) ? 1 : 0);
+      block += (plan[i].direct ? 0 : cdiv(r.MN4, 256)) + (p.bias_part ? cdiv(p.bias_cols, 64) : 0);
     }
     for (int s = m; s < ATB_GROUP_MAX; ++s) g.task0[s] = rg.block0[s] = 0x7fffffff;
     if (task >= 0x7fffffffLL || block >= 0x7fffffffLL) return D3F_EINVAL;
     atb_grouped_kernel<<<(unsigned)task, 256, ATB_LDS_BYTES, stream>>>(g);
     D3F_LAUNCH_CHECK();
-    atb_grouped_reduce_kernel<<<(unsigned)block, 1024, 0, stream>>>(rg);
-    D3F_LAUNCH_CHECK();
+    if (block > 0) {        // (nothing to sum when every problem of the launch wrote its result directly)
+      atb_grouped_reduce_kernel<<<(unsigned)block, 1024, 0, stream>>>(rg);
+      D3F_LAUNCH_CHECK();
+    }
   }
   kpconv_timing_close(timing, stream);
   return D3F_OK;

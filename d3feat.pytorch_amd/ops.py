@@ -558,8 +558,9 @@ class _KPConvFn(torch.autograd.Function):
             # few points, wide layers (bottom of the U-Net): grad_W = wf^T (g/nn) is an ordinary GEMM with a short
             # reduction -- a library call; the reduction-parallel kernel is for the tall-skinny upper levels
             gon = go / nn.unsqueeze(1)
-            with _region("kpconv_dw_gemm[Nq=%d,Cin=%d,Cout=%d]" % (Nq, Cin, Cout), 4 * Nq * (K * Cin + Cout)):
-                torch.mm(wf.t(), gon, out=gw.view(K * Cin, Cout))
+            if not _queue_small_weight_grad(gon, wf, Nq, Cout, K * Cin, gw.view(K * Cin, Cout)):
+                with _region("kpconv_dw_gemm[Nq=%d,Cin=%d,Cout=%d]" % (Nq, Cin, Cout), 4 * Nq * (K * Cin + Cout)):
+                    torch.mm(wf.t(), gon, out=gw.view(K * Cin, Cout))
             gw_native = None
         if gx_native is not None and 0 < Nq < _GEMM_DX_MAX_ROWS and L.d3f_kpconv_grad_input_supported(Cin, K, H, Ns):
             # same layers: gW = (g/nn) W^T over all queries is one library GEMM; the kernel only scatters
@@ -663,7 +664,7 @@ class _KPConvGemmBiasActFn(torch.autograd.Function):
                 # x := g / nn [Nq, Cout], grad_out := wf [Nq, K Cin]: grad_W [K Cin, Cout] = wf^T (g / nn)
                 _grad_weight_atb(gon, wf, Nq, Cout, K * Cin, gw.view(K * Cin, Cout), bias_part, bias_blocks, gb, None,
                                  "kpconv_dw_atb")
-            else:
+            elif not _queue_small_weight_grad(gon, wf, Nq, Cout, K * Cin, gw.view(K * Cin, Cout)):
                 torch.mm(wf.t(), gon, out=gw.view(K * Cin, Cout))
         rev = ctx.rev
         if ctx.needs_input_grad[3] and rev is not None and rev.rel is not None and Cout >= _GEMM_DX_AGG_MIN_COUT \
@@ -934,7 +935,16 @@ def _add_deposited(holder, go, weight):
     if c.is_contiguous() and c.dtype == go.dtype and c.shape == (go.shape[0], weight.shape[1]):
         if _WG_GROUP is not None:
             # the deposited buffer may be a queued operand of a weight gradient that has not run yet (the masked gradient
-            # of the block's last unary layer IS the shortcut's gradient): accumulate out of place
+            # of the block's last unary layer IS the shortcut's gradient): accumulate out of place -- on the row-streaming
+            # kernel where it serves the shape (it reads `add` and writes a separate output anyway: no extra traffic; the
+            # library's out-of-place addmm first copies c, 58 MB at level 0)
+            N, Cout, Cin = int(go.shape[0]), int(go.shape[1]), int(weight.shape[1])
+            L = _native.lib()
+            if go.is_contiguous() and weight.is_contiguous() and L.d3f_linear_fused_supported(N, Cin, Cout):
+                gx = torch.empty_like(c)
+                _native.check(L.d3f_linear_grad_input(_p(go), _p(weight), N, Cin, Cout, _p(c), _p(gx), _stream()),
+                              "d3f_linear_grad_input")
+                return gx
             return torch.addmm(c, go, weight)
         return c.addmm_(go, weight)      # beta = 1, in place: the deposited buffer has no other reader left
     return torch.mm(go, weight).add_(c)
@@ -967,10 +977,10 @@ class _LinearFn(torch.autograd.Function):
             if N >= _SPLITK_MIN_ROWS and L.d3f_linear_grad_weight_supported(N, Cin, Cout):
                 gw = slot if slot is not None else torch.empty_like(weight)
                 _grad_weight_atb(x, go, N, Cin, Cout, gw, None, 0, None, None, "linear_dw")
-            elif slot is not None:
-                gw = torch.mm(go.t(), x, out=slot)
             else:
-                gw = torch.mm(go.t(), x)
+                gw = slot if slot is not None else torch.empty_like(weight)
+                if not _queue_small_weight_grad(x, go, N, Cin, Cout, gw):
+                    torch.mm(go.t(), x, out=gw)
         return gx, (_adoptable(gw, ctx.gw_slot) if gw is not None else None), None, None
 
 
@@ -1043,7 +1053,9 @@ class _LinearBiasActFn(torch.autograd.Function):
                 _grad_weight_atb(x, gm, N, Cin, Cout, gw, bias_part, bias_blocks, first, second, "linear_dw")
                 bias_part = None
             else:
-                gw = torch.mm(gm.t(), x, out=slot) if slot is not None else torch.mm(gm.t(), x)
+                gw = slot if slot is not None else torch.empty_like(weight)
+                if not _queue_small_weight_grad(x, gm, N, Cin, Cout, gw):
+                    torch.mm(gm.t(), x, out=gw)
         if bias_part is not None:      # (not reached: the fold implies the A^T B path)
             _native.check(L.d3f_bias_sum(_p(bias_part), bias_blocks, Cout, _p(first), _p(second), _stream()),
                           "d3f_bias_sum")
@@ -1154,6 +1166,23 @@ class weight_grad_group(object):
         return False
 
 
+def _queue_small_weight_grad(x, gm, N, Cin, Cout, gw):
+    """Few-row weight gradients (the bottom levels: 462 / 1713 rows against 512 ... 7680 x 512 outputs) are library
+    GEMMs when launched where autograd reaches them; inside a weight_grad_group they join the stage's grouped launch
+    (undivided reduction, one task per 64 x 64 output block, written straight to the target).  True when queued."""
+    g = _WG_GROUP
+    if g is None or not GROUP_SMALL_ROW_GRADS or N < 1 or Cin % 16 or Cout % 16:
+        return False
+    if x.data_ptr() % 16 or gm.data_ptr() % 16 or not x.is_contiguous() or not gm.is_contiguous():
+        return False
+    g.add(x, gm, N, Cin, Cout, gw, None, 0, None, None)
+    return True
+
+
+# False: weight gradients below _SPLITK_MIN_ROWS rows stay library GEMMs even inside a group (A/B measurements)
+GROUP_SMALL_ROW_GRADS = True
+
+
 def _grad_weight_atb(x, gm, N, Cin, Cout, gw, bias_part, bias_blocks, first, second, label):
     """grad_W [Cout, Cin] = gm^T x on the reduction-parallel kernels; with ``bias_part`` the second stage also sums the
     bias partials into ``first`` (/ ``second``).  Inside a weight_grad_group the problem is only queued."""
@@ -1257,10 +1286,10 @@ class _LinearLibBiasActFn(torch.autograd.Function):
                 gw = slot if slot is not None else torch.empty_like(weight)
                 _grad_weight_atb(x, gm, N, Cin, Cout, gw, bias_part, bias_blocks, first, second, "linear_dw")
                 bias_part = None
-            elif slot is not None:
-                gw = torch.mm(gm.t(), x, out=slot)
             else:
-                gw = torch.mm(gm.t(), x)
+                gw = slot if slot is not None else torch.empty_like(weight)
+                if not _queue_small_weight_grad(x, gm, N, Cin, Cout, gw):
+                    torch.mm(gm.t(), x, out=gw)
         if bias_part is not None:      # (not reached: fold implies the A^T B path)
             _native.check(L.d3f_bias_sum(_p(bias_part), bias_blocks, Cout, _p(first), _p(second), _stream()),
                           "d3f_bias_sum")
@@ -1341,10 +1370,11 @@ class _UpsampleLinearFn(torch.autograd.Function):
         if ctx.needs_input_grad[3]:
             slot = ctx.gw_slot
             gw = slot if slot is not None else torch.empty_like(weight)
-            torch.mm(gt.t(), xc, out=gw[:, :Cc])      # the GEMMs write their column block of W's gradient in place
+            if not _queue_small_weight_grad(xc, gt, Nc, Cc, Cout, gw[:, :Cc]):
+                torch.mm(gt.t(), xc, out=gw[:, :Cc])  # the GEMMs write their column block of W's gradient in place
             if atb:   # (the grouped second stage writes the column block of W's gradient in place: row stride Cc + Cs)
                 _grad_weight_atb(skip, gm, N, Cs, Cout, gw[:, Cc:], bias_part, bias_blocks, first, second, "linear_dw")
-            else:
+            elif not _queue_small_weight_grad(skip, gm, N, Cs, Cout, gw[:, Cc:]):
                 torch.mm(gm.t(), skip, out=gw[:, Cc:])
             gw = _adoptable(gw, slot)
         return gxc, None, gskip, gw, g1, g2, None, None

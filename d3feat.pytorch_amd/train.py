@@ -1181,6 +1181,45 @@ class TrainStep:
         return loss.detach(), desc.detach(), det.detach(), acc.detach()
 
 
+class LaneThread(object):
+    """A host thread that belongs to one lane of PairLanes: everything the lane CAPTURES runs here (PairLanes.capture),
+    so that the lane's library GEMMs are recorded with the BLAS handle -- and its device workspace -- of this thread and
+    of no other lane.  Jobs run with autograd's multithreading off: backward nodes execute on the calling thread, not on
+    autograd's one worker per device (whose single handle every lane's backward GEMMs would share)."""
+
+    def __init__(self, device, index):
+        import queue
+        import threading
+        self.device = device
+        self._jobs = queue.Queue()
+        self._thread = threading.Thread(target=self._loop, name="d3f-lane-%d" % index, daemon=True)
+        self._thread.start()
+
+    def _loop(self):
+        if self.device.type == 'cuda':
+            torch.cuda.set_device(self.device)
+        while True:
+            fn, box, done = self._jobs.get()
+            try:
+                with torch.autograd.set_multithreading_enabled(False):
+                    box.append((True, fn()))
+            except BaseException as e:   # noqa: B036 -- handed to the caller of run()
+                box.append((False, e))
+            finally:
+                done.set()
+
+    def run(self, fn):
+        """fn() on the lane's thread; returns its result (or raises what it raised)."""
+        import threading
+        box, done = [], threading.Event()
+        self._jobs.put((fn, box, done))
+        done.wait()
+        ok, val = box[0]
+        if not ok:
+            raise val
+        return val
+
+
 class PairLanes:
     """Several fragment pairs IN FLIGHT on one GPU, meeting at one optimizer step.
 
@@ -1221,6 +1260,8 @@ class PairLanes:
 
     caps = property(lambda self: self.engines[0].caps)
     pairs_per_step = property(lambda self: self.P * self.Q)
+    CAPTURE_IN_THREADS = True     # (False: every lane captured from the calling thread, rounds 3-5 -- A/B experiments)
+    PROBE_DEADLINE_S = 20.0       # probe_overlap: longest a concurrent replay of the lanes' graphs may take
 
     def _exchange_stream(self):
         """The stream the multi-rank join runs on (shared with the clones for other capacity classes)."""
@@ -1266,10 +1307,25 @@ class PairLanes:
                     eng.stream.synchronize()
                 ser = min(ser, time.perf_counter() - t0)
                 t0 = time.perf_counter()
+                marks = []
                 for eng, g in zip(self.engines, graphs):
                     with torch.cuda.stream(eng.stream):
                         g.replay()
-                torch.cuda.synchronize(dev)
+                        ev = torch.cuda.Event()
+                        ev.record(eng.stream)
+                        marks.append(ev)
+                # bounded: the first concurrent re-replay of the lanes' graphs is where a captured library kernel that
+                # cannot run beside its own copies would stall for good (rounds 4-5) -- poll, never block
+                while not all(ev.query() for ev in marks):
+                    if time.perf_counter() - t0 > self.PROBE_DEADLINE_S:
+                        raise RuntimeError(
+                            "PairLanes: the lanes' network graphs did not finish a concurrent replay within %.0f s (the "
+                            "same graphs replay one after the other in %.1f ms): a captured kernel does not survive "
+                            "running beside its copies in the other lanes' graphs.  Known cause: library GEMMs of several "
+                            "lanes recorded with ONE BLAS handle (shared device workspace) -- PairLanes.CAPTURE_IN_THREADS "
+                            "= True gives every lane its own.  The GPU queue is stuck; end the process."
+                            % (self.PROBE_DEADLINE_S, ser * 1e3))
+                    time.sleep(0.0005)
                 con = min(con, time.perf_counter() - t0)
             return ser, con
         ser, con = measure()
@@ -1322,12 +1378,40 @@ class PairLanes:
         """``item``: one pair (repeated to fill every stack) or the ``lanes * stack`` pairs of a step."""
         per_lane = self.deal(item) if is_stack(item) and len(item) == self.P * self.Q and self.P * self.Q > 1 else [
             (tuple([item] * self.Q) if self.Q > 1 else item)] * self.P
+        if not self.CAPTURE_IN_THREADS or self.P < 2:
+            out = None
+            for eng, it in zip(self.engines, per_lane):
+                eng.stream.wait_stream(torch.cuda.current_stream(self.ts.device))
+                with torch.cuda.stream(eng.stream):
+                    out = eng.capture(it)
+                eng.stream.synchronize()
+            return out
+        # Every lane is captured on a host thread of ITS OWN (LaneThread: alive as long as the lanes; also used by the
+        # clones for other capacity classes), with autograd's backward on that thread instead of its per-device worker.
+        # Why: PyTorch hands every host THREAD its own BLAS handle, and a rocBLAS handle owns the device workspace
+        # (split-K partial sums, stream-K flags) whose address a captured library GEMM gets baked in.  Captured from one
+        # thread -- and with every backward GEMM issued by autograd's one device thread -- the graphs of ALL lanes held
+        # the SAME workspace and then replayed concurrently: with the library's default solution picks the first joint
+        # replay of 4 lanes x 3 stacked pairs stalled for good, 6 of 6 runs in round 5 and 2 of 2 in round 6 before this
+        # change, 0 of 4 after it (profiles/r06_stall_root_cause.txt).  One handle per lane makes the condition
+        # impossible by construction instead of avoided by solution selection.
+        dev = self.ts.device
+        cur = torch.cuda.current_stream(dev)
+        lane_threads = self._join.setdefault('threads', [])
+        while len(lane_threads) < self.P:
+            lane_threads.append(LaneThread(dev, len(lane_threads)))
         out = None
-        for eng, it in zip(self.engines, per_lane):
-            eng.stream.wait_stream(torch.cuda.current_stream(self.ts.device))
-            with torch.cuda.stream(eng.stream):
-                out = eng.capture(it)
-            eng.stream.synchronize()
+        for eng, it, th in zip(self.engines, per_lane, lane_threads):
+            def job(eng=eng, it=it):
+                eng.stream.wait_stream(cur)
+                with torch.cuda.stream(eng.stream):
+                    r = eng.capture(it)
+                eng.stream.synchronize()
+                return r
+            out = th.run(job)            # one capture at a time; the thread keeps its handle afterwards
+        # the first concurrent replay of what was just recorded, against a deadline: a captured kernel that cannot run
+        # beside its copies shows up HERE as a RuntimeError, not as a training stream that stalls for good later
+        self.probe_overlap(reps=1, redeal=False)
         return out
 
     def step_graph(self, items, next_items=None):

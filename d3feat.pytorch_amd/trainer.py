@@ -105,7 +105,8 @@ def _get(args, name, default):
 
 
 class Trainer(object):
-    AUTO_LANES, AUTO_STACK, AUTO_MIN_STEPS = 4, 3, 8      # the default schedule of the hipGraph path (see __init__)
+    AUTO_LANES, AUTO_STACK, AUTO_MIN_STEPS = 4, 3, 8      # args.fast_schedule (see __init__)
+    FAST_LR_SCALE = 1.0     # learning-rate factor of fast_schedule (profiles/r06_train_curve_schedules.txt)
 
     def __init__(self, args):
         self.config = args
@@ -142,34 +143,51 @@ class Trainer(object):
                 print("note: use_batch_norm=True -> eager training path (no hipGraph replay)")
             self.use_graph = False
         self._captured = False
-        # Pairs per optimizer step and GPU.  Unless pinned (``pairs_in_flight`` / ``stacked_pairs``) or opted out of
-        # (``reference_schedule = True``: one pair per step, reference dataloader.py:73), the hipGraph path trains on
-        # AUTO_LANES x AUTO_STACK pairs per step -- what an MI355X needs to be busy (bench.py: 576 pairs/s against 269 on
-        # the reference's schedule) -- when an epoch holds at least AUTO_MIN_STEPS such steps per rank.
-        pinned = _get(args, 'pairs_in_flight', None) is not None or _get(args, 'stacked_pairs', None) is not None
+        # Pairs per optimizer step and GPU.  DEFAULT: the reference's schedule -- one pair per optimizer step
+        # (dataloader.py:73 batch size 1, trainer.py:89-111), so a run with the reference's config reproduces the
+        # reference's optimisation trajectory (hyper-parameters of training_3DMatch.py:62-81 are tuned for it).
+        # OPT-IN: ``args.fast_schedule = True`` trains on AUTO_LANES x AUTO_STACK = 12 pairs per step and GPU (4 network
+        # graphs in flight x 3 pairs stacked in each: what an MI355X needs to be busy, bench.py 2.1x the pairs/s); every
+        # update is then the MEAN gradient of 12 x ranks pairs, i.e. 12x fewer updates per epoch.
+        # profiles/r06_train_curve_schedules.txt compares the schedules on one pair stream at equal pairs seen; the rule
+        # it supports is applied when ``args.fast_schedule_lr_scale`` is left at None (see FAST_LR_SCALE), and printed.
+        # ``pairs_in_flight`` / ``stacked_pairs`` pin any other schedule (no scaling applied: the caller's business).
         self.lanes = max(1, int(_get(args, 'pairs_in_flight', 1)))
         self.stack = max(1, int(_get(args, 'stacked_pairs', 1)))
+        pinned = _get(args, 'pairs_in_flight', None) is not None or _get(args, 'stacked_pairs', None) is not None
+        self.lr_scale = 1.0
         if _get(args, 'reference_schedule', False):
             self.lanes = self.stack = 1
-        elif not pinned and self.use_graph and self.device.type == 'cuda':
+        elif _get(args, 'fast_schedule', False) and not pinned and self.use_graph and self.device.type == 'cuda':
             per_rank = len(self.train_loader.dataset) // max(1, getattr(self.train_loader, 'batch_size', 1)) // self.world
             if per_rank >= self.AUTO_MIN_STEPS * self.AUTO_LANES * self.AUTO_STACK:
                 self.lanes, self.stack = self.AUTO_LANES, self.AUTO_STACK
-                # the stacked shapes run on TunableOp-selected library GEMMs, like bench.py: the shipped table for the
-                # S1-class capacities, the other shapes tuned while a capacity class is captured (rocBLAS candidates).
-                # On the library's DEFAULT picks one of the 4 x 3 shapes gets a solution that never finishes on a later
-                # graph replay (profiles/r05_hipblaslt_hang.txt); D3F_NO_TUNED_GEMMS=1 leaves the process untouched
-                if os.environ.get("D3F_NO_TUNED_GEMMS") != "1" and not torch.cuda.tunable.is_enabled():
-                    from . import enable_tuned_gemms
-                    enable_tuned_gemms()
+                scale = _get(args, 'fast_schedule_lr_scale', None)
+                self.lr_scale = float(self.FAST_LR_SCALE if scale is None else scale)
+                if self.lr_scale != 1.0:
+                    self.optimizer.lr = self.optimizer.lr * self.lr_scale
+                    self.optimizer.initial_lr = self.optimizer.initial_lr * self.lr_scale
+                    self.scheduler.base_lrs = [lr * self.lr_scale for lr in self.scheduler.base_lrs]
+                    self.scheduler._last_lr = [self.optimizer.lr]
                 if self.rank == 0:
-                    print("note: training on %d x %d = %d fragment pairs per optimizer step and GPU (%d network graphs in "
-                          "flight x %d pairs stacked in each); every update is the MEAN gradient of those pairs x %d rank(s) "
-                          "-- a batch of %d where the reference steps once per pair (dataloader.py:73) -- at the configured "
-                          "learning rate %g (scale it if you want the per-pair step size).  args.reference_schedule = True, "
-                          "or pairs_in_flight / stacked_pairs, pins the schedule."
-                          % (self.lanes, self.stack, self.lanes * self.stack, self.lanes, self.stack, self.world,
-                             self.lanes * self.stack * self.world, float(_get(args, 'lr', 0.0))))
+                    print("note: fast_schedule -- %d x %d = %d fragment pairs per optimizer step and GPU; every update is "
+                          "the MEAN gradient of those pairs x %d rank(s), a batch of %d where the reference steps once per "
+                          "pair (dataloader.py:73); learning rate x %g -> %g (profiles/r06_train_curve_schedules.txt)"
+                          % (self.lanes, self.stack, self.lanes * self.stack, self.world,
+                             self.lanes * self.stack * self.world, self.lr_scale,
+                             float(self.optimizer.param_groups[0]['lr'])))
+            elif self.rank == 0:
+                print("note: fast_schedule needs %d pairs per rank and epoch (%d here): training one pair per step"
+                      % (self.AUTO_MIN_STEPS * self.AUTO_LANES * self.AUTO_STACK, per_rank))
+        if self.lanes * self.stack > 1 and _get(args, 'tuned_gemms', False):
+            # TunableOp-selected library GEMMs (the shipped table + tuning of the missing shapes while a class is
+            # captured) are an OPTIMISATION (~6 % of a step) the caller opts into -- process-wide state is not toggled
+            # behind their back.  They are NOT needed for safety any more: every lane records its GEMMs with a BLAS handle
+            # of its own (train.PairLanes.capture), and an unreadable / version-mismatched table is reported, not ignored.
+            from . import enable_tuned_gemms
+            if not enable_tuned_gemms() and self.rank == 0:
+                print("WARNING: tuned_gemms requested but tuned/tunableop_gfx950.csv was not accepted by this PyTorch / "
+                      "ROCm stack (validators differ): the library's default GEMM picks are used")
         if self.lanes * self.stack > 1 and not self.use_graph:
             if self.rank == 0:
                 print("note: pairs_in_flight=%d / stacked_pairs=%d need the hipGraph path; training one pair per step"
@@ -365,10 +383,14 @@ class Trainer(object):
         pend, self._pending_agree = getattr(self, '_pending_agree', None), None
         if pend is not None and pend[0] == key:
             _, t, work = pend
-            work.wait()
             if t.is_cuda:
+                # work.wait() orders the CURRENT stream behind the collective: it has to be the stream the flag is read
+                # on (waited for on the training stream, the .item() copy on the agree stream could read this rank's own
+                # un-reduced flag while another rank posts late -- ranks would then disagree on graph vs eager path)
                 with torch.cuda.stream(self._agree_stream):
+                    work.wait()
                     return bool(int(t.item()))
+            work.wait()
             return bool(int(t.item()))
         if pend is not None:          # (a posted agreement nobody reads would leave the ranks' collectives out of step)
             pend[2].wait()

@@ -12,6 +12,11 @@ from d3feat_pytorch_amd.datasets import dataloader as dl
 from d3feat_pytorch_amd.train import TrainStep
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 12
+# A/B switches of THIS script (the package reads no environment for them): PROF_GROUP=0 launches every weight gradient
+# where autograd reaches it (rounds 1-5), PROF_SMALL=0 keeps the few-row weight gradients on the library GEMM
+from d3feat_pytorch_amd import ops as _ops
+_ops.GROUP_WEIGHT_GRADS = os.environ.get("PROF_GROUP", "1") != "0"
+_ops.GROUP_SMALL_ROW_GRADS = os.environ.get("PROF_SMALL", "1") != "0"
 d3f.enable_tuned_gemms()
 dev = torch.device("cuda:0")
 cfg = cfgmod.default_config()

@@ -374,12 +374,11 @@ def test_bench_paths_at_s1_size_reproduce_the_reference_run(golden_s1):
     # (c) lanes x stacked pairs: 2 x 2, and 4 x 3 -- bench.py's default, the configuration the driver's number is measured
     # on (114 688-row level 0, its own tuned-GEMM rows and stream deal)
     import d3feat_pytorch_amd as d3f
-    for n_lanes, n_stack in ((2, 2), (4, 3)):
-        if (n_lanes, n_stack) == (4, 3) and os.environ.get('D3F_TEST_NO_TABLE') != '1':
-            # bench.py's configuration INCLUDING its library-GEMM selection (the shipped TunableOp table holds these
-            # shapes): on the library's default picks one of the 4 x 3 shapes gets a solution that never finishes on a
-            # later graph replay (profiles/r05_hipblaslt_hang.txt: memset graph nodes lose their fill value on this HIP
-            # runtime), with the table the engine captures the solutions the driver's run captures
+    # 4 x 3 twice: on the library's DEFAULT GEMM picks -- which stalled 6 of 6 in the first joint replay while all lanes'
+    # graphs were recorded with one BLAS handle (rounds 4-5; profiles/r06_stall_root_cause.txt) -- and on bench.py's
+    # selection (the shipped TunableOp table: the solutions the driver's run captures)
+    for n_lanes, n_stack, table in ((2, 2, False), (4, 3, False), (4, 3, True)):
+        if table:
             assert d3f.enable_tuned_gemms()
         lanes = PairLanes(ts, n_lanes, stack=n_stack)
         lanes.enable_graph(TrainStep.capacities_for([[n_stack * n for n in sizes[0]]], slack=1.0),
@@ -1068,10 +1067,11 @@ def test_trainer_consumes_threedmatch_pickles(golden_s0, tmp_path):
     assert not torch.equal(before, tr.engine.flat.data)
 
 
-def test_trainer_default_schedule_fills_the_gpu_unless_opted_out(capsys):
-    """Trainer(args) on the hipGraph path: 4 network graphs in flight x 3 stacked pairs per optimizer step unless the
-    schedule is pinned or ``reference_schedule`` asks for the reference's one pair per step (dataloader.py:73); an epoch
-    too short for 8 such steps keeps the reference schedule.  The batch-size consequence is printed, not only documented."""
+def test_trainer_keeps_the_reference_schedule_unless_asked(capsys):
+    """Trainer(args) trains one pair per optimizer step like the reference (dataloader.py:73, trainer.py:89-111) unless the
+    caller opts into ``fast_schedule`` (4 network graphs in flight x 3 stacked pairs per step; the batch-size consequence
+    and the learning-rate factor are printed) or pins ``pairs_in_flight`` / ``stacked_pairs``; an epoch too short for 8
+    fast steps keeps one pair per step.  Nothing process-wide (TunableOp) is switched on behind the caller's back."""
     from d3feat_pytorch_amd.trainer import Trainer
 
     def args(n, **kw):
@@ -1082,18 +1082,79 @@ def test_trainer_default_schedule_fills_the_gpu_unless_opted_out(capsys):
         for k, v in kw.items():
             setattr(cfg, k, v)
         return cfg
+    was_on = torch.cuda.tunable.is_enabled()
     tr = Trainer(args(200))
+    assert (tr.lanes, tr.stack, tr.group) == (1, 1, 1) and "fragment pairs per optimizer step" not in capsys.readouterr().out
+    tr = Trainer(args(200, fast_schedule=True))
     out = capsys.readouterr().out
     assert (tr.lanes, tr.stack, tr.group) == (4, 3, 12) and "12 fragment pairs per optimizer step" in out
-    assert "reference_schedule" in out and "learning rate" in out
-    tr = Trainer(args(200, reference_schedule=True))
-    assert (tr.lanes, tr.stack) == (1, 1) and "fragment pairs per optimizer step" not in capsys.readouterr().out
+    assert "learning rate x" in out and "r06_train_curve_schedules" in out
+    assert abs(tr.optimizer.lr - cfgmod.default_config().lr * Trainer.FAST_LR_SCALE) < 1e-12
+    tr = Trainer(args(200, fast_schedule=True, fast_schedule_lr_scale=2.0))
+    assert abs(tr.optimizer.lr - 2.0 * cfgmod.default_config().lr) < 1e-12 and tr.scheduler.base_lrs == [tr.optimizer.lr]
+    tr = Trainer(args(200, fast_schedule=True, reference_schedule=True))
+    assert (tr.lanes, tr.stack) == (1, 1)
     tr = Trainer(args(200, pairs_in_flight=2))
     assert (tr.lanes, tr.stack) == (2, 1)
-    tr = Trainer(args(40))               # 3 steps of 12 per epoch: not worth a 12-pair schedule
-    assert (tr.lanes, tr.stack) == (1, 1)
-    assert torch.cuda.tunable.is_enabled()        # (the default schedule brought the tuned library-GEMM selection along)
-    torch.cuda.tunable.enable(False)
+    tr = Trainer(args(40, fast_schedule=True))   # 3 steps of 12 per epoch: not worth a 12-pair schedule
+    assert (tr.lanes, tr.stack) == (1, 1) and "fast_schedule needs" in capsys.readouterr().out
+    assert torch.cuda.tunable.is_enabled() == was_on
+    tr = Trainer(args(200, fast_schedule=True, tuned_gemms=True))     # the table is an explicit opt-in
+    assert torch.cuda.tunable.is_enabled()
+    torch.cuda.tunable.enable(was_on)
+
+
+def test_every_lane_captures_with_a_blas_handle_of_its_own_and_the_probe_is_bounded():
+    """What makes concurrent replay of the lanes' graphs safe on ANY library GEMM selection: lane k's captures run on
+    LaneThread k (autograd's backward included), and PyTorch gives every host thread its own BLAS handle -- on ROCm the
+    owner of the device workspace a captured GEMM gets baked in.  And the probe of the first concurrent replay polls against
+    a deadline: a stuck replay is a RuntimeError naming the hazard, never an indefinite wait."""
+    from d3feat_pytorch_amd.train import LaneThread, PairLanes, TrainStep
+    dev = torch.device(DEV)
+    threads = [LaneThread(dev, k) for k in range(4)]
+    handles = [t.run(torch.cuda.current_blas_handle) for t in threads]
+    assert len(set(handles + [torch.cuda.current_blas_handle()])) == 5
+    assert handles == [t.run(torch.cuda.current_blas_handle) for t in threads]      # a lane keeps its handle
+
+    def which_thread():   # backward of a job runs on the lane's thread, not on autograd's device worker
+        import threading
+        seen = []
+
+        class Spy(torch.autograd.Function):
+            @staticmethod
+            def forward(ctx, x):
+                return x * 2
+
+            @staticmethod
+            def backward(ctx, g):
+                seen.append(threading.current_thread().name)
+                return g * 2
+        x = torch.ones(4, device=dev, requires_grad=True)
+        Spy.apply(x).sum().backward()
+        return seen[0], threading.current_thread().name
+    bwd, own = threads[1].run(which_thread)
+    assert bwd == own == "d3f-lane-1"
+    with pytest.raises(ZeroDivisionError):       # a job's exception reaches the caller
+        threads[0].run(lambda: 1 // 0)
+    # the engine: two lanes captured through their threads; a deadline of "already expired" turns the probe into a clean error
+    cfg = cfgmod.default_config(first_features_dim=16, num_node=64)
+    raw = synthetic.make_pair(21, 22, _gpu_subsample, n_raw=40000, scale=0.2, num_node=64)
+    item = tuple(torch.from_numpy(np.ascontiguousarray(a)).to(DEV) for a in raw)
+    ts = TrainStep(cfg, [30] * 5, dev, seed=0)
+    sizes = [[int(t.shape[0]) for t in ts.build_batch(item)['points']]]
+    lanes = PairLanes(ts, 2)
+    lanes.enable_graph(TrainStep.capacities_for(sizes, slack=1.0), num_corr=int(item[4].shape[0]))
+    lanes.capture(item)
+    assert len(lanes._join['threads']) == 2
+    assert lanes.overlap['factor'] > 0           # capture ended with the bounded concurrent-replay probe
+    lanes.PROBE_DEADLINE_S = -1.0
+    with pytest.raises(RuntimeError, match="did not finish a concurrent replay"):
+        lanes.probe_overlap(reps=1, redeal=False)
+    torch.cuda.synchronize()
+    del lanes.PROBE_DEADLINE_S
+    outs = lanes.step_graph([item, item], [item, item])
+    lanes.synchronize()
+    assert all(bool(torch.isfinite(o[0]).all()) for o in outs) and lanes.check_status() == (0, 0)
 
 
 def test_two_rank_bench_control_flow_on_one_gpu():

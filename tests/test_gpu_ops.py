@@ -545,7 +545,9 @@ def _group_call(problems):
 # multiple of 8, a problem with fewer rows than one partition group, the S1 stack's largest shapes
 _GROUP_SHAPES = [(114688, 384, 32), (23872, 256, 256), (6208, 512, 512), (6208, 128, 1920), (23871, 64, 960),
                  (114683, 32, 480), (38001, 64, 128), (4099, 16, 16), (5003, 48, 80), (7001, 32, 16), (9013, 16, 64),
-                 (333, 64, 64), (61, 32, 32), (100003, 16, 48), (12345, 96, 160)]
+                 (333, 64, 64), (61, 32, 32), (100003, 16, 48), (12345, 96, 160),
+                 # few rows x large outputs: the undivided ("direct") form, written straight to the (strided) target
+                 (462, 512, 7680), (1713, 256, 3840), (462, 2048, 1024), (159, 512, 2048), (1001, 1024, 512)]
 
 
 @pytest.mark.parametrize("task_us", [0, 5])
@@ -588,7 +590,7 @@ def test_grouped_weight_gradients_match_float64(task_us):
         for (x, go, gw, bpart, gb, gb2), (w0, b0) in zip(probs, first):
             assert torch.equal(gw, w0)
             assert b0 is None or torch.equal(gb, b0)
-        for k in (1, 4, 9):                                     # a problem alone == the problem inside the group
+        for k in (1, 4, 9, 16, 19):                             # a problem alone == the problem inside the group
             x, go, gw, bpart, gb, gb2 = probs[k]
             gw.fill_(0.0)
             _group_call([probs[k]])
