@@ -969,7 +969,7 @@ def main():
             if os.path.exists(tpath):
                 with open(tpath) as f:
                     entry = json.load(f).get(KERNEL_NAMES[dom].split(" ")[0], {})
-                traffic = entry.get("hbm_bytes_per_launch")
+                traffic = entry.get("hbm_bytes_per_launch_pair", entry.get("hbm_bytes_per_launch"))
                 # the counters were collected on the kernel source whose SHA is stored with them (profiles/pmc_traffic.py)
                 src = entry.get("source")
                 if traffic is not None and src:

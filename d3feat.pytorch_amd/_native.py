@@ -138,20 +138,24 @@ STATUS_BITS = {1: "a query has more in-radius candidates than the kernel can ran
                2: "a point lies outside the addressable cell grid",
                4: "voxel hash table full",
                8: "a pyramid level needs more rows than its capacity (raise the capacities)",
-               16: "a point has more in-radius neighbors than the reverse (wide) table holds"}
+               16: "a point has more in-radius neighbors than the reverse (wide) table holds",
+               32: "an upsampling query has no coarse point within the guaranteed nearest bound (a coarse level lost "
+                   "voxels, or the bound passed to query_prefix is wrong)"}
 
 
-def build(verbose=False, jobs=None):
+def build(verbose=False, jobs=None, extra_flags=(), out=None, objdir=None):
     """Compile every HIP source for gfx950 into the in-tree shared library (cross-compiles without a GPU).
-    One object per source under ``build/`` (recompiled only when the source or a header changed), then one link."""
+    One object per source under ``build/`` (recompiled only when the source or a header changed), then one link.
+    ``extra_flags`` / ``out`` / ``objdir``: a MEASUREMENT build of the same sources next to the product (e.g.
+    -DD3F_ATB_PROBE=1 into profiles/experiments/, profiles/atb_loop_probe.py); the product build takes neither."""
     # -ffp-contract=off: HIP's __fmul_rn/__fadd_rn are plain operators on AMD, so with the default contract=fast
     # the compiler fuses the "exact" d2 = (dx*dx + dy*dy) + dz*dz into FMAs and the strict d2 < r2 test / the
     # distance order stop matching the reference's x86 arithmetic bit for bit.  Fusion is requested explicitly
     # (fmaf / MFMA) where it is wanted.
     from concurrent.futures import ThreadPoolExecutor
     flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-Wno-pass-failed", "-fPIC",
-             "-I" + os.path.join(_REPO, "include")]
-    objdir = os.path.join(_PKG_DIR, "build")
+             "-I" + os.path.join(_REPO, "include")] + list(extra_flags)
+    objdir = objdir or os.path.join(_PKG_DIR, "build")
     os.makedirs(objdir, exist_ok=True)
     headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hpp", ".h"))]
     headers.append(os.path.join(_REPO, "include", "d3feat_hip.h"))
@@ -170,11 +174,11 @@ def build(verbose=False, jobs=None):
 
     with ThreadPoolExecutor(max_workers=jobs or min(8, os.cpu_count() or 1)) as pool:
         objs = list(pool.map(compile_one, SOURCES))
-    cmd = ["hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB_PATH] + objs
+    cmd = ["hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out or LIB_PATH] + objs
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)
-    return LIB_PATH
+    return out or LIB_PATH
 
 
 def _needs_build():

@@ -272,13 +272,18 @@ __device__ __forceinline__ void atb_task_body(const float* __restrict__ A, const
     }
   };
 
+  // D3F_ATB_PROBE (a MEASUREMENT BUILD of this file, profiles/atb_loop_probe.py; never defined in the product): bit 0 =
+  // no LDS-DMA (the MFMA / fragment-read side alone), bit 1 = no MFMAs (the LDS-DMA side alone); results are garbage
+#ifndef D3F_ATB_PROBE
+#define D3F_ATB_PROBE 0
+#endif
 #pragma unroll
   for (int i = 0; i < S; ++i)
-    if (i < n_my) issue(i, i);
+    if (i < n_my && !(D3F_ATB_PROBE & 1)) issue(i, i);
   int slot = 0;
   for (int it = 0; it < n_my; ++it) {
     // groups it .. min(it + S, n_my) - 1 are in flight; group `it` has landed once at most the others are outstanding
-    wait_groups<G, S - 1>(min(S - 1, n_my - 1 - it));
+    if (!(D3F_ATB_PROBE & 1)) wait_groups<G, S - 1>(min(S - 1, n_my - 1 - it));
     const int rg = r0 + (wave + 4 * it) * ROWS;
     const float* sA = (const float*)(ring + slot * SB);
     const float* sB = (const float*)(ring + slot * SB + A_BYTES);
@@ -294,11 +299,12 @@ __device__ __forceinline__ void atb_task_body(const float* __restrict__ A, const
         for (int u = 0; u < TJ; ++u) b[ks][u] = 0.0f;
       }
     }
-    if (it + S < n_my) {
+    if (it + S < n_my && !(D3F_ATB_PROBE & 1)) {
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the slot's fragments are in registers: refill it now,
       issue(it + S, slot);                                 // under this slot's own MFMAs
     }
     __builtin_amdgcn_sched_barrier(0);   // (the scheduler otherwise sinks every read back in front of its own MFMAs)
+    if (!(D3F_ATB_PROBE & 2))
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
@@ -576,7 +582,7 @@ static AtbPlan atb_plan(int R, int M, int N, bool can_direct = false) {
   const double f_slot = 157.3e12 / 512, w_slot = 6.3e12 / 512;
   const double row_s = fmax(2.0 * BM * BN / f_slot, 4.0 * ((double)BM / a.nbj + (double)BN / a.nbi) / w_slot);
   int us = tunables().atb_task_us;
-  if (us < 1) us = 20;
+  if (us < 1) us = 40;      // (profiles/atb_group_bench.py --step: 862 / 845 / 837 us at 20 / 40 / 80 -- fewer slabs)
   double rows = us * 1e-6 / row_s;
   if (rows < 256) rows = 256;
   a.direct = 0;

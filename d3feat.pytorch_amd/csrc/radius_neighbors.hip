@@ -138,7 +138,7 @@ __global__ __launch_bounds__(kQueryWaves * 64) void radius_query_kernel(
     const int32_t* __restrict__ end, const float4* __restrict__ pts, const uint64_t* __restrict__ key, int width,
     int32_t* __restrict__ out_idx, int32_t* __restrict__ out_counts, int32_t* __restrict__ max_count,
     int32_t* __restrict__ status, int32_t* __restrict__ out_wide, int wide_width, uint64_t* __restrict__ out_last_key,
-    int max_count_group, float r2_prefix, float prune_r) {
+    int max_count_group, float r2_prefix, float prune_r, int flag_empty) {
   __shared__ WaveScratch scratch[kQueryWaves];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int qi = blockIdx.x * kQueryWaves + wave;
@@ -251,6 +251,10 @@ __global__ __launch_bounds__(kQueryWaves * 64) void radius_query_kernel(
       if (T > __hip_atomic_load(mc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(mc, T);
     }
     if (T > kCand) atomicOr(status, D3F_ST_CAND_OVERFLOW);
+    // prefix form with a nearest bound: the caller vouched for a support within the bound of every query (the engine:
+    // the voxel diagonal).  A row that found none is a broken promise -- e.g. a coarse level that overflowed its
+    // capacity and dropped the query's voxel --, not an empty neighborhood: say so instead of handing out a shadow row
+    if (flag_empty && T == 0) atomicOr(status, D3F_ST_NO_NEAREST);
     if (out_wide && T > wide_width) atomicOr(status, D3F_ST_WIDE_OVERFLOW);
   }
   const int Tc = T < kCand ? T : kCand;
@@ -446,7 +450,8 @@ static int radius_query_launch(const void* grid_ws, const float* queries, int Nq
   radius_query_kernel<<<d3f::cdiv(Nq, kQueryWaves), kQueryWaves * 64, 0, stream>>>(
       queries, Nq, q_len, s_len, B, Ns, inv_cell, r2, g.M - 1, g.start, g.end, g.pts, g.key, width, out_idx,
       out_counts, max_count, status, out_wide, wide_width, out_last_key, max_count_group,
-      prefix_radius > 0.0f ? prefix_radius * prefix_radius : 0.0f, nearest_bound > 0.0f ? nearest_bound : radius);
+      prefix_radius > 0.0f ? prefix_radius * prefix_radius : 0.0f, nearest_bound > 0.0f ? nearest_bound : radius,
+      (prefix_radius > 0.0f && nearest_bound > 0.0f) ? 1 : 0);
   D3F_LAUNCH_CHECK();
   return D3F_OK;
 }

@@ -410,8 +410,10 @@ def reverse_table_of(neighb_inds, Nq, H, Ns, rev=None):
 # at the 2k-point level the two forms tie (4.096 vs 4.098 ms per step) -- the gather form is taken there too, it has no
 # atomics and is bit-reproducible; below that (581 / 159 points x 256 / 512 channels) the scatter stays ahead (4.25 ms
 # with the gather form at 581 points, 4.57 ms at 159: the chip is filled by splitting channels, which the gather form
-# pays for with repeated aggregation).
-DX_GATHER_MIN_ROWS = int(__import__('os').environ.get('D3F_DX_GATHER_MIN_ROWS', 2000))   # (env: experiments)
+# pays for with repeated aggregation).  Round 6 (3 stacked pairs: 114k / 24k / 6.2k / 1.7k / 0.5k rows; the wide layers
+# now run the transposed aggregation + GEMM form, not the fused gather kernel): 1000 rows puts the 1.7k-row level on
+# it as well -- 581.6 against 578.8 pairs/s at 2000, 575 / 574 at 300 / 100 -- and takes its float atomics away.
+DX_GATHER_MIN_ROWS = int(__import__('os').environ.get('D3F_DX_GATHER_MIN_ROWS', 1000))   # (env: experiments)
 
 
 # width of the search-form transpose of a conv table (the whole in-radius list of a point; S1: mean 41, max 68 at the

@@ -779,14 +779,25 @@ class TrainStep:
 
         def ok(t, dtype):
             return isinstance(t, torch.Tensor) and t.device == self.device and t.dtype == dtype and t.is_contiguous()
+        if len(pairs) != self.stack:
+            return False
         for q, it in enumerate(pairs):
             corr, dk = it[4], it[5]
             if not (ok(corr, torch.int64) and ok(dk, torch.float64)):
+                return False
+            dst_corr, dst_dk, dst_mask = (st.corr, st.dk, st.mask) if self.stack == 1 else (st.corr[q], st.dk[q], st.mask[q])
+            # the one launch copies BYTE COUNTS of the sources to raw destination pointers: every source must have
+            # exactly its destination's extent (the copy_() path raised on a mismatched item; here it would be an
+            # out-of-bounds device write into the graph-fed static buffers)
+            if tuple(corr.shape) != tuple(dst_corr.shape) or tuple(dk.shape) != tuple(dst_dk.shape) \
+                    or dst_mask.numel() != dk.numel():
                 return False
             for p, f in ((it[0], it[2]), (it[1], it[3])):
                 if not ok(p, torch.float32) or (f is not None and not ok(f, torch.float32)):
                     return False
                 n = int(p.shape[0])
+                if p.dim() != 2 or p.shape[1] != 3 or off + n > int(st.pts.shape[0]):
+                    return False
                 jobs.append((p, st.pts[off:off + n]))
                 if f is not None:
                     if f.numel() != n * st.feat.shape[1]:
@@ -794,7 +805,6 @@ class TrainStep:
                     jobs.append((f, st.feat[off:off + n]))
                 off += n
                 lens.append(n)
-            dst_corr, dst_dk, dst_mask = (st.corr, st.dk, st.mask) if self.stack == 1 else (st.corr[q], st.dk[q], st.mask[q])
             jobs += [(corr, dst_corr), (dk, dst_dk), (dk, dst_mask, 'mask')]
         if self.stack == 1:
             st.lens[0] = lens[0]

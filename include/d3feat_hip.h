@@ -37,6 +37,7 @@ extern "C" {
 #define D3F_ST_TABLE_FULL 4     /* voxel hash table full (workspace sized for fewer points) */
 #define D3F_ST_CAPACITY 8       /* an output needed more rows than the caller's capacity */
 #define D3F_ST_WIDE_OVERFLOW 16 /* a point has more in-radius neighbors than the wide (reverse) table holds */
+#define D3F_ST_NO_NEAREST 32    /* d3f_radius_query_prefix with a nearest bound: a query has no support within the bound */
 
 const char* d3f_version(void);
 int d3f_device_arch_ok(void); /* 1 if the current HIP device is gfx950, 0 otherwise, <0 = -(hipError_t) */
@@ -62,7 +63,7 @@ int d3f_debug_kernel_timing_end(float* ms_out, int32_t* shapes_out, int cap);
  * (process-wide; set them before the launches they concern, not concurrently with them).  The experiment scripts under
  * profiles/ and the tests are the only callers; 0 = "the built-in choice" for every field. */
 typedef struct d3f_tunables {
-  int32_t atb_task_us;        /* grouped A^T B: modelled duration of one workgroup's task in us (0 = 20) */
+  int32_t atb_task_us;        /* grouped A^T B: modelled duration of one workgroup's task in us (0 = 40) */
   int32_t atb_form;           /* one-problem weight gradients: 0 = by size, 1 = always the first (direct-load) form,
                                * 2 = always the grouped (LDS-DMA ring) kernels */
   int32_t atb_first_form_wgs; /* first form: workgroups along the reduction (0 = by shape) */

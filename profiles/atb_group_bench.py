@@ -23,10 +23,52 @@ PEAK = 157.3e12
 
 L = _native.lib()
 dev = torch.device("cuda:0")
+
+
+def shapes_of_a_step(Q=3):
+    """(R, M, N) of every problem a 3-pair stack's training step queues (ops.WeightGradGroup), in queue order -- the 28
+    many-row problems above plus the few-row weight gradients of the bottom levels that join the group."""
+    import numpy as np
+    from d3feat_pytorch_amd import config as cfgmod, ops, synthetic
+    from d3feat_pytorch_amd.datasets import dataloader as dl
+    from d3feat_pytorch_amd.train import TrainStep
+    cfg = cfgmod.default_config()
+
+    def sub(p, l, d):
+        a, b = dl.batch_grid_subsampling_kpconv(torch.as_tensor(p).to(dev), torch.as_tensor(l).to(dev), sampleDl=d)
+        return a.cpu().numpy(), b.cpu().numpy()
+    stack = tuple(tuple(torch.from_numpy(np.ascontiguousarray(a)).to(dev) for a in synthetic.make_pair(2 * q + 1, 2 * q + 2, sub))
+                  for q in range(Q))
+    ts = TrainStep(cfg, [42] * 5, dev, seed=0)
+    sizes = [[sum(int(ts.build_batch(it)['points'][l].shape[0]) for it in stack) for l in range(5)]]
+    ts.enable_graph(TrainStep.capacities_for(sizes, slack=1.0), num_corr=int(stack[0][4].shape[0]), stack=Q)
+    seen = []
+    flush = ops.WeightGradGroup.flush
+
+    def spy(self):
+        seen.append([(t[3], t[5], t[4]) for t in self.problems])    # (N, Cout, Cin) = (R, M, N)
+        return flush(self)
+    ops.WeightGradGroup.flush = spy
+    try:
+        ts._static_step(stack)
+        torch.cuda.synchronize()
+    finally:
+        ops.WeightGradGroup.flush = flush
+    return seen[-1]
+
+
 probs = []
 g = torch.Generator(device=dev).manual_seed(1)
-for shp in SHAPES:
-    for _ in range(COUNT.get(shp, 1)):
+ALL = []
+if "--step" in sys.argv:
+    sys.argv.remove("--step")
+    ALL = shapes_of_a_step()
+    print("shapes of a 3-pair stack's step:", ALL)
+else:
+    for shp in SHAPES:
+        ALL += [shp] * COUNT.get(shp, 1)
+for shp in ALL:
+    for _ in range(1):
         R, M, N = shp
         A = torch.randn(R, M, device=dev, generator=g)      # grad_out [R, Cout = M]
         B = torch.randn(R, N, device=dev, generator=g)      # x [R, Cin = N]

@@ -30,7 +30,8 @@ for line in open(src):
 KERNELS = {'kpconv_fwd_fused_kernel': 'kpconv_fwd_fused', 'kpconv_dx_gather_kernel': 'kpconv_dx_gather',
            'kpconv_bwd_dx_kernel': 'kpconv_bwd_dx', 'atb_partial_kernel': 'atb_partial',
            'kpconv_agg_fwd_kernel': 'kpconv_agg_fwd', 'kpconv_agg_rev_kernel': 'kpconv_agg_rev',
-           'rowgemm_kernel': 'rowgemm'}
+           'rowgemm_kernel': 'rowgemm', 'atb_grouped_kernel': 'atb_grouped_kernel',
+           'atb_grouped_reduce_kernel': 'atb_grouped_reduce'}
 rows, by_kernel = [], {}
 for name, v in data.items():
     if not v or 'GRBM_GUI_ACTIVE' not in v:

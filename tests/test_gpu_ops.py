@@ -205,6 +205,16 @@ def test_radius_query_prefix_rows_are_the_leading_part_of_the_full_rows(native, 
             assert np.array_equal(gotb[i], got[i]), i
             checked += 1
     assert checked > q.shape[0] // 2
+    # ... and a query WITHOUT a support inside the bound breaks the caller's promise: flagged (D3F_ST_NO_NEAREST), never
+    # a silent all-shadow row (the 40 far-away queries above)
+    with pytest.raises(RuntimeError, match="nearest bound"):
+        grid.status.raise_if_set()
+    grid.status.word.zero_()
+    near = np.nonzero([full[i][0] < ns and np.sum((q[i] - s[full[i][0]]) ** 2) < 0.9 * b2 for i in range(q.shape[0])])[0]
+    near = near[near < int(ql[0])][:64]       # (queries of the first cloud: they see the first cloud's supports)
+    ok_rows = grid.query_prefix(cu(q[near]), cu(np.array([near.size, 0], np.int32)), width, prefix, nearest_bound=bound)
+    grid.status.raise_if_set()                # every query has its nearest support within the bound: no flag
+    assert ok_rows.shape[0] == near.size and near.size > 8
 
 
 # ------------------------------------------------------------------------------------------------ KPConv
