@@ -277,6 +277,8 @@ __device__ __forceinline__ void atb_task_body(const float* __restrict__ A, const
 #ifndef D3F_ATB_PROBE
 #define D3F_ATB_PROBE 0
 #endif
+  // (tried, round 6: unequal static wave priorities -- s_setprio by a hash of the task index -- so that the two waves a
+  // SIMD holds do not sit in their load segments at the same time: 2-3 % SLOWER on every tile shape; not kept)
 #pragma unroll
   for (int i = 0; i < S; ++i)
     if (i < n_my && !(D3F_ATB_PROBE & 1)) issue(i, i);
