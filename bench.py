@@ -294,6 +294,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-tuned-gemm", action="store_true", help="library-default GEMM kernels instead of the shipped "
                                                                  "TunableOp table (d3feat.pytorch_amd/tuned/)")
+    ap.add_argument("--no-tune-missing", action="store_true",
+                    help="library-GEMM shapes the shipped table lacks run on the library's default pick instead of being "
+                         "tuned while the graphs are captured (kernel traces without thousands of tuning candidates)")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
     ap.add_argument("--lanes", type=int, default=4,
                     help="network graphs in flight per GPU (train.PairLanes): each on streams and graphs of its own, one "
@@ -382,8 +385,13 @@ def main():
     _native.lib()  # fail loudly if the HIP library is missing
     import d3feat_pytorch_amd as d3f
     tuned = False
+    if args.no_tune_missing:
+        d3f.TUNE_MISSING_GEMMS = False
     if not args.no_tuned_gemm and not os.environ.get("PYTORCH_TUNABLEOP_ENABLED"):
         tuned = d3f.enable_tuned_gemms()
+        if not tuned:     # loud: the 4 x 3 step is safe without the table (one BLAS handle per lane), only ~4 % slower
+            print("WARNING: tuned/tunableop_gfx950.csv was not accepted by this PyTorch / ROCm stack (validators differ): "
+                  "library-default GEMM picks", file=sys.stderr)
 
     cfg = cfgmod.default_config()
 

@@ -20,14 +20,6 @@ import os as _os
 # the user exported wins.
 _HWQ_SET_HERE = "GPU_MAX_HW_QUEUES" not in _os.environ
 _os.environ.setdefault("GPU_MAX_HW_QUEUES", "32")
-# Library-GEMM selection (enable_tuned_gemms / tuning_missing_gemms below) considers rocBLAS solutions only.  Round 4,
-# measured: with hipBLASLt candidates in the race, shapes tuned during a capture (stacked pairs: 4160- and 8256-row
-# operands) sometimes got a hipBLASLt winner whose kernel never finished on the SECOND replay of the captured graph --
-# the training stream stalled for good (profiles/r04_notes.txt: `4 lanes x 2 stacked` hung in 2 of 3 processes, never
-# with PYTORCH_TUNABLEOP_HIPBLASLT_ENABLED=0 or without tuning; the same family of finding as the memset nodes of
-# DESIGN.md section 5 that are not re-executed on replay).  368 of the 375 rows of the shipped table were rocBLAS
-# winners anyway.  Read by PyTorch when TunableOp first runs; a value the user exported wins.
-_os.environ.setdefault("PYTORCH_TUNABLEOP_HIPBLASLT_ENABLED", "0")
 # set when the variable had to be set HERE and the HIP runtime was already up (it is then ignored: train.PairLanes warns)
 import sys as _sys
 HIP_WAS_INITIALISED_AT_IMPORT = bool(_HWQ_SET_HERE and 'torch' in _sys.modules
@@ -71,9 +63,13 @@ def enable_tuned_gemms(path=None, tune_missing=False):
     import os
     import torch
     tunable = torch.cuda.tunable
-    if path is None:     # (D3F_TUNABLEOP_TABLE: another table, e.g. one produced by profiles/tune_under_load_experiment.py)
-        path = os.environ.get("D3F_TUNABLEOP_TABLE") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "tuned",
-                                                                     "tunableop_gfx950.csv")
+    if path is None:
+        path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tuned", "tunableop_gfx950.csv")
+    # rocBLAS candidates only (368 of the 375 shipped rows are rocBLAS winners).  Rounds 4-5 kept hipBLASLt out of the race
+    # because its winners stalled under concurrent replay; that stall was the shared BLAS handle (round 6,
+    # profiles/r06_stall_root_cause.txt), but the shipped table was tuned without them.  Read by PyTorch when TunableOp
+    # first runs; a value the user exported wins.  Set HERE, by the opt-in, not at import.
+    os.environ.setdefault("PYTORCH_TUNABLEOP_HIPBLASLT_ENABLED", "0")
     if not os.path.exists(path):
         return False
     tunable.enable(True)
@@ -90,6 +86,8 @@ def enable_tuned_gemms(path=None, tune_missing=False):
 
 import contextlib as _contextlib
 
+TUNE_MISSING_GEMMS = True
+
 
 @_contextlib.contextmanager
 def tuning_missing_gemms(max_ms=10, max_iterations=20):
@@ -101,8 +99,8 @@ def tuning_missing_gemms(max_ms=10, max_iterations=20):
     (profiles/tune_on_capture_experiment.py).  No effect (yields False) unless ``enable_tuned_gemms`` is on."""
     import torch
     tunable = torch.cuda.tunable
-    if not (torch.cuda.is_available() and tunable.is_enabled()) or _os.environ.get("D3F_NO_TUNE_MISSING") == "1":
-        yield False      # (the variable: kernel traces of bench.py without thousands of tuning candidates in them)
+    if not (torch.cuda.is_available() and tunable.is_enabled()) or not TUNE_MISSING_GEMMS:
+        yield False      # (TUNE_MISSING_GEMMS = False: kernel traces of bench.py without thousands of tuning candidates)
         return
     prev = (tunable.tuning_is_enabled(), tunable.get_max_tuning_duration(), tunable.get_max_tuning_iterations())
     tunable.set_max_tuning_duration(int(max_ms))

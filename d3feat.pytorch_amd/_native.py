@@ -218,11 +218,11 @@ def lib():
     return _lib
 
 
-_TRACE = bool(os.environ.get("D3F_TRACE"))
+TRACE = False     # debugging: name every C-ABI call on stderr and fence it (set _native.TRACE = True)
 
 
 def check(rc, what):
-    if _TRACE:  # debugging aid: name every C-ABI call and fence it, so a device fault can be attributed
+    if TRACE:  # debugging aid: name every C-ABI call and fence it, so a device fault can be attributed
         import sys
         import torch
         sys.stderr.write("[d3f] %s\n" % what)

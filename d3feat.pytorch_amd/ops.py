@@ -413,7 +413,7 @@ def reverse_table_of(neighb_inds, Nq, H, Ns, rev=None):
 # pays for with repeated aggregation).  Round 6 (3 stacked pairs: 114k / 24k / 6.2k / 1.7k / 0.5k rows; the wide layers
 # now run the transposed aggregation + GEMM form, not the fused gather kernel): 1000 rows puts the 1.7k-row level on
 # it as well -- 581.6 against 578.8 pairs/s at 2000, 575 / 574 at 300 / 100 -- and takes its float atomics away.
-DX_GATHER_MIN_ROWS = int(__import__('os').environ.get('D3F_DX_GATHER_MIN_ROWS', 1000))   # (env: experiments)
+DX_GATHER_MIN_ROWS = 1000
 
 
 # width of the search-form transpose of a conv table (the whole in-radius list of a point; S1: mean 41, max 68 at the
@@ -455,13 +455,13 @@ _GEMM_DX_MAX_ROWS = 4096
 # (0.15 - 0.2 of the f32 matrix rate, profiles/r04_step_timeline_stack4.txt); as aggregation kernel (registers -> HBM,
 # csrc/kpconv_aggregate.hip) + tall GEMMs every contraction gets 128-row tiles.  Same split for the grad-input over
 # the exact-form reverse table (transposed aggregation + GEMM with the permuted weights).
-_GEMM_PATH_MIN_CIN = int(__import__('os').environ.get('D3F_GEMM_PATH_MIN_CIN', 64))           # (env: experiments)
-_GEMM_DX_AGG_MIN_COUT = int(__import__('os').environ.get('D3F_GEMM_DX_AGG_MIN_COUT', 64))     # (env: experiments)
+_GEMM_PATH_MIN_CIN = 64
+_GEMM_DX_AGG_MIN_COUT = 64
 
 
 _DW_LIBRARY_MIN_OUT = 1920 * 128
 _DW_LIBRARY_MAX_ROWS = 16384
-_DW_LIBRARY = __import__('os').environ.get('D3F_DW_LIBRARY', '1') != '0'
+_DW_LIBRARY = True
 
 
 def _takes_gemm_path(Nq, Cin):
@@ -1067,8 +1067,8 @@ class _LinearBiasActFn(torch.autograd.Function):
 
 # The bias gradient's second pass rides in the weight gradient's second-stage launch (csrc/linear.hip,
 # atb_reduce_bias_kernel) whenever both are two-pass forms: N >= 4096 rows for the epilogue's backward and the A^T B
-# kernel for grad_W.  D3F_FOLD_BIAS_SUM=0: two launches as before (experiments).
-_FOLD_BIAS_SUM = __import__('os').environ.get('D3F_FOLD_BIAS_SUM', '1') != '0'
+# kernel for grad_W.  False: two launches as before (experiments).
+_FOLD_BIAS_SUM = True
 
 
 def _epilogue_backward(go, out, slope, N, C, gm, first, second, pre, row_div, fold):
@@ -1399,7 +1399,7 @@ def upsample_linear_bias_act(x_coarse, inds, skip, weight, bias1=None, bias2=Non
 # rows from which the unary blocks use the fused row-streaming kernels instead of library GEMM + epilogue launch
 _FUSED_LINEAR_MIN_ROWS = 4096
 # library GEMM + epilogue as ONE autograd node (_LinearLibBiasActFn); D3F_MERGED_UNARY=0: the two nodes of rounds 1-4
-_MERGED_UNARY = __import__('os').environ.get('D3F_MERGED_UNARY', '1') != '0'
+_MERGED_UNARY = True
 
 
 def linear_bias_act(x, weight, bias1=None, add=None, bias2=None, slope=0.1, grad_holder=None, grad_deposit=None,

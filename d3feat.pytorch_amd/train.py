@@ -242,6 +242,9 @@ class GuardedSGD:
         return ok
 
 
+KEEP_GRAPH_TEMPLATES = True
+
+
 def new_graph():
     """A torch.cuda.CUDAGraph whose hipGraph_t template is KEPT next to the instantiated executable graph.
 
@@ -252,8 +255,9 @@ def new_graph():
     in this package captures a memset (every clear is a kernel, csrc/common.hpp), but a library call inside a captured
     step may.  (This does NOT cure the library-GEMM solutions that never finish on a later replay -- hipBLASLt winners,
     the default pick of one 4 x 3 stacked shape: they hang with the templates kept as well, profiles/r05_hipblaslt_hang.txt;
-    the engine captures TunableOp-selected rocBLAS solutions.)  D3F_DROP_GRAPH_TEMPLATES=1: the default form."""
-    if os.environ.get("D3F_DROP_GRAPH_TEMPLATES") == "1":
+    the engine captures TunableOp-selected rocBLAS solutions.  Round 6 found that cause: one BLAS handle behind all lanes'
+    graphs, profiles/r06_stall_root_cause.txt.)  KEEP_GRAPH_TEMPLATES = False: PyTorch's default form (experiments)."""
+    if not KEEP_GRAPH_TEMPLATES:
         return torch.cuda.CUDAGraph()
     try:
         return torch.cuda.CUDAGraph(keep_graph=True)
@@ -264,7 +268,7 @@ def new_graph():
 def finish_graph(g):
     """After the capture: a kept-template graph is instantiated explicitly (the default form does it in capture_end)."""
     inst = getattr(g, 'instantiate', None)
-    if inst is not None and os.environ.get("D3F_DROP_GRAPH_TEMPLATES") != "1":
+    if inst is not None and KEEP_GRAPH_TEMPLATES:
         try:
             inst()
         except RuntimeError:       # (already instantiated: the default form)
@@ -372,7 +376,7 @@ class TrainStep:
         # 0..CUT-1, 38k/8k points) still have ~1/3 of the backward's run time ahead of them.  With split_backward the
         # network is cut at the input of encoder block CUT: the "deep" bucket (blocks CUT.. + decoder) is all-reduced
         # over xGMI while the backward of the fine levels runs.
-        self.split_backward = world_size > 1 or os.environ.get("D3F_SPLIT_BACKWARD") == "1"  # env: measure it on 1 GPU
+        self.split_backward = world_size > 1 or self.SPLIT_BACKWARD_ON_ONE_RANK
         self.CUT = 5
         shallow = [p for b in list(self.model.encoder_blocks)[:self.CUT] for p in b.parameters() if p.requires_grad]
         self.n_shallow = len(shallow)
@@ -408,8 +412,12 @@ class TrainStep:
     # training builds the transposes of the KPConv tables with the pyramid (gather-form grad-input); inference does not
     reverse_tables = True
     # the captured / static-shape pyramids carry their upsampling tables in the prefix form (column 0 + the part within
-    # the pooling radius: all the step reads; datasets.dataloader._pool_tables).  D3F_FULL_UPSAMPLES=1: the full 2 r rows
-    engine_upsamples = os.environ.get("D3F_FULL_UPSAMPLES") != "1"
+    # the pooling radius: all the step reads; datasets.dataloader._pool_tables).  False: the full 2 r rows (A/B experiments)
+    engine_upsamples = True
+    # the two-stage backward of the multi-rank step on ONE rank (what its cut costs without an exchange: measurements)
+    SPLIT_BACKWARD_ON_ONE_RANK = False
+    # one launch for a step's input loads (ops.copy_buffers); False: one copy_() per tensor (A/B experiments)
+    FUSED_INPUT_LOAD = True
 
     def build_batch(self, item):
         batch = dl.collate_fn_descriptor([item], self.config, self.limits, device=self.device, exact_width=False,
@@ -772,7 +780,7 @@ class TrainStep:
         loss's neighbor mask) when every tensor of the item already sits on the device in the buffers' dtypes and is
         contiguous -- what ``upload`` returns; ~25 copy launches per stacked step before, on the stream that also replays
         the lane's graphs.  Returns False (nothing done) otherwise."""
-        if self.device.type != 'cuda' or os.environ.get("D3F_SEPARATE_INPUT_COPIES") == "1":
+        if self.device.type != 'cuda' or not self.FUSED_INPUT_LOAD:
             return False
         pairs = self.pairs_of(item)
         jobs, off, lens = [], 0, []
@@ -944,10 +952,6 @@ class TrainStep:
         # on top of each other (round 5: the root of round 4's "hipBLASLt winner never finishes on a later replay",
         # profiles/r05_hipblaslt_hang.txt; with rocBLAS split-K solutions the same sharing is a silent race).
         cap = getattr(self, 'stream', None) if getattr(self, 'lane', None) is not None else None
-        if os.environ.get('D3F_CLEAR_BLAS_WS') == '1':
-            torch._C._cuda_clearCublasWorkspaces()
-        if os.environ.get('D3F_SHARED_CAPTURE_STREAM') == '1':     # (experiments: rounds 1-4's behaviour)
-            cap = None
         for i in range(self.NSETS):
             g = new_graph()
             with torch.cuda.graph(g, stream=cap, capture_error_mode=_CAPTURE_MODE):
@@ -1271,6 +1275,7 @@ class PairLanes:
     caps = property(lambda self: self.engines[0].caps)
     pairs_per_step = property(lambda self: self.P * self.Q)
     CAPTURE_IN_THREADS = True     # (False: every lane captured from the calling thread, rounds 3-5 -- A/B experiments)
+    JOIN_ON_HOST = False          # (True: the host waits for the lanes' events instead of the join stream: measurements)
     PROBE_DEADLINE_S = 20.0       # probe_overlap: longest a concurrent replay of the lanes' graphs may take
 
     def _exchange_stream(self):
@@ -1436,7 +1441,7 @@ class PairLanes:
             nxt = items if next_items is None else self.deal(next_items)
         self.ts.opt.use_grad_scale(1.0 / (self.P * self.Q * max(1, self.ts.world)))
         outs = []
-        host_join = os.environ.get("D3F_LANES_JOIN", "stream") == "host"     # measurement knob
+        host_join = self.JOIN_ON_HOST
         split = self.split              # several ranks: two-stage lanes, the deep bucket exchanged under stage 2
         for k, eng in enumerate(self.engines):
             eng._ensure_loaded(items[k])

@@ -36,3 +36,41 @@ def test_no_gpu_calls_needed_for_size_queries():
     assert lib.d3f_grid_subsample_ws_bytes(1000, 2) > 0
     assert lib.d3f_kpconv_ws_bytes(100, 100, 40, 15, 32, 32) >= 2 * 100 * 15 * 32 * 4
     assert lib.d3f_circle_det_loss_stats_floats(128) == 6 * 128
+
+
+def test_tunables_struct_round_trips_and_rejects_nonsense():
+    """d3f_get_tunables / d3f_set_tunables: the library's only knobs (it reads no environment); defaults are all zero."""
+    lib = _native.lib()
+    t = _native.Tunables()
+    lib.d3f_get_tunables(ctypes.byref(t))
+    assert [getattr(t, n) for n, _ in _native.Tunables._fields_ if n != "reserved"] == [0, 0, 0, 0, 0]
+    assert ctypes.sizeof(t) == 64
+    old = _native.set_tunables(atb_task_us=33, atb_form=2)
+    lib.d3f_get_tunables(ctypes.byref(t))
+    assert (t.atb_task_us, t.atb_form) == (33, 2)
+    _native.set_tunables(**old)
+    bad = _native.Tunables()
+    bad.atb_form = 7
+    assert lib.d3f_set_tunables(ctypes.byref(bad)) == -1
+    assert lib.d3f_set_tunables(None) == -1
+    lib.d3f_get_tunables(ctypes.byref(t))
+    assert (t.atb_task_us, t.atb_form) == (0, 0)
+
+
+def test_grouped_weight_gradient_plan_is_a_host_computation():
+    """d3f_linear_grad_weight_group_ws_bytes needs no GPU: slab bytes of a queue; few rows against a large aligned target
+    take no slab at all (undivided reduction written straight to the target); unsupported widths give 0."""
+    lib = _native.lib()
+    arr = (_native.AtbProblem * 2)()
+    for q, (n, cin, cout) in zip(arr, ((114688, 32, 128), (512, 512, 7680))):
+        q.x, q.grad_out, q.grad_w = 0x10000, 0x20000, 0x30000       # (addresses are only checked for alignment here)
+        q.N, q.Cin, q.Cout, q.ldw = n, cin, cout, cin
+    both = lib.d3f_linear_grad_weight_group_ws_bytes(arr, 2)
+    first = lib.d3f_linear_grad_weight_group_ws_bytes(arr, 1)
+    assert first > 256 and (first - 256) % (128 * 32 * 4) == 0     # whole slabs of the 128 x 32 gradient
+    assert both == first                                            # the direct problem adds nothing
+    arr[1].grad_w = 0x30004                                         # not 16-byte aligned: partitions + slabs after all
+    assert lib.d3f_linear_grad_weight_group_ws_bytes(arr, 2) >= first + 8 * 7680 * 512 * 4
+    arr[1].Cin = 24
+    assert lib.d3f_linear_grad_weight_group_ws_bytes(arr, 2) == 0
+    assert lib.d3f_linear_grad_weight_group_ws_bytes(None, 2) == 0
