@@ -317,9 +317,10 @@ def main():
     args = ap.parse_args()
     # D3F_BENCH_WATCHDOG=<seconds>: dump every thread's Python stack and exit if the run is still going by then (a hung
     # capture / tuning pass on a rented GPU box costs the whole call's budget otherwise); D3F_BENCH_LOG=1: stage stamps
-    if os.environ.get("D3F_BENCH_WATCHDOG"):
-        import faulthandler
-        faulthandler.dump_traceback_later(float(os.environ["D3F_BENCH_WATCHDOG"]), exit=True)
+    # Default 30 minutes (a full default run takes ~2): a blind multi-GPU submission that stalls -- e.g. lane replays beside
+    # RCCL kernels, which no one-GPU box could try -- ends with stacks on stderr instead of holding the driver's lease.
+    import faulthandler
+    faulthandler.dump_traceback_later(float(os.environ.get("D3F_BENCH_WATCHDOG", "1800")), exit=True)
     t_begin = time.time()
 
     def stage(msg):
