@@ -20,7 +20,7 @@ _vp, _i, _f, _sz = C.c_void_p, C.c_int, C.c_float, C.c_size_t
 class Tunables(C.Structure):
     """d3f_tunables of include/d3feat_hip.h: the library's knobs (it never reads the environment)."""
     _fields_ = [("atb_task_us", C.c_int32), ("atb_form", C.c_int32), ("atb_first_form_wgs", C.c_int32),
-                ("match_wgs", C.c_int32), ("agg_through_lds", C.c_int32), ("reserved", C.c_int32 * 11)]
+                ("match_wgs", C.c_int32), ("agg_through_lds", C.c_int32), ("atb_pipe", C.c_int32), ("reserved", C.c_int32 * 10)]
 
 
 class AtbProblem(C.Structure):

@@ -209,7 +209,8 @@ struct AtbTask {       // one problem of a grouped launch, first stage
   int rpw, P;          // rows per partition (a multiple of 64), live partitions
   int tile;            // 16 TI + TJ
   int ldp;             // row stride of `part` (N for slabs, the caller's ldc when direct)
-  int direct;          // 1: task t = output block t (no partitions, no slab, no second stage)
+  int direct;          // bit 0: task t = output block t (no partitions, no slab, no second stage); bit 1: the
+                       // software-pipelined body (wide tiles, operands below 4 GiB)
 };
 struct AtbGroup {
   int n, pad;
@@ -218,6 +219,45 @@ struct AtbGroup {
 };
 
 extern __shared__ __attribute__((aligned(1024))) unsigned char atb_smem[];
+
+// the 4 waves of a workgroup hold partial sums of the same output block: combined in a fixed order (wave 0 + 1 + 2 + 3)
+// through LDS -- the rings are free by then -- and stored by wave 0
+template <int TI, int TJ>
+__device__ __forceinline__ void atb_combine_store(f32x4 (&acc)[TI][TJ], float* __restrict__ pp, int ldp, int m0, int n0) {
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int li = lane & 15, lk = lane >> 4;
+  constexpr int NT = TI * TJ;
+  float* red = (float*)atb_smem;                          // [3][NT * 256]
+  __syncthreads();                                        // every wave is out of its ring
+  if (wave > 0) {
+#pragma unroll
+    for (int i = 0; i < TI; ++i)
+#pragma unroll
+      for (int u = 0; u < TJ; ++u)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) red[(wave - 1) * (NT * 256) + ((i * TJ + u) * 4 + r) * 64 + lane] = acc[i][u][r];
+  }
+  __syncthreads();
+  if (wave == 0) {
+    // D[i][j] (i = 4 lk + r, j = li) of tile (ti, u) is C[m0 + TI i + ti][n0 + TJ j + u]: a lane stores its TJ columns of
+    // one row as one 16 / 8 / 4-byte vector
+#pragma unroll
+    for (int i = 0; i < TI; ++i)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float v[TJ];
+#pragma unroll
+        for (int u = 0; u < TJ; ++u) {
+          const int e = ((i * TJ + u) * 4 + r) * 64 + lane;
+          v[u] = ((acc[i][u][r] + red[e]) + red[NT * 256 + e]) + red[2 * NT * 256 + e];
+        }
+        float* dst = pp + (size_t)(m0 + TI * (4 * lk + r) + i) * ldp + n0 + TJ * li;
+        if constexpr (TJ == 4) *(float4*)dst = make_float4(v[0], v[TJ > 1 ? 1 : 0], v[TJ > 2 ? 2 : 0], v[TJ > 3 ? 3 : 0]);
+        else if constexpr (TJ == 2) *(float2*)dst = make_float2(v[0], v[TJ > 1 ? 1 : 0]);
+        else dst[0] = v[0];
+      }
+  }
+}
 
 // task t of a problem: partition p = (t % 8) + 8 (t / 8 / nblk), output block (t / 8) % nblk
 template <int TI, int TJ>
@@ -317,39 +357,154 @@ __device__ __forceinline__ void atb_task_body(const float* __restrict__ A, const
     slot = (slot + 1 == S) ? 0 : slot + 1;
   }
 
-  // combine the 4 waves in a fixed order (wave 0 + 1 + 2 + 3) through LDS -- the rings are free now
-  constexpr int NT = TI * TJ;
-  float* red = (float*)atb_smem;                          // [3][NT * 256]
-  float* pp = part + (size_t)p * M * N;                   // (direct: p = 0)
-  __syncthreads();                                        // every wave is out of its ring
-  if (wave > 0) {
+  atb_combine_store<TI, TJ>(acc, part + (size_t)p * M * N, ldp, m0, n0);   // (direct: p = 0)
+}
+
+// ---- software-pipelined task body (round 6, the wide tiles: 64 x 64, 64 x 32, 32 x 64) ------------------------------------
+// The plain body above runs [wait DMA] [8 fragment reads] [wait] [G DMA issues + their address arithmetic] [MFMAs] one
+// after the other: a wave's MFMA stream pauses for ~0.3 of a slot's time, and the probe builds put the loop at 0.66 of the
+// matrix rate with the DMA side and 0.83 without (profiles/r06_atb_loop_probe.txt).  Here a slot's MFMAs run on fragments
+// read DURING the previous slot's MFMAs (two register sets), and both the refill of the slot just freed and the
+// fragment reads of the next slot are dealt into the MFMA stream a piece every few MFMAs:
+//   block k:  s_waitcnt vmcnt(0)                          (slot k + 1, issued during block k - 1, has landed)
+//             MFMA x STEP, DMA piece 0 of group k + 2 -> slot k % 2 (its fragments went to registers in block k - 1) ...
+//             MFMA x STEP, fragment read 0 of slot (k + 1) % 2 -> the other register set ...
+// LDS-DMA goes through BUFFER loads (buffer_load_dwordx4 ... offen lds): the per-lane offset of a piece is one VGPR that
+// advances by a uniform stride per group -- no 64-bit address arithmetic in the loop --, and rows past the operand's end
+// (the ragged last partition) come back as ZEROS by the resource's range check: no clamp, no masking of fragments.
+// (The range check covers the VGPR offset only, so the whole offset lives there; operands must stay below 4 GiB.)
+__device__ __forceinline__ void lds_dma16_buf(__amdgpu_buffer_rsrc_t rsrc, unsigned voff, unsigned lds_addr) {
+  unsigned keep;
+  asm volatile(
+      "s_mov_b32 %0, m0\n\t"
+      "s_mov_b32 m0, %3\n\t"
+      "s_nop 0\n\t"
+      "buffer_load_dwordx4 %1, %2, 0 offen lds\n\t"
+      "s_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "v"(voff), "s"(rsrc), "s"(lds_addr)
+      : "memory");
+}
+
+template <int TI, int TJ>
+__device__ __forceinline__ void atb_task_body_pipe(const float* __restrict__ A, const float* __restrict__ B,
+                                                   float* __restrict__ part, int R, int M, int N, int rpw, int P, int t,
+                                                   int ldp, int direct) {
+  constexpr int KS = 4, ROWS = 4 * KS, BM = 16 * TI, BN = 16 * TJ;
+  constexpr int A_BYTES = ROWS * BM * 4, B_BYTES = ROWS * BN * 4, SB = A_BYTES + B_BYTES;
+  constexpr int NA = A_BYTES / 1024, NB = B_BYTES / 1024, G = NA + NB;   // (= TI, TJ, TI + TJ)
+  constexpr int NM = KS * TI * TJ, EXTRAS = G + 2 * KS;     // MFMAs of a slot; DMA pieces + fragment reads dealt into them
+  static_assert(2 * SB <= ATB_RING_BYTES, "two slots per wave");
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int li = lane & 15, lk = lane >> 4;
+  const int nbj = N / BN, nblk = (M / BM) * nbj;
+  const int p = direct ? 0 : (t & 7) + 8 * ((t >> 3) / nblk), blk = direct ? t : (t >> 3) % nblk;
+  if (p >= P || blk >= nblk) return;
+  const int m0 = (blk / nbj) * BM, n0 = (blk % nbj) * BN;
+  const int r0 = p * rpw, r1 = min(R, r0 + rpw);
+  const int ngroups = (r1 - r0 + ROWS - 1) / ROWS;
+  const int n_my = (ngroups - wave + 3) >> 2;           // the 4 waves interleave groups of ROWS rows
+  unsigned char* ring = atb_smem + wave * ATB_RING_BYTES;
+  const unsigned ring_addr = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)ring);
+  const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(A), 0, (unsigned)((size_t)R * M * 4), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(B), 0, (unsigned)((size_t)R * N * 4), 0x00020000);
+  // byte offset of every piece of the wave's NEXT group to load (lane's 16-byte element), advanced by 64 rows per group
+  unsigned voA[NA], voB[NB];
 #pragma unroll
-    for (int i = 0; i < TI; ++i)
-#pragma unroll
-      for (int u = 0; u < TJ; ++u)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) red[(wave - 1) * (NT * 256) + ((i * TJ + u) * 4 + r) * 64 + lane] = acc[i][u][r];
+  for (int j = 0; j < NA; ++j) {
+    const int e = j * 64 + lane, row = e / (4 * TI), col = (e % (4 * TI)) * 4;
+    voA[j] = (unsigned)(((size_t)(r0 + wave * ROWS + row) * M + m0 + col) * 4);
   }
-  __syncthreads();
-  if (wave == 0) {
-    // D[i][j] (i = 4 lk + r, j = li) of tile (ti, u) is C[m0 + TI i + ti][n0 + TJ j + u]: a lane stores its TJ columns of
-    // one row as one 16 / 8 / 4-byte vector
 #pragma unroll
-    for (int i = 0; i < TI; ++i)
+  for (int j = 0; j < NB; ++j) {
+    const int e = j * 64 + lane, row = e / (4 * TJ), col = (e % (4 * TJ)) * 4;
+    voB[j] = (unsigned)(((size_t)(r0 + wave * ROWS + row) * N + n0 + col) * 4);
+  }
+  const unsigned strideA = 4u * ROWS * (unsigned)M * 4u, strideB = 4u * ROWS * (unsigned)N * 4u;
+
+  f32x4 acc[TI][TJ];
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        float v[TJ];
+  for (int i = 0; i < TI; ++i)
 #pragma unroll
-        for (int u = 0; u < TJ; ++u) {
-          const int e = ((i * TJ + u) * 4 + r) * 64 + lane;
-          v[u] = ((acc[i][u][r] + red[e]) + red[NT * 256 + e]) + red[2 * NT * 256 + e];
-        }
-        float* dst = pp + (size_t)(m0 + TI * (4 * lk + r) + i) * ldp + n0 + TJ * li;
-        if constexpr (TJ == 4) *(float4*)dst = make_float4(v[0], v[TJ > 1 ? 1 : 0], v[TJ > 2 ? 2 : 0], v[TJ > 3 ? 3 : 0]);
-        else if constexpr (TJ == 2) *(float2*)dst = make_float2(v[0], v[TJ > 1 ? 1 : 0]);
-        else dst[0] = v[0];
+    for (int u = 0; u < TJ; ++u) acc[i][u] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  // piece x (0 .. G - 1: the A pieces, then the B pieces) of the next group to load, into `slot`
+  auto dma_piece = [&](int x, int slot) {
+    const unsigned sa = ring_addr + (unsigned)slot * SB;
+#pragma unroll
+    for (int j = 0; j < NA; ++j)
+      if (x == j) {
+        lds_dma16_buf(rsA, voA[j], __builtin_amdgcn_readfirstlane(sa + j * 1024));
+        voA[j] += strideA;
       }
+#pragma unroll
+    for (int j = 0; j < NB; ++j)
+      if (x == NA + j) {
+        lds_dma16_buf(rsB, voB[j], __builtin_amdgcn_readfirstlane(sa + A_BYTES + j * 1024));
+        voB[j] += strideB;
+      }
+  };
+  // fragment read y (0 .. 2 KS - 1: A of k-step y / 2 when even, B when odd) of `slot`
+  auto read_frag = [&](int y, int slot, float (&a)[KS][TI], float (&b)[KS][TJ]) {
+    const float* sA = (const float*)(ring + slot * SB);
+    const float* sB = (const float*)(ring + slot * SB + A_BYTES);
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      if (y == 2 * ks) lds_frag<TI>(sA + (4 * ks + lk) * BM, li, a[ks]);
+      if (y == 2 * ks + 1) lds_frag<TJ>(sB + (4 * ks + lk) * BN, li, b[ks]);
+    }
+  };
+  // one slot's MFMAs on (a, b); dealt into them: the refill of `slot` (do_dma) and the next slot's fragments into (a2, b2)
+  auto block = [&](float (&a)[KS][TI], float (&b)[KS][TJ], float (&a2)[KS][TI], float (&b2)[KS][TJ], int slot,
+                   bool do_dma, bool do_read) {
+#pragma unroll
+    for (int m = 0; m < NM; ++m) {
+      const int ks = m / (TI * TJ), u = (m / TI) % TJ, i = m % TI;
+      acc[i][u] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[ks][i], b[ks][u], acc[i][u], 0, 0, 0);
+      // extras [m EXTRAS / NM, (m + 1) EXTRAS / NM) follow MFMA m: evenly dealt, whatever the ratio (the 16-wide tiles have
+      // more extras than MFMAs)
+#pragma unroll
+      for (int e = 0; e < (EXTRAS + NM - 1) / NM; ++e) {      // (constant trip count: the MFMA loop unrolls completely)
+        const int x = (m * EXTRAS) / NM + e;
+        if (x >= ((m + 1) * EXTRAS) / NM) continue;
+        if (x < G) {
+          if (do_dma) {
+            if (x == 0) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // every fragment of `slot` is in registers
+            dma_piece(x, slot);
+          }
+        } else if (do_read) {
+          read_frag(x - G, slot ^ 1, a2, b2);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+  };
+
+  if (n_my > 0) {
+    float a0[KS][TI], b0[KS][TJ], a1[KS][TI], b1[KS][TJ];
+#pragma unroll
+    for (int x = 0; x < G; ++x) dma_piece(x, 0);
+    if (n_my > 1) {
+#pragma unroll
+      for (int x = 0; x < G; ++x) dma_piece(x, 1);
+      wait_vmcnt<G>();                                   // group 0 has landed
+    } else {
+      wait_vmcnt<0>();
+    }
+#pragma unroll
+    for (int y = 0; y < 2 * KS; ++y) read_frag(y, 0, a0, b0);
+    __builtin_amdgcn_sched_barrier(0);
+    for (int it = 0; it < n_my; it += 2) {
+      // block `it` on (a0, b0) from slot 0; block `it + 1` on (a1, b1) from slot 1
+      wait_vmcnt<0>();                                   // slot 1 (group it + 1), issued a block ago, has landed
+      block(a0, b0, a1, b1, 0, it + 2 < n_my, it + 1 < n_my);
+      if (it + 1 < n_my) {
+        wait_vmcnt<0>();                                 // slot 0 (group it + 2)
+        block(a1, b1, a0, b0, 1, it + 3 < n_my, it + 2 < n_my);
+      }
+    }
   }
+  atb_combine_store<TI, TJ>(acc, part + (size_t)p * M * N, ldp, m0, n0);   // (direct: p = 0)
 }
 
 __global__ __launch_bounds__(256, 2) void atb_grouped_kernel(const AtbGroup g) {
@@ -363,14 +518,20 @@ __global__ __launch_bounds__(256, 2) void atb_grouped_kernel(const AtbGroup g) {
   const AtbTask& k = g.t[i];
   const int t = L - g.task0[i];
 #define D3F_ATB_TILE(I, J) \
-  case (I) * 16 + (J): atb_task_body<I, J>(k.A, k.B, k.part, k.R, k.M, k.N, k.rpw, k.P, t, k.ldp, k.direct); break
-  switch (k.tile) {
+  case (I) * 16 + (J): atb_task_body<I, J>(k.A, k.B, k.part, k.R, k.M, k.N, k.rpw, k.P, t, k.ldp, k.direct & 1); break
+#define D3F_ATB_PIPE(I, J) \
+  case 256 + (I) * 16 + (J): atb_task_body_pipe<I, J>(k.A, k.B, k.part, k.R, k.M, k.N, k.rpw, k.P, t, k.ldp, k.direct & 1); break
+  switch (k.tile + ((k.direct & 2) ? 256 : 0)) {      // (direct bit 1: the software-pipelined body)
     D3F_ATB_TILE(1, 1); D3F_ATB_TILE(1, 2); D3F_ATB_TILE(1, 4);
     D3F_ATB_TILE(2, 1); D3F_ATB_TILE(2, 2); D3F_ATB_TILE(2, 4);
     D3F_ATB_TILE(4, 1); D3F_ATB_TILE(4, 2); D3F_ATB_TILE(4, 4);
+    D3F_ATB_PIPE(1, 1); D3F_ATB_PIPE(1, 2); D3F_ATB_PIPE(1, 4);
+    D3F_ATB_PIPE(2, 1); D3F_ATB_PIPE(2, 2); D3F_ATB_PIPE(2, 4);
+    D3F_ATB_PIPE(4, 1); D3F_ATB_PIPE(4, 2); D3F_ATB_PIPE(4, 4);
     default: break;
   }
 #undef D3F_ATB_TILE
+#undef D3F_ATB_PIPE
 }
 
 // Second stage of a grouped launch.  Problem i owns blocks [block0[i], block0[i + 1]): its first c_blocks blocks sum the
@@ -698,7 +859,11 @@ int atb_group_launch(const AtbProblem* probs, int n, void* ws, hipStream_t strea
       g.t[s].P = plan[i].P;
       g.t[s].tile = plan[i].ti * 16 + plan[i].tj;
       g.t[s].ldp = plan[i].direct ? p.ldc : p.N;
-      g.t[s].direct = plan[i].direct;
+      // the software-pipelined body: operands a 32-bit buffer offset reaches (tunables().atb_pipe = 1: never; n >= 2:
+      // only tiles of at least n 16 x 16 accumulators -- A/B measurements)
+      const bool wide = plan[i].ti * plan[i].tj >= (tunables().atb_pipe >= 2 ? tunables().atb_pipe : 1);
+      const bool fits = ((size_t)p.R + 256) * p.M * 4 < 0xffffffffull && ((size_t)p.R + 256) * p.N * 4 < 0xffffffffull;
+      g.t[s].direct = plan[i].direct | ((wide && fits && tunables().atb_pipe != 1) ? 2 : 0);
       task += plan[i].ntasks;
       AtbReduceTask& r = rg.t[s];
       rg.block0[s] = (int)block;

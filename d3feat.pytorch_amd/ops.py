@@ -1398,6 +1398,7 @@ def upsample_linear_bias_act(x_coarse, inds, skip, weight, bias1=None, bias2=Non
 
 # rows from which the unary blocks use the fused row-streaming kernels instead of library GEMM + epilogue launch
 _FUSED_LINEAR_MIN_ROWS = 4096
+_FUSED_LINEAR_MAX_CIN = 64     # (wider inputs: the library GEMM's deeper tiling + an epilogue launch wins, re-measured in round 6)
 # library GEMM + epilogue as ONE autograd node (_LinearLibBiasActFn); D3F_MERGED_UNARY=0: the two nodes of rounds 1-4
 _MERGED_UNARY = True
 
@@ -1412,7 +1413,7 @@ def linear_bias_act(x, weight, bias1=None, add=None, bias2=None, slope=0.1, grad
     N, Cin, Cout = int(x.shape[0]), int(x.shape[1]), int(weight.shape[0])
     # measured (profiles/unary_gemm_microbench.py): the fused kernel beats library GEMM + epilogue launch for
     # Cin <= 64 (7-21 us vs 10-27 us at 38k rows), not for Cin >= 128 where the library's deeper tiling wins
-    if N >= _FUSED_LINEAR_MIN_ROWS and Cin <= 64 and _native.lib().d3f_linear_fused_supported(N, Cin, Cout):
+    if N >= _FUSED_LINEAR_MIN_ROWS and Cin <= _FUSED_LINEAR_MAX_CIN and _native.lib().d3f_linear_fused_supported(N, Cin, Cout):
         b1 = _f32(bias1, "bias1") if bias1 is not None else None
         b2 = _f32(bias2, "bias2") if bias2 is not None else None
         a = _f32(add, "add") if add is not None else None

@@ -69,7 +69,9 @@ typedef struct d3f_tunables {
   int32_t atb_first_form_wgs; /* first form: workgroups along the reduction (0 = by shape) */
   int32_t match_wgs;          /* d3f_mutual_nn: target number of workgroups (0 = 2048) */
   int32_t agg_through_lds;    /* general-path KPConv aggregation: 1 = stage the tile through LDS (experiment) */
-  int32_t reserved[11];
+  int32_t atb_pipe;           /* grouped A^T B task body: 0 = software-pipelined, 1 = the plain one, n >= 2 = pipelined only for
+                               * tiles of at least n 16x16 accumulators (A/B measurements) */
+  int32_t reserved[10];
 } d3f_tunables;
 void d3f_get_tunables(d3f_tunables* out);
 int d3f_set_tunables(const d3f_tunables* in);

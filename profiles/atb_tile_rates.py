@@ -21,6 +21,9 @@ CASES = [("64x64 tiles, split reduction   16384 x 1024 x 1024", [(16384, 1024, 1
          ("16x64 tiles                    114624 x 16 x 64 x32", [(114624, 16, 64)] * 32),
          ("64x64 tiles, 2 blocks          114624 x 128 x 64 x8", [(114624, 128, 64)] * 8),
          ("64x64 tiles, 15 blocks         23808 x 960 x 64 x8", [(23808, 960, 64)] * 8)]
+pipe = int(sys.argv[1]) if len(sys.argv) > 1 else 0
+_native.set_tunables(atb_pipe=pipe)
+print("# tunables().atb_pipe = %d (%s task body on the wide tiles)" % (pipe, "plain" if pipe else "software-pipelined"))
 for label, shapes in CASES:
     ps = []
     g = torch.Generator(device=dev).manual_seed(1)

@@ -1,0 +1,24 @@
+"""bench.py with module constants of the package overridden first (the package reads no environment):
+    python profiles/bench_with.py ops._FUSED_LINEAR_MAX_CIN=256 train.PairLanes.JOIN_ON_HOST=True -- --quick --steps 20
+Everything before `--` is `<module>.<attr>[.<attr>]=<python literal>`, everything after goes to bench.py."""
+import ast
+import importlib
+import os
+import sys
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+args = sys.argv[1:]
+cut = args.index("--") if "--" in args else len(args)
+import d3feat_pytorch_amd  # noqa: E402,F401
+for spec in args[:cut]:
+    path, value = spec.split("=", 1)
+    parts = path.split(".")
+    obj = importlib.import_module("d3feat_pytorch_amd." + parts[0]) if parts[0] != "d3f" else d3feat_pytorch_amd
+    for p in parts[1:-1]:
+        obj = getattr(obj, p)
+    setattr(obj, parts[-1], ast.literal_eval(value))
+    print("set %s = %r" % (path, getattr(obj, parts[-1])), file=sys.stderr)
+sys.argv = [os.path.join(REPO, "bench.py")] + args[cut + 1:]
+import bench  # noqa: E402
+bench.main()

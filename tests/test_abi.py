@@ -43,7 +43,7 @@ def test_tunables_struct_round_trips_and_rejects_nonsense():
     lib = _native.lib()
     t = _native.Tunables()
     lib.d3f_get_tunables(ctypes.byref(t))
-    assert [getattr(t, n) for n, _ in _native.Tunables._fields_ if n != "reserved"] == [0, 0, 0, 0, 0]
+    assert [getattr(t, n) for n, _ in _native.Tunables._fields_ if n != "reserved"] == [0, 0, 0, 0, 0, 0]
     assert ctypes.sizeof(t) == 64
     old = _native.set_tunables(atb_task_us=33, atb_form=2)
     lib.d3f_get_tunables(ctypes.byref(t))

@@ -560,13 +560,15 @@ _GROUP_SHAPES = [(114688, 384, 32), (23872, 256, 256), (6208, 512, 512), (6208, 
                  (462, 512, 7680), (1713, 256, 3840), (462, 2048, 1024), (159, 512, 2048), (1001, 1024, 512)]
 
 
-@pytest.mark.parametrize("task_us", [0, 5])
-def test_grouped_weight_gradients_match_float64(task_us):
+@pytest.mark.parametrize("task_us,pipe", [(0, 0), (5, 0), (0, 1), (5, 1)])
+def test_grouped_weight_gradients_match_float64(task_us, pipe):
     """d3f_linear_grad_weight_group: ALL problems in one launch pair == float64 grad_out^T x per problem, bit-identical
     on a second run and when a problem is computed alone; bias partial sums finished by the same second stage; a
     strided target (column block of a wider matrix) written in place with its neighbours untouched.  task_us = 5:
-    four times as many row partitions (ragged last partitions, partition counts off the multiples of 8)."""
-    old = _native.set_tunables(atb_task_us=task_us)
+    four times as many row partitions (ragged last partitions, partition counts off the multiples of 8).  pipe = 0: the
+    software-pipelined task body (buffer-load LDS-DMA, rows past the operand zero-filled by the range check); 1: the
+    plain one (the fallback for operands beyond 4 GiB)."""
+    old = _native.set_tunables(atb_task_us=task_us, atb_pipe=pipe)
     try:
         rng = np.random.default_rng(5)
         probs, refs = [], []
