@@ -127,8 +127,34 @@ struct WaveScratch {
   int st[32];
 };
 
+// x of lane (l ^ j) for the butterfly distances of a 64-lane wave WITHOUT the LDS crossbar: __shfl_xor compiles to
+// ds_bpermute_b32 (an LDS-pipe instruction with its address arithmetic and ~100 cycles of dependent latency) -- the
+// 64-key bitonic network of a query is 21 dependent exchanges of a 64-bit key = 42 of them.  Distances 1, 2, 8 are one
+// DPP move (quad_perm / row_ror), 4 is two (row_shl / row_shr under complementary bank masks), 16 and 32 are gfx950's
+// v_permlane16_swap / v_permlane32_swap (rows of the two operands exchanged; the lane's row bit picks the half).
+__device__ __forceinline__ uint32_t lane_xor(uint32_t x, int j, int lane) {
+  switch (j) {
+    case 1: return (uint32_t)__builtin_amdgcn_update_dpp((int)x, (int)x, 0xB1, 0xF, 0xF, false);    // quad_perm [1,0,3,2]
+    case 2: return (uint32_t)__builtin_amdgcn_update_dpp((int)x, (int)x, 0x4E, 0xF, 0xF, false);    // quad_perm [2,3,0,1]
+    case 4: {
+      int r = __builtin_amdgcn_update_dpp((int)x, (int)x, 0x104, 0xF, 0x5, false);                  // banks 0, 2 <- lane + 4
+      return (uint32_t)__builtin_amdgcn_update_dpp(r, (int)x, 0x114, 0xF, 0xA, false);              // banks 1, 3 <- lane - 4
+    }
+    case 8: return (uint32_t)__builtin_amdgcn_update_dpp((int)x, (int)x, 0x128, 0xF, 0xF, false);   // row_ror:8
+    case 16: {
+      const auto p = __builtin_amdgcn_permlane16_swap(x, x, false, false);
+      return (lane & 16) ? p[0] : p[1];
+    }
+    case 32: {
+      const auto p = __builtin_amdgcn_permlane32_swap(x, x, false, false);
+      return (lane & 32) ? p[0] : p[1];
+    }
+    default: return __shfl_xor(x, j, 64);
+  }
+}
 __device__ __forceinline__ uint64_t shfl_xor_u64(uint64_t v, int m) {
-  const uint32_t lo = __shfl_xor((uint32_t)v, m, 64), hi = __shfl_xor((uint32_t)(v >> 32), m, 64);
+  const int lane = threadIdx.x & 63;
+  const uint32_t lo = lane_xor((uint32_t)v, m, lane), hi = lane_xor((uint32_t)(v >> 32), m, lane);
   return ((uint64_t)hi << 32) | lo;
 }
 
@@ -181,14 +207,16 @@ __global__ __launch_bounds__(kQueryWaves * 64) void radius_query_kernel(
     ws.nkey[lane] = nk;
     ws.st[lane] = st;
   }
+  // inclusive prefix over lanes 0..31 (27 cells) by DPP: shifts inside the rows of 16 (out-of-row sources read 0), then
+  // row 0's total broadcast into row 1 -- five LDS-crossbar shuffles and their waits gone
   int incl = len;
-#pragma unroll
-  for (int o = 1; o < 32; o <<= 1) {
-    const int t = __shfl_up(incl, o, 64);
-    if (lane >= o) incl += t;
-  }
+  incl += __builtin_amdgcn_update_dpp(0, incl, 0x111, 0xF, 0xF, true);    // row_shr:1
+  incl += __builtin_amdgcn_update_dpp(0, incl, 0x112, 0xF, 0xF, true);    // row_shr:2
+  incl += __builtin_amdgcn_update_dpp(0, incl, 0x114, 0xF, 0xF, true);    // row_shr:4
+  incl += __builtin_amdgcn_update_dpp(0, incl, 0x118, 0xF, 0xF, true);    // row_shr:8
+  incl += __builtin_amdgcn_update_dpp(0, incl, 0x142, 0xA, 0xF, false);   // row_bcast:15 into rows 1 and 3
   if (lane < 32) ws.pre[lane] = incl - len;  // exclusive prefix; entries 27..31 == total
-  const int P = __shfl(incl, 31, 64);
+  const int P = __builtin_amdgcn_readlane(incl, 31);
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
