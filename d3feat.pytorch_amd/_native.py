@@ -12,7 +12,7 @@ _REPO = os.path.dirname(_PKG_DIR)
 LIB_PATH = os.path.join(_PKG_DIR, "libd3feat_hip.so")
 CSRC = os.path.join(_PKG_DIR, "csrc")
 SOURCES = ["radius_neighbors.hip", "grid_subsample.hip", "kpconv.hip", "kpconv_fused.hip", "kpconv_aggregate.hip", "kpconv_small.hip", "kpconv_deform.hip", "pool.hip", "detection.hip", "loss.hip",
-           "reverse_table.hip", "kpconv_dx_gather.hip", "matching.hip", "elementwise.hip", "batchnorm.hip", "linear.hip", "optimizer.hip", "misc.hip"]
+           "reverse_table.hip", "kpconv_dx_gather.hip", "matching.hip", "elementwise.hip", "batchnorm.hip", "linear.hip", "gemm_epilogue.hip", "optimizer.hip", "misc.hip"]
 
 _vp, _i, _f, _sz = C.c_void_p, C.c_int, C.c_float, C.c_size_t
 
@@ -20,7 +20,8 @@ _vp, _i, _f, _sz = C.c_void_p, C.c_int, C.c_float, C.c_size_t
 class Tunables(C.Structure):
     """d3f_tunables of include/d3feat_hip.h: the library's knobs (it never reads the environment)."""
     _fields_ = [("atb_task_us", C.c_int32), ("atb_form", C.c_int32), ("atb_first_form_wgs", C.c_int32),
-                ("match_wgs", C.c_int32), ("agg_through_lds", C.c_int32), ("atb_pipe", C.c_int32), ("reserved", C.c_int32 * 10)]
+                ("match_wgs", C.c_int32), ("agg_through_lds", C.c_int32), ("atb_pipe", C.c_int32), ("xw_rows", C.c_int32), ("xw_split", C.c_int32),
+                ("reserved", C.c_int32 * 8)]
 
 
 class AtbProblem(C.Structure):
@@ -91,6 +92,10 @@ SIGNATURES = {
     "d3f_linear_grad_weight_ws_bytes": (_sz, [_i, _i, _i]),
     "d3f_linear_grad_weight": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _sz, _vp]),
     "d3f_linear_grad_weight_bias": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _sz, _vp, _i, _i, _vp, _vp, _vp]),
+    "d3f_gemm_epilogue_supported": (_i, [_i, _i, _i, _i, _i]),
+    "d3f_gemm_epilogue_ws_bytes": (_sz, [_i, _i, _i]),
+    "d3f_gemm_epilogue": (_i, [_vp, _i, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _i, _vp, _f, _vp, _i, _vp, _i, _vp, _sz,
+                               _vp]),
     "d3f_bias_act_backward_blocks": (_i, [_i, _i]),
     "d3f_bias_act_backward_partial": (_i, [_vp, _vp, _f, _i, _i, _vp, _vp, _vp, _sz, _vp]),
     "d3f_bias_sum": (_i, [_vp, _i, _i, _vp, _vp, _vp]),

@@ -12,7 +12,11 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from .. import ops
-from .blocks import KPConv, NearestUpsampleBlock, ResnetBottleneckBlock, UnaryBlock, block_decider  # noqa: F401
+from .blocks import (KPConv, LastUnaryBlock, NearestUpsampleBlock, ResnetBottleneckBlock, UnaryBlock,  # noqa: F401
+                     block_decider)
+
+# False: the descriptor head runs on the concatenated level-0 matrix as in rounds 1-5 (A/B measurements)
+UPSAMPLED_HEAD = True
 
 
 def p2p_fitting_regularizer(net, deform_fitting_power=None, repulse_extent=None):
@@ -124,6 +128,16 @@ class KPFCNN(nn.Module):
                         skip = skips.pop()
                         x = ops.upsample_linear_bias_act(x, inds, skip, op.mlp.weight, op.mlp.bias,
                                                          op.batch_norm.bias, slope=1.0 if op.no_relu else 0.1,
+                                                         skip_grad_deposit=getattr(skip, '_d3f_grad_in', None))
+                        continue
+                    if isinstance(op, LastUnaryBlock) and UPSAMPLED_HEAD and (x.shape[1] * 4) % 16 == 0 \
+                            and op.mlp.bias is not None:
+                        # the descriptor head (plain Linear, reference blocks.py:518-541) behind the last upsample +
+                        # concat: the same split -- the 256 upsampled channels are multiplied on the 4.8x fewer coarse
+                        # rows, the level-0 concatenation [N, 384] is never formed, and the backward pools 32 gradient
+                        # columns back to the coarse rows instead of scattering 256 (round 6)
+                        skip = skips.pop()
+                        x = ops.upsample_linear_bias_act(x, inds, skip, op.mlp.weight, op.mlp.bias, None, slope=1.0,
                                                          skip_grad_deposit=getattr(skip, '_d3f_grad_in', None))
                         continue
                     x = ops.closest_pool(x, inds, skip=skips.pop())

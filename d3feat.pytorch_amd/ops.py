@@ -468,6 +468,15 @@ def _takes_gemm_path(Nq, Cin):
     return 0 < Nq < _GEMM_DX_MAX_ROWS or (Nq > 0 and Cin >= _GEMM_PATH_MIN_CIN)
 
 
+def _kpconv_gw(gon, weights, Nq, K, Cin, Cout):
+    """gW [Nq, K Cin] = (g / nn) [Nq, Cout] @ W^T, W viewed [K Cin, Cout]: the per-query gradient of the weighted features
+    the scatter-form grad-input kernel distributes (few-point layers)."""
+    w2 = weights.view(K * Cin, Cout)
+    if _own_gemm("kpconv_gw", gon, w2, GEMM_NT, Nq, Cout, K * Cin):
+        return gemm_epilogue(gon, w2, GEMM_NT, Nq, Cout, K * Cin)
+    return torch.mm(gon, w2.t())
+
+
 class _KPConvFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, q_pts, s_pts, idx, x, kernel_points, weights, extent, rev=None, ready=None):
@@ -568,7 +577,7 @@ class _KPConvFn(torch.autograd.Function):
             # same layers: gW = (g/nn) W^T over all queries is one library GEMM; the kernel only scatters
             if gon is None:
                 gon = go / nn.unsqueeze(1)
-            gwf = torch.mm(gon, weights.view(K * Cin, Cout).t())
+            gwf = _kpconv_gw(gon, weights, Nq, K, Cin, Cout)
             nbytes = L.d3f_kpconv_ws_bytes(Nq, Ns, H, K, Cin, 64)
             ws = _ws(nbytes, x.device)
             with _region("kpconv_dx_scatter[Nq=%d,Cin=%d,H=%d]" % (Nq, Cin, H), 4 * Nq * K * Cin + 4 * Nq * H * (1 + Cin)):
@@ -627,11 +636,16 @@ class _KPConvGemmBiasActFn(torch.autograd.Function):
         ctx.keep, ctx.gx_buf = keep, gx_buf
         want_b = bias is not None and ctx.needs_input_grad[6]
         gbuf = torch.empty((1, Cout), dtype=torch.float32, device=dev) if want_b else None
-        raw = torch.mm(wf, weights.view(K * Cin, Cout))
-        out = torch.empty_like(raw)
-        _native.check(L.d3f_bias_act_forward(_p(raw), _p(bias), None, None, float(slope), Nq, Cout, _p(out), _p(gbuf),
-                                             Cout if want_b else 0, _p(nn), None, 0, 0, _stream()),
-                      "d3f_bias_act_forward")
+        if _own_gemm("kpconv_fwd", wf, weights, GEMM_NN, Nq, K * Cin, Cout, 0, None, None, bias):
+            # contraction + / nn + bias + LeakyReLU in one launch (csrc/gemm_epilogue.hip)
+            out = gemm_epilogue(wf, weights, GEMM_NN, Nq, K * Cin, Cout, row_div=nn, bias1=bias, slope=slope,
+                                zero_init=gbuf if want_b else None)
+        else:
+            raw = torch.mm(wf, weights.view(K * Cin, Cout))
+            out = torch.empty_like(raw)
+            _native.check(L.d3f_bias_act_forward(_p(raw), _p(bias), None, None, float(slope), Nq, Cout, _p(out), _p(gbuf),
+                                                 Cout if want_b else 0, _p(nn), None, 0, 0, _stream()),
+                          "d3f_bias_act_forward")
         ctx.save_for_backward(q_pts, s_pts, idx, x, kernel_points, weights, nn, wf, out)
         ctx.gbuf, ctx.extent, ctx.slope, ctx.want_b = gbuf, float(extent), float(slope), want_b
         ctx.gw_slot = _grad_slot(weights)
@@ -678,8 +692,12 @@ class _KPConvGemmBiasActFn(torch.autograd.Function):
                 _native.check(L.d3f_kpconv_aggregate_transposed(_p(rev.rel), rev.width, Ns, Nq, _p(kernel_points), K,
                                                                 ctx.extent, None, _p(gon), Cout, _p(agg), _stream()),
                               "d3f_kpconv_aggregate_transposed")
-            wp = weights.permute(0, 2, 1).contiguous().view(K * Cout, Cin)
-            gx = torch.mm(agg, wp)
+            if _own_gemm("kpconv_dx", agg, weights, GEMM_NT, Ns, K * Cout, Cin, Cout):
+                # W' read in place from W [K, Cin, Cout] (block form of the reduction): no permuted copy of the weights
+                gx = gemm_epilogue(agg, weights, GEMM_NT, Ns, K * Cout, Cin, kblock=Cout)
+            else:
+                wp = weights.permute(0, 2, 1).contiguous().view(K * Cout, Cin)
+                gx = torch.mm(agg, wp)
         elif ctx.needs_input_grad[3] and rev is not None:
             # gather form: one launch instead of the gW GEMM + atomic scatter (gon is already / nn)
             gx = torch.empty_like(x)
@@ -697,7 +715,7 @@ class _KPConvGemmBiasActFn(torch.autograd.Function):
             pre = 1 if gx is not None else 0
             if gx is None:
                 gx = torch.empty_like(x)
-            gwf = torch.mm(gon, weights.view(K * Cin, Cout).t())
+            gwf = _kpconv_gw(gon, weights, Nq, K, Cin, Cout)
             nbytes = L.d3f_kpconv_ws_bytes(Nq, Ns, H, K, Cin, 64)
             ws = _ws(nbytes, x.device)
             with _region("kpconv_dx_scatter[Nq=%d,Cin=%d,H=%d]" % (Nq, Cin, H), 4 * Nq * K * Cin + 4 * Nq * H * (1 + Cin)):
@@ -932,6 +950,11 @@ def grad_tap(x, holder):
 def _add_deposited(holder, go, weight):
     """grad_x = go @ weight (+ the sibling branch's deposited gradient, accumulated by the GEMM itself)."""
     c = holder.collect() if holder is not None else None
+    N, Cout, Cin = int(go.shape[0]), int(go.shape[1]), int(weight.shape[1])
+    if go.is_contiguous() and weight.is_contiguous() and \
+            (c is None or (c.is_contiguous() and c.dtype == go.dtype and c.shape == (N, Cin))) and \
+            _own_gemm("unary_dx", go, weight, GEMM_NN, N, Cout, Cin, 0, None, None, c):
+        return gemm_epilogue(go, weight, GEMM_NN, N, Cout, Cin, add=c)      # (out of place: safe beside queued operands)
     if c is None:
         return torch.mm(go, weight)
     if c.is_contiguous() and c.dtype == go.dtype and c.shape == (go.shape[0], weight.shape[1]):
@@ -950,6 +973,65 @@ def _add_deposited(holder, go, weight):
             return torch.addmm(c, go, weight)
         return c.addmm_(go, weight)      # beta = 1, in place: the deposited buffer has no other reader left
     return torch.mm(go, weight).add_(c)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# Own f32-MFMA GEMM with the block's epilogue fused (csrc/gemm_epilogue.hip): the contractions of the wide / few-row
+# layers -- KPConv's wf @ W (models/blocks.py:362-374) with / nn + bias + LeakyReLU, nn.Linear of the unary blocks
+# (:481-541) with bias + residual + LeakyReLU, and their grad-input products
+# ---------------------------------------------------------------------------------------------------------------
+GEMM_NT, GEMM_NN = 0, 1
+# False: every such product is a library GEMM followed by its epilogue launch (rounds 1-5; A/B measurements)
+OWN_GEMM = True
+
+
+def _al16(*ts):
+    return all(t is None or t.data_ptr() % 16 == 0 for t in ts)
+
+
+def gemm_epilogue_ok(x, w, mode, R, K, N, kblock=0, ldx=None, ldw=None, *others):
+    """True when d3f_gemm_epilogue serves this product (shape, alignment, leading dimensions)."""
+    if not OWN_GEMM or R < 1:
+        return False
+    ldx = K if ldx is None else ldx
+    ldw = (K if mode == GEMM_NT else N) if ldw is None else ldw
+    if (ldx | ldw) & 3 or not _al16(x, w, *others):
+        return False
+    return bool(_native.lib().d3f_gemm_epilogue_supported(int(R), int(K), int(N), int(mode), int(kblock)))
+
+
+def gemm_epilogue(x, w, mode, R, K, N, kblock=0, ldx=None, ldw=None, row_div=None, bias1=None, add=None, bias2=None,
+                  slope=1.0, zero_init=None, out=None):
+    """out [R, N] = act(x [R, K] . B / row_div + bias1 + add + bias2) in one launch (two when the reduction is split).
+    mode GEMM_NT: B = w [N, ldw] (y = x w^T); kblock > 0: w is [K / kblock][N][kblock] (KPConv weights read as the
+    permuted matrix of the transposed-aggregation grad-input).  mode GEMM_NN: B = w [K, ldw].  ``out`` may be a
+    row-strided view.  Raises RuntimeError when the product is not supported (callers ask gemm_epilogue_ok first)."""
+    L = _native.lib()
+    ldx = K if ldx is None else int(ldx)
+    ldw = (K if mode == GEMM_NT else N) if ldw is None else int(ldw)
+    if out is None:
+        out = torch.empty((R, N), dtype=torch.float32, device=x.device)
+    ldy = int(out.stride(0)) if out.dim() == 2 else N
+    ldadd = int(add.stride(0)) if add is not None else 0
+    nbytes = int(L.d3f_gemm_epilogue_ws_bytes(int(R), int(K), int(N)))
+    ws = _ws(nbytes, x.device)
+    zn = int(zero_init.numel()) if zero_init is not None else 0
+    with _region("gemm_epilogue[R=%d,K=%d,N=%d,mode=%d]" % (R, K, N, mode), 4 * (R * K + K * N + R * N)):
+        _native.check(L.d3f_gemm_epilogue(_p(x), ldx, _p(w), ldw, int(mode), int(kblock), int(R), int(K), int(N),
+                                          _p(row_div), _p(bias1), _p(add), ldadd, _p(bias2), float(slope), _p(out), ldy,
+                                          _p(zero_init), zn, _p(ws), nbytes, _stream()), "d3f_gemm_epilogue")
+    return out
+
+
+# which products go to the own kernel (the others stay library GEMMs): kinds of OWN_GEMM_KINDS, by shape rule
+OWN_GEMM_KINDS = {"kpconv_fwd", "kpconv_dx", "kpconv_gw", "unary_fwd", "unary_dx", "decoder"}
+
+
+def _own_gemm(kind, x, w, mode, R, K, N, kblock=0, ldx=None, ldw=None, *others):
+    """Policy + capability: True when the product `kind` of this shape runs on d3f_gemm_epilogue."""
+    if kind not in OWN_GEMM_KINDS:
+        return False
+    return gemm_epilogue_ok(x, w, mode, R, K, N, kblock, ldx, ldw, *others)
 
 
 # ---------------------------------------------------------------------------------------------------------------
@@ -1221,13 +1303,20 @@ class _LinearLibBiasActFn(torch.autograd.Function):
         L = _native.lib()
         ctx.holder, ctx.dep = holder, deposit
         N, C = int(x.shape[0]), int(weight.shape[0])
-        raw = torch.mm(x, weight.t())
-        out = torch.empty_like(raw)
         nb = int(b1 is not None and ctx.needs_input_grad[2]) + int(b2 is not None and ctx.needs_input_grad[4])
         gbuf = torch.empty((nb, C), dtype=torch.float32, device=x.device) if nb else None
         ctx.gbuf, ctx.slope = gbuf, float(slope)
         ctx.has = (b1 is not None, add is not None, b2 is not None)
         ctx.gw_slot = _grad_slot(weight)
+        Cin = int(x.shape[1])
+        if pack is None and x.is_contiguous() and weight.is_contiguous() and (add is None or add.is_contiguous()) and \
+                _own_gemm("unary_fwd", x, weight, GEMM_NT, N, Cin, C, 0, None, None, b1, add, b2):
+            # x W^T + both biases + residual + LeakyReLU in one launch (csrc/gemm_epilogue.hip)
+            out = gemm_epilogue(x, weight, GEMM_NT, N, Cin, C, bias1=b1, add=add, bias2=b2, slope=slope, zero_init=gbuf)
+            ctx.save_for_backward(x, weight, out)
+            return out
+        raw = torch.mm(x, weight.t())
+        out = torch.empty_like(raw)
         if pack is not None:
             s_pts, want_clear = pack
             spack = torch.empty(16 * N, dtype=torch.uint8, device=x.device)
@@ -1314,8 +1403,15 @@ class _UpsampleLinearFn(torch.autograd.Function):
         N, Cs = int(skip.shape[0]), int(skip.shape[1])
         Cout, H = int(weight.shape[0]), int(idx.shape[1])
         w1, w2 = weight[:, :Cc], weight[:, Cc:]
-        t = torch.mm(xc, w1.t())                      # [Nc, Cout] on the coarse rows
-        y = torch.mm(skip, w2.t())                    # [N, Cout]
+        ldw = int(weight.stride(0))
+        if xc.is_contiguous() and _own_gemm("decoder", xc, w1, GEMM_NT, Nc, Cc, Cout, 0, None, ldw):
+            t = gemm_epilogue(xc, w1, GEMM_NT, Nc, Cc, Cout, ldw=ldw)
+        else:
+            t = torch.mm(xc, w1.t())                  # [Nc, Cout] on the coarse rows
+        if skip.is_contiguous() and _own_gemm("decoder", skip, w2, GEMM_NT, N, Cs, Cout, 0, None, ldw):
+            y = gemm_epilogue(skip, w2, GEMM_NT, N, Cs, Cout, ldw=ldw)
+        else:
+            y = torch.mm(skip, w2.t())                # [N, Cout]
         out = torch.empty_like(y)
         nb = int(b1 is not None and ctx.needs_input_grad[4]) + int(b2 is not None and ctx.needs_input_grad[5])
         # backward targets, cleared by the forward launch on the side: bias-gradient rows + the pooled gradient [Nc, Cout]
@@ -1364,8 +1460,18 @@ class _UpsampleLinearFn(torch.autograd.Function):
         _native.check(L.d3f_closest_pool_backward(_p(gm), Cout, _p(idx), N, H, Cout, Nc, _p(gt), pre_t, _stream()),
                       "d3f_closest_pool_backward")
         w1, w2 = weight[:, :Cc], weight[:, Cc:]
-        gxc = torch.mm(gt, w1) if ctx.needs_input_grad[0] else None
-        gskip = torch.mm(gm, w2) if ctx.needs_input_grad[2] else None
+        ldw = int(weight.stride(0))
+        gxc = gskip = None
+        if ctx.needs_input_grad[0]:
+            if _own_gemm("decoder", gt, w1, GEMM_NN, Nc, Cout, Cc, 0, None, ldw):
+                gxc = gemm_epilogue(gt, w1, GEMM_NN, Nc, Cout, Cc, ldw=ldw)
+            else:
+                gxc = torch.mm(gt, w1)
+        if ctx.needs_input_grad[2]:
+            if _own_gemm("decoder", gm, w2, GEMM_NN, N, Cout, Cs, 0, None, ldw):
+                gskip = gemm_epilogue(gm, w2, GEMM_NN, N, Cout, Cs, ldw=ldw)
+            else:
+                gskip = torch.mm(gm, w2)
         if gskip is not None and ctx.skip_dep is not None and ctx.skip_dep.deposit(gskip):
             gskip = None    # handed to the encoder block that consumes the same skip tensor (GradHolder)
         gw = None

@@ -71,7 +71,9 @@ typedef struct d3f_tunables {
   int32_t agg_through_lds;    /* general-path KPConv aggregation: 1 = stage the tile through LDS (experiment) */
   int32_t atb_pipe;           /* grouped A^T B task body: 0 = software-pipelined, 1 = the plain one, n >= 2 = pipelined only for
                                * tiles of at least n 16x16 accumulators (A/B measurements) */
-  int32_t reserved[10];
+  int32_t xw_rows;            /* d3f_gemm_epilogue: 0 = by shape, 2 / 4 = 32- / 64-row output blocks (A/B measurements) */
+  int32_t xw_split;           /* d3f_gemm_epilogue: 0 = by shape, 1 = never split the reduction, 8 q = 8 q partitions */
+  int32_t reserved[8];
 } d3f_tunables;
 void d3f_get_tunables(d3f_tunables* out);
 int d3f_set_tunables(const d3f_tunables* in);
@@ -280,6 +282,27 @@ int d3f_linear_bias_act_forward(const float* x, const float* weight, int N, int 
  * produced for the same tensor, accumulated in the epilogue instead of by a separate launch) */
 int d3f_linear_grad_input(const float* grad_out, const float* weight, int N, int Cin, int Cout, const float* add,
                           float* grad_x, void* stream);
+/* The contractions of the wide / few-row layers with their epilogue, y [R,N] = act(x [R,K] . B / row_div + bias1 + add +
+ * bias2), as ONE f32-MFMA launch (two when the reduction is split: few rows against a long reduction) -- what the
+ * reference computes as torch.matmul followed by separate bias / residual / LeakyReLU ops:
+ *   KPConv's `torch.matmul(weighted_features, self.weights)` summed over kernel points (models/blocks.py:362-374) with
+ *   the /neighbor-count of :376-380 and the bias + LeakyReLU of :473,:598,:676 (mode 1, B = weights viewed [K Cin, Cout],
+ *   row_div = neighbor counts); nn.Linear of UnaryBlock (:481-541, y = x W^T: mode 0, B = weight [N, K]) with the
+ *   residual add of :686; and autograd's grad-input products g W (mode 1) / g W^T (mode 0).
+ * mode 0: B [N, ldw] reduction-contiguous (rows = output columns); kblock > 0: B is [K / kblock][N][kblock] -- the
+ *   reduction index b kblock + o of output column n lives at w + (b N + n) kblock + o, i.e. KPConv's weights
+ *   [K, Cin, Cout] read as the permuted matrix W'[k, o, c] = W[k, c, o] of the transposed-aggregation grad-input
+ *   (ldw is ignored).
+ * mode 1: B [K, ldw] (rows = reduction indices).
+ * K and N multiples of 16; x, w, y, add, biases 16-byte aligned, leading dimensions multiples of 4.  row_div / bias1 /
+ * add [R, ldadd] / bias2 optional, slope = 1: no activation.  zero_init / zero_n as in d3f_bias_act_forward.
+ * ws >= d3f_gemm_epilogue_ws_bytes(R, K, N) (slabs of a split reduction; may be 256 bytes).  Bit-reproducible. */
+int d3f_gemm_epilogue_supported(int R, int K, int N, int mode, int kblock);
+size_t d3f_gemm_epilogue_ws_bytes(int R, int K, int N);
+int d3f_gemm_epilogue(const float* x, int ldx, const float* w, int ldw, int mode, int kblock, int R, int K, int N,
+                      const float* row_div, const float* bias1, const float* add, int ldadd, const float* bias2,
+                      float slope, float* y, int ldy, float* zero_init, int zero_n, void* ws, size_t ws_bytes,
+                      void* stream);
 size_t d3f_linear_grad_weight_ws_bytes(int N, int Cin, int Cout);
 int d3f_linear_grad_weight(const float* x, const float* grad_out, int N, int Cin, int Cout, float* grad_w, void* ws,
                            size_t ws_bytes, void* stream);

@@ -15,7 +15,9 @@ for spec in args[:cut]:
     path, value = spec.split("=", 1)
     parts = path.split(".")
     obj = importlib.import_module("d3feat_pytorch_amd." + parts[0]) if parts[0] != "d3f" else d3feat_pytorch_amd
-    for p in parts[1:-1]:
+    for i, p in enumerate(parts[1:-1]):
+        if not hasattr(obj, p):      # a sub-module that nothing imported yet (models.architectures)
+            importlib.import_module("d3feat_pytorch_amd." + ".".join(parts[:i + 2]))
         obj = getattr(obj, p)
     setattr(obj, parts[-1], ast.literal_eval(value))
     print("set %s = %r" % (path, getattr(obj, parts[-1])), file=sys.stderr)

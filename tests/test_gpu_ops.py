@@ -611,6 +611,94 @@ def test_grouped_weight_gradients_match_float64(task_us, pipe):
         _native.set_tunables(**old)
 
 
+# (R, K, N): the step's own shapes (KPConv contractions, unary blocks, decoder) + ragged rows, 16- and 32-wide outputs
+_XW_SHAPES = [(512, 7680, 512), (477, 3840, 256), (1792, 1920, 128), (6208, 960, 64), (23808, 128, 256), (1743, 1024, 1024),
+              (512, 2048, 512), (6159, 256, 512), (100, 64, 16), (37, 16, 32), (3001, 192, 96), (1, 128, 64), (257, 1024, 48)]
+
+
+def _xw_ref(x, b, row_div, b1, add, b2, slope):
+    v = x.double() @ b.double()
+    if row_div is not None:
+        v = v / row_div.double()[:, None]
+    for t in (b1, add, b2):
+        if t is not None:
+            v = v + t.double()
+    return torch.where(v > 0, v, v * slope).cpu().numpy()
+
+
+@pytest.mark.parametrize("rows,split", [(0, 0), (2, 1), (4, 8), (2, 16), (4, 1)])
+def test_gemm_epilogue_matches_float64(rows, split):
+    """d3f_gemm_epilogue (own f32-MFMA GEMM with the block's epilogue): y = act(x B / row_div + b1 + add + b2) for
+    B = w^T (nn.Linear, blocks.py:481-541), B = w (KPConv's wf @ W, blocks.py:362-374, and grad-input products) and the
+    block form (KPConv weights read as the permuted matrix of the transposed-aggregation grad-input) vs float64; every
+    tile shape (rows = 2 / 4: 32- / 64-row blocks), undivided and split reductions (8 / 16 partitions), ragged row
+    counts, row-strided operands and outputs, all epilogue combinations; bit-identical on a second run."""
+    old = _native.set_tunables(xw_rows=rows, xw_split=split)
+    try:
+        rng = np.random.default_rng(11)
+        for k, (R, K, N) in enumerate(_XW_SHAPES):
+            for mode in (ops.GEMM_NT, ops.GEMM_NN):
+                padx, padw, pady = (16 if k % 3 == 1 else 0), (32 if k % 2 == 1 else 0), (16 if k % 4 == 2 else 0)
+                xf = torch.from_numpy(rng.normal(size=(R, K + padx)).astype(np.float32)).cuda()
+                x = xf[:, :K]
+                if mode == ops.GEMM_NT:
+                    wf_ = torch.from_numpy(rng.normal(size=(N, K + padw)).astype(np.float32)).cuda()
+                    w, b = wf_[:, :K], wf_[:, :K].t()
+                else:
+                    wf_ = torch.from_numpy(rng.normal(size=(K, N + padw)).astype(np.float32)).cuda()
+                    w, b = wf_[:, :N], wf_[:, :N]
+                combo = (k + mode) % 4
+                row_div = torch.from_numpy(rng.integers(1, 40, size=R).astype(np.float32)).cuda() if combo in (1, 3) else None
+                b1 = torch.from_numpy(rng.normal(size=N).astype(np.float32)).cuda() if combo >= 1 else None
+                add = torch.from_numpy(rng.normal(size=(R, N)).astype(np.float32)).cuda() if combo >= 2 else None
+                b2 = torch.from_numpy(rng.normal(size=N).astype(np.float32)).cuda() if combo == 3 else None
+                slope = 1.0 if combo == 0 else 0.1
+                full = torch.full((R, N + 2 * pady), 7.0, dtype=torch.float32, device="cuda")
+                out = full[:, pady:pady + N]
+                zi = torch.full((3 * N,), 5.0, device="cuda") if combo == 1 else None
+                assert ops.gemm_epilogue_ok(x, w, mode, R, K, N, 0, x.stride(0), w.stride(0), b1, add, b2)
+                ops.gemm_epilogue(x, w, mode, R, K, N, 0, x.stride(0), w.stride(0), row_div, b1, add, b2, slope, zi, out)
+                ref = _xw_ref(x, b, row_div, b1, add, b2, slope)
+                assert rel_err(out.cpu().numpy(), ref) < 2e-5, (R, K, N, mode, combo)
+                if pady:
+                    assert bool((full[:, :pady] == 7.0).all()) and bool((full[:, -pady:] == 7.0).all())
+                if zi is not None:
+                    assert bool((zi == 0.0).all())
+                first = out.clone()
+                out.fill_(0.0)
+                ops.gemm_epilogue(x, w, mode, R, K, N, 0, x.stride(0), w.stride(0), row_div, b1, add, b2, slope, None, out)
+                assert torch.equal(out, first), (R, K, N, mode)
+        # block form: A [Ns, Kp Cout] . W', W'[k, o, c] = W[k, c, o], read in place from W [Kp, Cin, Cout]
+        for (Ns, Kp, Cin, Cout) in [(1792, 15, 256, 256), (6208, 15, 128, 128), (23801, 15, 64, 64), (300, 3, 16, 192)]:
+            A = torch.from_numpy(rng.normal(size=(Ns, Kp * Cout)).astype(np.float32)).cuda()
+            W = torch.from_numpy(rng.normal(size=(Kp, Cin, Cout)).astype(np.float32)).cuda()
+            addend = torch.from_numpy(rng.normal(size=(Ns, Cin)).astype(np.float32)).cuda()
+            assert ops.gemm_epilogue_ok(A, W, ops.GEMM_NT, Ns, Kp * Cout, Cin, Cout)
+            out = ops.gemm_epilogue(A, W, ops.GEMM_NT, Ns, Kp * Cout, Cin, kblock=Cout, add=addend)
+            ref = (A.double() @ W.permute(0, 2, 1).reshape(Kp * Cout, Cin).double() + addend.double()).cpu().numpy()
+            assert rel_err(out.cpu().numpy(), ref) < 2e-5, (Ns, Kp, Cin, Cout)
+    finally:
+        _native.set_tunables(**old)
+
+
+def test_gemm_epilogue_rejects_bad_arguments():
+    L = _native.lib()
+    assert not L.d3f_gemm_epilogue_supported(100, 24, 64, 0, 0)        # K no multiple of 16
+    assert not L.d3f_gemm_epilogue_supported(100, 64, 40, 0, 0)        # N no multiple of 16
+    assert not L.d3f_gemm_epilogue_supported(100, 960, 64, 1, 64)      # the block form belongs to mode 0
+    assert not L.d3f_gemm_epilogue_supported(100, 960, 64, 0, 48)      # blocks of 64 reduction indices
+    x = torch.zeros((100, 64), device="cuda")
+    w = torch.zeros((32, 64), device="cuda")
+    y = torch.zeros((100, 32), device="cuda")
+    st = torch.cuda.current_stream().cuda_stream
+    args = lambda xp, ldx: (xp, ldx, w.data_ptr(), 64, 0, 0, 100, 64, 32, None, None, None, 0, None, 1.0, y.data_ptr(),
+                            32, None, 0, None, 0, st)
+    assert L.d3f_gemm_epilogue(*args(x.data_ptr(), 64)) == 0
+    assert L.d3f_gemm_epilogue(*args(x.data_ptr() + 4, 64)) == -1      # 16-byte alignment
+    assert L.d3f_gemm_epilogue(*args(x.data_ptr(), 32)) == -1          # leading dimension below K
+    torch.cuda.synchronize()
+
+
 def test_grouped_launch_with_more_problems_than_one_table_holds():
     """60 problems > the 48 entries of one kernel-argument table: the call splits into two launch pairs."""
     rng = np.random.default_rng(6)
