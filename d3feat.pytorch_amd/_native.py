@@ -21,7 +21,7 @@ class Tunables(C.Structure):
     """d3f_tunables of include/d3feat_hip.h: the library's knobs (it never reads the environment)."""
     _fields_ = [("atb_task_us", C.c_int32), ("atb_form", C.c_int32), ("atb_first_form_wgs", C.c_int32),
                 ("match_wgs", C.c_int32), ("agg_through_lds", C.c_int32), ("atb_pipe", C.c_int32), ("xw_rows", C.c_int32), ("xw_split", C.c_int32),
-                ("reserved", C.c_int32 * 8)]
+                ("rowgemm_wide", C.c_int32), ("reserved", C.c_int32 * 7)]
 
 
 class AtbProblem(C.Structure):

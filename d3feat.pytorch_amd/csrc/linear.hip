@@ -1079,10 +1079,16 @@ static int rowgemm_launch(const float* X, const float* W, int N, int K, int M, c
 #define D3F_RG(MBW, CS)                                                                                  \
   rowgemm_kernel<MBW, CS, WT, EPI><<<cdiv(N, 16 * (4 / CS)), 256, 0, stream>>>(X, W, N, K, b1, add, b2, slope, Y, \
                                                                                zinit, zn)
+  // 64 / 128 outputs at the many-row level: a lane owns 4 consecutive columns (16-byte accesses of `add` / Y, half the
+  // column groups per row tile) -- 114624 x 32 -> 128 + residual 37.8 -> 32.7 us, grad-input 128 -> 64 37.1 -> 28.2
+  // (profiles/rowgemm_bench.py); with fewer rows the launch has too few workgroups and the narrow dealing wins.
+  // tunables().rowgemm_wide: 0 = by rows, 1 = never, 2 = always.
+  const int rw = tunables().rowgemm_wide;
+  const bool wide = rw == 2 || (rw == 0 && N >= 65536);
   switch (M) {
     case 32: D3F_RG(1, 2); break;
-    case 64: D3F_RG(2, 2); break;
-    case 128: D3F_RG(2, 4); break;
+    case 64: if (wide) D3F_RG(4, 1); else D3F_RG(2, 2); break;
+    case 128: if (wide) D3F_RG(4, 2); else D3F_RG(2, 4); break;
     case 256: D3F_RG(4, 4); break;
     default: return D3F_EINVAL;
   }

@@ -1023,14 +1023,25 @@ def gemm_epilogue(x, w, mode, R, K, N, kblock=0, ldx=None, ldw=None, row_div=Non
     return out
 
 
-# which products go to the own kernel (the others stay library GEMMs): kinds of OWN_GEMM_KINDS, by shape rule
-OWN_GEMM_KINDS = {"kpconv_fwd", "kpconv_dx", "kpconv_gw", "unary_fwd", "unary_dx", "decoder"}
+# which products go to the own kernel (the others stay library GEMMs).  Measured per shape against the library GEMM + its
+# epilogue launch (profiles/gemm_epilogue_bench.py -> profiles/r06_gemm_epilogue_bench.txt) and per kind inside the 4 x 3
+# step (profiles/calls/r06_gemm_kinds_ab.sh): the own kernel wins where the library's pick is poor or the fused epilogue
+# is a large share -- KPConv contractions of the bottom levels (<= 1024 rows x 3840 / 7680: split reduction) and of the
+# many-row levels, unary blocks at >= 16k rows -- and loses on the mid-size square-ish products of levels 2-3 and the
+# decoder, where the library's shared-panel tiles reach 0.65-0.75 of the matrix rate.
+OWN_GEMM_KINDS = {"kpconv_fwd", "unary_fwd", "unary_dx"}
+OWN_GEMM_RULES = True     # False: every product of an enabled kind (A/B measurements)
 
 
 def _own_gemm(kind, x, w, mode, R, K, N, kblock=0, ldx=None, ldw=None, *others):
     """Policy + capability: True when the product `kind` of this shape runs on d3f_gemm_epilogue."""
     if kind not in OWN_GEMM_KINDS:
         return False
+    if OWN_GEMM_RULES:
+        if kind == "kpconv_fwd" and 1024 < R < 4096:
+            return False
+        if kind in ("unary_fwd", "unary_dx") and R < 16384:
+            return False
     return gemm_epilogue_ok(x, w, mode, R, K, N, kblock, ldx, ldw, *others)
 
 

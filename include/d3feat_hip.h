@@ -73,7 +73,9 @@ typedef struct d3f_tunables {
                                * tiles of at least n 16x16 accumulators (A/B measurements) */
   int32_t xw_rows;            /* d3f_gemm_epilogue: 0 = by shape, 2 / 4 = 32- / 64-row output blocks (A/B measurements) */
   int32_t xw_split;           /* d3f_gemm_epilogue: 0 = by shape, 1 = never split the reduction, 8 q = 8 q partitions */
-  int32_t reserved[8];
+  int32_t rowgemm_wide;       /* row-streaming unary kernels, 4 consecutive columns per lane at 64 / 128 outputs: 0 = from 65536 rows,
+                               * 1 = never, 2 = always (A/B measurements) */
+  int32_t reserved[7];
 } d3f_tunables;
 void d3f_get_tunables(d3f_tunables* out);
 int d3f_set_tunables(const d3f_tunables* in);
