@@ -265,10 +265,15 @@ __global__ __launch_bounds__(256) void det_bwd_aux_kernel(const float* __restric
     n = (int)(t / H);
     h = (int)(t % H);
   }
+  // The detector loss reads the scores of the correspondences only (reference utils/loss.py:140-158 on
+  // scores[corr], trainer.py:96-101): the incoming gradient is zero at all but a few hundred of the N points, and a point
+  // without gradient would add +-0 to 1 + H addresses -- nothing, bit for bit (grad_feat starts at 0).  Whole waves leave
+  // here: 233 -> 12 us per 3-pair stack.
+  const float ds = gscore[n];
+  if (ds == 0.0f) return;
   const float4 a0 = *(const float4*)(aux + (size_t)n * 8);      // f*, alpha*, beta*, u*
   const float4 a1 = *(const float4*)(aux + (size_t)n * 8 + 4);  // dmax, num, c*, c'
   const int cstar = __float_as_int(a1.z);
-  const float ds = gscore[n];
   const float sig = a0.w > 20.0f ? 1.0f : 1.0f / (1.0f + expf(-a0.w));
   const float du = ds * a0.z * sig;
   if (h == 0) {
@@ -334,14 +339,17 @@ __device__ __forceinline__ void group_range(const d3f::RowGroups& rg, int cap_ro
   end = (size_t)r1 * C;
 }
 
-// S = sum(df * f), ties = #{feat == fmax}; per group of clouds (blockIdx.y): acc[2 g], acc[2 g + 1]
+// S = sum(df * f), ties = #{feat == fmax}; per group of clouds (blockIdx.y) and block: part[(g * DET_RED_BLOCKS + block) * 2
+// + {0, 1}] -- partial sums, added up in block order by the finalize kernel (no float atomics: the tie term has the same bits
+// on every replay)
+constexpr int DET_RED_BLOCKS = 128;
 __global__ __launch_bounds__(256) void det_reduce_kernel(const float* __restrict__ feat, const float* __restrict__ df,
                                                          int cap_rows, int C, const float* __restrict__ fmax,
-                                                         float* __restrict__ acc /*[2 G]*/, d3f::RowGroups rg) {
+                                                         float* __restrict__ part, d3f::RowGroups rg) {
   size_t beg, n;
   group_range(rg, cap_rows, C, beg, n);
   fmax += blockIdx.y;
-  acc += 2 * blockIdx.y;
+  float* acc = part + ((size_t)blockIdx.y * DET_RED_BLOCKS + blockIdx.x) * 2;
   const float mx = fmaxf(*fmax, 0.0f), denom = mx + 1e-6f;
   float s = 0.0f, t = (blockIdx.x == 0 && threadIdx.x == 0 && mx == 0.0f) ? 1.0f : 0.0f;  // the zero shadow row ties at 0
   for (size_t i = beg + (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
@@ -358,20 +366,38 @@ __global__ __launch_bounds__(256) void det_reduce_kernel(const float* __restrict
   }
   __syncthreads();
   if (threadIdx.x == 0) {
-    atomicAdd(&acc[0], (sh[0][0] + sh[0][1]) + (sh[0][2] + sh[0][3]));
-    atomicAdd(&acc[1], (sh[1][0] + sh[1][1]) + (sh[1][2] + sh[1][3]));
+    acc[0] = (sh[0][0] + sh[0][1]) + (sh[0][2] + sh[0][3]);
+    acc[1] = (sh[1][0] + sh[1][1]) + (sh[1][2] + sh[1][3]);
   }
 }
 
 // grad_feat = df / g  +  [feat == max] * ( -S / g ) / ties        (g = max + 1e-6; d g / d feat flows to the arg-max)
 __global__ void det_finalize_kernel(const float* __restrict__ feat, int cap_rows, int C, const float* __restrict__ fmax,
-                                    const float* __restrict__ acc, float* __restrict__ gfeat, d3f::RowGroups rg) {
+                                    const float* __restrict__ part, int red_blocks, float* __restrict__ gfeat,
+                                    d3f::RowGroups rg) {
   size_t beg, n;
   group_range(rg, cap_rows, C, beg, n);
   fmax += blockIdx.y;
-  acc += 2 * blockIdx.y;
+  part += (size_t)blockIdx.y * DET_RED_BLOCKS * 2;
+  // the reduce kernel's per-block partials in block order: the first wave sums them (two per lane, butterfly), every
+  // workgroup the same way
+  __shared__ float tot[2];
+  if (threadIdx.x < 64) {
+    float s = 0.0f, t = 0.0f;
+    for (int b = threadIdx.x; b < red_blocks; b += 64) {
+      s += part[2 * b];
+      t += part[2 * b + 1];
+    }
+    s = d3f::wave_sum(s);
+    t = d3f::wave_sum(t);
+    if (threadIdx.x == 0) {
+      tot[0] = s;
+      tot[1] = t;
+    }
+  }
+  __syncthreads();
   const float mx = fmaxf(*fmax, 0.0f), denom = mx + 1e-6f;
-  const float tie_term = (-acc[0] / denom) / fmaxf(acc[1], 1.0f);
+  const float tie_term = (-tot[0] / denom) / fmaxf(tot[1], 1.0f);
   for (size_t i = beg + (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
     float gval = gfeat[i] / denom;
     if (feat[i] == mx) gval += tie_term;
@@ -444,7 +470,11 @@ int d3f_detection_scores_forward(const float* feat, int N, int C, const int32_t*
   return D3F_OK;
 }
 
-size_t d3f_detection_scores_ws_bytes(int N, int C) { (void)N; (void)C; return 256; }
+size_t d3f_detection_scores_ws_bytes(int N, int C) {
+  (void)N;
+  (void)C;
+  return 8 * (size_t)DET_RED_BLOCKS * D3F_MAX_BATCH;   // per-block partial sums of every group of clouds
+}
 
 static int det_backward_impl(const float* feat, int N, int C, const int32_t* idx, int H, const float* feat_max,
                              const float* grad_scores, const float* aux, float* grad_feat, const int32_t* len, int B,
@@ -453,25 +483,24 @@ static int det_backward_impl(const float* feat, int N, int C, const int32_t* idx
     return D3F_EINVAL;
   if (len && (B < 1 || B > D3F_MAX_BATCH || group < 1)) return D3F_EINVAL;
   const int G = len ? d3f::cdiv(B, group) : 1;
-  if (ws_bytes < 8 * (size_t)G) return D3F_EWORKSPACE;
+  if (ws_bytes < 8 * (size_t)G * DET_RED_BLOCKS) return D3F_EWORKSPACE;
   if (N == 0) return D3F_OK;
   const d3f::RowGroups rg = {len, B, group};
   hipStream_t stream = (hipStream_t)stream_;
   const size_t n = (size_t)N * C;
   if (d3f::zero_async(grad_feat, sizeof(float) * n, stream) != hipSuccess) return D3F_ELAUNCH;
-  if (d3f::zero_async(ws, 8 * (size_t)G, stream) != hipSuccess) return D3F_ELAUNCH;
   const int grid = d3f::cdiv(N, 4);
   if (aux) det_bwd_aux_kernel<<<d3f::cdiv((long long)N * H, 256), 256, 0, stream>>>(aux, N, C, idx, H, grad_scores, grad_feat);
   else if (C <= 16) det_bwd_kernel<16><<<grid, 256, 0, stream>>>(feat, N, C, idx, H, feat_max, grad_scores, grad_feat, rg);
   else if (C <= 32) det_bwd_kernel<32><<<grid, 256, 0, stream>>>(feat, N, C, idx, H, feat_max, grad_scores, grad_feat, rg);
   else det_bwd_kernel<64><<<grid, 256, 0, stream>>>(feat, N, C, idx, H, feat_max, grad_scores, grad_feat, rg);
   int blocks = d3f::cdiv((long long)n, 256 * 8 * G);
-  if (blocks > 128) blocks = 128;
+  if (blocks > DET_RED_BLOCKS) blocks = DET_RED_BLOCKS;
   if (blocks < 1) blocks = 1;
   det_reduce_kernel<<<dim3(blocks, G), 256, 0, stream>>>(feat, grad_feat, N, C, feat_max, (float*)ws, rg);
   int fblocks = d3f::cdiv((long long)n, 256 * G);
   if (fblocks < 1) fblocks = 1;
-  det_finalize_kernel<<<dim3(fblocks, G), 256, 0, stream>>>(feat, N, C, feat_max, (const float*)ws, grad_feat, rg);
+  det_finalize_kernel<<<dim3(fblocks, G), 256, 0, stream>>>(feat, N, C, feat_max, (const float*)ws, blocks, grad_feat, rg);
   D3F_LAUNCH_CHECK();
   return D3F_OK;
 }

@@ -1900,16 +1900,17 @@ class _DetScoreFn(torch.autograd.Function):
         N, C, H = int(feat.shape[0]), int(feat.shape[1]), int(idx.shape[1])
         gs = grad_scores.contiguous().float()
         gf = torch.empty_like(feat)
-        ws = _ws(256, feat.device)
+        nws = int(_native.lib().d3f_detection_scores_ws_bytes(N, C))
+        ws = _ws(nws, feat.device)
         with _region("detection_bwd[N=%d]" % N, 4 * N * H + 4 * N * H * C + 12 * N * C + 4 * N):
             if ctx.groups is not None:   # stacked pairs: the normaliser's gradient stays inside each pair
                 lens, group = ctx.groups
                 _native.check(_native.lib().d3f_detection_scores_backward_groups(
                     _p(feat), N, C, _p(idx), H, _p(fmax), _p(gs), _p(ctx.aux), _p(gf), _p(lens), int(lens.numel()),
-                    group, _p(ws), 256, _stream()), "d3f_detection_scores_backward_groups")
+                    group, _p(ws), nws, _stream()), "d3f_detection_scores_backward_groups")
             else:
                 _native.check(_native.lib().d3f_detection_scores_backward(_p(feat), N, C, _p(idx), H, _p(fmax), _p(gs),
-                                                                          _p(ctx.aux), _p(gf), _p(ws), 256, _stream()),
+                                                                          _p(ctx.aux), _p(gf), _p(ws), nws, _stream()),
                               "d3f_detection_scores_backward")
         return gf, None, None, None, None, None
 

@@ -481,7 +481,10 @@ int d3f_detection_scores_backward(const float* feat, int N, int C, const int32_t
                                   size_t ws_bytes, void* stream);
 /* the same for stacked reference batches (len [B] + group as in the forward; feat_max [ceil(B/group)]): the gradient
  * through the normaliser stays inside each group -- P fragment pairs stacked into one TRAINING batch keep the
- * per-pair maximum of architectures.py:342 and its arg-max gradient.  ws >= 8 bytes per group. */
+ * per-pair maximum of architectures.py:342 and its arg-max gradient.  ws >= d3f_detection_scores_ws_bytes (per-block partial
+ * sums of every group, added up in a fixed order: no float atomics in the normaliser's gradient).  A point whose incoming
+ * gradient is exactly 0 -- all but the correspondences of the detector loss, utils/loss.py:140-158 -- contributes nothing and
+ * is skipped. */
 int d3f_detection_scores_backward_groups(const float* feat, int N, int C, const int32_t* idx, int H,
                                          const float* feat_max, const float* grad_scores, const float* aux,
                                          float* grad_feat, const int32_t* len, int B, int group, void* ws,
