@@ -455,7 +455,7 @@ _GEMM_DX_MAX_ROWS = 4096
 # (0.15 - 0.2 of the f32 matrix rate, profiles/r04_step_timeline_stack4.txt); as aggregation kernel (registers -> HBM,
 # csrc/kpconv_aggregate.hip) + tall GEMMs every contraction gets 128-row tiles.  Same split for the grad-input over
 # the exact-form reverse table (transposed aggregation + GEMM with the permuted weights).
-_GEMM_PATH_MIN_CIN = 64
+_GEMM_PATH_MIN_CIN = 32      # (round 6: 32 -- the level-0 layers' forward too: 266 -> 207 us alone, +1.2 % inside the 4 x 3 step)
 _GEMM_DX_AGG_MIN_COUT = 64
 
 
@@ -1027,10 +1027,13 @@ def gemm_epilogue(x, w, mode, R, K, N, kblock=0, ldx=None, ldw=None, row_div=Non
 # epilogue launch (profiles/gemm_epilogue_bench.py -> profiles/r06_gemm_epilogue_bench.txt) and per kind inside the 4 x 3
 # step (profiles/calls/r06_gemm_kinds_ab.sh): the own kernel wins where the library's pick is poor or the fused epilogue
 # is a large share -- KPConv contractions of the bottom levels (<= 1024 rows x 3840 / 7680: split reduction) and of the
-# many-row levels, unary blocks at >= 16k rows -- and loses on the mid-size square-ish products of levels 2-3 and the
-# decoder, where the library's shared-panel tiles reach 0.65-0.75 of the matrix rate.
-OWN_GEMM_KINDS = {"kpconv_fwd", "unary_fwd", "unary_dx"}
+# many-row levels -- and loses on the mid-size square-ish products of levels 2-3 and the decoder, where the library's
+# shared-panel tiles reach 0.65-0.75 of the matrix rate.  Inside the step only the KPConv kind pays (+1.0 %); the unary
+# kinds ("unary_fwd", "unary_dx": >= 16k rows by rule), "kpconv_dx", "kpconv_gw" and "decoder" measured 0 ... -1.4 %
+# and stay library GEMMs (the kernel serves them all: tests/test_gpu_ops.py::test_gemm_epilogue_matches_float64).
+OWN_GEMM_KINDS = {"kpconv_fwd"}
 OWN_GEMM_RULES = True     # False: every product of an enabled kind (A/B measurements)
+OWN_GEMM_TALL_ROWS = 1 << 30
 
 
 def _own_gemm(kind, x, w, mode, R, K, N, kblock=0, ldx=None, ldw=None, *others):
@@ -1038,8 +1041,8 @@ def _own_gemm(kind, x, w, mode, R, K, N, kblock=0, ldx=None, ldw=None, *others):
     if kind not in OWN_GEMM_KINDS:
         return False
     if OWN_GEMM_RULES:
-        if kind == "kpconv_fwd" and 1024 < R < 4096:
-            return False
+        if kind == "kpconv_fwd" and not (R <= 1024 or 4096 <= R < 16384 or R >= OWN_GEMM_TALL_ROWS):
+            return False       # (levels 1 and 3 of a 3-pair stack: 43 vs 33 + 5 us and 45 vs 38 + 5 us inside the step)
         if kind in ("unary_fwd", "unary_dx") and R < 16384:
             return False
     return gemm_epilogue_ok(x, w, mode, R, K, N, kblock, ldx, ldw, *others)

@@ -76,7 +76,13 @@ def main():
         return np.concatenate(out)
 
     print("# %d points in %d clouds" % (pts.shape[0], len(frags)))
-    for kind in ("pipeline", "cell", "morton"):
+    kinds = ("pipeline", "cell", "morton")
+    if len(sys.argv) > 1:          # e.g. `gemm32`: the pipeline's order only, KPConv from 32 channels up on the aggregation + GEMM path
+        kinds = ("pipeline",)
+        if sys.argv[1] == "gemm32":
+            ops._GEMM_PATH_MIN_CIN = 32
+            ops._GEMM_DX_AGG_MIN_COUT = 32
+    for kind in kinds:
         o = order(kind)
         p = torch.from_numpy(pts[o]).to(DEV)
         ln = torch.from_numpy(lens).to(DEV)
