@@ -43,7 +43,10 @@ def test_tunables_struct_round_trips_and_rejects_nonsense():
     lib = _native.lib()
     t = _native.Tunables()
     lib.d3f_get_tunables(ctypes.byref(t))
-    assert [getattr(t, n) for n, _ in _native.Tunables._fields_ if n != "reserved"] == [0, 0, 0, 0, 0, 0]
+    names = [n for n, _ in _native.Tunables._fields_ if n != "reserved"]
+    assert names == ["atb_task_us", "atb_form", "atb_first_form_wgs", "match_wgs", "agg_through_lds", "atb_pipe",
+                     "xw_rows", "xw_split", "rowgemm_wide"]
+    assert [getattr(t, n) for n in names] == [0] * len(names)
     assert ctypes.sizeof(t) == 64
     old = _native.set_tunables(atb_task_us=33, atb_form=2)
     lib.d3f_get_tunables(ctypes.byref(t))
@@ -52,9 +55,31 @@ def test_tunables_struct_round_trips_and_rejects_nonsense():
     bad = _native.Tunables()
     bad.atb_form = 7
     assert lib.d3f_set_tunables(ctypes.byref(bad)) == -1
+    for field, value in (("xw_rows", 5), ("xw_split", 65), ("rowgemm_wide", 3)):
+        bad = _native.Tunables()
+        setattr(bad, field, value)
+        assert lib.d3f_set_tunables(ctypes.byref(bad)) == -1, field
     assert lib.d3f_set_tunables(None) == -1
     lib.d3f_get_tunables(ctypes.byref(t))
     assert (t.atb_task_us, t.atb_form) == (0, 0)
+
+
+def test_gemm_epilogue_support_and_workspace_are_host_computations():
+    """d3f_gemm_epilogue_supported / _ws_bytes need no GPU: multiples of 16, the block form only for reduction-contiguous
+    weights in blocks of 64; a split reduction (few rows against a long reduction) asks for its slabs."""
+    lib = _native.lib()
+    assert lib.d3f_gemm_epilogue_supported(512, 7680, 512, 1, 0) == 1
+    assert lib.d3f_gemm_epilogue_supported(1792, 3840, 256, 0, 256) == 1
+    assert lib.d3f_gemm_epilogue_supported(1792, 3840, 256, 1, 256) == 0
+    assert lib.d3f_gemm_epilogue_supported(1792, 3840, 250, 0, 0) == 0
+    assert lib.d3f_gemm_epilogue_supported(0, 64, 64, 0, 0) == 0
+    assert lib.d3f_gemm_epilogue_ws_bytes(512, 7680, 512) >= 8 * 512 * 512 * 4       # 8 partitions of the reduction
+    assert lib.d3f_gemm_epilogue_ws_bytes(114624, 128, 32) == 256                      # undivided: no slabs
+    old = _native.set_tunables(xw_split=1)
+    try:
+        assert lib.d3f_gemm_epilogue_ws_bytes(512, 7680, 512) == 256
+    finally:
+        _native.set_tunables(**old)
 
 
 def test_grouped_weight_gradient_plan_is_a_host_computation():
