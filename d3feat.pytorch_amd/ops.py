@@ -1045,6 +1045,8 @@ def _own_gemm(kind, x, w, mode, R, K, N, kblock=0, ldx=None, ldw=None, *others):
             return False       # (levels 1 and 3 of a 3-pair stack: 43 vs 33 + 5 us and 45 vs 38 + 5 us inside the step)
         if kind in ("unary_fwd", "unary_dx") and R < 16384:
             return False
+        if kind == "kpconv_dx" and R > 1024:
+            return False
     return gemm_epilogue_ok(x, w, mode, R, K, N, kblock, ldx, ldw, *others)
 
 
