@@ -92,6 +92,7 @@ SIGNATURES = {
     "d3f_linear_grad_weight_ws_bytes": (_sz, [_i, _i, _i]),
     "d3f_linear_grad_weight": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _sz, _vp]),
     "d3f_linear_grad_weight_bias": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _sz, _vp, _i, _i, _vp, _vp, _vp]),
+    "d3f_permute_kpconv_weights": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _vp]),
     "d3f_gemm_epilogue_supported": (_i, [_i, _i, _i, _i, _i]),
     "d3f_gemm_epilogue_ws_bytes": (_sz, [_i, _i, _i]),
     "d3f_gemm_epilogue": (_i, [_vp, _i, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _i, _vp, _f, _vp, _i, _vp, _i, _vp, _sz,

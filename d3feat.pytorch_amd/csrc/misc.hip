@@ -31,6 +31,36 @@ __global__ __launch_bounds__(256) void copy_many_kernel(CopyJobs jobs) {
   }
 }
 
+// One launch for the permuted copies W'[k][o][c] = W[k][c][o] of several KPConv weight tensors [K, Cin, Cout] (what the
+// transposed-aggregation grad-input contracts with: reference autograd of torch.matmul(weighted_features, self.weights),
+// models/blocks.py:369-374, seen from the supports).  Job j by the workgroups with blockIdx.y == j; a workgroup moves
+// 32 x 32 tiles through LDS (both sides coalesced), tile t of a job = (k, c-tile, o-tile).
+struct PermuteJobs {
+  const float* src[16];
+  float* dst[16];
+  int K[16], Cin[16], Cout[16];
+};
+__global__ __launch_bounds__(256) void permute_weights_kernel(PermuteJobs jobs) {
+  __shared__ float tile[32][33];
+  const int j = blockIdx.y;
+  const int K = jobs.K[j], Cin = jobs.Cin[j], Cout = jobs.Cout[j];
+  const int tc = Cin / 32, to = Cout / 32, ntiles = K * tc * to;
+  const float* src = jobs.src[j];
+  float* dst = jobs.dst[j];
+  const int lx = threadIdx.x & 31, ly = threadIdx.x >> 5;     // 32 x 8 threads
+  for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
+    const int k = t / (tc * to), r = t - k * tc * to, ct = r / to, ot = r - ct * to;
+    const float* s = src + ((size_t)k * Cin + ct * 32) * Cout + ot * 32;
+    float* d = dst + ((size_t)k * Cout + ot * 32) * Cin + ct * 32;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) tile[ly + 8 * i][lx] = s[(size_t)(ly + 8 * i) * Cout + lx];     // tile[c][o]
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) d[(size_t)(ly + 8 * i) * Cin + lx] = tile[lx][ly + 8 * i];        // dst[o][c]
+    __syncthreads();
+  }
+}
+
 }  // namespace
 
 namespace d3f {
@@ -81,6 +111,33 @@ int d3f_copy_buffers(const void* const* srcs, void* const* dsts, const size_t* b
   if (blocks > 256) blocks = 256;
   if (blocks < 1) blocks = 1;
   copy_many_kernel<<<dim3((unsigned)blocks, (unsigned)m), 256, 0, (hipStream_t)stream>>>(jobs);
+  D3F_LAUNCH_CHECK();
+  return D3F_OK;
+}
+
+int d3f_permute_kpconv_weights(const float* const* srcs, float* const* dsts, const int* K, const int* Cin,
+                               const int* Cout, int n, void* stream) {
+  if (n < 0 || n > 16 || (n > 0 && (!srcs || !dsts || !K || !Cin || !Cout))) return D3F_EINVAL;
+  if (n == 0) return D3F_OK;
+  PermuteJobs jobs;
+  long long most = 0;
+  for (int j = 0; j < n; ++j) {
+    if (!srcs[j] || !dsts[j] || K[j] < 1 || Cin[j] < 32 || Cout[j] < 32 || Cin[j] % 32 || Cout[j] % 32) return D3F_EINVAL;
+    jobs.src[j] = srcs[j];
+    jobs.dst[j] = dsts[j];
+    jobs.K[j] = K[j];
+    jobs.Cin[j] = Cin[j];
+    jobs.Cout[j] = Cout[j];
+    const long long tiles = (long long)K[j] * (Cin[j] / 32) * (Cout[j] / 32);
+    if (tiles > most) most = tiles;
+  }
+  for (int j = n; j < 16; ++j) {
+    jobs.src[j] = nullptr;
+    jobs.dst[j] = nullptr;
+    jobs.K[j] = jobs.Cin[j] = jobs.Cout[j] = 0;
+  }
+  const unsigned blocks = (unsigned)(most > 512 ? 512 : most);
+  permute_weights_kernel<<<dim3(blocks, (unsigned)n), 256, 0, (hipStream_t)stream>>>(jobs);
   D3F_LAUNCH_CHECK();
   return D3F_OK;
 }

@@ -3,6 +3,9 @@ has it).  Every function here launches hand-written HIP kernels from ``libd3feat
 CPU fallback.  Reference locations are cited per operator.
 """
 import numpy as np
+import ctypes
+import threading
+
 import torch
 
 from . import _native
@@ -598,6 +601,59 @@ class _KPConvFn(torch.autograd.Function):
         return None, None, None, gx, None, (_adoptable(gw, ctx.gw_slot) if gw is not None else None), None, None, None
 
 
+# The transposed-aggregation grad-input contracts with the permuted weights W'[k, o, c] = W[k, c, o].  One
+# permute + copy launch per layer (9 per 3-pair stack, 63 us) became ONE launch per backward pass: the forward of every
+# such layer queues its weights, the first grad-input that needs a permuted matrix launches d3f_permute_kpconv_weights
+# for the whole queue.  Per host thread (every lane captures on a thread of its own).  False: one launch per layer.
+BATCH_WEIGHT_PERMUTES = True
+_WPERM = threading.local()
+
+
+def _wperm_state():
+    st = getattr(_WPERM, 'st', None)
+    if st is None:
+        st = _WPERM.st = {'queue': {}, 'ready': {}}
+    return st
+
+
+def _queue_weight_permute(weights):
+    st = _wperm_state()
+    key = weights.data_ptr()
+    st['ready'].pop(key, None)          # (a new forward: whatever an earlier backward left behind is stale)
+    if len(st['queue']) >= 64:          # forwards without a backward: start over
+        st['queue'].clear()
+    st['queue'][key] = weights
+
+
+def _permuted_weights(weights):
+    """W' [K * Cout, Cin] of ``weights`` [K, Cin, Cout]."""
+    K, Cin, Cout = int(weights.shape[0]), int(weights.shape[1]), int(weights.shape[2])
+    st = _wperm_state()
+    key = weights.data_ptr()
+    wp = st['ready'].pop(key, None)
+    if wp is None and BATCH_WEIGHT_PERMUTES and key in st['queue']:
+        jobs = [w for w in st['queue'].values() if w.shape[1] % 32 == 0 and w.shape[2] % 32 == 0 and w.is_contiguous()]
+        st['queue'].clear()
+        st['ready'].clear()
+        for j0 in range(0, len(jobs), 16):
+            part = jobs[j0:j0 + 16]
+            outs = [torch.empty((w.shape[0] * w.shape[2], w.shape[1]), dtype=torch.float32, device=w.device) for w in part]
+            n = len(part)
+            srcs = (ctypes.c_void_p * n)(*[w.data_ptr() for w in part])
+            dsts = (ctypes.c_void_p * n)(*[o.data_ptr() for o in outs])
+            ks = (ctypes.c_int * n)(*[int(w.shape[0]) for w in part])
+            cis = (ctypes.c_int * n)(*[int(w.shape[1]) for w in part])
+            cos = (ctypes.c_int * n)(*[int(w.shape[2]) for w in part])
+            _native.check(_native.lib().d3f_permute_kpconv_weights(srcs, dsts, ks, cis, cos, n, _stream()),
+                          "d3f_permute_kpconv_weights")
+            for w, o in zip(part, outs):
+                st['ready'][w.data_ptr()] = o
+        wp = st['ready'].pop(key, None)
+    if wp is None:
+        wp = weights.permute(0, 2, 1).contiguous().view(K * Cout, Cin)
+    return wp
+
+
 class _KPConvGemmBiasActFn(torch.autograd.Function):
     """act(KPConv(x) + bias) for the few-point / wide layers (bottom of the U-Net), as
         aggregation kernel -> wf [Nq, K*Cin], nn      library GEMM  raw = wf @ W       epilogue  act(raw/nn + bias)
@@ -649,6 +705,9 @@ class _KPConvGemmBiasActFn(torch.autograd.Function):
         ctx.save_for_backward(q_pts, s_pts, idx, x, kernel_points, weights, nn, wf, out)
         ctx.gbuf, ctx.extent, ctx.slope, ctx.want_b = gbuf, float(extent), float(slope), want_b
         ctx.gw_slot = _grad_slot(weights)
+        if BATCH_WEIGHT_PERMUTES and ctx.needs_input_grad[3] and rev is not None and rev.rel is not None and \
+                Cout >= _GEMM_DX_AGG_MIN_COUT and L.d3f_kpconv_aggregate_transposed_supported(Cout, K):
+            _queue_weight_permute(weights)      # (its grad-input contracts with W': one launch for all such layers)
         return out
 
     @staticmethod
@@ -696,8 +755,7 @@ class _KPConvGemmBiasActFn(torch.autograd.Function):
                 # W' read in place from W [K, Cin, Cout] (block form of the reduction): no permuted copy of the weights
                 gx = gemm_epilogue(agg, weights, GEMM_NT, Ns, K * Cout, Cin, kblock=Cout)
             else:
-                wp = weights.permute(0, 2, 1).contiguous().view(K * Cout, Cin)
-                gx = torch.mm(agg, wp)
+                gx = torch.mm(agg, _permuted_weights(weights))
         elif ctx.needs_input_grad[3] and rev is not None:
             # gather form: one launch instead of the gW GEMM + atomic scatter (gon is already / nn)
             gx = torch.empty_like(x)

@@ -284,6 +284,12 @@ int d3f_linear_bias_act_forward(const float* x, const float* weight, int N, int 
  * produced for the same tensor, accumulated in the epilogue instead of by a separate launch) */
 int d3f_linear_grad_input(const float* grad_out, const float* weight, int N, int Cin, int Cout, const float* add,
                           float* grad_x, void* stream);
+/* W'[k][o][c] = W[k][c][o] for up to 16 KPConv weight tensors [K, Cin, Cout] in ONE launch (Cin, Cout multiples of 32):
+ * the permuted matrices the transposed-aggregation grad-input contracts with -- autograd's grad of
+ * torch.matmul(weighted_features, self.weights) (models/blocks.py:369-374) w.r.t. the features, seen from the supports.
+ * All pointer / size arrays are HOST arrays of n entries; the tensors are device memory. */
+int d3f_permute_kpconv_weights(const float* const* srcs_host, float* const* dsts_host, const int* K_host,
+                               const int* Cin_host, const int* Cout_host, int n, void* stream);
 /* The contractions of the wide / few-row layers with their epilogue, y [R,N] = act(x [R,K] . B / row_div + bias1 + add +
  * bias2), as ONE f32-MFMA launch (two when the reduction is split: few rows against a long reduction) -- what the
  * reference computes as torch.matmul followed by separate bias / residual / LeakyReLU ops:

@@ -681,6 +681,48 @@ def test_gemm_epilogue_matches_float64(rows, split):
         _native.set_tunables(**old)
 
 
+def test_batched_weight_permute_equals_torch_and_one_launch_serves_a_backward():
+    """d3f_permute_kpconv_weights: W'[k, o, c] = W[k, c, o] for several KPConv weight tensors in one launch == torch's
+    permute; ops._permuted_weights launches it once for every queued layer and never hands out a copy of an earlier step."""
+    import ctypes
+    rng = np.random.default_rng(4)
+    ws = [torch.from_numpy(rng.normal(size=shp).astype(np.float32)).cuda()
+          for shp in [(15, 64, 64), (15, 128, 128), (3, 32, 96), (15, 256, 256), (1, 32, 32)]]
+    n = len(ws)
+    outs = [torch.empty((w.shape[0] * w.shape[2], w.shape[1]), device="cuda") for w in ws]
+    arr = lambda t, v: (t * n)(*v)
+    rc = _native.lib().d3f_permute_kpconv_weights(
+        arr(ctypes.c_void_p, [w.data_ptr() for w in ws]), arr(ctypes.c_void_p, [o.data_ptr() for o in outs]),
+        arr(ctypes.c_int, [w.shape[0] for w in ws]), arr(ctypes.c_int, [w.shape[1] for w in ws]),
+        arr(ctypes.c_int, [w.shape[2] for w in ws]), n, torch.cuda.current_stream().cuda_stream)
+    assert rc == 0
+    for w, o in zip(ws, outs):
+        assert torch.equal(o, w.permute(0, 2, 1).contiguous().view(o.shape))
+    # the queue: three layers registered by their forward, the first request serves all of them
+    st = ops._wperm_state()
+    st['queue'].clear()                               # (whatever earlier tests' forwards without a backward left behind)
+    st['ready'].clear()
+    for w in ws[:3]:
+        ops._queue_weight_permute(w)
+    first = ops._permuted_weights(ws[1])
+    assert torch.equal(first, ws[1].permute(0, 2, 1).contiguous().view(first.shape))
+    assert len(st['queue']) == 0 and set(st['ready']) == {ws[0].data_ptr(), ws[2].data_ptr()}
+    assert torch.equal(ops._permuted_weights(ws[0]), outs[0]) and ws[0].data_ptr() not in st['ready']
+    ws[2].mul_(2.0)                                   # a new step: the weights changed, the forward queues them again
+    ops._queue_weight_permute(ws[2])
+    assert ws[2].data_ptr() not in st['ready']        # the stale copy is gone
+    again = ops._permuted_weights(ws[2])
+    assert torch.equal(again, ws[2].permute(0, 2, 1).contiguous().view(again.shape))
+    assert torch.equal(ops._permuted_weights(ws[3]), outs[3])      # never queued: permuted on the spot
+    # bad arguments
+    assert _native.lib().d3f_permute_kpconv_weights(None, None, None, None, None, 1, None) == -1
+    bad = torch.zeros((2, 48, 32), device="cuda")      # Cin no multiple of 32
+    assert _native.lib().d3f_permute_kpconv_weights(
+        (ctypes.c_void_p * 1)(bad.data_ptr()), (ctypes.c_void_p * 1)(outs[0].data_ptr()), (ctypes.c_int * 1)(2),
+        (ctypes.c_int * 1)(48), (ctypes.c_int * 1)(32), 1, torch.cuda.current_stream().cuda_stream) == -1
+    torch.cuda.synchronize()
+
+
 def test_gemm_epilogue_rejects_bad_arguments():
     L = _native.lib()
     assert not L.d3f_gemm_epilogue_supported(100, 24, 64, 0, 0)        # K no multiple of 16
