@@ -604,25 +604,26 @@ class _KPConvFn(torch.autograd.Function):
 # The transposed-aggregation grad-input contracts with the permuted weights W'[k, o, c] = W[k, c, o].  One
 # permute + copy launch per layer (9 per 3-pair stack, 63 us) became ONE launch per backward pass: the forward of every
 # such layer queues its weights, the first grad-input that needs a permuted matrix launches d3f_permute_kpconv_weights
-# for the whole queue.  Per host thread (every lane captures on a thread of its own).  False: one launch per layer.
+# for the whole queue.  The queue is process-wide, not per thread: a forward on the calling thread is followed by its
+# backward on autograd's device thread (or, for a lane, on the lane's capture thread); steps are recorded / run one at a
+# time, the lock only keeps the two dictionaries consistent.  False: one launch per layer.
 BATCH_WEIGHT_PERMUTES = True
-_WPERM = threading.local()
+_WPERM = {'queue': {}, 'ready': {}}
+_WPERM_LOCK = threading.Lock()
 
 
 def _wperm_state():
-    st = getattr(_WPERM, 'st', None)
-    if st is None:
-        st = _WPERM.st = {'queue': {}, 'ready': {}}
-    return st
+    return _WPERM
 
 
 def _queue_weight_permute(weights):
     st = _wperm_state()
     key = weights.data_ptr()
-    st['ready'].pop(key, None)          # (a new forward: whatever an earlier backward left behind is stale)
-    if len(st['queue']) >= 64:          # forwards without a backward: start over
-        st['queue'].clear()
-    st['queue'][key] = weights
+    with _WPERM_LOCK:
+        st['ready'].pop(key, None)          # (a new forward: whatever an earlier backward left behind is stale)
+        if len(st['queue']) >= 64:          # forwards without a backward: start over
+            st['queue'].clear()
+        st['queue'][key] = weights
 
 
 def _permuted_weights(weights):
@@ -630,11 +631,15 @@ def _permuted_weights(weights):
     K, Cin, Cout = int(weights.shape[0]), int(weights.shape[1]), int(weights.shape[2])
     st = _wperm_state()
     key = weights.data_ptr()
-    wp = st['ready'].pop(key, None)
-    if wp is None and BATCH_WEIGHT_PERMUTES and key in st['queue']:
-        jobs = [w for w in st['queue'].values() if w.shape[1] % 32 == 0 and w.shape[2] % 32 == 0 and w.is_contiguous()]
-        st['queue'].clear()
-        st['ready'].clear()
+    with _WPERM_LOCK:
+        wp = st['ready'].pop(key, None)
+        jobs = []
+        if wp is None and BATCH_WEIGHT_PERMUTES and key in st['queue']:
+            jobs = [w for w in st['queue'].values()
+                    if w.shape[1] % 32 == 0 and w.shape[2] % 32 == 0 and w.is_contiguous() and w.device == weights.device]
+            st['queue'].clear()
+            st['ready'].clear()
+    if jobs:
         for j0 in range(0, len(jobs), 16):
             part = jobs[j0:j0 + 16]
             outs = [torch.empty((w.shape[0] * w.shape[2], w.shape[1]), dtype=torch.float32, device=w.device) for w in part]
@@ -646,9 +651,11 @@ def _permuted_weights(weights):
             cos = (ctypes.c_int * n)(*[int(w.shape[2]) for w in part])
             _native.check(_native.lib().d3f_permute_kpconv_weights(srcs, dsts, ks, cis, cos, n, _stream()),
                           "d3f_permute_kpconv_weights")
-            for w, o in zip(part, outs):
-                st['ready'][w.data_ptr()] = o
-        wp = st['ready'].pop(key, None)
+            with _WPERM_LOCK:
+                for w, o in zip(part, outs):
+                    st['ready'][w.data_ptr()] = o
+        with _WPERM_LOCK:
+            wp = st['ready'].pop(key, None)
     if wp is None:
         wp = weights.permute(0, 2, 1).contiguous().view(K * Cout, Cin)
     return wp
