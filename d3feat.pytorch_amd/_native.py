@@ -21,7 +21,7 @@ class Tunables(C.Structure):
     """d3f_tunables of include/d3feat_hip.h: the library's knobs (it never reads the environment)."""
     _fields_ = [("atb_task_us", C.c_int32), ("atb_form", C.c_int32), ("atb_first_form_wgs", C.c_int32),
                 ("match_wgs", C.c_int32), ("agg_through_lds", C.c_int32), ("atb_pipe", C.c_int32), ("xw_rows", C.c_int32), ("xw_split", C.c_int32),
-                ("rowgemm_wide", C.c_int32), ("reserved", C.c_int32 * 7)]
+                ("rowgemm_wide", C.c_int32), ("rowgemm_rt", C.c_int32), ("reserved", C.c_int32 * 6)]
 
 
 class AtbProblem(C.Structure):
@@ -88,6 +88,8 @@ SIGNATURES = {
     "d3f_linear_grad_weight_supported": (_i, [_i, _i, _i]),
     "d3f_linear_fused_supported": (_i, [_i, _i, _i]),
     "d3f_linear_bias_act_forward": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp, _f, _vp, _vp, _i, _vp]),
+    "d3f_linear_pair_supported": (_i, [_i, _i, _i, _i]),
+    "d3f_linear_pair_bias_act_forward": (_i, [_vp, _vp, _i, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _f, _vp, _vp, _i, _vp]),
     "d3f_linear_grad_input": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp]),
     "d3f_linear_grad_weight_ws_bytes": (_sz, [_i, _i, _i]),
     "d3f_linear_grad_weight": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _sz, _vp]),

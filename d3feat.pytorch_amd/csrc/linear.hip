@@ -1069,6 +1069,129 @@ __global__ __launch_bounds__(256) void rowgemm_kernel(const float* __restrict__ 
   }
 }
 
+// The FORWARD product for the many-row layers with a short reduction (K = 16 KT <= 64): the weight fragments of the wave's
+// column group stay in REGISTERS (KT x MBW x 4 values per lane) while the wave walks two consecutive 16-row tiles, and the
+// second tile's x fragments and `add` rows are requested before the first tile's MFMAs.  rowgemm_kernel re-reads its
+// weights from L2 for every 16 rows with the loads right in front of the MFMAs that need them: bound by L2 latency per
+// k-step, not by HBM -- 114624 x 32 -> 128 + residual 32.7 -> 25.8 us (5.1 TB/s), 114624 x 64 -> 32 18.8 -> 15.2,
+// 23808 x 64 -> 256 + residual 23.9 -> 18.7 (profiles/rowgemm_bench.py; four tiles per wave: the same; the grad-input
+// products, with their longer reductions, gain nothing and keep rowgemm_kernel).
+// KT2 > 0: a SECOND product into the same output, Y = act(X W^T + X2 W2^T + b1 + b2 + b3 + b4) -- the last unary block
+// of a bottleneck and its shortcut unary (reference models/blocks.py:658-686) as one launch: the [N, M] shortcut tensor is
+// never written and read back.
+template <int MBW, int CS, int KT, int KT2>
+__global__ __launch_bounds__(256) void rowgemm_rt_kernel(const float* __restrict__ X, const float* __restrict__ W,
+                                                         const float* __restrict__ X2, const float* __restrict__ W2,
+                                                         int N, const float* __restrict__ b1,
+                                                         const float* __restrict__ add, const float* __restrict__ b2,
+                                                         const float* __restrict__ b3, const float* __restrict__ b4,
+                                                         float slope, float* __restrict__ Y, float* __restrict__ zinit,
+                                                         int zn) {
+  constexpr int M = 16 * MBW * CS, K = 16 * KT, K2 = 16 * KT2, RT = 2;
+  typedef typename VecT<MBW>::type VO;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int li = lane & 15, lk = lane >> 4;
+  if (zinit && blockIdx.x == 0)
+    for (int t = threadIdx.x; t < zn; t += blockDim.x) zinit[t] = 0.0f;
+  const int tile0 = (blockIdx.x * (4 / CS) + wave / CS) * RT;     // first of the wave's RT row tiles
+  const int c0 = (wave % CS) * 16 * MBW;
+  if (tile0 * 16 >= N) return;
+  const int cbase = c0 + MBW * li;
+  // weight fragments: wq[kt][nb][t] = W[cbase + nb][16 kt + 4 lk + t]
+  float wq[KT + KT2][MBW][4];
+#pragma unroll
+  for (int kt = 0; kt < KT + KT2; ++kt)
+#pragma unroll
+    for (int nb = 0; nb < MBW; ++nb) {
+      const float4 b = kt < KT ? *(const float4*)(W + (size_t)(cbase + nb) * K + 16 * kt + 4 * lk)
+                               : *(const float4*)(W2 + (size_t)(cbase + nb) * K2 + 16 * (kt - KT) + 4 * lk);
+      wq[kt][nb][0] = b.x; wq[kt][nb][1] = b.y; wq[kt][nb][2] = b.z; wq[kt][nb][3] = b.w;
+    }
+  float bias1[MBW], bias2[MBW];
+#pragma unroll
+  for (int nb = 0; nb < MBW; ++nb) {
+    bias1[nb] = b1 ? b1[cbase + nb] : 0.0f;
+    bias2[nb] = b2 ? b2[cbase + nb] : 0.0f;
+    if (KT2 > 0) {   // (b1 + b2) + (b3 + b4): the separate launches add b1, then the shortcut (which carries b3 + b4), then b2
+      bias1[nb] = (bias1[nb] + bias2[nb]) + ((b3 ? b3[cbase + nb] : 0.0f) + (b4 ? b4[cbase + nb] : 0.0f));
+      bias2[nb] = 0.0f;
+    }
+  }
+  auto load_x = [&](int tile, float4 (&a)[KT + KT2]) {
+    const size_t row = (size_t)min(tile * 16 + li, N - 1);
+#pragma unroll
+    for (int kt = 0; kt < KT + KT2; ++kt)
+      a[kt] = kt < KT ? *(const float4*)(X + row * K + 4 * lk + 16 * kt)
+                      : *(const float4*)(X2 + row * K2 + 4 * lk + 16 * (kt - KT));
+  };
+  auto load_add = [&](int tile, VO (&av)[4]) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = min(tile * 16 + 4 * lk + r, N - 1);
+      av[r] = *(const VO*)(add + (size_t)row * M + cbase);
+    }
+  };
+  float4 a[KT + KT2], an[KT + KT2];
+  VO av[4], avn[4];
+  load_x(tile0, a);
+  if (add) load_add(tile0, av);
+#pragma unroll
+  for (int rt = 0; rt < RT; ++rt) {
+    const int tile = tile0 + rt;
+    if (tile * 16 >= N) break;
+    const bool more = rt + 1 < RT && (tile + 1) * 16 < N;
+    if (more) {                      // the next tile's operands are on their way during this tile's MFMAs
+      load_x(tile + 1, an);
+      if (add) load_add(tile + 1, avn);
+    }
+    f32x4 acc[MBW];
+#pragma unroll
+    for (int nb = 0; nb < MBW; ++nb) acc[nb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kt = 0; kt < KT + KT2; ++kt)
+#pragma unroll
+      for (int nb = 0; nb < MBW; ++nb) {
+        acc[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[kt].x, wq[kt][nb][0], acc[nb], 0, 0, 0);
+        acc[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[kt].y, wq[kt][nb][1], acc[nb], 0, 0, 0);
+        acc[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[kt].z, wq[kt][nb][2], acc[nb], 0, 0, 0);
+        acc[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[kt].w, wq[kt][nb][3], acc[nb], 0, 0, 0);
+      }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = tile * 16 + 4 * lk + r;
+      if (row < N) {
+        float v[MBW];
+#pragma unroll
+        for (int nb = 0; nb < MBW; ++nb) v[nb] = acc[nb][r];
+        if (b1 || KT2 > 0) {
+#pragma unroll
+          for (int nb = 0; nb < MBW; ++nb) v[nb] += bias1[nb];
+        }
+        if (add) {
+#pragma unroll
+          for (int nb = 0; nb < MBW; ++nb) v[nb] += vget<MBW>(av[r], nb);
+        }
+        if (b2 && KT2 == 0) {
+#pragma unroll
+          for (int nb = 0; nb < MBW; ++nb) v[nb] += bias2[nb];
+        }
+#pragma unroll
+        for (int nb = 0; nb < MBW; ++nb) v[nb] = v[nb] > 0.0f ? v[nb] : v[nb] * slope;
+        float* dst = Y + (size_t)row * M + cbase;
+        if constexpr (MBW == 4) *(float4*)dst = make_float4(v[0], v[MBW > 1 ? 1 : 0], v[MBW > 2 ? 2 : 0], v[MBW > 3 ? 3 : 0]);
+        else if constexpr (MBW == 2) *(float2*)dst = make_float2(v[0], v[MBW > 1 ? 1 : 0]);
+        else dst[0] = v[0];
+      }
+    }
+    if (more) {
+#pragma unroll
+      for (int kt = 0; kt < KT + KT2; ++kt) a[kt] = an[kt];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) av[r] = avn[r];
+    }
+  }
+}
+
 bool rowgemm_supported(int N, int K, int M) {
   return N >= 1 && K >= 16 && K % 16 == 0 && K <= 1024 && (M == 32 || M == 64 || M == 128 || M == 256);
 }
@@ -1085,6 +1208,26 @@ static int rowgemm_launch(const float* X, const float* W, int N, int K, int M, c
   // tunables().rowgemm_wide: 0 = by rows, 1 = never, 2 = always.
   const int rw = tunables().rowgemm_wide;
   const bool wide = rw == 2 || (rw == 0 && N >= 65536);
+  // forward with a short reduction: weights in registers over two row tiles per wave (rowgemm_rt_kernel).
+  // tunables().rowgemm_rt: 0 = from 4096 rows, 1 = never
+  const int kt = K / 16;
+  if (WT && EPI && tunables().rowgemm_rt != 1 && N >= 4096 && (kt == 1 || kt == 2 || kt == 4)) {
+#define D3F_RGT2(MBW, CS, KT) \
+  rowgemm_rt_kernel<MBW, CS, KT, 0><<<cdiv(N, 32 * (4 / CS)), 256, 0, stream>>>(X, W, nullptr, nullptr, N, b1, add, b2, nullptr, nullptr, slope, Y, zinit, zn)
+#define D3F_RGT(MBW, CS) \
+  do { if (kt == 1) D3F_RGT2(MBW, CS, 1); else if (kt == 2) D3F_RGT2(MBW, CS, 2); else D3F_RGT2(MBW, CS, 4); } while (0)
+    switch (M) {
+      case 32: D3F_RGT(1, 2); break;
+      case 64: if (wide) D3F_RGT(4, 1); else D3F_RGT(2, 2); break;
+      case 128: if (wide) D3F_RGT(4, 2); else D3F_RGT(2, 4); break;
+      case 256: D3F_RGT(4, 4); break;
+      default: return D3F_EINVAL;
+    }
+#undef D3F_RGT
+#undef D3F_RGT2
+    D3F_LAUNCH_CHECK();
+    return D3F_OK;
+  }
   switch (M) {
     case 32: D3F_RG(1, 2); break;
     case 64: if (wide) D3F_RG(4, 1); else D3F_RG(2, 2); break;
@@ -1093,6 +1236,31 @@ static int rowgemm_launch(const float* X, const float* W, int N, int K, int M, c
     default: return D3F_EINVAL;
   }
 #undef D3F_RG
+  D3F_LAUNCH_CHECK();
+  return D3F_OK;
+}
+
+// unary2 + shortcut unary of a bottleneck in one launch (rowgemm_rt_kernel with KT2 > 0): served while both weight
+// matrices fit the registers -- the level-0 bottleneck (32 | 64 -> 128 channels) and its half-width kin
+bool rowgemm_pair_supported(int N, int K1, int K2, int M) {
+  return N >= 4096 && ((M == 128 && K1 == 32 && K2 == 64) || (M == 64 && K1 == 16 && K2 == 32));
+}
+
+static int rowgemm_pair_launch(const float* X1, const float* W1, int K1, const float* X2, const float* W2, int K2, int N,
+                               int M, const float* b1, const float* b2, const float* b3, const float* b4, float slope,
+                               float* Y, float* zinit, int zn, hipStream_t stream) {
+  if (!rowgemm_pair_supported(N, K1, K2, M)) return D3F_EINVAL;
+  const int rw = tunables().rowgemm_wide;
+  const bool wide = rw == 2 || (rw == 0 && N >= 65536);
+#define D3F_RGPT(MBW, CS, KA, KB)                                                                                      \
+  rowgemm_rt_kernel<MBW, CS, KA, KB><<<cdiv(N, 32 * (4 / CS)), 256, 0, stream>>>(X1, W1, X2, W2, N, b1, nullptr, b2, b3, \
+                                                                                  b4, slope, Y, zinit, zn)
+  if (M == 128) {
+    if (wide) D3F_RGPT(4, 2, 2, 4); else D3F_RGPT(2, 4, 2, 4);
+  } else {
+    if (wide) D3F_RGPT(4, 1, 1, 2); else D3F_RGPT(2, 2, 1, 2);
+  }
+#undef D3F_RGPT
   D3F_LAUNCH_CHECK();
   return D3F_OK;
 }
@@ -1165,6 +1333,21 @@ int d3f_linear_bias_act_forward(const float* x, const float* weight, int N, int 
   if (!x || !weight || !out || !d3f::rowgemm_supported(N, Cin, Cout) || (zero_init && zero_n < 1)) return D3F_EINVAL;
   return d3f::rowgemm_launch<true, true>(x, weight, N, Cin, Cout, bias1, add, bias2, slope, out, zero_init, zero_n,
                                          (hipStream_t)stream);
+}
+
+int d3f_linear_pair_supported(int N, int Cin1, int Cin2, int Cout) {
+  return d3f::rowgemm_pair_supported(N, Cin1, Cin2, Cout) ? 1 : 0;
+}
+
+/* out [N,Cout] = act(x1 [N,Cin1] @ w1[Cout,Cin1]^T + x2 [N,Cin2] @ w2[Cout,Cin2]^T + bias1 + bias2 + bias3 + bias4) */
+int d3f_linear_pair_bias_act_forward(const float* x1, const float* w1, int Cin1, const float* x2, const float* w2, int Cin2,
+                                     int N, int Cout, const float* bias1, const float* bias2, const float* bias3,
+                                     const float* bias4, float slope, float* out, float* zero_init, int zero_n,
+                                     void* stream) {
+  if (!x1 || !w1 || !x2 || !w2 || !out || !d3f::rowgemm_pair_supported(N, Cin1, Cin2, Cout) || (zero_init && zero_n < 1))
+    return D3F_EINVAL;
+  return d3f::rowgemm_pair_launch(x1, w1, Cin1, x2, w2, Cin2, N, Cout, bias1, bias2, bias3, bias4, slope, out, zero_init,
+                                  zero_n, (hipStream_t)stream);
 }
 
 /* grad_x [N,Cin] = grad_out [N,Cout] @ weight [Cout,Cin] (+ add [N,Cin], optional) */

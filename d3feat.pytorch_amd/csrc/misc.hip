@@ -76,7 +76,8 @@ void d3f_get_tunables(d3f_tunables* out) {
 int d3f_set_tunables(const d3f_tunables* in) {
   if (!in || in->atb_task_us < 0 || in->atb_form < 0 || in->atb_form > 2 || in->atb_first_form_wgs < 0 ||
       in->match_wgs < 0 || in->atb_pipe < 0 || in->atb_pipe > 16 || in->xw_rows < 0 || in->xw_rows > 4 || in->xw_split < 0 ||
-      in->xw_split > 64 || in->rowgemm_wide < 0 || in->rowgemm_wide > 2)
+      in->xw_split > 64 || in->rowgemm_wide < 0 || in->rowgemm_wide > 2 ||
+      in->rowgemm_rt < 0 || in->rowgemm_rt > 1)
     return D3F_EINVAL;
   d3f::g_tunables = *in;
   return D3F_OK;

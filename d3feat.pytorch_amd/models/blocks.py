@@ -356,13 +356,22 @@ class ResnetBottleneckBlock(nn.Module):
             incoming = getattr(features, '_d3f_grad_in', None) if strided else None
             shortcut = ops.max_pool(features, inds, grad_deposit=holder, grad_incoming=incoming,
                                     **_pool_width(self.layer_ind, batch)) if strided else features
-            if isinstance(self.unary_shortcut, UnaryBlock):
+            pair = isinstance(self.unary_shortcut, UnaryBlock) and ops.linear_pair_supported(
+                q_pts.shape[0], self.unary2.in_dim, shortcut.shape[1], self.out_dim, shortcut, self.unary2.mlp.weight,
+                self.unary_shortcut.mlp.weight)
+            if isinstance(self.unary_shortcut, UnaryBlock) and not pair:
                 shortcut = self.unary_shortcut(shortcut, grad_deposit=None if strided else holder)
-            elif not strided:
+            elif not strided and not pair:
                 shortcut = ops.grad_tap(features, holder)
             x = ops.kpconv_bias_act(q_pts, s_pts, inds, x, self.KPConv.kernel_points, self.KPConv.weights,
                                     self.KPConv.KP_extent, self.batch_norm_conv.bias, slope=0.1,
                                     influence=self.KPConv.KP_influence, aggregation=self.KPConv.aggregation_mode)
+            if pair:
+                # unary2 and the shortcut unary write ONE output in one launch: the shortcut tensor is never formed
+                u2, us = self.unary2, self.unary_shortcut
+                return ops.linear_pair_bias_act(x, u2.mlp.weight, u2.mlp.bias, u2.batch_norm.bias, shortcut, us.mlp.weight,
+                                                us.mlp.bias, us.batch_norm.bias, slope=0.1,
+                                                grad_deposit2=None if strided else holder)
             return self.unary2(x, residual=shortcut)
         if not self.use_bn and x.is_cuda and not self.KPConv.deformable:
             x = ops.kpconv_bias_act(q_pts, s_pts, inds, x, self.KPConv.kernel_points, self.KPConv.weights,

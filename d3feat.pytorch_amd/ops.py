@@ -1228,6 +1228,125 @@ class _LinearBiasActFn(torch.autograd.Function):
                 gm if ctx.has[1] and ctx.needs_input_grad[3] else None, g2, None, None, None)
 
 
+class _LinearPairBiasActFn(torch.autograd.Function):
+    """act(x1 W1^T + x2 W2^T + b1a + b1b + b2a + b2b) in ONE launch (d3f_linear_pair_bias_act_forward): the last unary
+    block of a bottleneck and its shortcut unary (reference blocks.py:658-686) -- the shortcut tensor is never formed.
+    Backward: ONE epilogue pass (masked gradient + the column sums all four biases share), grad_x1 = g W1 and
+    grad_x2 = g W2 on the row-streaming kernel, both weight gradients queued / launched on the reduction-parallel kernel."""
+
+    @staticmethod
+    def forward(ctx, x1, w1, b1a, b1b, x2, w2, b2a, b2b, slope, deposit2=None):
+        L = _native.lib()
+        ctx.dep2 = deposit2
+        N, C1, C2, Cout = int(x1.shape[0]), int(x1.shape[1]), int(x2.shape[1]), int(w1.shape[0])
+        out = torch.empty((N, Cout), dtype=torch.float32, device=x1.device)
+        ctx.want = tuple(b is not None and ctx.needs_input_grad[i] for b, i in ((b1a, 2), (b1b, 3), (b2a, 6), (b2b, 7)))
+        nb = 2 if any(ctx.want) else 0
+        gbuf = torch.empty((nb, Cout), dtype=torch.float32, device=x1.device) if nb else None
+        with _region("linear_pair_fwd[N=%d,Cin=%d|%d,Cout=%d]" % (N, C1, C2, Cout),
+                     4 * N * (C1 + C2 + Cout) + 4 * (C1 + C2) * Cout):
+            _native.check(L.d3f_linear_pair_bias_act_forward(_p(x1), _p(w1), C1, _p(x2), _p(w2), C2, N, Cout, _p(b1a),
+                                                             _p(b1b), _p(b2a), _p(b2b), float(slope), _p(out), _p(gbuf),
+                                                             nb * Cout, _stream()), "d3f_linear_pair_bias_act_forward")
+        ctx.save_for_backward(x1, w1, x2, w2, out)
+        ctx.gbuf, ctx.slope = gbuf, float(slope)
+        ctx.slots = (_grad_slot(w1), _grad_slot(w2))
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        x1, w1, x2, w2, out = ctx.saved_tensors
+        L = _native.lib()
+        N, C1, C2, Cout = int(x1.shape[0]), int(x1.shape[1]), int(x2.shape[1]), int(w1.shape[0])
+        go = grad_out.contiguous()
+        first = second = None
+        pre = 0
+        if any(ctx.want):
+            gbuf, pre = ctx.gbuf, 1
+            ctx.gbuf = None
+            if gbuf is None:
+                gbuf, pre = torch.empty((2, Cout), dtype=torch.float32, device=go.device), 0
+            first, second = gbuf.unbind(0)
+        need_w1, need_w2 = ctx.needs_input_grad[1], ctx.needs_input_grad[5]
+        atb1 = need_w1 and bool(L.d3f_linear_grad_weight_supported(N, C1, Cout))
+        atb2 = need_w2 and bool(L.d3f_linear_grad_weight_supported(N, C2, Cout))
+        fold = _FOLD_BIAS_SUM and atb1 and atb2 and _WG_GROUP is not None
+        gm = torch.empty_like(go) if ctx.slope != 1.0 else go
+        bias_part, bias_blocks = None, 0
+        if ctx.slope != 1.0 or first is not None:
+            bias_part, bias_blocks = _epilogue_backward(go, out, ctx.slope, N, Cout, gm if ctx.slope != 1.0 else None, first,
+                                                        second, pre, None, fold and first is not None)
+        third = fourth = None
+        if first is not None:
+            third, fourth = torch.empty_like(first), torch.empty_like(first)
+        gx1 = gx2 = None
+        if ctx.needs_input_grad[0]:
+            gx1 = torch.empty_like(x1)
+            _native.check(L.d3f_linear_grad_input(_p(gm), _p(w1), N, C1, Cout, None, _p(gx1), _stream()),
+                          "d3f_linear_grad_input")
+        if ctx.needs_input_grad[4]:
+            gx2 = torch.empty_like(x2)
+            _native.check(L.d3f_linear_grad_input(_p(gm), _p(w2), N, C2, Cout, None, _p(gx2), _stream()),
+                          "d3f_linear_grad_input")
+            if ctx.dep2 is not None and ctx.dep2.deposit(gx2):
+                gx2 = None
+        gw1 = gw2 = None
+        if need_w1:
+            gw1 = ctx.slots[0] if ctx.slots[0] is not None else torch.empty_like(w1)
+            if atb1:
+                _grad_weight_atb(x1, gm, N, C1, Cout, gw1, bias_part, bias_blocks, first, second, "linear_dw")
+            else:
+                torch.mm(gm.t(), x1, out=gw1)
+        if need_w2:
+            gw2 = ctx.slots[1] if ctx.slots[1] is not None else torch.empty_like(w2)
+            if atb2:
+                # (the second problem finishes the same bias partials into the shortcut's two bias gradients)
+                _grad_weight_atb(x2, gm, N, C2, Cout, gw2, bias_part, bias_blocks, third, fourth, "linear_dw")
+            else:
+                torch.mm(gm.t(), x2, out=gw2)
+        if first is not None and bias_part is None:     # (no fold: the epilogue pass finished first / second itself)
+            third.copy_(first)
+            fourth.copy_(first)
+        elif first is not None and not (atb1 and atb2):  # (fold implies both problems are queued: not reached)
+            _native.check(L.d3f_bias_sum(_p(bias_part), bias_blocks, Cout, _p(first), _p(second), _stream()), "d3f_bias_sum")
+            third.copy_(first)
+            fourth.copy_(first)
+        g = [first if ctx.want[0] else None, second if ctx.want[1] else None, third if ctx.want[2] else None,
+             fourth if ctx.want[3] else None]
+        return (gx1, (_adoptable(gw1, ctx.slots[0]) if gw1 is not None else None), g[0], g[1],
+                gx2, (_adoptable(gw2, ctx.slots[1]) if gw2 is not None else None), g[2], g[3], None, None)
+
+
+# False: unary2 and the shortcut unary of a bottleneck stay two launches (A/B measurements)
+FUSE_UNARY_PAIR = True
+
+
+def linear_pair_supported(N, C1, C2, Cout, *tensors):
+    """Whether linear_pair_bias_act serves a pair of these dimensions (the level-0 bottleneck's: (32 | 64) -> 128 from 4096
+    rows); ``tensors``: operands already at hand, checked for device / dtype / layout."""
+    if not FUSE_UNARY_PAIR:
+        return False
+    for t in tensors:
+        if not (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous() and t.data_ptr() % 16 == 0):
+            return False
+    L = _native.lib()
+    N, C1, C2, Cout = int(N), int(C1), int(C2), int(Cout)
+    return bool(L.d3f_linear_pair_supported(N, C1, C2, Cout)) and bool(L.d3f_linear_fused_supported(N, C1, Cout)) \
+        and bool(L.d3f_linear_fused_supported(N, C2, Cout))
+
+
+def linear_pair_bias_act(x1, w1, b1a, b1b, x2, w2, b2a, b2b, slope=0.1, grad_deposit2=None):
+    """act(x1 @ w1^T + b1a + b1b + x2 @ w2^T + b2a + b2b): unary2(x1) + unary_shortcut(x2) + LeakyReLU of a bottleneck
+    block in one launch (reference blocks.py:658-686).  grad_deposit2: x2's gradient is handed to a sibling branch
+    (GradHolder) instead of being returned."""
+    f = lambda t, n: _f32(t, n) if t is not None else None
+    if not linear_pair_supported(x1.shape[0], x1.shape[1], x2.shape[1], w1.shape[0], x1, x2, w1, w2):
+        raise RuntimeError("linear_pair_bias_act: unsupported operands x1%s x2%s w1%s w2%s" % (
+            tuple(x1.shape), tuple(x2.shape), tuple(w1.shape), tuple(w2.shape)))
+    return _LinearPairBiasActFn.apply(_f32(x1, "x1"), _f32(w1, "w1"), f(b1a, "bias"), f(b1b, "bias"), _f32(x2, "x2"),
+                                      _f32(w2, "w2"), f(b2a, "bias"), f(b2b, "bias"), float(slope), grad_deposit2)
+
+
 # The bias gradient's second pass rides in the weight gradient's second-stage launch (csrc/linear.hip,
 # atb_reduce_bias_kernel) whenever both are two-pass forms: N >= 4096 rows for the epilogue's backward and the A^T B
 # kernel for grad_W.  False: two launches as before (experiments).

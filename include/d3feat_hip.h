@@ -75,7 +75,9 @@ typedef struct d3f_tunables {
   int32_t xw_split;           /* d3f_gemm_epilogue: 0 = by shape, 1 = never split the reduction, 8 q = 8 q partitions */
   int32_t rowgemm_wide;       /* row-streaming unary kernels, 4 consecutive columns per lane at 64 / 128 outputs: 0 = from 65536 rows,
                                * 1 = never, 2 = always (A/B measurements) */
-  int32_t reserved[7];
+  int32_t rowgemm_rt;         /* forward row-streaming unary kernels with the weights in registers over two row tiles per wave:
+                               * 0 = from 4096 rows at reductions of 16 / 32 / 64, 1 = never (A/B measurements) */
+  int32_t reserved[6];
 } d3f_tunables;
 void d3f_get_tunables(d3f_tunables* out);
 int d3f_set_tunables(const d3f_tunables* in);
@@ -280,6 +282,15 @@ int d3f_linear_fused_supported(int N, int Cin, int Cout);
 int d3f_linear_bias_act_forward(const float* x, const float* weight, int N, int Cin, int Cout, const float* bias1,
                                 const float* add, const float* bias2, float slope, float* out, float* zero_init,
                                 int zero_n, void* stream);
+/* The last unary block of a bottleneck AND its shortcut unary in one launch (models/blocks.py:658-686: unary2(x),
+ * unary_shortcut(features), leaky_relu(x + shortcut)): out = act(x1 w1^T + x2 w2^T + bias1 + bias2 + bias3 + bias4); the
+ * [N, Cout] shortcut tensor is never formed.  Served while both weight matrices stay in registers
+ * (d3f_linear_pair_supported: from 4096 rows, (Cin1 | Cin2) -> Cout = (32 | 64) -> 128 or (16 | 32) -> 64). */
+int d3f_linear_pair_supported(int N, int Cin1, int Cin2, int Cout);
+int d3f_linear_pair_bias_act_forward(const float* x1, const float* w1, int Cin1, const float* x2, const float* w2, int Cin2,
+                                     int N, int Cout, const float* bias1, const float* bias2, const float* bias3,
+                                     const float* bias4, float slope, float* out, float* zero_init, int zero_n,
+                                     void* stream);
 /* grad_x [N,Cin] = grad_out [N,Cout] @ weight [Cout,Cin] (+ add [N,Cin] when given: the gradient another branch
  * produced for the same tensor, accumulated in the epilogue instead of by a separate launch) */
 int d3f_linear_grad_input(const float* grad_out, const float* weight, int N, int Cin, int Cout, const float* add,

@@ -45,7 +45,7 @@ def test_tunables_struct_round_trips_and_rejects_nonsense():
     lib.d3f_get_tunables(ctypes.byref(t))
     names = [n for n, _ in _native.Tunables._fields_ if n != "reserved"]
     assert names == ["atb_task_us", "atb_form", "atb_first_form_wgs", "match_wgs", "agg_through_lds", "atb_pipe",
-                     "xw_rows", "xw_split", "rowgemm_wide"]
+                     "xw_rows", "xw_split", "rowgemm_wide", "rowgemm_rt"]
     assert [getattr(t, n) for n in names] == [0] * len(names)
     assert ctypes.sizeof(t) == 64
     old = _native.set_tunables(atb_task_us=33, atb_form=2)
@@ -55,7 +55,7 @@ def test_tunables_struct_round_trips_and_rejects_nonsense():
     bad = _native.Tunables()
     bad.atb_form = 7
     assert lib.d3f_set_tunables(ctypes.byref(bad)) == -1
-    for field, value in (("xw_rows", 5), ("xw_split", 65), ("rowgemm_wide", 3)):
+    for field, value in (("xw_rows", 5), ("xw_split", 65), ("rowgemm_wide", 3), ("rowgemm_rt", 2)):
         bad = _native.Tunables()
         setattr(bad, field, value)
         assert lib.d3f_set_tunables(ctypes.byref(bad)) == -1, field

@@ -5,6 +5,7 @@ Tolerance: the north star asks descriptors/scores within 1e-4 (fp32); operator o
 import numpy as np
 import pytest
 import torch
+from contextlib import nullcontext as _nullcontext
 
 from d3feat_pytorch_amd import config as cfgmod
 from d3feat_pytorch_amd import _native, ops
@@ -721,6 +722,56 @@ def test_batched_weight_permute_equals_torch_and_one_launch_serves_a_backward():
         (ctypes.c_void_p * 1)(bad.data_ptr()), (ctypes.c_void_p * 1)(outs[0].data_ptr()), (ctypes.c_int * 1)(2),
         (ctypes.c_int * 1)(48), (ctypes.c_int * 1)(32), 1, torch.cuda.current_stream().cuda_stream) == -1
     torch.cuda.synchronize()
+
+
+@pytest.mark.parametrize("N", [4096 + 37, 70001])
+def test_linear_pair_equals_the_two_unary_launches(N):
+    """ops.linear_pair_bias_act (unary2 + shortcut unary + LeakyReLU of a bottleneck in one launch, reference
+    blocks.py:658-686; the forward kernel keeps both weight matrices in registers) == linear_bias_act(x1, residual =
+    linear_bias_act(x2)): outputs to rounding, all eight gradients (two inputs, two weights, four biases) against the
+    composition and against float64; the shortcut input's gradient handed to a GradHolder when asked."""
+    rng = np.random.default_rng(8)
+    mk = lambda *shape: torch.from_numpy(rng.normal(size=shape).astype(np.float32)).cuda().requires_grad_(True)
+    x1, x2 = mk(N, 32), mk(N, 64)
+    w1, w2 = mk(128, 32), mk(128, 64)
+    bs = [mk(128) for _ in range(4)]
+    assert ops.linear_pair_supported(N, 32, 64, 128, x1, x2, w1, w2)
+    g = torch.from_numpy(rng.normal(size=(N, 128)).astype(np.float32)).cuda()
+    leaves = [x1, w1, bs[0], bs[1], x2, w2, bs[2], bs[3]]
+
+    def grads(fn, **kw):
+        for t in leaves:
+            t.grad = None
+        with ops.weight_grad_group() if kw.get('group') else _nullcontext():
+            out = fn()
+            torch.autograd.backward(out, g)
+        return out.detach(), [t.grad.clone() if t.grad is not None else None for t in leaves]
+
+    two = lambda: ops.linear_bias_act(x1, w1, bs[0], ops.linear_bias_act(x2, w2, bs[2], None, bs[3], slope=1.0), bs[1], slope=0.1)
+    one = lambda: ops.linear_pair_bias_act(x1, w1, bs[0], bs[1], x2, w2, bs[2], bs[3], slope=0.1)
+    o2, g2 = grads(two)
+    o1, g1 = grads(one)
+    assert rel_err(o1.cpu().numpy(), o2.cpu().numpy()) < 2e-6
+    v = x1.detach().double() @ w1.detach().double().t() + x2.detach().double() @ w2.detach().double().t() + \
+        sum(b.detach().double() for b in bs)
+    ref = torch.where(v > 0, v, 0.1 * v)
+    assert rel_err(o1.cpu().numpy(), ref.cpu().numpy()) < 2e-6
+    gm = g.double() * torch.where(v > 0, 1.0, 0.1)
+    want = [gm @ w1.detach().double(), gm.t() @ x1.detach().double(), gm.sum(0), gm.sum(0),
+            gm @ w2.detach().double(), gm.t() @ x2.detach().double(), gm.sum(0), gm.sum(0)]
+    for a, b, w in zip(g1, g2, want):
+        assert rel_err(a.cpu().numpy(), w.cpu().numpy()) < BWD_TOL and rel_err(b.cpu().numpy(), w.cpu().numpy()) < BWD_TOL
+    # inside a weight_grad_group: the bias gradients ride in the grouped second stage; same values
+    _, g3 = grads(one, group=True)
+    for a, w in zip(g3, want):
+        assert rel_err(a.cpu().numpy(), w.cpu().numpy()) < BWD_TOL
+    # the shortcut input's gradient deposited with a sibling branch
+    holder = ops.GradHolder()
+    for t in leaves:
+        t.grad = None
+    out = ops.linear_pair_bias_act(x1, w1, bs[0], bs[1], x2, w2, bs[2], bs[3], slope=0.1, grad_deposit2=holder)
+    torch.autograd.backward(out, g)
+    assert x2.grad is None and rel_err(holder.collect().cpu().numpy(), want[4].cpu().numpy()) < BWD_TOL
 
 
 def test_gemm_epilogue_rejects_bad_arguments():
