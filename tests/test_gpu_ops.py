@@ -1051,6 +1051,36 @@ def test_detection_scores(c):
     assert (ref_w != 0).sum() > 10 and (naive != 0).sum() < (ref_w != 0).sum()   # the data does tell the two apart
 
 
+def test_detection_backward_with_the_sparse_gradient_of_the_detector_loss():
+    """The detector loss reads the scores of the correspondences only (reference utils/loss.py:140-158), so the gradient
+    entering the backward is zero at most points; the backward kernel leaves at such a point.  Against the oracle's
+    autograd on a gradient that is non-zero at 3 % of the points; rows that neither carry a gradient nor neighbor a point
+    that does must come out exactly zero (but for the arg-max row of the normaliser)."""
+    rng = np.random.default_rng(21)
+    n, h, c = 5000, 40, 32
+    feat = rng.normal(size=(n, c)).astype(np.float32)
+    idx = rng.integers(0, n + 1, size=(n, h)).astype(np.int64)
+    idx[:, 0] = np.arange(n)
+    go = rng.normal(size=(n, 1)).astype(np.float32)
+    go[rng.random(n) > 0.03] = 0.0
+    assert 50 < int((go != 0).sum()) < 400
+    tf = torch.from_numpy(feat).requires_grad_(True)
+    ops_ref.detection_scores(tf, torch.from_numpy(idx), training=True).backward(torch.from_numpy(go))
+    gf = cu(feat).requires_grad_(True)
+    ops.detection_scores(gf, cu(idx), training=True).backward(cu(go))
+    assert rel_err(gf.grad.cpu().numpy(), tf.grad.numpy()) < BWD_TOL
+    # rows that neither carry a gradient nor neighbor a point that does receive the normaliser's term only
+    touched = np.zeros(n + 1, bool)
+    act = np.nonzero(go[:, 0])[0]
+    touched[act] = True
+    touched[idx[act].reshape(-1)] = True
+    quiet = ~touched[:n]
+    assert quiet.sum() > 100
+    fmax_rows = np.any(feat == feat.max(), axis=1)
+    g = gf.grad.cpu().numpy()
+    assert np.all(g[quiet & ~fmax_rows] == 0.0)
+
+
 # ------------------------------------------------------------------------------------------------ loss
 @pytest.mark.parametrize("m", [128, 64, 37])
 def test_circle_det_loss(m):
