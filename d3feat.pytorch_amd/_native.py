@@ -53,6 +53,10 @@ SIGNATURES = {
     "d3f_copy_buffers": (_i, [_vp, _vp, _vp, _vp, _i, C.c_double, _vp]),
     "d3f_radius_grid_build_prezeroed": (_i, [_vp, _i, _vp, _i, _f, _vp, _sz, _vp, _vp]),
     "d3f_radius_query_prefix": (_i, [_vp, _vp, _i, _vp, _i, _vp, _i, _f, _f, _f, _f, _i, _vp, _vp, _vp]),
+    "d3f_radius_query_prefix_missing": (_i, [_vp, _vp, _i, _vp, _i, _vp, _i, _f, _f, _f, _f, _i, _vp, _vp, _vp, _vp]),
+    "d3f_radius_query_pool_transposed": (_i, [_vp, _vp, _i, _vp, _i, _vp, _i, _f, _f, _i, _vp, _vp, _vp, _i, _vp, _vp, _vp,
+                                              _vp]),
+    "d3f_upsample_rows_rank": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp]),
     "d3f_grid_subsample_ws_bytes": (_sz, [_i, _i]),
     "d3f_grid_subsample": (_i, [_vp, _i, _vp, _i, _f, _i, _i, _vp, _i, _vp, _vp, _vp, _sz, _vp, _vp]),
     "d3f_grid_subsample_ex": (_i, [_vp, _i, _vp, _i, _f, _i, _i, _vp, _i, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _sz,

@@ -120,6 +120,8 @@ __global__ void grid_scatter_kernel(const float* __restrict__ s, int Ns, const i
   key[pos] = k;
 }
 
+constexpr int kUpKeys = 32;   // transposed lists: coarse points ranked per fine point (one per lane of half a wave)
+
 struct WaveScratch {
   uint64_t cand[kCand];
   uint64_t nkey[32];
@@ -164,11 +166,14 @@ __global__ __launch_bounds__(kQueryWaves * 64) void radius_query_kernel(
     const int32_t* __restrict__ end, const float4* __restrict__ pts, const uint64_t* __restrict__ key, int width,
     int32_t* __restrict__ out_idx, int32_t* __restrict__ out_counts, int32_t* __restrict__ max_count,
     int32_t* __restrict__ status, int32_t* __restrict__ out_wide, int wide_width, uint64_t* __restrict__ out_last_key,
-    int max_count_group, float r2_prefix, float prune_r, int flag_empty) {
+    int max_count_group, float r2_prefix, float prune_r, int flag_empty, const int32_t* __restrict__ done_rows,
+    int32_t* __restrict__ tr_counts, uint64_t* __restrict__ tr_keys) {
   __shared__ WaveScratch scratch[kQueryWaves];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int qi = blockIdx.x * kQueryWaves + wave;
   if (qi >= Nq) return;  // no workgroup barrier below: waves are independent
+  // rows another producer has filled already (d3f_upsample_rows_from_pool: the transpose of the pooling search's lists)
+  if (done_rows && done_rows[qi] > 0) return;
   WaveScratch& ws = scratch[wave];
   volatile uint64_t* cand = ws.cand;
   if (qi >= d3f::batch_offset(q_len, B)) {  // Nq is a row capacity: rows past sum(q_len) get an all-shadow row
@@ -287,6 +292,17 @@ __global__ __launch_bounds__(kQueryWaves * 64) void radius_query_kernel(
   }
   const int Tc = T < kCand ? T : kCand;
   int32_t* row = out_idx ? out_idx + (size_t)qi * width : nullptr;
+  if (tr_counts) {
+    // the TRANSPOSE of this search on the side (d3f_radius_query_pool_transposed): every support s found within the radius
+    // gets the key (d2 bits, this query) appended to its own list -- the same pair seen from s, with the same distance bits
+    for (int i = lane; i < Tc; i += 64) {
+      const uint64_t k = cand[i];
+      const uint32_t sidx = (uint32_t)k;
+      const int slot = atomicAdd(&tr_counts[sidx], 1);
+      if (slot < kUpKeys) tr_keys[(size_t)sidx * kUpKeys + slot] = (k & 0xffffffff00000000ull) | (uint32_t)qi;
+      else atomicOr(status, D3F_ST_WIDE_OVERFLOW);
+    }
+  }
 
   if (Tc <= 64) {
     // rank in registers: 64-key bitonic network over the wave
@@ -358,6 +374,32 @@ __global__ void zero_many_kernel(ZeroJobs jobs) {
   const size_t stride = (size_t)gridDim.x * blockDim.x, t0 = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   for (int j = 0; j < jobs.n; ++j)
     for (size_t i = t0; i < jobs.words[j]; i += stride) jobs.p[j][i] = 0u;
+}
+
+// ---- upsampling rows as the transpose of the pooling search (d3f_radius_query_pool_transposed + d3f_upsample_rows_rank) ----
+
+// 32 lanes per fine point: its keys ranked by a 32-key bitonic network (15 compare-exchange steps, all inside the half
+// wave), the row written in 128-byte runs.  Rows without a key are left alone.
+__global__ __launch_bounds__(256) void up_rank_kernel(const int32_t* __restrict__ counts, const uint64_t* __restrict__ keys,
+                                                      int Nf, int Nc, int width, int32_t* __restrict__ up) {
+  const int lane = threadIdx.x & 63, l32 = lane & 31;
+  const int f = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 2 + (lane >> 5);
+  const int n = f < Nf ? min(counts[f], kUpKeys) : 0;
+  uint64_t v = l32 < n ? keys[(size_t)f * kUpKeys + l32] : ~0ull;
+#pragma unroll
+  for (int k = 2; k <= 32; k <<= 1) {
+#pragma unroll
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      const uint64_t o = shfl_xor_u64(v, j);
+      const bool up_dir = (l32 & k) == 0, lower = (l32 & j) == 0;
+      const uint64_t mn = v < o ? v : o, mx = v < o ? o : v;
+      v = (lower == up_dir) ? mn : mx;
+    }
+  }
+  if (n > 0) {
+    int32_t* row = up + (size_t)f * width;
+    for (int c = l32; c < width; c += 32) row[c] = c < n ? (int32_t)(uint32_t)v : Nc;
+  }
 }
 
 }  // namespace
@@ -433,7 +475,9 @@ static int radius_query_launch(const void* grid_ws, const float* queries, int Nq
                                const int32_t* s_len, int B, float grid_radius, float radius, int width,
                                int32_t* out_idx, int32_t* out_counts, int32_t* max_count, int32_t* out_wide,
                                int wide_width, uint64_t* out_last_key, int max_count_group, int32_t* status,
-                               void* stream_, float prefix_radius, float nearest_bound);
+                               void* stream_, float prefix_radius, float nearest_bound,
+                               const int32_t* done_rows = nullptr, int32_t* tr_counts = nullptr,
+                               uint64_t* tr_keys = nullptr);
 
 int d3f_radius_query_ex(const void* grid_ws, const float* queries, int Nq, const int32_t* q_len, int Ns,
                         const int32_t* s_len, int B, float grid_radius, float radius, int width, int32_t* out_idx,
@@ -458,11 +502,56 @@ int d3f_radius_query_prefix(const void* grid_ws, const float* queries, int Nq, c
                              nullptr, nullptr, 0, nullptr, 0, status, stream_, prefix_radius, nearest_bound);
 }
 
+/* d3f_radius_query_prefix for the rows nobody has filled yet: rows with done_rows[q] > 0 are left untouched (see
+ * d3f_upsample_rows_from_pool). */
+int d3f_radius_query_prefix_missing(const void* grid_ws, const float* queries, int Nq, const int32_t* q_len, int Ns,
+                                    const int32_t* s_len, int B, float grid_radius, float radius, float prefix_radius,
+                                    float nearest_bound, int width, int32_t* out_idx, const int32_t* done_rows,
+                                    int32_t* status, void* stream_) {
+  if (!(prefix_radius > 0.0f) || !(prefix_radius <= radius) || !out_idx || !done_rows) return D3F_EINVAL;
+  if (nearest_bound != 0.0f && !(nearest_bound >= prefix_radius && nearest_bound <= radius)) return D3F_EINVAL;
+  return radius_query_launch(grid_ws, queries, Nq, q_len, Ns, s_len, B, grid_radius, radius, width, out_idx, nullptr,
+                             nullptr, nullptr, 0, nullptr, 0, status, stream_, prefix_radius, nearest_bound, done_rows);
+}
+
+/* A pooling search (coarse queries over the fine cloud, reference datasets/dataloader.py:141-146) that leaves its TRANSPOSE
+ * behind: besides the capped table, its max count(s) and the last kept keys (as d3f_radius_query_ex), every fine point f
+ * found within the radius of coarse query c gets the key (d2 bits << 32 | c) appended to tr_keys[32 f ...], tr_counts[f]
+ * counting them (cleared by the caller).  The pairs are exactly those of the upsampling search at the same radius seen
+ * from the fine side, and d2 is the same bits either way round ((a - b)^2 == (b - a)^2, same summation order):
+ * d3f_upsample_rows_rank turns the lists into the engine's upsampling rows.  More than 32 coarse points around a fine
+ * point set D3F_ST_WIDE_OVERFLOW. */
+int d3f_radius_query_pool_transposed(const void* grid_ws, const float* queries, int Nq, const int32_t* q_len, int Ns,
+                                     const int32_t* s_len, int B, float grid_radius, float radius, int width,
+                                     int32_t* out_idx, int32_t* max_count, uint64_t* out_last_key, int max_count_group,
+                                     int32_t* tr_counts, uint64_t* tr_keys, int32_t* status, void* stream_) {
+  if (!tr_counts || !tr_keys || !out_idx) return D3F_EINVAL;
+  return radius_query_launch(grid_ws, queries, Nq, q_len, Ns, s_len, B, grid_radius, radius, width, out_idx, nullptr,
+                             max_count, nullptr, 0, out_last_key, max_count_group, status, stream_, 0.0f, 0.0f, nullptr,
+                             tr_counts, tr_keys);
+}
+
+/* The training engine's upsampling rows (prefix form: the coarse points within the POOLING radius of every fine point,
+ * ranked by (d2, index): dataloader.py:147-152 restricted to what closest_pool, models/blocks.py:79-91, and the transposed
+ * pooling table read) from the lists d3f_radius_query_pool_transposed left: rows of `up` [Nf, width] (shadow = Nc) with at
+ * least one key are ranked and written; rows with counts[f] == 0 -- a fine point whose own voxel's barycentre lies
+ * farther than the pooling radius, and the padding rows -- are for d3f_radius_query_prefix_missing. */
+int d3f_upsample_rows_rank(const int32_t* counts, const uint64_t* keys, int Nf, int Nc, int width, int32_t* up,
+                           void* stream_) {
+  if (!counts || !keys || !up || Nf < 0 || Nc < 0 || width < 1) return D3F_EINVAL;
+  if (Nf > 0) {
+    up_rank_kernel<<<d3f::cdiv(Nf, 8), 256, 0, (hipStream_t)stream_>>>(counts, keys, Nf, Nc, width, up);
+    D3F_LAUNCH_CHECK();
+  }
+  return D3F_OK;
+}
+
 static int radius_query_launch(const void* grid_ws, const float* queries, int Nq, const int32_t* q_len, int Ns,
                                const int32_t* s_len, int B, float grid_radius, float radius, int width,
                                int32_t* out_idx, int32_t* out_counts, int32_t* max_count, int32_t* out_wide,
                                int wide_width, uint64_t* out_last_key, int max_count_group, int32_t* status,
-                               void* stream_, float prefix_radius, float nearest_bound) {
+                               void* stream_, float prefix_radius, float nearest_bound, const int32_t* done_rows,
+                               int32_t* tr_counts, uint64_t* tr_keys) {
   if (!grid_ws || !queries || !q_len || !s_len || (!out_idx && !out_wide) || !status || Nq < 0 || Ns < 0 || B < 1 ||
       max_count_group < 0 ||
       B > D3F_MAX_BATCH || width < 1 || width > kCand || !(radius > 0.0f) || !(grid_radius >= radius) ||
@@ -479,7 +568,7 @@ static int radius_query_launch(const void* grid_ws, const float* queries, int Nq
       queries, Nq, q_len, s_len, B, Ns, inv_cell, r2, g.M - 1, g.start, g.end, g.pts, g.key, width, out_idx,
       out_counts, max_count, status, out_wide, wide_width, out_last_key, max_count_group,
       prefix_radius > 0.0f ? prefix_radius * prefix_radius : 0.0f, nearest_bound > 0.0f ? nearest_bound : radius,
-      (prefix_radius > 0.0f && nearest_bound > 0.0f) ? 1 : 0);
+      (prefix_radius > 0.0f && nearest_bound > 0.0f) ? 1 : 0, done_rows, tr_counts, tr_keys);
   D3F_LAUNCH_CHECK();
   return D3F_OK;
 }

@@ -191,6 +191,55 @@ class RadiusGrid:
                 "d3f_radius_query_prefix")
         return out
 
+    def query_pool_transposed(self, queries, q_len, width, max_group=0, mx_out=None):
+        """A pooling search over this (fine) cloud -- (table, device max count(s), last kept keys) as
+        ``query(want_max=True, want_last_key=True)`` -- that also leaves its transpose behind: ``(counts [Ns] int32, keys
+        [32 Ns] int64)``, per fine point the (d2 bits, coarse query) keys of the coarse queries that found it
+        (d3f_radius_query_pool_transposed); ``RadiusGrid.prefix_rows_from_transposed`` ranks them into upsampling rows."""
+        q = _f32(queries, "queries")
+        q_len = _lens(q_len, q.device, "q_batches")
+        if q_len.numel() != self.s_len.numel():
+            raise RuntimeError("Wrong number of batch elements: different for queries and supports ")
+        Nq = int(q.shape[0])
+        out = torch.empty((Nq, int(width)), dtype=torch.int32, device=q.device)
+        n_mx = -(-int(q_len.numel()) // int(max_group)) if max_group else 1
+        mx = mx_out if mx_out is not None else torch.zeros(n_mx, dtype=torch.int32, device=q.device)
+        if mx.numel() != n_mx or mx.dtype != torch.int32:
+            raise RuntimeError("mx_out must hold %d int32 counters" % n_mx)
+        lkey = torch.empty(Nq, dtype=torch.int64, device=q.device)
+        counts = torch.empty(self.Ns, dtype=torch.int32, device=q.device)
+        keys = torch.empty(32 * max(self.Ns, 1), dtype=torch.int64, device=q.device)
+        zero_buffers([counts])
+        with _region("radius_query_pool_transposed[Nq=%d,Ns=%d]" % (Nq, self.Ns), 12 * Nq + 12 * self.Ns + 4 * Nq * int(width)):
+            _native.check(_native.lib().d3f_radius_query_pool_transposed(
+                _p(self.ws), _p(q), Nq, _p(q_len), self.Ns, _p(self.s_len), int(q_len.numel()), self.radius, self.radius,
+                int(width), _p(out), _p(mx), _p(lkey), int(max_group), _p(counts), _p(keys), _p(self.status.word),
+                _stream()), "d3f_radius_query_pool_transposed")
+        return out, mx, lkey, (counts, keys)
+
+    def prefix_rows_from_transposed(self, queries, q_len, width, prefix_radius, transposed, nearest_bound=0.0):
+        """The rows of ``query_prefix`` (this grid = the COARSE cloud, ``queries`` = the fine cloud) ranked from the lists a
+        pooling search at ``prefix_radius`` left behind (``query_pool_transposed`` on the fine cloud's grid): the pairs are
+        the same and so are the bits of their distances, so nothing is searched for a second time
+        (d3f_upsample_rows_rank); the few fine points without a coarse point inside the radius -- and the padding rows --
+        are searched as before (d3f_radius_query_prefix_missing)."""
+        q = _f32(queries, "queries")
+        q_len = _lens(q_len, q.device, "q_batches")
+        counts, keys = transposed
+        Nq = int(q.shape[0])
+        if int(counts.numel()) != Nq:
+            raise RuntimeError("transposed lists of %d points for %d queries" % (int(counts.numel()), Nq))
+        L = _native.lib()
+        out = torch.empty((Nq, int(width)), dtype=torch.int32, device=q.device)
+        with _region("upsample_rows_rank[Nf=%d,Nc=%d]" % (Nq, self.Ns), 256 * Nq + 4 * Nq * int(width)):
+            _native.check(L.d3f_upsample_rows_rank(_p(counts), _p(keys), Nq, self.Ns, int(width), _p(out), _stream()),
+                          "d3f_upsample_rows_rank")
+            _native.check(L.d3f_radius_query_prefix_missing(
+                _p(self.ws), _p(q), Nq, _p(q_len), self.Ns, _p(self.s_len), int(q_len.numel()), self.radius, self.radius,
+                float(prefix_radius), float(nearest_bound), int(width), _p(out), _p(counts), _p(self.status.word),
+                _stream()), "d3f_radius_query_prefix_missing")
+        return out
+
     def query(self, queries, q_len, width, want_counts=False, want_max=False, radius=None, wide=0, want_last_key=False,
               table=True, max_group=0, mx_out=None):
         """int32 [Nq, width] neighbor table (+ per-query uncapped counts, + device max count).
@@ -423,6 +472,9 @@ DX_GATHER_MIN_ROWS = 1000
 # 80 % limit of 42).  More than that sets D3F_ST_WIDE_OVERFLOW.  A pooling table's transpose is read off the
 # upsampling table (coarse points within 2r of a fine point, nearest first: those within r -- mean 7, max 18 -- lead).
 REV_WIDTH_CONV = 96
+# the engine's upsampling rows ranked from the transpose the POOLING search leaves behind (RadiusGrid.query_pool_transposed
+# / prefix_rows_from_transposed); False: the upsampling rows are searched for (rounds 4-6)
+UPSAMPLES_FROM_POOL = True
 
 
 def wants_reverse_table(Ns):

@@ -103,6 +103,28 @@ int d3f_zero_buffers(void* const* ptrs, const size_t* bytes, int n, void* stream
  * dsts[j][i] (uint8) = srcs[j][i] (float64 dist_keypts) > threshold (utils/loss.py:119), i < bytes[j] / 8.  n <= 24. */
 int d3f_copy_buffers(const void* const* srcs, void* const* dsts, const size_t* bytes, const int* kinds, int n,
                      double threshold, void* stream);
+/* d3f_radius_query_prefix for the rows nobody has filled yet: a row q with done_rows[q] > 0 is left untouched. */
+int d3f_radius_query_prefix_missing(const void* grid_ws, const float* queries, int Nq, const int32_t* q_len, int Ns,
+                                    const int32_t* s_len, int B, float grid_radius, float radius, float prefix_radius,
+                                    float nearest_bound, int width, int32_t* out_idx, const int32_t* done_rows,
+                                    int32_t* status, void* stream);
+/* A pooling search (coarse queries over the fine cloud, reference datasets/dataloader.py:141-146) that leaves its TRANSPOSE
+ * behind: capped table, max count(s) and last kept keys as d3f_radius_query_ex, and every fine point f found within the
+ * radius of coarse query c gets the key (d2 bits << 32 | c) appended to tr_keys[32 f ...] (scratch of 32 Ns uint64),
+ * tr_counts[f] [Ns] int32 (cleared by the caller) counting them.  These are the pairs of the upsampling search at the same
+ * radius seen from the fine side, with the same distance bits.  More than 32 coarse points around a fine point set
+ * D3F_ST_WIDE_OVERFLOW. */
+int d3f_radius_query_pool_transposed(const void* grid_ws, const float* queries, int Nq, const int32_t* q_len, int Ns,
+                                     const int32_t* s_len, int B, float grid_radius, float radius, int width,
+                                     int32_t* out_idx, int32_t* max_count, uint64_t* out_last_key, int max_count_group,
+                                     int32_t* tr_counts, uint64_t* tr_keys, int32_t* status, void* stream);
+/* The training engine's upsampling rows (prefix form: the coarse points within the POOLING radius of every fine point,
+ * ranked by (d2, index): dataloader.py:147-152 restricted to what closest_pool, models/blocks.py:79-91, and the transposed
+ * pooling table read) ranked from those lists: rows of `up` [Nf, width] (shadow = Nc) with at least one key are written;
+ * rows with counts[f] == 0 (the fine point's own voxel barycentre lies farther than the pooling radius; padding rows) are
+ * for d3f_radius_query_prefix_missing. */
+int d3f_upsample_rows_rank(const int32_t* counts, const uint64_t* keys, int Nf, int Nc, int width, int32_t* up,
+                           void* stream);
 int d3f_radius_grid_build_prezeroed(const float* supports, int Ns, const int32_t* s_len, int B, float radius,
                                     void* grid_ws, size_t grid_ws_bytes, int32_t* status, void* stream);
 /* Query: out_idx [Nq,width] gets, per query, the in-radius supports of the same batch element, ordered by

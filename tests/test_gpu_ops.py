@@ -8,7 +8,7 @@ import torch
 from contextlib import nullcontext as _nullcontext
 
 from d3feat_pytorch_amd import config as cfgmod
-from d3feat_pytorch_amd import _native, ops
+from d3feat_pytorch_amd import _native, ops, synthetic
 from d3feat_pytorch_amd.datasets import dataloader as dl
 from d3feat_pytorch_amd.geometric_registration.common import build_correspondence
 from oracle import ops_ref
@@ -25,6 +25,11 @@ def cu(a, dtype=None):
     if dtype is not None:
         t = t.to(dtype)
     return t.to(DEV)
+
+
+def _gpu_subsample(points, lengths, dlen):
+    p, b = dl.batch_grid_subsampling_kpconv(cu(points), cu(lengths), sampleDl=dlen)
+    return p.cpu().numpy(), b.cpu().numpy()
 
 
 def _cloud(rng, n, scale=(2.0, 1.5, 0.6)):
@@ -157,6 +162,42 @@ def test_radius_neighbors_edge_cases(native):
     ref = native.batch_query(s, s, [3000], [3000], radius=0.15, max_neighbors=30)
     got = dl.batch_neighbors_kpconv(cu(s), cu(s), [3000], [3000], 0.15, 30).cpu().numpy()
     assert np.array_equal(got, ref)
+
+
+@pytest.mark.parametrize("seed,width,pool_voxels", [(3, 40, 2.5), (4, 12, 2.5), (5, 40, 1.0)])
+def test_upsampling_rows_from_the_pooling_lists_equal_the_prefix_search(seed, width, pool_voxels):
+    """The engine's upsampling rows ranked from the TRANSPOSE a pooling search leaves behind
+    (d3f_radius_query_pool_transposed -> d3f_upsample_rows_rank) + a search for the rows without a coarse point inside the
+    radius (d3f_radius_query_prefix_missing) == RadiusGrid.query_prefix, bit for bit: voxel-subsampled fragments (every fine
+    point has its voxel's barycentre nearby -- some farther than the pooling radius), two clouds, padding rows."""
+    rng = np.random.default_rng(seed)
+    dl0 = 0.03
+    frags = [synthetic.make_fragment(seed + k, _gpu_subsample, n_raw=60000, scale=0.3) for k in range(2)]
+    fine = np.concatenate(frags, 0)
+    fl = np.array([f.shape[0] for f in frags], np.int32)
+    cpts, cl = dl.batch_grid_subsampling_kpconv(cu(fine), cu(fl), sampleDl=2 * dl0)
+    pool_r, up_r = pool_voxels * dl0, 5.0 * dl0          # (1.0: some fine points have NO coarse point inside the radius)
+    pad = 37                                             # capacity-shaped inputs: rows past the live count
+    fine_cap = torch.cat([cu(fine), torch.zeros((pad, 3), device=DEV)])
+    coarse_cap = torch.cat([cpts, torch.zeros((pad, 3), device=DEV)])
+    fgrid = ops.RadiusGrid(fine_cap, cu(fl), pool_r)
+    cgrid = ops.RadiusGrid(coarse_cap, cl, up_r)
+    bound = min(up_r, max(pool_r, 1.1 * 2 * dl0 * 3.0 ** 0.5))
+    want = cgrid.query_prefix(fine_cap, cu(fl), width, pool_r, nearest_bound=bound)
+    tab, mx, lkey, transposed = fgrid.query_pool_transposed(coarse_cap, cl, width)
+    got = cgrid.prefix_rows_from_transposed(fine_cap, cu(fl), width, pool_r, transposed, nearest_bound=bound)
+    ref_tab, ref_mx, ref_lkey = fgrid.query(coarse_cap, cl, width, want_max=True, want_last_key=True)
+    assert torch.equal(tab, ref_tab) and torch.equal(mx, ref_mx) and torch.equal(lkey, ref_lkey)   # the search itself: unchanged
+    fgrid.status.raise_if_set()
+    cgrid.status.raise_if_set()
+    assert torch.equal(got, want)
+    nc = int(coarse_cap.shape[0])
+    counts = (want[:fine.shape[0]] < nc).sum(1)
+    assert int(counts.max()) > (3 if pool_voxels > 2 else 1)              # ranked rows ...
+    if pool_voxels < 2:                                                    # ... and rows that hold the nearest point only
+        d = (fine_cap[:fine.shape[0]] - coarse_cap[want[:fine.shape[0], 0].long()]).norm(dim=1)
+        assert int((d >= pool_r).sum()) > 5
+    assert bool((want[fine.shape[0]:] == nc).all())                        # padding rows: all shadow
 
 
 @pytest.mark.parametrize("radius,prefix,width", [(0.30, 0.15, 40), (0.30, 0.05, 24), (0.2, 0.2, 64), (0.35, 0.12, 8)])
