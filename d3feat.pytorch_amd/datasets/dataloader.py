@@ -147,7 +147,7 @@ def _conv_table(grid_for, pts, lens, level, e, lim, reverse_tables, want_max=Fal
 
 
 def _pool_tables(grid_for, pts, lens, level, e, lim, reverse_tables, status, group=0, engine_upsamples=False,
-                 mx_out=None):
+                 mx_out=None, tr_counts=None):
     """(pools[l], device max count, upsamples[l]) (dataloader.py:141-152).  The transpose of the pooling table (coarse
     points around every fine point, radius r) is the leading part of the rows of the upsampling table (same point
     pairs, radius 2r, nearest first): nothing extra is searched, the pooling query only adds its last-kept keys."""
@@ -160,7 +160,7 @@ def _pool_tables(grid_for, pts, lens, level, e, lim, reverse_tables, status, gro
         # level 0 of a 3-pair stack)
         bound = min(float(e['up_r']), max(float(e['pool_r']), 1.1 * float(e['dl']) * 3.0 ** 0.5))
         tab, mx, lkey, transposed = grid.query_pool_transposed(pts[level + 1], lens[level + 1], lim, max_group=group,
-                                                               mx_out=mx_out)
+                                                               mx_out=mx_out, counts=tr_counts)
         up = grid_for(level + 1, e['up_r']).prefix_rows_from_transposed(pts[level], lens[level], lim, e['pool_r'],
                                                                         transposed, nearest_bound=bound)
         rev = ops.filter_reverse_table(ops.ReverseTable(up, pts[level + 1].shape[0], lim, ns, last_key=lkey,
@@ -216,7 +216,13 @@ def build_pyramid_static(points, lengths, config, neighborhood_limits, capacitie
     n_mx = -(-int(lens[0].numel()) // int(group)) if group else 1
     mx_all = torch.empty(max(1, n_pool * n_mx), dtype=torch.int32, device=dev)
     spaces = [ops.RadiusGrid.workspace(n, dev) for n in rows]
-    ops.zero_buffers([z for _, z in spaces] + [mx_all] + ([status.word] if clear_status else []))
+    # (the per-fine-point counters of the pooling searches' transposes, all levels in one buffer: cleared with the rest)
+    tr_all = None
+    if engine_upsamples and ops.UPSAMPLES_FROM_POOL and reverse_tables and len(spaces) <= 5:
+        tr_all = torch.empty(sum(rows[:n_pool]), dtype=torch.int32, device=dev)
+    ops.zero_buffers([z for _, z in spaces] + [mx_all] + ([tr_all] if tr_all is not None else []) +
+                     ([status.word] if clear_status else []))
+    tr_off = [sum(rows[:l]) for l in range(n_pool + 1)]
     for e in walk.layers:
         if e['pool']:
             out, out_len, _, _ = ops.grid_subsample_raw(pts[-1], lens[-1], e['dl'], order=order, status=status,
@@ -253,7 +259,8 @@ def build_pyramid_static(points, lengths, config, neighborhood_limits, capacitie
             # static width = the limit; the reference trims to min(limit, max_count) (dataloader.py:64-66).  Only max_pool
             # can tell the difference (a full row gains zero-valued shadow candidates): it gets max_count, on the device
             tab, mx, up = _pool_tables(grid_for, pts, lens, level, e, lim, reverse_tables, status, group=group,
-                                       engine_upsamples=engine_upsamples, mx_out=mx_all[level * n_mx:(level + 1) * n_mx])
+                                       engine_upsamples=engine_upsamples, mx_out=mx_all[level * n_mx:(level + 1) * n_mx],
+                                       tr_counts=tr_all[tr_off[level]:tr_off[level + 1]] if tr_all is not None else None)
             pools.append(tab)
             pools_width.append(mx)
             upsamples.append(up)

@@ -191,7 +191,7 @@ class RadiusGrid:
                 "d3f_radius_query_prefix")
         return out
 
-    def query_pool_transposed(self, queries, q_len, width, max_group=0, mx_out=None):
+    def query_pool_transposed(self, queries, q_len, width, max_group=0, mx_out=None, counts=None):
         """A pooling search over this (fine) cloud -- (table, device max count(s), last kept keys) as
         ``query(want_max=True, want_last_key=True)`` -- that also leaves its transpose behind: ``(counts [Ns] int32, keys
         [32 Ns] int64)``, per fine point the (d2 bits, coarse query) keys of the coarse queries that found it
@@ -207,9 +207,12 @@ class RadiusGrid:
         if mx.numel() != n_mx or mx.dtype != torch.int32:
             raise RuntimeError("mx_out must hold %d int32 counters" % n_mx)
         lkey = torch.empty(Nq, dtype=torch.int64, device=q.device)
-        counts = torch.empty(self.Ns, dtype=torch.int32, device=q.device)
+        if counts is None:          # (``counts``: [Ns] int32 the caller has cleared -- a pyramid build clears all at once)
+            counts = torch.empty(self.Ns, dtype=torch.int32, device=q.device)
+            zero_buffers([counts])
+        elif counts.numel() != self.Ns or counts.dtype != torch.int32:
+            raise RuntimeError("counts must hold %d int32 counters" % self.Ns)
         keys = torch.empty(32 * max(self.Ns, 1), dtype=torch.int64, device=q.device)
-        zero_buffers([counts])
         with _region("radius_query_pool_transposed[Nq=%d,Ns=%d]" % (Nq, self.Ns), 12 * Nq + 12 * self.Ns + 4 * Nq * int(width)):
             _native.check(_native.lib().d3f_radius_query_pool_transposed(
                 _p(self.ws), _p(q), Nq, _p(q_len), self.Ns, _p(self.s_len), int(q_len.numel()), self.radius, self.radius,
