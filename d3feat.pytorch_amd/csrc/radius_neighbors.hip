@@ -299,8 +299,8 @@ __global__ __launch_bounds__(kQueryWaves * 64) void radius_query_kernel(
       const uint64_t k = cand[i];
       const uint32_t sidx = (uint32_t)k;
       const int slot = atomicAdd(&tr_counts[sidx], 1);
+      // (a list that outgrows its 32 slots is dropped by the ranking kernel and searched for like an empty one)
       if (slot < kUpKeys) tr_keys[(size_t)sidx * kUpKeys + slot] = (k & 0xffffffff00000000ull) | (uint32_t)qi;
-      else atomicOr(status, D3F_ST_WIDE_OVERFLOW);
     }
   }
 
@@ -380,11 +380,15 @@ __global__ void zero_many_kernel(ZeroJobs jobs) {
 
 // 32 lanes per fine point: its keys ranked by a 32-key bitonic network (15 compare-exchange steps, all inside the half
 // wave), the row written in 128-byte runs.  Rows without a key are left alone.
-__global__ __launch_bounds__(256) void up_rank_kernel(const int32_t* __restrict__ counts, const uint64_t* __restrict__ keys,
+__global__ __launch_bounds__(256) void up_rank_kernel(int32_t* __restrict__ counts, const uint64_t* __restrict__ keys,
                                                       int Nf, int Nc, int width, int32_t* __restrict__ up) {
   const int lane = threadIdx.x & 63, l32 = lane & 31;
   const int f = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 2 + (lane >> 5);
-  const int n = f < Nf ? min(counts[f], kUpKeys) : 0;
+  int n = f < Nf ? counts[f] : 0;
+  if (n > kUpKeys) {      // more coarse points around this fine point than a list holds (a volumetric cloud): no row from
+    n = 0;                // here, the count goes back to 0 and the masked search that follows ranks the row in full
+    if (l32 == 0) counts[f] = 0;
+  }
   uint64_t v = l32 < n ? keys[(size_t)f * kUpKeys + l32] : ~0ull;
 #pragma unroll
   for (int k = 2; k <= 32; k <<= 1) {
@@ -519,8 +523,8 @@ int d3f_radius_query_prefix_missing(const void* grid_ws, const float* queries, i
  * found within the radius of coarse query c gets the key (d2 bits << 32 | c) appended to tr_keys[32 f ...], tr_counts[f]
  * counting them (cleared by the caller).  The pairs are exactly those of the upsampling search at the same radius seen
  * from the fine side, and d2 is the same bits either way round ((a - b)^2 == (b - a)^2, same summation order):
- * d3f_upsample_rows_rank turns the lists into the engine's upsampling rows.  More than 32 coarse points around a fine
- * point set D3F_ST_WIDE_OVERFLOW. */
+ * d3f_upsample_rows_rank turns the lists into the engine's upsampling rows.  A list that outgrows its 32 slots keeps
+ * counting; the ranking drops it and the row is searched for like an empty one. */
 int d3f_radius_query_pool_transposed(const void* grid_ws, const float* queries, int Nq, const int32_t* q_len, int Ns,
                                      const int32_t* s_len, int B, float grid_radius, float radius, int width,
                                      int32_t* out_idx, int32_t* max_count, uint64_t* out_last_key, int max_count_group,
@@ -535,8 +539,9 @@ int d3f_radius_query_pool_transposed(const void* grid_ws, const float* queries, 
  * ranked by (d2, index): dataloader.py:147-152 restricted to what closest_pool, models/blocks.py:79-91, and the transposed
  * pooling table read) from the lists d3f_radius_query_pool_transposed left: rows of `up` [Nf, width] (shadow = Nc) with at
  * least one key are ranked and written; rows with counts[f] == 0 -- a fine point whose own voxel's barycentre lies
- * farther than the pooling radius, and the padding rows -- are for d3f_radius_query_prefix_missing. */
-int d3f_upsample_rows_rank(const int32_t* counts, const uint64_t* keys, int Nf, int Nc, int width, int32_t* up,
+ * farther than the pooling radius, and the padding rows -- are for d3f_radius_query_prefix_missing; so are the rows
+ * whose list outgrew its 32 slots (counts[f] is set back to 0). */
+int d3f_upsample_rows_rank(int32_t* counts, const uint64_t* keys, int Nf, int Nc, int width, int32_t* up,
                            void* stream_) {
   if (!counts || !keys || !up || Nf < 0 || Nc < 0 || width < 1) return D3F_EINVAL;
   if (Nf > 0) {

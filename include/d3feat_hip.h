@@ -112,8 +112,8 @@ int d3f_radius_query_prefix_missing(const void* grid_ws, const float* queries, i
  * behind: capped table, max count(s) and last kept keys as d3f_radius_query_ex, and every fine point f found within the
  * radius of coarse query c gets the key (d2 bits << 32 | c) appended to tr_keys[32 f ...] (scratch of 32 Ns uint64),
  * tr_counts[f] [Ns] int32 (cleared by the caller) counting them.  These are the pairs of the upsampling search at the same
- * radius seen from the fine side, with the same distance bits.  More than 32 coarse points around a fine point set
- * D3F_ST_WIDE_OVERFLOW. */
+ * radius seen from the fine side, with the same distance bits.  A list that outgrows its 32 slots keeps counting (the
+ * ranking drops it and the row is searched for). */
 int d3f_radius_query_pool_transposed(const void* grid_ws, const float* queries, int Nq, const int32_t* q_len, int Ns,
                                      const int32_t* s_len, int B, float grid_radius, float radius, int width,
                                      int32_t* out_idx, int32_t* max_count, uint64_t* out_last_key, int max_count_group,
@@ -122,8 +122,8 @@ int d3f_radius_query_pool_transposed(const void* grid_ws, const float* queries, 
  * ranked by (d2, index): dataloader.py:147-152 restricted to what closest_pool, models/blocks.py:79-91, and the transposed
  * pooling table read) ranked from those lists: rows of `up` [Nf, width] (shadow = Nc) with at least one key are written;
  * rows with counts[f] == 0 (the fine point's own voxel barycentre lies farther than the pooling radius; padding rows) are
- * for d3f_radius_query_prefix_missing. */
-int d3f_upsample_rows_rank(const int32_t* counts, const uint64_t* keys, int Nf, int Nc, int width, int32_t* up,
+ * for d3f_radius_query_prefix_missing, and so are the rows whose list outgrew its 32 slots: counts[f] is set back to 0. */
+int d3f_upsample_rows_rank(int32_t* counts, const uint64_t* keys, int Nf, int Nc, int width, int32_t* up,
                            void* stream);
 int d3f_radius_grid_build_prezeroed(const float* supports, int Ns, const int32_t* s_len, int B, float radius,
                                     void* grid_ws, size_t grid_ws_bytes, int32_t* status, void* stream);

@@ -200,6 +200,28 @@ def test_upsampling_rows_from_the_pooling_lists_equal_the_prefix_search(seed, wi
     assert bool((want[fine.shape[0]:] == nc).all())                        # padding rows: all shadow
 
 
+def test_upsampling_rows_with_more_coarse_points_than_a_transposed_list_holds():
+    """A volumetric cloud: fine points with up to ~60 'coarse' points inside the radius -- more than the 32 slots of a
+    transposed list.  Such a list is dropped by the ranking kernel and the row is searched for like an empty one: the rows
+    still equal RadiusGrid.query_prefix bit for bit and no status bit is raised."""
+    rng = np.random.default_rng(9)
+    fl, cl = np.array([3000, 2000], np.int32), np.array([2500, 1800], np.int32)
+    fine = (rng.random((int(fl.sum()), 3)) * 0.5).astype(np.float32)
+    coarse = (rng.random((int(cl.sum()), 3)) * 0.5).astype(np.float32)
+    r, width = 0.09, 48
+    fgrid = ops.RadiusGrid(cu(fine), cu(fl), r)
+    cgrid = ops.RadiusGrid(cu(coarse), cu(cl), 2 * r)
+    want = cgrid.query_prefix(cu(fine), cu(fl), width, r)
+    tab, mx, lkey, transposed = fgrid.query_pool_transposed(cu(coarse), cu(cl), width)
+    assert int(transposed[0].max()) > 40                       # lists that outgrow their 32 slots exist ...
+    got = cgrid.prefix_rows_from_transposed(cu(fine), cu(fl), width, r, transposed)
+    fgrid.status.raise_if_set()
+    cgrid.status.raise_if_set()
+    assert torch.equal(got, want)
+    long_rows = (want < coarse.shape[0]).sum(1) > 32
+    assert int(long_rows.sum()) > 50 and bool((transposed[0][long_rows] == 0).all())     # ... and went the other way
+
+
 @pytest.mark.parametrize("radius,prefix,width", [(0.30, 0.15, 40), (0.30, 0.05, 24), (0.2, 0.2, 64), (0.35, 0.12, 8)])
 def test_radius_query_prefix_rows_are_the_leading_part_of_the_full_rows(native, radius, prefix, width):
     """d3f_radius_query_prefix (the upsampling tables inside the training engine): row q = the entries of the full ranked
